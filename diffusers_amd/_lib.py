@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI declared in ``include/diffusers_amd.h``.
+
+There is NO fallback: if ``libdiffusers_amd.so`` is missing or a symbol is absent the import of any compute path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "_C" / "libdiffusers_amd.so"
+
+# ---- constants mirrored from include/diffusers_amd.h ----
+DA_OK = 0
+ERRORS = {1: "DA_ERR_INVALID", 2: "DA_ERR_LAUNCH", 3: "DA_ERR_UNSUPPORTED"}
+ACT_NONE, ACT_GEGLU, ACT_GELU_TANH, ACT_SILU, ACT_GELU_ERF = 0, 1, 2, 3, 4
+TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64 = 0, 1, 2, 3, 4
+STAGE_REGISTER, STAGE_LDS_DIRECT = 0, 1
+DTYPE_BF16, DTYPE_F32 = 0, 1
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
+        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("residual", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int), ("ld_rowvec", C.c_int),
+        ("rows_per_batch", C.c_int),
+        ("alpha", C.c_float), ("out_scale", C.c_float),
+        ("act", C.c_int), ("out_f32", C.c_int), ("conv", C.c_int),
+        ("Hin", C.c_int), ("Win", C.c_int), ("C1", C.c_int), ("C2", C.c_int),
+        ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("pad", C.c_int),
+        ("tile", C.c_int), ("staging", C.c_int),
+    ]
+
+
+class AttentionParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int), ("H", C.c_int), ("Sq", C.c_int), ("Skv", C.c_int), ("Skv_alloc", C.c_int), ("D", C.c_int),
+        ("q_batch_stride", C.c_longlong), ("k_batch_stride", C.c_longlong),
+        ("vt_batch_stride", C.c_longlong), ("o_batch_stride", C.c_longlong),
+        ("q_row_stride", C.c_int), ("k_row_stride", C.c_int), ("vt_ld", C.c_int), ("o_row_stride", C.c_int),
+        ("scale", C.c_float),
+    ]
+
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "da_version": (_i, []),
+    "da_gemm_bf16": (_i, [C.POINTER(GemmParams), _vp]),
+    "da_attention_bf16": (_i, [C.POINTER(AttentionParams), _vp]),
+    "da_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "da_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "da_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "da_softmax_rows_f32_bf16": (_i, [_vp, _vp, _i, _i, _ll, _ll, _vp]),
+    "da_euler_scale_model_input": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
+    "da_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
+    "da_x0_linear_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
+    "da_flowmatch_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
+    "da_advance_step": (_i, [_vp, _vp]),
+    "da_mul_scalar": (_i, [_vp, _vp, _f, _ll, _i, _vp]),
+    "da_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp]),
+    "da_linear_small_m_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "da_conv_thin_in_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "da_conv_thin_out_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libdiffusers_amd.so (building is a separate, explicit step: ``python -m diffusers_amd.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m diffusers_amd.build` "
+            "(or __graft_entry__.build()). diffusers_amd has no CPU / PyTorch fallback path."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != DA_OK:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(status, status)}")

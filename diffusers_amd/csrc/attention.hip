@@ -1,0 +1,274 @@
+// Flash-style scaled-dot-product attention forward for gfx950 (MI355X), bf16 in / bf16 out, fp32 softmax.
+//
+// Replaces F.scaled_dot_product_attention at diffusers models/attention_processor.py:2767 (AttnProcessor2_0, UNet
+// self/cross attention) and models/attention_dispatch.py:3709 (_native_attention, Flux / Wan).  No mask, no dropout,
+// not causal -- exactly what the five BASELINE configs use.
+//
+// Layout: q/k/out are token-major [B][S][H*D] views with arbitrary row strides (so the fused QK projection output
+// can be consumed in place); V is consumed TRANSPOSED, vt[(h*D+d)][b*vt_batch_stride + s], which the projection GEMM
+// produces for free by swapping its operands (out^T = W . X^T).  That keeps every MFMA operand K-contiguous:
+//
+//   S^T[kv][q] = K[kv][:] . Q[q][:]^T      A = K tile (LDS), B = Q (registers)         v_mfma_f32_32x32x16_bf16
+//   O^T[d][q]  = V^T[d][kv] . P^T[kv][q]   A = V^T tile (LDS), B = P^T (registers, straight from the S^T accumulators)
+//
+// With the "swapped" product each lane owns ONE query (column lane&31): the row max / row sum are in-lane plus one
+// lane^32 exchange, the online-softmax rescale is a per-lane scalar, and P never leaves registers: the MFMA K-index
+// permutation that the C/D layout imposes on P is simply applied to the V^T fragment reads as well.
+//
+// One block = 4 waves = 128 queries of one (batch, head); KV tiles of 64, double-buffered in LDS (register staged).
+#include "common.cuh"
+
+namespace {
+
+template <int D>
+struct AttnCfg {
+  static constexpr int CPR = D / 8;              // 16-byte chunks per K row
+  static constexpr int KBYTES = 64 * D * 2;      // K tile  [64][D]
+  static constexpr int VBYTES = D * 128;         // V^T tile [D][64]
+  static constexpr int STAGE = KBYTES + VBYTES;
+  static constexpr int KCH = (64 * CPR) / 256;   // K chunks staged per thread
+  static constexpr int VCH = (D * 8) / 256;      // V^T chunks staged per thread
+};
+
+template <int D>
+__device__ __forceinline__ int k_swz(int row) {
+  return (D == 64) ? ((row >> 1) & 7) : (row & 15);
+}
+
+template <int D>
+__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
+  using C = AttnCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const uint16_t* __restrict__ Q = (const uint16_t*)p.q + (size_t)b * p.q_batch_stride + (size_t)h * D;
+  const uint16_t* __restrict__ K = (const uint16_t*)p.k + (size_t)b * p.k_batch_stride + (size_t)h * D;
+  const uint16_t* __restrict__ VT = (const uint16_t*)p.vt + (size_t)h * D * p.vt_ld + (size_t)b * p.vt_batch_stride;
+  uint16_t* __restrict__ O = (uint16_t*)p.out + (size_t)b * p.o_batch_stride + (size_t)h * D;
+
+  // ---- Q fragments (MFMA B operand): lane (q = l31, hi) holds Q[q][16*ks + 8*hi + 0..7] ----
+  bf16x8_t qf[D / 16];
+  {
+    const int q = q0 + l31;
+    const bool ok = q < p.Sq;
+    const uint16_t* qp = Q + (size_t)(ok ? q : 0) * p.q_row_stride + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      uint4 v = *(const uint4*)(qp + 16 * ks);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+
+  // ---- staging assignment ----
+  // K: chunk id = t + 256*i -> row = id / CPR, c = id % CPR ; V^T: id -> row d = id / 8, c = id % 8
+  uint4 kg[C::KCH], vg[C::VCH];
+
+  auto issue = [&](int tile) {
+    const int kv0 = tile * 64;
+#pragma unroll
+    for (int i = 0; i < C::KCH; ++i) {
+      const int id = t + 256 * i;
+      const int row = id / C::CPR, c = id % C::CPR;
+      const int kv = kv0 + row;
+      const bool ok = kv < p.Skv_alloc;
+      const uint16_t* src = K + (size_t)(ok ? kv : 0) * p.k_row_stride + c * 8;
+      uint4 v = *(const uint4*)src;
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      kg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < C::VCH; ++i) {
+      const int id = t + 256 * i;
+      const int d = id >> 3, c = id & 7;
+      const int kv = kv0 + c * 8;
+      const bool ok = kv < p.Skv_alloc;  // Skv_alloc is a multiple of 8
+      const uint16_t* src = VT + (size_t)d * p.vt_ld + (ok ? kv : 0);
+      uint4 v = *(const uint4*)src;
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      vg[i] = v;
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned char* kb = smem + buf * C::STAGE;
+    unsigned char* vb = kb + C::KBYTES;
+#pragma unroll
+    for (int i = 0; i < C::KCH; ++i) {
+      const int id = t + 256 * i;
+      const int row = id / C::CPR, c = id % C::CPR;
+      *(uint4*)(kb + row * (2 * D) + ((c ^ k_swz<D>(row)) << 4)) = kg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < C::VCH; ++i) {
+      const int id = t + 256 * i;
+      const int d = id >> 3, c = id & 7;
+      const int g = (d >> 1) & 15;  // 8-byte slot swizzle; slots (2c, 2c+1) -> (2c^g, (2c+1)^g)
+      uint4 v = vg[i];
+      if (g & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+      *(uint4*)(vb + d * 128 + ((c ^ (g >> 1)) << 4)) = v;
+    }
+  };
+
+  f32x16_t o[D / 32];
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  const int ntiles = (p.Skv + 63) >> 6;
+  const int ksw = k_swz<D>(l31);           // K fragment swizzle of this lane's row
+  const int vsw = (l31 >> 1) & 15;         // V^T 8-byte slot swizzle of this lane's row
+
+  issue(0);
+  commit(0);
+  __syncthreads();
+
+  for (int j = 0; j < ntiles; ++j) {
+    const int cur = j & 1;
+    const bool more = (j + 1 < ntiles);
+    if (more) issue(j + 1);
+
+    const unsigned char* kb = smem + cur * C::STAGE;
+    const unsigned char* vb = kb + C::KBYTES;
+
+    // ---- S^T = K . Q^T : two 32-kv tiles ----
+    f32x16_t s[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+      const unsigned char* krow = kb + (32 * st + l31) * (2 * D);
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(krow + (((2 * ks + hi) ^ ksw) << 4));
+        s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax; lane owns query l31, kv index of s[st][r] = 32*st + (r&3) + 8*(r>>2) + 4*hi ----
+    const int kv0 = j * 64;
+    float mx = -1e30f;
+    if (kv0 + 64 > p.Skv) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + 32 * st + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          s[st][r] = (kv < p.Skv) ? s[st][r] * sl2 : -1e30f;
+        }
+    } else {
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[st][r] *= sl2;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[st][r] - m_new);
+        s[st][r] = e;
+        psum += e;
+      }
+    l_run = l_run * alpha + psum;  // per-half partial; halves are combined after the loop
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+    // ---- P^T fragments: MFMA u (K=16) takes registers 8*(u&1)..+7 of tile u>>1 ----
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bf16x8_t f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (__bf16)s[u >> 1][8 * (u & 1) + e];
+      pf[u] = f;
+    }
+
+    // ---- O^T += V^T . P^T ; V^T fragment of lane (d = 32*dt + l31, hi): kv 16u+4hi+{0..3} and 16u+8+4hi+{0..3} ----
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+      const unsigned char* vrow = vb + (32 * dt + l31) * 128;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint2 a0 = *(const uint2*)(vrow + (((4 * u + hi) ^ vsw) << 3));
+        const uint2 a1 = *(const uint2*)(vrow + (((4 * u + 2 + hi) ^ vsw) << 3));
+        const uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), pf[u], o[dt], 0, 0, 0);
+      }
+    }
+
+    if (more) commit(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < p.Sq) {
+    uint16_t* op = O + (size_t)q * p.o_row_stride;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        pk.y = pack_bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(uint2*)(op + 32 * dt + 8 * g + 4 * hi) = pk;
+      }
+  }
+}
+
+template <int D>
+int launch_attn(const da_attention_params& p, hipStream_t s) {
+  using C = AttnCfg<D>;
+  const size_t lds = 2 * C::STAGE;
+  auto kern = attn_fwd_kernel<D>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DA_ERR_LAUNCH;
+      attr_set = true;
+    }
+  }
+  dim3 grid((p.Sq + 127) / 128, p.H, p.B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+}  // namespace
+
+extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
+  if (!pp) return DA_ERR_INVALID;
+  const da_attention_params& p = *pp;
+  if (!p.q || !p.k || !p.vt || !p.out) return DA_ERR_INVALID;
+  if (p.B <= 0 || p.H <= 0 || p.Sq <= 0 || p.Skv <= 0) return DA_ERR_INVALID;
+  if (p.Skv_alloc < p.Skv || (p.Skv_alloc & 7)) return DA_ERR_INVALID;
+  if ((p.q_row_stride & 7) || (p.k_row_stride & 7) || (p.vt_ld & 7) || (p.vt_batch_stride & 7) || (p.o_row_stride & 3))
+    return DA_ERR_UNSUPPORTED;
+  if ((p.q_batch_stride & 7) || (p.k_batch_stride & 7) || (p.o_batch_stride & 3)) return DA_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  switch (p.D) {
+    case 64: return launch_attn<64>(p, s);
+    case 128: return launch_attn<128>(p, s);
+  }
+  return DA_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,66 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of diffusers_amd.
+// Written for wave64 + MFMA only; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "diffusers_amd.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+
+#define DA_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return DA_ERR_LAUNCH;            \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// unpack 8 bf16 held in a uint4 into 8 floats
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = bf_lo(v.x); f[1] = bf_hi(v.x);
+  f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+  f[4] = bf_lo(v.z); f[5] = bf_hi(v.z);
+  f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]);
+  v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// erf-GELU (torch F.gelu default, approximate="none")
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// tanh-GELU (torch approximate="tanh")
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

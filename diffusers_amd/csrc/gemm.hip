@@ -1,0 +1,393 @@
+// bf16 MFMA GEMM / implicit-GEMM conv3x3 for gfx950 (MI355X).
+//
+// One kernel template serves every dense contraction on the denoising hot path:
+//   * nn.Linear           out[M][N] = X[M][K] . W[N][K]^T           (reference: torch F.linear call sites,
+//                          diffusers models/attention_processor.py:2743-2777, models/activations.py:113-124,
+//                          models/attention.py:1717-1742)
+//   * nn.Conv2d 3x3 / s1,s2 / pad 1 on channels-last activations as an implicit GEMM
+//                          (reference: models/resnet.py:340-373, models/downsampling.py:145,
+//                          models/upsampling.py:177-190 with the nearest-2x gather fused into the A loader,
+//                          models/unets/unet_2d_blocks.py:2444 with the skip concat read from two base pointers)
+//
+// Design (CDNA4): 256 threads = 4 waves (2x2), each wave owns MT x NT tiles of 32x32 computed with
+// v_mfma_f32_32x32x16_bf16.  The MFMA "A" operand is the WEIGHT tile and the "B" operand the ACTIVATION tile, so
+// each lane ends up holding 4 consecutive output channels of one output row -> 8-byte packed bf16 stores and
+// per-lane fused epilogues (bias, per-batch channel vector, residual, GEGLU / GELU / SiLU).
+// K is consumed in 64-wide slices (one 128-byte line per tile row) through a double-buffered LDS image whose
+// 16-byte slots are XOR-swizzled with ((row>>1)&7) so every ds_read_b128 lane group is bank-conflict free.
+// Staging is either register-staged (global_load_dwordx4 -> ds_write_b128) or direct-to-LDS
+// (global_load_lds_dwordx4, swizzle applied on the per-lane SOURCE address, LDS image lane-linear).
+#include "common.cuh"
+#include "diffusers_amd.h"
+
+namespace {
+
+__device__ uint4 g_zero_line[8];  // 128 B of zeros: source for out-of-bounds rows in the direct-to-LDS path
+
+struct RowInfo {      // per staged activation row (implicit GEMM gather state)
+  int base;           // linear: row index (or -1 if out of range); conv: b*Hin
+  int oy, ox;         // conv: oy*stride - pad, ox*stride - pad
+};
+
+template <int MT, int NT, bool CONV, bool GLDS>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(const da_gemm_params p) {
+  constexpr int BM = 64 * MT, BN = 64 * NT;
+  constexpr int XR = BM / 32, WR = BN / 32;  // staged rows per thread
+  constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of tiles ----
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const uint16_t* __restrict__ A = (const uint16_t*)p.A;
+  const uint16_t* __restrict__ A2 = (const uint16_t*)p.A2;
+  const uint16_t* __restrict__ Wt = (const uint16_t*)p.W;
+
+  // ---- staging assignment: thread t stages LDS slot (row = (t>>3)+32*i, pos = t&7) from source chunk sc ----
+  const int srow = t >> 3;
+  const int spos = t & 7;
+  const int sc = spos ^ ((t >> 4) & 7);  // (row>>1)&7 == (t>>4)&7 for every i
+
+  RowInfo xr[XR];
+  const int Hv = CONV ? (p.Hin << p.up) : 0, Wv = CONV ? (p.Win << p.up) : 0;
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    const int m = m0 + srow + 32 * i;
+    if (CONV) {
+      if (m < p.M) {
+        const int hw = p.Hout * p.Wout;
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int oy = rem / p.Wout;
+        const int ox = rem - oy * p.Wout;
+        xr[i].base = b * p.Hin;
+        xr[i].oy = oy * p.stride - p.pad;
+        xr[i].ox = ox * p.stride - p.pad;
+      } else {
+        xr[i].base = 0;
+        xr[i].oy = -100000;  // never in range
+        xr[i].ox = -100000;
+      }
+    } else {
+      xr[i].base = (m < p.M) ? m : -1;
+      xr[i].oy = 0;
+      xr[i].ox = 0;
+    }
+  }
+  int wrow[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int n = n0 + srow + 32 * i;
+    wrow[i] = (n < p.N) ? n : -1;
+  }
+
+  const int nk = p.K >> 6;
+  const int Ctot = CONV ? (p.C1 + p.C2) : 0;
+  const int tiles_per_tap = CONV ? (Ctot >> 6) : 1;
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 xg0, xg1, xg2, xg3, wg0, wg1, wg2, wg3;  // named (not arrays) so they never land in scratch
+  xg0 = xg1 = xg2 = xg3 = wg0 = wg1 = wg2 = wg3 = make_uint4(0, 0, 0, 0);
+
+  // source pointer of activation row i for K-slice kt (a 128-byte line of zeros when the slot must be zero,
+  // so every staging load is unconditional and the compiler keeps them all in flight)
+  const uint16_t* zline = (const uint16_t*)g_zero_line;
+  auto x_src = [&](int i, int kt) -> const uint16_t* {
+    if (CONV) {
+      const int tap = kt / tiles_per_tap;
+      const int c0 = (kt - tap * tiles_per_tap) << 6;
+      const int kh = tap / p.conv, kw = tap - kh * p.conv;  // p.conv = kernel size (1 or 3)
+      const int iy = xr[i].oy + kh, ix = xr[i].ox + kw;
+      if ((unsigned)iy >= (unsigned)Hv || (unsigned)ix >= (unsigned)Wv) return zline;
+      const int sy = iy >> p.up, sx = ix >> p.up;
+      const size_t pix = (size_t)(xr[i].base + sy) * p.Win + sx;
+      if (c0 < p.C1) return A + pix * p.C1 + c0 + sc * 8;
+      return A2 + pix * p.C2 + (c0 - p.C1) + sc * 8;
+    } else {
+      if (xr[i].base < 0) return zline;
+      return A + (size_t)xr[i].base * p.lda + ((size_t)kt << 6) + sc * 8;
+    }
+  };
+  auto w_src = [&](int i, int kt) -> const uint16_t* {
+    if (wrow[i] < 0) return zline;
+    return Wt + (size_t)wrow[i] * p.ldw + ((size_t)kt << 6) + sc * 8;
+  };
+
+  // Staging is written as macros (not lambdas) so the staged registers stay in VGPRs.
+#define DA_STAGE_ISSUE(KT, BUF)                                                                                        \
+  do {                                                                                                                 \
+    if (GLDS) {                                                                                                        \
+      unsigned char* xb_ = smem + (BUF) * STAGE;                                                                       \
+      unsigned char* wb_ = xb_ + XBYTES;                                                                               \
+      _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                                                 \
+        const uint16_t* s_ = x_src(i, (KT));                                                                           \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,                            \
+                                         (__attribute__((address_space(3))) void*)(xb_ + (i * 4 + wave) * 1024), 16,   \
+                                         0, 0);                                                                        \
+      }                                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < WR; ++i) {                                                                 \
+        const uint16_t* s_ = w_src(i, (KT));                                                                           \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,                            \
+                                         (__attribute__((address_space(3))) void*)(wb_ + (i * 4 + wave) * 1024), 16,   \
+                                         0, 0);                                                                        \
+      }                                                                                                                \
+    } else {                                                                                                           \
+      xg0 = *(const uint4*)x_src(0, (KT));                                                                             \
+      xg1 = *(const uint4*)x_src(1, (KT));                                                                             \
+      if constexpr (XR > 2) {                                                                                          \
+        xg2 = *(const uint4*)x_src(2, (KT));                                                                           \
+        xg3 = *(const uint4*)x_src(3, (KT));                                                                           \
+      }                                                                                                                \
+      wg0 = *(const uint4*)w_src(0, (KT));                                                                             \
+      wg1 = *(const uint4*)w_src(1, (KT));                                                                             \
+      if constexpr (WR > 2) {                                                                                          \
+        wg2 = *(const uint4*)w_src(2, (KT));                                                                           \
+        wg3 = *(const uint4*)w_src(3, (KT));                                                                           \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+#define DA_STAGE_COMMIT(BUF)                                                                                           \
+  do {                                                                                                                 \
+    if (!GLDS) {                                                                                                       \
+      unsigned char* xb_ = smem + (BUF) * STAGE;                                                                       \
+      unsigned char* wb_ = xb_ + XBYTES;                                                                               \
+      unsigned char* xs_ = xb_ + srow * 128 + spos * 16;                                                               \
+      unsigned char* ws_ = wb_ + srow * 128 + spos * 16;                                                               \
+      *(uint4*)(xs_) = xg0;                                                                                            \
+      *(uint4*)(xs_ + 32 * 128) = xg1;                                                                                 \
+      if constexpr (XR > 2) {                                                                                          \
+        *(uint4*)(xs_ + 64 * 128) = xg2;                                                                               \
+        *(uint4*)(xs_ + 96 * 128) = xg3;                                                                               \
+      }                                                                                                                \
+      *(uint4*)(ws_) = wg0;                                                                                            \
+      *(uint4*)(ws_ + 32 * 128) = wg1;                                                                                 \
+      if constexpr (WR > 2) {                                                                                          \
+        *(uint4*)(ws_ + 64 * 128) = wg2;                                                                               \
+        *(uint4*)(ws_ + 96 * 128) = wg3;                                                                               \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+
+  // fragment read offsets (bytes) inside a tile: row (l31) * 128 + ((2*ks+hi) ^ ((l31>>1)&7)) * 16
+  const int fsw = (l31 >> 1) & 7;
+  const int frow = l31 * 128;
+
+  auto compute = [&](int buf) {
+    const unsigned char* xb = smem + buf * STAGE + (wm * MT * 32) * 128 + frow;
+    const unsigned char* wb = smem + buf * STAGE + XBYTES + (wn * NT * 32) * 128 + frow;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = ((2 * ks + hi) ^ fsw) << 4;
+      bf16x8_t wf[NT], xf[MT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8_t*)(wb + j * 32 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *(const bf16x8_t*)(xb + i * 32 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: double-buffered LDS, one barrier per K slice (last slice peeled) ----
+  DA_STAGE_ISSUE(0, 0);
+  DA_STAGE_COMMIT(0);
+  if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    const int cur = kt & 1;
+    DA_STAGE_ISSUE(kt + 1, cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next slice's loads in flight under this slice's MFMAs
+    compute(cur);
+    DA_STAGE_COMMIT(cur ^ 1);
+    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  compute((nk - 1) & 1);
+#undef DA_STAGE_ISSUE
+#undef DA_STAGE_COMMIT
+
+  // ---- epilogue: lane holds, for output row m (= lane&31 within the 32-tile), channels 8*(r>>2)+4*hi+(r&3) ----
+  const uint16_t* __restrict__ bias = (const uint16_t*)p.bias;
+  const uint16_t* __restrict__ rowvec = (const uint16_t*)p.rowvec;
+  const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
+  const bool geglu = (p.act == DA_ACT_GEGLU);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + (wm * MT + i) * 32 + l31;
+    if (m >= p.M) continue;
+    const int bidx = (rowvec != nullptr) ? (m / p.rows_per_batch) : 0;
+    if (geglu) {
+      // packed weight rows: per 64 rows = [32 value rows | 32 gate rows]; NT == 2 -> j=0 value, j=1 gate
+      if (NT == 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cin = 8 * g + 4 * hi;                  // channel inside the 32-wide half
+          const int nv = n0 + wn * 64 + cin;               // packed row of value
+          const int no = (n0 >> 1) + wn * 32 + cin;        // output column
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float hv = acc[i][0][4 * g + e] * p.alpha;
+            float gv = acc[i][NT - 1][4 * g + e] * p.alpha;
+            if (bias) {
+              hv += bf2f(bias[nv + e]);
+              gv += bf2f(bias[nv + 32 + e]);
+            }
+            // reference rounds the projection to bf16 before chunk/gelu/mul (activations.py:113-124)
+            hv = bf2f(f2bf(hv));
+            gv = bf2f(f2bf(gv));
+            o[e] = hv * bf2f(f2bf(gelu_erf_f(gv)));
+          }
+          uint2 pk;
+          pk.x = pack_bf2(o[0], o[1]);
+          pk.y = pack_bf2(o[2], o[3]);
+          *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + no) = pk;
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + (wn * NT + j) * 32 + 8 * g + 4 * hi;
+        if (n >= p.N) continue;  // N is a multiple of 4 (checked on the host)
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * p.alpha;
+        if (bias) {
+          const uint2 bv = *(const uint2*)(bias + n);
+          o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y);
+        }
+        if (rowvec) {
+          const uint2 rv = *(const uint2*)(rowvec + (size_t)bidx * p.ld_rowvec + n);
+          o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
+        }
+        if (p.act == DA_ACT_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = gelu_tanh_f(bf2f(f2bf(o[e])));
+        } else if (p.act == DA_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = silu_f(bf2f(f2bf(o[e])));
+        } else if (p.act == DA_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(bf2f(f2bf(o[e])));
+        }
+        if (resid) {
+          const uint2 rv = *(const uint2*)(resid + (size_t)m * p.ldr + n);
+          o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
+        }
+        if (p.out_scale != 1.0f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= p.out_scale;
+        }
+        if (p.out_f32) {
+          *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          uint2 pk;
+          pk.x = pack_bf2(o[0], o[1]);
+          pk.y = pack_bf2(o[2], o[3]);
+          *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + n) = pk;
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int NT, bool CONV, bool GLDS>
+int launch(const da_gemm_params& p, hipStream_t s) {
+  constexpr int BM = 64 * MT, BN = 64 * NT;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const size_t lds = (size_t)(BM + BN) * 128 * 2;
+  auto kern = igemm_bf16_kernel<MT, NT, CONV, GLDS>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DA_ERR_LAUNCH;
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+template <bool CONV, bool GLDS>
+int dispatch_tile(const da_gemm_params& p, int tile, hipStream_t s) {
+  switch (tile) {
+    case DA_TILE_128x128: return launch<2, 2, CONV, GLDS>(p, s);
+    case DA_TILE_64x128: return launch<1, 2, CONV, GLDS>(p, s);
+    case DA_TILE_128x64: return launch<2, 1, CONV, GLDS>(p, s);
+    case DA_TILE_64x64: return launch<1, 1, CONV, GLDS>(p, s);
+  }
+  return DA_ERR_INVALID;
+}
+
+int pick_tile(const da_gemm_params& p) {
+  // Fill the 256 CUs (two resident 128x128 blocks each) before growing the tile.
+  auto nblk = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  if (p.act == DA_ACT_GEGLU) return (nblk(128, 128) >= 384) ? DA_TILE_128x128 : DA_TILE_64x128;
+  if (nblk(128, 128) >= 384) return DA_TILE_128x128;
+  if (p.N <= 64) return DA_TILE_128x64;
+  if (nblk(64, 128) >= 384) return DA_TILE_64x128;
+  return DA_TILE_64x64;
+}
+
+}  // namespace
+
+extern "C" int da_gemm_bf16(const da_gemm_params* pp, void* stream) {
+  if (!pp) return DA_ERR_INVALID;
+  da_gemm_params p = *pp;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return DA_ERR_INVALID;
+  if ((p.K & 63) || (p.N & 3) || (p.ldc & 3)) return DA_ERR_UNSUPPORTED;
+  if (!p.A || !p.W || !p.C) return DA_ERR_INVALID;
+  if (p.residual && (p.ldr & 3)) return DA_ERR_UNSUPPORTED;
+  if (p.rowvec && (p.rows_per_batch <= 0 || (p.ld_rowvec & 3))) return DA_ERR_INVALID;
+  if (p.alpha == 0.0f) p.alpha = 1.0f;
+  if (p.out_scale == 0.0f) p.out_scale = 1.0f;
+  if (p.conv) {
+    if (p.C1 <= 0 || (p.C1 & 63) || (p.C2 & 63) || p.C2 < 0) return DA_ERR_UNSUPPORTED;
+    if (p.C2 > 0 && !p.A2) return DA_ERR_INVALID;
+    if (p.conv != 1 && p.conv != 3) return DA_ERR_UNSUPPORTED;
+    if (p.K != p.conv * p.conv * (p.C1 + p.C2)) return DA_ERR_INVALID;
+    if (p.stride != 1 && p.stride != 2) return DA_ERR_UNSUPPORTED;
+    if (p.up != 0 && p.up != 1) return DA_ERR_INVALID;
+    if (p.Hin <= 0 || p.Win <= 0 || p.Hout <= 0 || p.Wout <= 0) return DA_ERR_INVALID;
+    if (p.M % (p.Hout * p.Wout)) return DA_ERR_INVALID;
+  } else {
+    if ((p.lda & 7) || (p.ldw & 7)) return DA_ERR_UNSUPPORTED;
+  }
+  if (p.act == DA_ACT_GEGLU && ((p.N & 127) || p.out_f32 || p.residual || p.rowvec)) return DA_ERR_UNSUPPORTED;
+  int tile = p.tile;
+  if (tile == DA_TILE_AUTO) tile = pick_tile(p);
+  if (p.act == DA_ACT_GEGLU && tile != DA_TILE_128x128 && tile != DA_TILE_64x128) return DA_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const bool glds = (p.staging == DA_STAGE_LDS_DIRECT);
+  if (p.conv) return glds ? dispatch_tile<true, true>(p, tile, s) : dispatch_tile<true, false>(p, tile, s);
+  return glds ? dispatch_tile<false, true>(p, tile, s) : dispatch_tile<false, false>(p, tile, s);
+}

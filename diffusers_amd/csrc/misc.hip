@@ -1,0 +1,268 @@
+// Small hot-path kernels that are not GEMM-shaped: sinusoidal timestep embedding, skinny (M <= 8) linear layers for
+// the embedding MLPs, and the two "thin" convolutions at the ends of the U-Net / VAE (Cin <= 16 or Cout <= 16) which
+// also convert between the reference's NCHW tensors and the engine's channels-last layout.
+//
+// Reference (diffusers src/diffusers/):
+//   get_timestep_embedding       models/embeddings.py:27-78 (+ Timesteps :1310-1326)
+//   TimestepEmbedding            models/embeddings.py:1262-1308   (Linear -> SiLU -> Linear, M = batch)
+//   time_emb_proj                models/resnet.py:345-349         (Linear(SiLU(temb)))
+//   conv_in / conv_out           models/unets/unet_2d_condition.py:1108,:1230 ; models/autoencoders/vae.py:286,:309
+//   post_quant_conv              models/autoencoders/autoencoder_kl.py:204
+#include "common.cuh"
+
+namespace {
+
+// out[b][:] = [sin | cos] (or [cos | sin] when flip) of t_b * exp(-ln(max_period) * i / (half - shift)), fp32 math.
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, const float* __restrict__ table,
+                                          const int* __restrict__ step_idx, void* __restrict__ out, int B, int dim,
+                                          int flip_sin_to_cos, float shift, float scale, float max_period, int out_f32) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * half) return;
+  const int b = idx / half, i = idx - b * half;
+  float tv;
+  if (table) tv = table[(size_t)(*step_idx) * 8 + 7];
+  else tv = t[b];
+  const float exponent = (-logf(max_period) * (float)i) / ((float)half - shift);
+  const float arg = scale * (tv * expf(exponent));
+  const float sv = sinf(arg), cv = cosf(arg);
+  const size_t o0 = (size_t)b * dim + (flip_sin_to_cos ? half + i : i);  // sin slot
+  const size_t o1 = (size_t)b * dim + (flip_sin_to_cos ? i : half + i);  // cos slot
+  if (out_f32) {
+    ((float*)out)[o0] = sv;
+    ((float*)out)[o1] = cv;
+  } else {
+    ((uint16_t*)out)[o0] = f2bf(sv);
+    ((uint16_t*)out)[o1] = f2bf(cv);
+  }
+}
+
+// Skinny linear: out[m][n] = act_out( sum_k act_in(x[m][k]) * W[n][k] + bias[n] ) (+ res[m][n]); M <= 8.
+// One wave per output column; lanes stride K with 16-byte loads; W is streamed once (HBM-bound GEMV regime).
+template <int MMAX>
+__global__ __launch_bounds__(256) void linear_small_m_kernel(const uint16_t* __restrict__ x,
+                                                             const uint16_t* __restrict__ W,
+                                                             const uint16_t* __restrict__ bias,
+                                                             const uint16_t* __restrict__ res,
+                                                             uint16_t* __restrict__ out, int M, int N, int K, int ldx,
+                                                             int ldo, int ldr, int act_in, int act_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[MMAX];
+#pragma unroll
+  for (int m = 0; m < MMAX; ++m) acc[m] = 0.f;
+  const uint16_t* wr = W + (size_t)n * K;
+  for (int k = lane * 8; k < K; k += 512) {
+    float wf[8];
+    unpack8(*(const uint4*)(wr + k), wf);
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) {
+      if (m < M) {
+        float xf[8];
+        unpack8(*(const uint4*)(x + (size_t)m * ldx + k), xf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xv = xf[e];
+          if (act_in == DA_ACT_SILU) xv = bf2f(f2bf(silu_f(xv)));
+          acc[m] += xv * wf[e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MMAX; ++m) acc[m] = wave_sum(acc[m]);
+  if (lane == 0) {
+    const float bv = bias ? bf2f(bias[n]) : 0.f;
+    for (int m = 0; m < M; ++m) {
+      float o = acc[m] + bv;
+      if (act_out == DA_ACT_SILU) o = silu_f(bf2f(f2bf(o)));
+      else if (act_out == DA_ACT_GELU_TANH) o = gelu_tanh_f(bf2f(f2bf(o)));
+      if (res) o = bf2f(f2bf(o)) + bf2f(res[(size_t)m * ldr + n]);
+      out[(size_t)m * ldo + n] = f2bf(o);
+    }
+  }
+}
+
+// Thin-input conv: Cin <= 16, k in {1,3}, stride 1, pad (k-1)/2.  Input NCHW or NHWC, output NHWC [B][H][W][Cout].
+// Thread = (pixel, 8 output channels).  weights: [Cout][k][k][Cin] bf16.  `batch_mod`: input batch index = b % batch_mod
+__global__ __launch_bounds__(256) void conv_thin_in_kernel(const uint16_t* __restrict__ x,
+                                                           const uint16_t* __restrict__ w,
+                                                           const uint16_t* __restrict__ bias,
+                                                           uint16_t* __restrict__ y, int B, int H, int W, int Cin,
+                                                           int Cout, int ks, int in_nchw, float in_div) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [Cout][ks*ks*Cin] as float
+  const int kk = ks * ks * Cin;
+  for (int i = threadIdx.x; i < Cout * kk; i += blockDim.x) wsm[i] = bf2f(w[i]);
+  __syncthreads();
+  const int cgroups = Cout >> 3;
+  const size_t total = (size_t)B * H * W * cgroups;
+  const int pad = (ks - 1) / 2;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cgroups);
+    const size_t pix = idx / cgroups;
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    const int b = (int)(pix / ((size_t)W * H));
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bf2f(bias[cg * 8 + e]) : 0.f;
+    for (int kh = 0; kh < ks; ++kh) {
+      const int iy = yh + kh - pad;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kw = 0; kw < ks; ++kw) {
+        const int ix = xw + kw - pad;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        for (int c = 0; c < Cin; ++c) {
+          const size_t off = in_nchw ? (((size_t)b * Cin + c) * H + iy) * W + ix : (((size_t)b * H + iy) * W + ix) * Cin + c;
+          float xv = bf2f(x[off]);
+          if (in_div != 1.0f) xv = bf2f(f2bf(__fdiv_rn(xv, in_div)));  // e.g. latents / vae.config.scaling_factor
+          const float* wp = wsm + (size_t)(cg * 8) * kk + (kh * ks + kw) * Cin + c;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += xv * wp[(size_t)e * kk];
+        }
+      }
+    }
+    *(uint4*)(y + pix * Cout + cg * 8) = pack8(acc);
+  }
+}
+
+// Thin-output conv 3x3 / pad 1: Cout <= 16, input NHWC [B][H][W][Cin] (Cin % 8 == 0), output NCHW (bf16 or fp32).
+// Thread = one output pixel, all Cout channels; weights [Cout][3][3][Cin] staged in LDS as bf16.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_thin_out_kernel(const uint16_t* __restrict__ x,
+                                                            const uint16_t* __restrict__ w,
+                                                            const uint16_t* __restrict__ bias, void* __restrict__ y,
+                                                            int B, int H, int W, int Cin, int out_f32) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t wsh[];  // [COUT][9*Cin]
+  const int kk = 9 * Cin;
+  for (int i = threadIdx.x * 8; i < COUT * kk; i += blockDim.x * 8) *(uint4*)(wsh + i) = *(const uint4*)(w + i);
+  __syncthreads();
+  const size_t total = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    const int b = (int)(pix / ((size_t)W * H));
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = bias ? bf2f(bias[o]) : 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = yh + kh - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = xw + kw - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const uint16_t* xp = x + (((size_t)b * H + iy) * W + ix) * Cin;
+        const uint16_t* wp = wsh + (kh * 3 + kw) * Cin;
+        for (int c = 0; c < Cin; c += 8) {
+          float xf[8];
+          unpack8(*(const uint4*)(xp + c), xf);
+#pragma unroll
+          for (int o = 0; o < COUT; ++o) {
+            float wf[8];
+            unpack8(*(const uint4*)(wp + (size_t)o * kk + c), wf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o] += xf[e] * wf[e];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      const size_t off = (((size_t)b * COUT + o) * H + yh) * W + xw;
+      if (out_f32) ((float*)y)[off] = acc[o];
+      else ((uint16_t*)y)[off] = f2bf(acc[o]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int da_timestep_embedding(const float* t, const float* table, const int* step_idx, void* out, int B,
+                                     int dim, int flip_sin_to_cos, float shift, float scale, float max_period,
+                                     int out_f32, void* stream) {
+  if ((!t && !table) || !out || B <= 0 || dim <= 0 || (dim & 1)) return DA_ERR_INVALID;
+  if (table && !step_idx) return DA_ERR_INVALID;
+  const int total = B * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, table,
+                     step_idx, out, B, dim, flip_sin_to_cos, shift, scale, max_period, out_f32);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_linear_small_m_bf16(const void* x, const void* W, const void* bias, const void* res, void* out, int M,
+                                      int N, int K, int ldx, int ldo, int ldr, int act_in, int act_out, void* stream) {
+  if (!x || !W || !out || M <= 0 || M > 8 || N <= 0 || K <= 0) return DA_ERR_INVALID;
+  if ((K & 7) || (ldx & 7)) return DA_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((N + 3) / 4), block(256);
+  if (M <= 2)
+    hipLaunchKernelGGL(linear_small_m_kernel<2>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)W,
+                       (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)out, M, N, K, ldx, ldo, ldr, act_in,
+                       act_out);
+  else
+    hipLaunchKernelGGL(linear_small_m_kernel<8>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)W,
+                       (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)out, M, N, K, ldx, ldo, ldr, act_in,
+                       act_out);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_conv_thin_in_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W,
+                                    int Cin, int Cout, int ksize, int in_nchw, float in_div, void* stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return DA_ERR_INVALID;
+  if (Cin <= 0 || Cin > 16 || Cout <= 0 || (Cout & 7) || (ksize != 1 && ksize != 3)) return DA_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)Cout * ksize * ksize * Cin * sizeof(float);
+  if (lds > 150 * 1024) return DA_ERR_UNSUPPORTED;
+  if (in_div == 0.f) in_div = 1.f;
+  auto kern = conv_thin_in_kernel;
+  static size_t lds_enabled = 48 * 1024;  // raise the dynamic-LDS cap once (not during graph capture)
+  if (lds > lds_enabled) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      return DA_ERR_LAUNCH;
+    lds_enabled = 150 * 1024;
+  }
+  size_t total = (size_t)B * H * W * (Cout / 8);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x,
+                     (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)y, B, H, W, Cin, Cout, ksize, in_nchw,
+                     in_div);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_conv_thin_out_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W,
+                                     int Cin, int Cout, int out_f32, void* stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return DA_ERR_INVALID;
+  if (Cin <= 0 || (Cin & 7) || Cout <= 0) return DA_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)Cout * 9 * Cin * sizeof(uint16_t);
+  if (lds > 150 * 1024) return DA_ERR_UNSUPPORTED;
+  size_t total = (size_t)B * H * W;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t s = (hipStream_t)stream;
+#define DA_CO(N)                                                                                                      \
+  do {                                                                                                                \
+    auto kern = conv_thin_out_kernel<N>;                                                                              \
+    static size_t lds_enabled = 48 * 1024;                                                                            \
+    if (lds > lds_enabled) {                                                                                          \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=           \
+          hipSuccess)                                                                                                 \
+        return DA_ERR_LAUNCH;                                                                                         \
+      lds_enabled = 150 * 1024;                                                                                       \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, (const uint16_t*)x, (const uint16_t*)w,       \
+                       (const uint16_t*)bias, y, B, H, W, Cin, out_f32);                                              \
+  } while (0)
+  switch (Cout) {
+    case 3: DA_CO(3); break;
+    case 4: DA_CO(4); break;
+    case 8: DA_CO(8); break;
+    case 16: DA_CO(16); break;
+    default: return DA_ERR_UNSUPPORTED;
+  }
+#undef DA_CO
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}

@@ -1,0 +1,329 @@
+// Normalisation kernels for gfx950 (MI355X): GroupNorm(+SiLU) on channels-last images, LayerNorm on token rows,
+// row softmax.  All are HBM-bound: 16-byte (8 x bf16) accesses per lane, fp32 statistics, one read + one write of
+// the tensor for the apply pass and one extra read for the GroupNorm statistics pass.
+//
+// Reference call sites (diffusers src/diffusers/):
+//   nn.GroupNorm(32, C)  models/resnet.py:326,:350  models/transformers/transformer_2d.py:466
+//                        models/unets/unet_2d_condition.py:1228  models/autoencoders/vae.py:305
+//                        models/attention_processor.py:2740 ; followed by SiLU at resnet.py:327,:362 etc.
+//   nn.LayerNorm(C)      models/attention.py:986,:1030,:1056 (BasicTransformerBlock norm1/2/3)
+#include "common.cuh"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics: grid (nblk, B).  Thread t owns channel chunk cc = t % (C/8) (8 channels) and pixel lane
+// prow = t / (C/8); it walks pixels prow, prow+k, ... of the block's slab.  Per-thread channel sums go to LDS and
+// G threads fold them per group in a fixed order (deterministic), writing one (sum, sumsq) partial per block.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1,
+                                float* __restrict__ ws, int HW, int C, int G, int pix_per_blk, int krows) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [krows][C][2]
+  const int cpr = C >> 3;
+  const int t = threadIdx.x;
+  const int cc = t % cpr, prow = t / cpr;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int p0 = blk * pix_per_blk;
+  const int p1 = min(HW, p0 + pix_per_blk);
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  // channels [0, C1) come from x ([B][HW][C1]), channels [C1, C) from x2 ([B][HW][C-C1]): fused torch.cat
+  const bool second = (cc * 8 >= C1);
+  const int Cs = second ? (C - C1) : C1;
+  const uint16_t* xb = (second ? x2 + (size_t)(cc * 8 - C1) : x + (size_t)cc * 8) + (size_t)b * HW * Cs;
+  for (int pix = p0 + prow; pix < p1; pix += krows) {
+    const uint4 v = *(const uint4*)(xb + (size_t)pix * Cs);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] += f[e];
+      q[e] += f[e] * f[e];
+    }
+  }
+  float* my = sm + ((size_t)prow * C + cc * 8) * 2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    my[2 * e] = s[e];
+    my[2 * e + 1] = q[e];
+  }
+  __syncthreads();
+  if (t < G) {
+    const int cpg = C / G;
+    float ts = 0.f, tq = 0.f;
+    for (int r = 0; r < krows; ++r) {
+      const float* row = sm + ((size_t)r * C + t * cpg) * 2;
+      for (int c = 0; c < cpg; ++c) {
+        ts += row[2 * c];
+        tq += row[2 * c + 1];
+      }
+    }
+    float* o = ws + (((size_t)b * gridDim.x + blk) * G + t) * 2;
+    o[0] = ts;
+    o[1] = tq;
+  }
+}
+
+// GroupNorm apply (+ optional SiLU): y = act((x - mean_g) * rstd_g * gamma_c + beta_c)
+__global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1,
+                                const uint16_t* __restrict__ gamma,
+                                const uint16_t* __restrict__ beta, uint16_t* __restrict__ y,
+                                const float* __restrict__ ws, int nblk_stats, int HW, int C, int G, float eps, int act,
+                                int pix_per_blk, int krows) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int cpr = C >> 3;
+  const int t = threadIdx.x;
+  const int cc = t % cpr, prow = t / cpr;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  if (t < G) {
+    double ts = 0.0, tq = 0.0;
+    const float* w = ws + ((size_t)b * nblk_stats * G + t) * 2;
+    for (int i = 0; i < nblk_stats; ++i) {
+      ts += (double)w[(size_t)i * G * 2];
+      tq += (double)w[(size_t)i * G * 2 + 1];
+    }
+    const double n = (double)HW * (double)(C / G);
+    const double mean = ts / n;
+    double var = tq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[t] = (float)mean;
+    s_rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  float a[8], c[8];
+  {
+    float gf[8], bf[8];
+    unpack8(*(const uint4*)(gamma + cc * 8), gf);
+    unpack8(*(const uint4*)(beta + cc * 8), bf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (cc * 8 + e) / cpg;
+      a[e] = s_rstd[g] * gf[e];
+      c[e] = bf[e] - s_mean[g] * a[e];
+    }
+  }
+  const int p0 = blk * pix_per_blk;
+  const int p1 = min(HW, p0 + pix_per_blk);
+  const size_t base = (size_t)b * HW * C + (size_t)cc * 8;
+  const bool second = (cc * 8 >= C1);
+  const int Cs = second ? (C - C1) : C1;
+  const uint16_t* xb = (second ? x2 + (size_t)(cc * 8 - C1) : x + (size_t)cc * 8) + (size_t)b * HW * Cs;
+  for (int pix = p0 + prow; pix < p1; pix += krows) {
+    const uint4 v = *(const uint4*)(xb + (size_t)pix * Cs);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float o = f[e] * a[e] + c[e];
+      if (act) {
+        o = bf2f(f2bf(o));  // reference rounds the GroupNorm output to bf16 before SiLU
+        o = silu_f(o);
+      }
+      f[e] = o;
+    }
+    *(uint4*)(y + base + (size_t)pix * C) = pack8(f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wave per row, the row lives in registers (NCH chunks of 8 per lane).
+// Optional AdaLN modulation: y = LN(x) * (1 + scale[b]) + shift[b]  (normalization.py:157-170, :194-202, :346-351)
+// ------------------------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ x,
+                                                        const uint16_t* __restrict__ gamma,
+                                                        const uint16_t* __restrict__ beta, uint16_t* __restrict__ y,
+                                                        const uint16_t* __restrict__ mod_scale,
+                                                        const uint16_t* __restrict__ mod_shift, int mod_ld,
+                                                        int rows_per_batch, int M, int C, int ldx, int ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunks = C >> 3;
+  float v[NCH][8];
+  const uint16_t* xr = x + (size_t)row * ldx;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunks) {
+      unpack8(*(const uint4*)(xr + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  sum = wave_sum(sum);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  sq = wave_sum(sq);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+  uint16_t* yr = y + (size_t)row * ldy;
+  const int bidx = mod_scale ? row / rows_per_batch : 0;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunks) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd;
+      if (gamma) {
+        float g[8];
+        unpack8(*(const uint4*)(gamma + ch * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= g[e];
+      }
+      if (beta) {
+        float bb[8];
+        unpack8(*(const uint4*)(beta + ch * 8), bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += bb[e];
+      }
+      if (mod_scale) {
+        float sc[8], sh[8];
+        unpack8(*(const uint4*)(mod_scale + (size_t)bidx * mod_ld + ch * 8), sc);
+        unpack8(*(const uint4*)(mod_shift + (size_t)bidx * mod_ld + ch * 8), sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(o[e])) * (1.0f + sc[e]) + sh[e];
+      }
+      *(uint4*)(yr + ch * 8) = pack8(o);
+    }
+  }
+}
+
+// Row softmax: fp32 scores [M][ld] -> bf16 probabilities [M][ldo]; one block per row (N up to 2^20).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, uint16_t* __restrict__ pr,
+                                                           int N, long long ld, long long ldo) {
+  __shared__ float red[8];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const float* row = s + (size_t)blockIdx.x * ld;
+  uint16_t* orow = pr + (size_t)blockIdx.x * ldo;
+  float mx = -3.0e38f;
+  for (int i = t * 4; i < N; i += 1024) {
+    const float4 v = *(const float4*)(row + i);
+    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = t * 4; i < N; i += 1024) {
+    const float4 v = *(const float4*)(row + i);
+    sum += __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + w] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int i = t * 4; i < N; i += 1024) {
+    const float4 v = *(const float4*)(row + i);
+    uint2 pk;
+    pk.x = pack_bf2(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv);
+    pk.y = pack_bf2(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
+    *(uint2*)(orow + i) = pk;
+  }
+}
+
+struct GnPlan {
+  int threads, krows, nblk, pix_per_blk;
+};
+GnPlan gn_plan(int B, int HW, int C) {
+  GnPlan g;
+  const int cpr = C / 8;
+  int k = 256 / cpr;
+  if (k < 1) k = 1;
+  while (k > 1 && cpr * k > 512) --k;
+  g.krows = k;
+  g.threads = cpr * k;
+  int nblk = 2048 / (B > 0 ? B : 1);
+  const int max_blk = (HW + 4 * k - 1) / (4 * k);  // at least 4 pixels per thread row
+  if (nblk > max_blk) nblk = max_blk;
+  if (nblk < 1) nblk = 1;
+  if (nblk > 256) nblk = 256;
+  int ppb = (HW + nblk - 1) / nblk;
+  ppb = ((ppb + k - 1) / k) * k;
+  g.pix_per_blk = ppb;
+  g.nblk = (HW + ppb - 1) / ppb;
+  return g;
+}
+
+}  // namespace
+
+extern "C" size_t da_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return 0;
+  GnPlan g = gn_plan(B, HW, C);
+  return (size_t)B * g.nblk * G * 2 * sizeof(float);
+}
+
+extern "C" int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const void* gamma, const void* beta,
+                                      void* y, void* workspace, int B, int HW, int C, int G, float eps, int act,
+                                      void* stream) {
+  if (!x || !gamma || !beta || !y || !workspace) return DA_ERR_INVALID;
+  if (!x2) C1 = C;
+  if (C1 <= 0 || C1 > C || (C1 & 7) || (x2 == nullptr && C1 != C)) return DA_ERR_INVALID;
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7)) return DA_ERR_UNSUPPORTED;
+  if (C / 8 > 512) return DA_ERR_UNSUPPORTED;
+  GnPlan g = gn_plan(B, HW, C);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)g.krows * C * 2 * sizeof(float);
+  if (lds > 64 * 1024) return DA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(g.nblk, B), dim3(g.threads), lds, s, (const uint16_t*)x, (const uint16_t*)x2,
+                     C1, (float*)workspace, HW, C, G, g.pix_per_blk, g.krows);
+  DA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(g.nblk, B), dim3(g.threads), 0, s, (const uint16_t*)x,
+                     (const uint16_t*)x2, C1, (const uint16_t*)gamma, (const uint16_t*)beta, (uint16_t*)y, (const float*)workspace, g.nblk, HW,
+                     C, G, eps, act, g.pix_per_blk, g.krows);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, const void* mod_scale,
+                                 const void* mod_shift, int mod_ld, int rows_per_batch, int M, int C, int ldx, int ldy,
+                                 float eps, void* stream) {
+  if (!x || !y) return DA_ERR_INVALID;
+  if (M <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7)) return DA_ERR_UNSUPPORTED;
+  if ((mod_scale == nullptr) != (mod_shift == nullptr)) return DA_ERR_INVALID;
+  if (mod_scale && (rows_per_batch <= 0 || (mod_ld & 7))) return DA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = (C / 8 + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+#define DA_LN(N)                                                                                                  \
+  hipLaunchKernelGGL(layernorm_kernel<N>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)gamma,          \
+                     (const uint16_t*)beta, (uint16_t*)y, (const uint16_t*)mod_scale, (const uint16_t*)mod_shift, \
+                     mod_ld, rows_per_batch, M, C, ldx, ldy, eps)
+  if (nch <= 1) DA_LN(1);
+  else if (nch <= 2) DA_LN(2);
+  else if (nch <= 3) DA_LN(3);
+  else if (nch <= 4) DA_LN(4);
+  else if (nch <= 6) DA_LN(6);
+  else if (nch <= 8) DA_LN(8);
+  else return DA_ERR_UNSUPPORTED;
+#undef DA_LN
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_softmax_rows_f32_bf16(const void* scores, void* probs, int M, int N, long long ld, long long ldo,
+                                        void* stream) {
+  if (!scores || !probs || M <= 0 || N <= 0 || (N & 3) || (ld & 3) || (ldo & 3)) return DA_ERR_INVALID;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)scores,
+                     (uint16_t*)probs, N, ld, ldo);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}

@@ -1,0 +1,292 @@
+"""Engine-side building blocks: each class owns its weights in the packed layout the gfx950 kernels consume and mirrors
+one reference nn.Module (cited per class, paths under the reference's src/diffusers/).
+
+Weights are taken from a reference-format ``state_dict`` (same key names and tensor shapes as the reference modules'
+``state_dict()``), so checkpoints / seeded reference models load unchanged.  Activations are channels-last bf16:
+images [B][H][W][C], tokens [B*S][C].
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+bf16 = torch.bfloat16
+
+
+class Weights:
+    """Reference-format state_dict view that moves tensors to the engine device as bf16 and tracks consumption."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device):
+        self.sd = state_dict
+        self.device = torch.device(device)
+        self.used = set()
+
+    def has(self, name: str) -> bool:
+        return name in self.sd
+
+    def get(self, name: str) -> torch.Tensor:
+        if name not in self.sd:
+            raise KeyError(f"missing weight '{name}' in state_dict")
+        self.used.add(name)
+        return self.sd[name].detach().to(device=self.device, dtype=bf16).contiguous()
+
+    def opt(self, name: str) -> Optional[torch.Tensor]:
+        return self.get(name) if name in self.sd else None
+
+    def unused(self):
+        return sorted(set(self.sd.keys()) - self.used)
+
+
+class Linear:
+    """nn.Linear; weight [N][K] is already the kernel's layout."""
+
+    def __init__(self, w: Weights, prefix: str):
+        self.weight = w.get(prefix + ".weight")
+        self.bias = w.opt(prefix + ".bias")
+
+    def __call__(self, x, **kw):
+        return ops.linear(x, self.weight, self.bias, **kw)
+
+
+class Conv3x3:
+    """nn.Conv2d(k=3, pad=1) as implicit GEMM (resnet.py:340,:365; downsampling.py:145; upsampling.py:186)."""
+
+    def __init__(self, w: Weights, prefix: str):
+        self.weight = ops.pack_conv_weight(w.get(prefix + ".weight"))
+        self.bias = w.opt(prefix + ".bias")
+        self.ksize = 3
+
+    def __call__(self, x, **kw):
+        return ops.conv2d_nhwc(x, self.weight, self.bias, ksize=3, **kw)
+
+
+class Conv1x1:
+    """nn.Conv2d(k=1): the resnet shortcut (resnet.py:373) and SD1.5's proj_in/proj_out (transformer_2d.py:468,:505)."""
+
+    def __init__(self, w: Weights, prefix: str):
+        wt = w.get(prefix + ".weight")
+        self.weight = wt.reshape(wt.shape[0], -1).contiguous()
+        self.bias = w.opt(prefix + ".bias")
+
+    def __call__(self, x, x2=None, **kw):
+        if x2 is None:
+            B, H, W_, C = x.shape
+            y = ops.linear(x.view(B * H * W_, C), self.weight, self.bias, **kw)
+            return y.view(B, H, W_, -1)
+        return ops.conv2d_nhwc(x, self.weight, self.bias, ksize=1, x2=x2, **kw)
+
+
+class GroupNorm:
+    def __init__(self, w: Weights, prefix: str, groups: int, eps: float):
+        self.weight = w.get(prefix + ".weight")
+        self.bias = w.get(prefix + ".bias")
+        self.groups, self.eps = groups, eps
+
+    def __call__(self, x, silu=False, x2=None):
+        return ops.group_norm_nhwc(x, self.weight, self.bias, self.groups, self.eps, silu=silu, x2=x2)
+
+
+class LayerNorm:
+    def __init__(self, w: Weights, prefix: str, eps: float = 1e-5, affine: bool = True):
+        self.weight = w.get(prefix + ".weight") if affine else None
+        self.bias = w.get(prefix + ".bias") if affine else None
+        self.eps = eps
+
+    def __call__(self, x, **kw):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, **kw)
+
+
+class ResnetBlock2D:
+    """models/resnet.py:319-377.  GroupNorm+SiLU -> conv3x3 (+ time_emb_proj(SiLU(temb)) per batch) -> GroupNorm+SiLU
+    -> conv3x3 (+ shortcut(x) residual, / output_scale_factor).  The input may be a (x, skip) pair: the U-Net skip
+    concat (unet_2d_blocks.py:2444) is never materialised, GroupNorm and the 1x1 shortcut read both sources."""
+
+    def __init__(self, w: Weights, prefix: str, groups: int, eps: float, output_scale_factor: float = 1.0):
+        self.norm1 = GroupNorm(w, prefix + ".norm1", groups, eps)
+        self.conv1 = Conv3x3(w, prefix + ".conv1")
+        self.has_temb = w.has(prefix + ".time_emb_proj.weight")
+        if self.has_temb:
+            self.time_emb_proj = Linear(w, prefix + ".time_emb_proj")
+        self.norm2 = GroupNorm(w, prefix + ".norm2", groups, eps)
+        self.conv2 = Conv3x3(w, prefix + ".conv2")
+        self.shortcut = Conv1x1(w, prefix + ".conv_shortcut") if w.has(prefix + ".conv_shortcut.weight") else None
+        self.out_scale = 1.0 / output_scale_factor
+
+    def __call__(self, x, temb=None, skip=None):
+        # temb: [B][temb_channels] bf16 (already the raw embedding; SiLU is fused into the skinny linear)
+        h = self.norm1(x, silu=True, x2=skip)
+        tvec = None
+        if self.has_temb and temb is not None:
+            tvec = ops.linear_small_m(temb, self.time_emb_proj.weight, self.time_emb_proj.bias, act_in=L.ACT_SILU)
+        h = self.conv1(h, rowvec=tvec)
+        h = self.norm2(h, silu=True)
+        if self.shortcut is not None:
+            res = self.shortcut(x, x2=skip)
+        else:
+            if skip is not None:
+                raise ValueError("ResnetBlock2D: concat input requires a conv_shortcut")
+            res = x
+        return self.conv2(h, residual=res, out_scale=self.out_scale)
+
+
+class Downsample2D:
+    """models/downsampling.py:130-147 (use_conv=True, padding=1): conv3x3 stride 2."""
+
+    def __init__(self, w: Weights, prefix: str):
+        self.conv = Conv3x3(w, prefix + ".conv")
+
+    def __call__(self, x):
+        return self.conv(x, stride=2)
+
+
+class Upsample2D:
+    """models/upsampling.py:140-192 (use_conv=True): nearest-2x interpolate fused into the conv's gather."""
+
+    def __init__(self, w: Weights, prefix: str):
+        self.conv = Conv3x3(w, prefix + ".conv")
+
+    def __call__(self, x):
+        return self.conv(x, up=True)
+
+
+class CrossKV:
+    """Step-invariant cross-attention keys / transposed values of one attention layer (hoisted out of the loop)."""
+
+    __slots__ = ("k", "vt", "skv", "skv_alloc", "batch")
+
+    def __init__(self, k, vt, skv, skv_alloc, batch):
+        self.k, self.vt, self.skv, self.skv_alloc, self.batch = k, vt, skv, skv_alloc, batch
+
+
+class Attention:
+    """models/attention_processor.py:52-309 + AttnProcessor2_0 (:2696-2787): to_q/to_k/to_v (no bias), SDPA, to_out[0].
+    Self-attention fuses Q and K into one GEMM and produces V already transposed (out^T = W_v . X^T) for the flash
+    kernel; cross-attention K / V^T depend only on the text embeddings and come from :meth:`precompute_kv`."""
+
+    def __init__(self, w: Weights, prefix: str, heads: int, cross: bool):
+        self.heads = heads
+        self.cross = cross
+        wq = w.get(prefix + ".to_q.weight")
+        wk = w.get(prefix + ".to_k.weight")
+        wv = w.get(prefix + ".to_v.weight")
+        self.inner = wq.shape[0]
+        self.head_dim = self.inner // heads
+        if cross:
+            self.wq, self.wk, self.wv = wq, wk, wv
+        else:
+            self.wqk = torch.cat([wq, wk], dim=0).contiguous()
+            self.wv = wv
+        self.to_out = Linear(w, prefix + ".to_out.0")
+        self.scale = self.head_dim ** -0.5
+
+    def precompute_kv(self, ehs_pad: torch.Tensor, batch: int, skv: int, skv_alloc: int) -> CrossKV:
+        """ehs_pad: [batch*skv_alloc][cross_dim], zero rows beyond skv in every batch."""
+        k = ops.linear(ehs_pad, self.wk)
+        vt = ops.linear(self.wv, ehs_pad)  # [inner][batch*skv_alloc] = V^T
+        return CrossKV(k, vt, skv, skv_alloc, batch)
+
+    def __call__(self, x, batch: int, seq: int, residual, kv: Optional[CrossKV] = None):
+        """x: [batch*seq][C] (already normalised); returns to_out(attn) + residual."""
+        Hh, D = self.heads, self.head_dim
+        if self.cross:
+            q = ops.linear(x, self.wq)
+            o = ops.attention(q, kv.k, kv.vt, B=batch, H=Hh, D=D, Sq=seq, Skv=kv.skv, Skv_alloc=kv.skv_alloc,
+                              q_row_stride=self.inner, k_row_stride=self.inner,
+                              q_batch_stride=seq * self.inner, k_batch_stride=kv.skv_alloc * self.inner,
+                              vt_ld=batch * kv.skv_alloc, vt_batch_stride=kv.skv_alloc, scale=self.scale)
+        else:
+            qk = ops.linear(x, self.wqk)       # [M][2*inner]
+            vt = ops.linear(self.wv, x)        # [inner][M]
+            o = ops.attention(qk, qk[:, self.inner:], vt, B=batch, H=Hh, D=D, Sq=seq, Skv=seq, Skv_alloc=seq,
+                              q_row_stride=2 * self.inner, k_row_stride=2 * self.inner,
+                              q_batch_stride=seq * 2 * self.inner, k_batch_stride=seq * 2 * self.inner,
+                              vt_ld=batch * seq, vt_batch_stride=seq, scale=self.scale)
+        return self.to_out(o, residual=residual)
+
+
+class FeedForwardGEGLU:
+    """models/attention.py:1682-1742 with activation_fn="geglu" (activations.py:93-124): GEGLU fused into the up
+    projection's epilogue, bias + residual fused into the down projection's."""
+
+    def __init__(self, w: Weights, prefix: str):
+        wp, bp = ops.pack_geglu(w.get(prefix + ".net.0.proj.weight"), w.opt(prefix + ".net.0.proj.bias"))
+        self.w1, self.b1 = wp, bp
+        self.out = Linear(w, prefix + ".net.2")
+
+    def __call__(self, x, residual):
+        h = ops.linear(x, self.w1, self.b1, act=L.ACT_GEGLU)
+        return self.out(h, residual=residual)
+
+
+class BasicTransformerBlock:
+    """models/attention.py:960-1080 (norm_type="layer_norm"): x += attn1(LN1 x); x += attn2(LN2 x, ctx); x += FF(LN3 x)."""
+
+    def __init__(self, w: Weights, prefix: str, heads: int):
+        self.norm1 = LayerNorm(w, prefix + ".norm1")
+        self.attn1 = Attention(w, prefix + ".attn1", heads, cross=False)
+        self.norm2 = LayerNorm(w, prefix + ".norm2")
+        self.attn2 = Attention(w, prefix + ".attn2", heads, cross=True)
+        self.norm3 = LayerNorm(w, prefix + ".norm3")
+        self.ff = FeedForwardGEGLU(w, prefix + ".ff")
+
+    def __call__(self, x, batch, seq, kv: CrossKV):
+        x = self.attn1(self.norm1(x), batch, seq, residual=x)
+        x = self.attn2(self.norm2(x), batch, seq, residual=x, kv=kv)
+        x = self.ff(self.norm3(x), residual=x)
+        return x
+
+
+class Transformer2DModel:
+    """models/transformers/transformer_2d.py:324-512 (continuous input).  In channels-last the reference's
+    NCHW<->(B,HW,C) permutes vanish: GroupNorm -> proj_in -> blocks -> proj_out (+ residual fused)."""
+
+    def __init__(self, w: Weights, prefix: str, heads: int, layers: int, groups: int):
+        self.norm = GroupNorm(w, prefix + ".norm", groups, 1e-6)
+        pw = w.get(prefix + ".proj_in.weight")
+        self.proj_in_w = pw.reshape(pw.shape[0], -1).contiguous()  # Linear (SDXL) or 1x1 conv (SD1.5): same GEMM
+        self.proj_in_b = w.opt(prefix + ".proj_in.bias")
+        self.blocks = [BasicTransformerBlock(w, f"{prefix}.transformer_blocks.{i}", heads) for i in range(layers)]
+        pw = w.get(prefix + ".proj_out.weight")
+        self.proj_out_w = pw.reshape(pw.shape[0], -1).contiguous()
+        self.proj_out_b = w.opt(prefix + ".proj_out.bias")
+
+    def precompute_kv(self, ehs_pad, batch, skv, skv_alloc):
+        return [blk.attn2.precompute_kv(ehs_pad, batch, skv, skv_alloc) for blk in self.blocks]
+
+    def __call__(self, x, kvs):
+        B, H, W_, C = x.shape
+        res = x.view(B * H * W_, C)
+        h = self.norm(x).view(B * H * W_, C)
+        h = ops.linear(h, self.proj_in_w, self.proj_in_b)
+        for blk, kv in zip(self.blocks, kvs):
+            h = blk(h, B, H * W_, kv)
+        h = ops.linear(h, self.proj_out_w, self.proj_out_b, residual=res)
+        return h.view(B, H, W_, C)
+
+
+class TimestepEmbedding:
+    """models/embeddings.py:1262-1308: Linear -> SiLU -> Linear on [B][dim] (skinny-M kernels)."""
+
+    def __init__(self, w: Weights, prefix: str):
+        self.l1 = Linear(w, prefix + ".linear_1")
+        self.l2 = Linear(w, prefix + ".linear_2")
+
+    def __call__(self, x, residual=None):
+        h = ops.linear_small_m(x, self.l1.weight, self.l1.bias, act_out=L.ACT_SILU)
+        return ops.linear_small_m(h, self.l2.weight, self.l2.bias, residual=residual)
+
+
+def pad_encoder_states(ehs: torch.Tensor):
+    """[B][S][C] -> ([B*S_alloc][C] zero padded, S, S_alloc) with S_alloc a multiple of 16 (16-byte aligned V^T rows)."""
+    B, S, C = ehs.shape
+    s_alloc = ((S + 15) // 16) * 16
+    if s_alloc == S:
+        return ehs.reshape(B * S, C).contiguous(), S, s_alloc
+    pad = torch.zeros((B, s_alloc, C), device=ehs.device, dtype=ehs.dtype)
+    pad[:, :S].copy_(ehs)
+    return pad.view(B * s_alloc, C), S, s_alloc

@@ -1,0 +1,347 @@
+"""Thin torch-tensor front end of the C ABI: pointer extraction, shape checks, output allocation.
+
+torch is used here only for device memory and the current HIP stream; every arithmetic op below is a hand-written
+gfx950 kernel in ``csrc/``.  Nothing in this module has a CPU or PyTorch fallback: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+bf16 = torch.bfloat16
+
+# Global knobs (tests / bench flip these to A/B the staging paths).
+DEFAULT_STAGING = L.STAGE_LDS_DIRECT
+DEFAULT_TILE = L.TILE_AUTO
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, name: str, dtype=bf16) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: diffusers_amd ops need a HIP device tensor (got {t.device}); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _rows2d(t: torch.Tensor, name: str) -> int:
+    """Leading dimension (elements) of a 2-D row-major view whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D tensor with contiguous last dim, got shape {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GEMM / conv
+# ----------------------------------------------------------------------------------------------------------------------
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
+           residual: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
+           alpha: float = 1.0, out_scale: float = 1.0, out: Optional[torch.Tensor] = None, out_f32: bool = False,
+           tile: Optional[int] = None, staging: Optional[int] = None) -> torch.Tensor:
+    """out[M][N] = epilogue(alpha * x[M][K] @ w[N][K]^T).  For act == GEGLU, w/bias are in the packed layout of
+    :func:`pack_geglu` and the output has N/2 columns."""
+    _req(x, "x"), _req(w, "w")
+    M, K = x.shape
+    N, Kw = w.shape
+    if K != Kw:
+        raise ValueError(f"linear: K mismatch {K} vs {Kw}")
+    n_out = N // 2 if act == L.ACT_GEGLU else N
+    if M <= 8 and act in (L.ACT_NONE, L.ACT_SILU, L.ACT_GELU_TANH) and rowvec is None and not out_f32 \
+            and alpha == 1.0 and out_scale == 1.0:
+        return linear_small_m(x, w, bias, act_out=act, residual=residual, out=out)
+    if out is None:
+        out = torch.empty((M, n_out), device=x.device, dtype=torch.float32 if out_f32 else bf16)
+    p = L.GemmParams()
+    p.A, p.A2, p.W, p.C = x.data_ptr(), None, w.data_ptr(), out.data_ptr()
+    p.bias, p.rowvec, p.residual = _ptr(bias), _ptr(rowvec), _ptr(residual)
+    p.M, p.N, p.K = M, N, K
+    p.lda, p.ldw, p.ldc = _rows2d(x, "x"), _rows2d(w, "w"), _rows2d(out, "out")
+    p.ldr = _rows2d(residual, "residual") if residual is not None else 0
+    p.ld_rowvec = _rows2d(rowvec, "rowvec") if rowvec is not None else 0
+    p.rows_per_batch = rows_per_batch
+    p.alpha, p.out_scale, p.act, p.out_f32, p.conv = alpha, out_scale, act, int(out_f32), 0
+    p.tile = DEFAULT_TILE if tile is None else tile
+    p.staging = DEFAULT_STAGING if staging is None else staging
+    L.check(L.load().da_gemm_bf16(C.byref(p), _stream()), "da_gemm_bf16(linear)")
+    return out
+
+
+def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, ksize: int = 3,
+                x2: Optional[torch.Tensor] = None, stride: int = 1, up: bool = False, pad: Optional[int] = None,
+                rowvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                out_scale: float = 1.0, act: int = L.ACT_NONE, tile: Optional[int] = None,
+                staging: Optional[int] = None) -> torch.Tensor:
+    """Implicit-GEMM Conv2d on channels-last tensors.  x: [B][H][W][C1] (x2: [B][H][W][C2] = fused channel concat),
+    w: [Cout][k][k][C1+C2] flattened to [Cout][k*k*(C1+C2)].  up=True fuses a nearest 2x upsample of the input.
+    rowvec [B][Cout] is added per batch (time embedding); residual is [B][Hout][Wout][Cout]."""
+    _req(x, "x"), _req(w, "w")
+    B, H, W_, C1 = x.shape
+    C2 = 0
+    if x2 is not None:
+        _req(x2, "x2")
+        if x2.shape[:3] != x.shape[:3]:
+            raise ValueError("conv2d_nhwc: x2 spatial shape mismatch")
+        C2 = x2.shape[3]
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise ValueError("conv2d_nhwc: inputs must be contiguous NHWC")
+    Cout, K = w.shape
+    if K != ksize * ksize * (C1 + C2):
+        raise ValueError(f"conv2d_nhwc: weight K={K} != {ksize}*{ksize}*{C1 + C2}")
+    if pad is None:
+        pad = (ksize - 1) // 2
+    Hv, Wv = (2 * H, 2 * W_) if up else (H, W_)
+    Hout = (Hv + 2 * pad - ksize) // stride + 1
+    Wout = (Wv + 2 * pad - ksize) // stride + 1
+    out = torch.empty((B, Hout, Wout, Cout), device=x.device, dtype=bf16)
+    p = L.GemmParams()
+    p.A, p.A2, p.W, p.C = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
+    p.bias, p.rowvec, p.residual = _ptr(bias), _ptr(rowvec), _ptr(residual)
+    p.M, p.N, p.K = B * Hout * Wout, Cout, K
+    p.lda, p.ldw, p.ldc = 0, K, Cout
+    if residual is not None:
+        _req(residual, "residual")
+        if tuple(residual.shape) != (B, Hout, Wout, Cout) or not residual.is_contiguous():
+            raise ValueError("conv2d_nhwc: residual must be contiguous [B][Hout][Wout][Cout]")
+        p.ldr = Cout
+    if rowvec is not None:
+        _req(rowvec, "rowvec")
+        p.ld_rowvec = _rows2d(rowvec, "rowvec")
+        p.rows_per_batch = Hout * Wout
+    p.alpha, p.out_scale, p.act, p.out_f32, p.conv = 1.0, out_scale, act, 0, ksize
+    p.Hin, p.Win, p.C1, p.C2, p.Hout, p.Wout = H, W_, C1, C2, Hout, Wout
+    p.stride, p.up, p.pad = stride, int(up), pad
+    p.tile = DEFAULT_TILE if tile is None else tile
+    p.staging = DEFAULT_STAGING if staging is None else staging
+    L.check(L.load().da_gemm_bf16(C.byref(p), _stream()), "da_gemm_bf16(conv)")
+    return out
+
+
+def linear_small_m(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act_in: int = L.ACT_NONE,
+                   act_out: int = L.ACT_NONE, residual: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, "x"), _req(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K or not w.is_contiguous():
+        raise ValueError("linear_small_m: weight must be contiguous [N][K]")
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=bf16)
+    L.check(L.load().da_linear_small_m_bf16(
+        x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, _rows2d(x, "x"),
+        _rows2d(out, "out"), _rows2d(residual, "residual") if residual is not None else 0, act_in, act_out, _stream()),
+        "da_linear_small_m_bf16")
+    return out
+
+
+def pack_geglu(w: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Reorder GEGLU.proj rows ([value(4d) ; gate(4d)], activations.py:104) into 64-row groups [32 value | 32 gate] so
+    one wave holds matching value/gate columns in the same lanes."""
+    n2 = w.shape[0]
+    n = n2 // 2
+    if n % 64:
+        raise ValueError("pack_geglu: inner dim must be a multiple of 64")
+    idx = torch.arange(n, device=w.device).view(n // 32, 32)
+    order = torch.cat([idx, idx + n], dim=1).reshape(-1)
+    wp = w.index_select(0, order).contiguous()
+    bp = bias.index_select(0, order).contiguous() if bias is not None else None
+    return wp, bp
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout][Cin][kh][kw] (torch) -> [Cout][kh*kw*Cin] (K index = tap * Cin + c)."""
+    co, ci, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------------------------------
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: int, D: int, Sq: int, Skv: int,
+              Skv_alloc: int, q_row_stride: int, k_row_stride: int, q_batch_stride: int, k_batch_stride: int,
+              vt_ld: int, vt_batch_stride: int, scale: Optional[float] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Flash attention over strided views; returns out [B*Sq][H*D]."""
+    _req(q, "q"), _req(k, "k"), _req(vt, "vt")
+    if out is None:
+        out = torch.empty((B * Sq, H * D), device=q.device, dtype=bf16)
+    p = L.AttentionParams()
+    p.q, p.k, p.vt, p.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    p.B, p.H, p.Sq, p.Skv, p.Skv_alloc, p.D = B, H, Sq, Skv, Skv_alloc, D
+    p.q_batch_stride, p.k_batch_stride, p.vt_batch_stride = q_batch_stride, k_batch_stride, vt_batch_stride
+    p.o_batch_stride = Sq * H * D
+    p.q_row_stride, p.k_row_stride, p.vt_ld, p.o_row_stride = q_row_stride, k_row_stride, vt_ld, H * D
+    p.scale = (D ** -0.5) if scale is None else scale
+    L.check(L.load().da_attention_bf16(C.byref(p), _stream()), "da_attention_bf16")
+    return out
+
+
+def softmax_rows(scores: torch.Tensor) -> torch.Tensor:
+    _req(scores, "scores", torch.float32)
+    M, N = scores.shape
+    out = torch.empty((M, N), device=scores.device, dtype=bf16)
+    L.check(L.load().da_softmax_rows_f32_bf16(scores.data_ptr(), out.data_ptr(), M, N, scores.stride(0), N, _stream()),
+            "da_softmax_rows_f32_bf16")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# norms
+# ----------------------------------------------------------------------------------------------------------------------
+_gn_ws = {}
+
+
+def group_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                    silu: bool = False, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm (+SiLU) on [B][H][W][C] or [B][HW][C]; x2 = second channel-concat source."""
+    _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise ValueError("group_norm_nhwc: contiguous channels-last input required")
+    B = x.shape[0]
+    C1 = x.shape[-1]
+    Ctot = C1 + (x2.shape[-1] if x2 is not None else 0)
+    HW = x.numel() // (B * C1)
+    lib = L.load()
+    nbytes = lib.da_groupnorm_workspace_bytes(B, HW, Ctot, groups)
+    ws = torch.empty((max(nbytes, 4) // 4,), device=x.device, dtype=torch.float32)
+    y = torch.empty(tuple(x.shape[:-1]) + (Ctot,), device=x.device, dtype=bf16)
+    L.check(lib.da_groupnorm_nhwc_bf16(x.data_ptr(), _ptr(x2), C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                       ws.data_ptr(), B, HW, Ctot, groups, eps, L.ACT_SILU if silu else L.ACT_NONE,
+                                       _stream()), "da_groupnorm_nhwc_bf16")
+    return y
+
+
+def layer_norm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float, *,
+               mod_scale: Optional[torch.Tensor] = None, mod_shift: Optional[torch.Tensor] = None,
+               rows_per_batch: int = 0) -> torch.Tensor:
+    _req(x, "x")
+    M, Cc = x.shape
+    y = torch.empty((M, Cc), device=x.device, dtype=bf16)
+    mod_ld = _rows2d(mod_scale, "mod_scale") if mod_scale is not None else 0
+    L.check(L.load().da_layernorm_bf16(x.data_ptr(), _ptr(gamma), _ptr(beta), y.data_ptr(), _ptr(mod_scale),
+                                       _ptr(mod_shift), mod_ld, rows_per_batch, M, Cc, _rows2d(x, "x"), Cc, eps,
+                                       _stream()), "da_layernorm_bf16")
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sampler
+# ----------------------------------------------------------------------------------------------------------------------
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == bf16:
+        return L.DTYPE_BF16
+    if t.dtype == torch.float32:
+        return L.DTYPE_F32
+    raise TypeError(f"sampler kernels support bf16 / fp32 latents, got {t.dtype}")
+
+
+def euler_scale_model_input(x: torch.Tensor, table: torch.Tensor, step_idx: torch.Tensor, rep: int = 1) -> torch.Tensor:
+    _req(x, "x", None)
+    out = torch.empty((rep * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+    L.check(L.load().da_euler_scale_model_input(x.data_ptr(), out.data_ptr(), table.data_ptr(), step_idx.data_ptr(),
+                                                rep, x.numel(), _dt(x), _stream()), "da_euler_scale_model_input")
+    return out
+
+
+def euler_step(eps: torch.Tensor, x: torch.Tensor, table: torch.Tensor, step_idx: torch.Tensor, *, cfg: bool,
+               guidance: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, "x", None)
+    if out is None:
+        out = torch.empty_like(x)
+    if eps.numel() != x.numel() * (2 if cfg else 1) or eps.dtype != x.dtype:
+        raise ValueError("euler_step: eps must be [2 x latents] with cfg, same dtype")
+    L.check(L.load().da_euler_step(eps.data_ptr(), x.data_ptr(), out.data_ptr(), table.data_ptr(), step_idx.data_ptr(),
+                                   int(cfg), guidance, x.numel(), _dt(x), _stream()), "da_euler_step")
+    return out
+
+
+def x0_linear_step(eps: torch.Tensor, x: torch.Tensor, noise: Optional[torch.Tensor], table: torch.Tensor,
+                   step_idx: torch.Tensor, *, cfg: bool, guidance: float,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, "x", None)
+    if out is None:
+        out = torch.empty_like(x)
+    if eps.numel() != x.numel() * (2 if cfg else 1) or eps.dtype != x.dtype:
+        raise ValueError("x0_linear_step: eps must be [2 x latents] with cfg, same dtype")
+    L.check(L.load().da_x0_linear_step(eps.data_ptr(), x.data_ptr(), _ptr(noise), out.data_ptr(), table.data_ptr(),
+                                       step_idx.data_ptr(), int(cfg), guidance, x.numel(), _dt(x), _stream()),
+            "da_x0_linear_step")
+    return out
+
+
+def flowmatch_step(v: torch.Tensor, x: torch.Tensor, table: torch.Tensor, step_idx: torch.Tensor, *, cfg: bool = False,
+                   guidance: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, "x", None)
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.load().da_flowmatch_step(v.data_ptr(), x.data_ptr(), out.data_ptr(), table.data_ptr(),
+                                       step_idx.data_ptr(), int(cfg), guidance, x.numel(), _dt(x), _stream()),
+            "da_flowmatch_step")
+    return out
+
+
+def mul_scalar(x: torch.Tensor, s: float) -> torch.Tensor:
+    _req(x, "x", None)
+    out = torch.empty_like(x)
+    L.check(L.load().da_mul_scalar(x.data_ptr(), out.data_ptr(), float(s), x.numel(), _dt(x), _stream()),
+            "da_mul_scalar")
+    return out
+
+
+def advance_step(step_idx: torch.Tensor) -> None:
+    L.check(L.load().da_advance_step(step_idx.data_ptr(), _stream()), "da_advance_step")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# misc
+# ----------------------------------------------------------------------------------------------------------------------
+def timestep_embedding(t: Optional[torch.Tensor], dim: int, *, batch: int, flip_sin_to_cos: bool, shift: float,
+                       scale: float = 1.0, max_period: float = 10000.0, table: Optional[torch.Tensor] = None,
+                       step_idx: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    """t: float32 device tensor [batch] (or table/step_idx: timestep read from column 7 of the sampler table)."""
+    dev = t.device if t is not None else table.device
+    out = torch.empty((batch, dim), device=dev, dtype=torch.float32 if out_f32 else bf16)
+    if t is not None:
+        _req(t, "t", torch.float32)
+    L.check(L.load().da_timestep_embedding(_ptr(t), _ptr(table), _ptr(step_idx), out.data_ptr(), batch, dim,
+                                           int(flip_sin_to_cos), shift, scale, max_period, int(out_f32), _stream()),
+            "da_timestep_embedding")
+    return out
+
+
+def conv_thin_in(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ksize: int, in_nchw: bool,
+                 in_div: float = 1.0) -> torch.Tensor:
+    """Conv2d with Cin <= 16.  x: NCHW [B][Cin][H][W] or NHWC; w: [Cout][k*k*Cin]; returns NHWC [B][H][W][Cout]."""
+    _req(x, "x"), _req(w, "w")
+    if not x.is_contiguous():
+        raise ValueError("conv_thin_in: contiguous input required")
+    if in_nchw:
+        B, Cin, H, W_ = x.shape
+    else:
+        B, H, W_, Cin = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((B, H, W_, Cout), device=x.device, dtype=bf16)
+    L.check(L.load().da_conv_thin_in_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, H, W_, Cin, Cout,
+                                          ksize, int(in_nchw), in_div, _stream()), "da_conv_thin_in_bf16")
+    return y
+
+
+def conv_thin_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, out_f32: bool = False) -> torch.Tensor:
+    """Conv2d 3x3 with small Cout.  x: NHWC; w: [Cout][9*Cin]; returns NCHW [B][Cout][H][W]."""
+    _req(x, "x"), _req(w, "w")
+    B, H, W_, Cin = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((B, Cout, H, W_), device=x.device, dtype=torch.float32 if out_f32 else bf16)
+    L.check(L.load().da_conv_thin_out_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, H, W_, Cin, Cout,
+                                           int(out_f32), _stream()), "da_conv_thin_out_bf16")
+    return y

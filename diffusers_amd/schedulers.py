@@ -1,0 +1,561 @@
+"""Schedulers with the reference's SchedulerMixin surface (set_timesteps / scale_model_input / step / timesteps / sigmas /
+init_noise_sigma / order / config) whose per-step tensor update is ONE fused HIP kernel (csrc/sampler.hip).
+
+Host side (schedule construction) is numpy / torch-CPU scalar math written to follow the reference formulas exactly:
+  EulerDiscreteScheduler          schedulers/scheduling_euler_discrete.py:203-276, :350-481, :326-348, :685-800
+  DDIMScheduler                   schedulers/scheduling_ddim.py:212-236, :334-382, :384-514
+  DDPMScheduler                   schedulers/scheduling_ddpm.py:348-416, :461-567
+  FlowMatchEulerDiscreteScheduler schedulers/scheduling_flow_match_euler_discrete.py:283-382, :423-523
+Per-step scalars are evaluated once with fp32 torch scalar ops (same ops, same order as the reference evaluates them
+every step) and stored in a device table of 8 floats per step; a device-resident step counter selects the row, so a
+denoising step is HIP-graph replayable.  ``step_cfg`` additionally fuses the classifier-free-guidance combine.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .unet_2d_condition import FrozenConfig
+
+
+@dataclass
+class SchedulerOutput:
+    prev_sample: torch.Tensor
+    pred_original_sample: Optional[torch.Tensor] = None
+
+
+def _betas(beta_schedule, beta_start, beta_end, n, trained_betas=None):
+    if trained_betas is not None:
+        return torch.tensor(trained_betas, dtype=torch.float32)
+    if beta_schedule == "linear":
+        return torch.linspace(beta_start, beta_end, n, dtype=torch.float32)
+    if beta_schedule == "scaled_linear":
+        return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    raise NotImplementedError(f"{beta_schedule} is not implemented")
+
+
+class _SchedulerBase:
+    order = 1
+    _defaults: dict = {}
+
+    def __init__(self, **kwargs):
+        unknown = set(kwargs) - set(self._defaults)
+        if unknown:
+            raise TypeError(f"{type(self).__name__}: unexpected config keys {sorted(unknown)}")
+        cfg = dict(self._defaults)
+        cfg.update(kwargs)
+        self.config = FrozenConfig(cfg)
+        self._step_index = None
+        self._begin_index = None
+        self._table = None          # device [n_steps][8] fp32
+        self._step_dev = None       # device int32 scalar
+        self._device = None
+        self.num_inference_steps = None
+
+    # -- reference-compatible index bookkeeping (scheduling_euler_discrete.py:293-324, :640-683) --
+    @property
+    def step_index(self):
+        return self._step_index
+
+    @property
+    def begin_index(self):
+        return self._begin_index
+
+    def set_begin_index(self, begin_index: int = 0):
+        self._begin_index = begin_index
+
+    def index_for_timestep(self, timestep, schedule_timesteps=None):
+        ts = self._timesteps_host if schedule_timesteps is None else np.asarray(schedule_timesteps.cpu())
+        tv = float(timestep) if not torch.is_tensor(timestep) else float(timestep.item())
+        idx = np.nonzero(ts == np.float32(tv))[0] if ts.dtype == np.float32 else np.nonzero(ts == tv)[0]
+        if len(idx) == 0:
+            raise ValueError(f"timestep {tv} is not in the schedule")
+        return int(idx[1] if len(idx) > 1 else idx[0])
+
+    def _init_step_index(self, timestep):
+        self._step_index = self.index_for_timestep(timestep) if self._begin_index is None else self._begin_index
+        self._sync_device_step()
+
+    def _sync_device_step(self):
+        if self._step_dev is not None:
+            self._step_dev.fill_(int(self._step_index))
+
+    def _upload(self, rows: np.ndarray, device):
+        self._device = torch.device(device) if device is not None else torch.device("cuda")
+        self._table = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(self._device)
+        self._step_dev = torch.zeros((), dtype=torch.int32, device=self._device)
+
+    def _advance(self):
+        self._step_index += 1
+        ops.advance_step(self._step_dev)
+
+    # engine extension: handles for graph capture
+    @property
+    def device_table(self):
+        return self._table
+
+    @property
+    def device_step(self):
+        return self._step_dev
+
+    def reset(self, index: int = 0):
+        """Rewind to step ``index`` (host mirror + device counter)."""
+        self._step_index = index
+        self._sync_device_step()
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class EulerDiscreteScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                     trained_betas=None, prediction_type="epsilon", interpolation_type="linear",
+                     use_karras_sigmas=False, use_exponential_sigmas=False, use_beta_sigmas=False, sigma_min=None,
+                     sigma_max=None, timestep_spacing="linspace", timestep_type="discrete", steps_offset=0,
+                     rescale_betas_zero_snr=False, final_sigmas_type="zero")
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        c = self.config
+        if c.use_karras_sigmas or c.use_exponential_sigmas or c.use_beta_sigmas or c.rescale_betas_zero_snr:
+            raise NotImplementedError("EulerDiscreteScheduler: karras/exponential/beta sigmas are not on the hot path")
+        if c.prediction_type != "epsilon" or c.timestep_type != "discrete" or c.interpolation_type != "linear":
+            raise NotImplementedError("EulerDiscreteScheduler: only epsilon / discrete / linear interpolation")
+        self.betas = _betas(c.beta_schedule, c.beta_start, c.beta_end, c.num_train_timesteps, c.trained_betas)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).flip(0)
+        ts = np.linspace(0, c.num_train_timesteps - 1, c.num_train_timesteps, dtype=float)[::-1].copy()
+        self.timesteps = torch.from_numpy(ts).to(dtype=torch.float32)
+        self._timesteps_host = self.timesteps.numpy()
+        self.sigmas = torch.cat([sig, torch.zeros(1)])
+        self.is_scale_input_called = False
+
+    @property
+    def init_noise_sigma(self):
+        max_sigma = self.sigmas.max()
+        if self.config.timestep_spacing in ("linspace", "trailing"):
+            return max_sigma
+        return (max_sigma ** 2 + 1) ** 0.5
+
+    def set_timesteps(self, num_inference_steps: int = None, device=None, timesteps=None, sigmas=None):
+        c = self.config
+        if timesteps is not None or sigmas is not None:
+            raise NotImplementedError("custom timesteps / sigmas are not supported by the HIP EulerDiscreteScheduler")
+        if num_inference_steps is None:
+            raise ValueError("Must pass exactly one of `num_inference_steps` or `timesteps` or `sigmas.")
+        self.num_inference_steps = num_inference_steps
+        n_train = c.num_train_timesteps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, n_train - 1, num_inference_steps, dtype=np.float32)[::-1].copy()
+        elif c.timestep_spacing == "leading":
+            ratio = n_train // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.float32)
+            ts += c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ratio = n_train / num_inference_steps
+            ts = (np.arange(n_train, 0, -ratio)).round().copy().astype(np.float32)
+            ts -= 1
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported. Please make sure to choose one of 'linspace', "
+                             "'leading' or 'trailing'.")
+        base = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sig = np.interp(ts, np.arange(0, len(base)), base)
+        if c.final_sigmas_type == "sigma_min":
+            last = float(((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5)
+        elif c.final_sigmas_type == "zero":
+            last = 0
+        else:
+            raise ValueError(f"`final_sigmas_type` must be one of 'zero', or 'sigma_min', but got {c.final_sigmas_type}")
+        sig = np.concatenate([sig, [last]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sig).to(dtype=torch.float32)  # kept on CPU like the reference
+        self.timesteps = torch.from_numpy(ts.astype(np.float32)).to(device=device)
+        self._timesteps_host = ts.astype(np.float32)
+        self._step_index = None
+        self._begin_index = None
+        rows = np.zeros((num_inference_steps, 8), dtype=np.float32)
+        for i in range(num_inference_steps):
+            s, s_next = self.sigmas[i], self.sigmas[i + 1]
+            rows[i, 0] = float(s)
+            rows[i, 1] = float(s_next)
+            rows[i, 2] = float(s_next - s)                 # dt, fp32 torch scalar arithmetic as the reference
+            rows[i, 3] = float((s ** 2 + 1) ** 0.5)        # scale_model_input denominator
+            rows[i, 7] = float(ts[i])
+        self._upload(rows, device)
+
+    def scale_model_input(self, sample, timestep=None, rep: int = 1):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        self.is_scale_input_called = True
+        return ops.euler_scale_model_input(sample, self._table, self._step_dev, rep=rep)
+
+    def step(self, model_output, timestep, sample, s_churn: float = 0.0, s_tmin: float = 0.0,
+             s_tmax: float = float("inf"), s_noise: float = 1.0, generator=None, return_dict: bool = True):
+        if isinstance(timestep, int) or (torch.is_tensor(timestep) and timestep.dtype in (torch.int32, torch.int64)):
+            raise ValueError("Passing integer indices (e.g. from `enumerate(timesteps)`) as timesteps to "
+                             "`EulerDiscreteScheduler.step()` is not supported. Make sure to pass one of the "
+                             "`scheduler.timesteps` as a timestep.")
+        if s_churn != 0.0:
+            raise NotImplementedError("s_churn > 0 (stochastic Euler) is not on the hot path")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        prev = ops.euler_step(model_output, sample, self._table, self._step_dev, cfg=False, guidance=0.0)
+        self._advance()
+        if not return_dict:
+            return (prev, None)
+        return SchedulerOutput(prev_sample=prev)
+
+    def step_cfg(self, model_output_2b, sample, guidance_scale: float, out=None):
+        """Engine extension: CFG combine + Euler step in one kernel; model_output_2b = [uncond ; cond]."""
+        if self._step_index is None:
+            self._init_step_index(self.timesteps[0])
+        prev = ops.euler_step(model_output_2b, sample, self._table, self._step_dev, cfg=True,
+                              guidance=float(guidance_scale), out=out)
+        self._advance()
+        return prev
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class DDIMScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                     trained_betas=None, clip_sample=True, set_alpha_to_one=True, steps_offset=0,
+                     prediction_type="epsilon", thresholding=False, dynamic_thresholding_ratio=0.995,
+                     clip_sample_range=1.0, sample_max_value=1.0, timestep_spacing="leading",
+                     rescale_betas_zero_snr=False)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        c = self.config
+        if c.prediction_type != "epsilon" or c.thresholding or c.rescale_betas_zero_snr:
+            raise NotImplementedError("DDIMScheduler: only epsilon prediction without thresholding")
+        self.betas = _betas(c.beta_schedule, c.beta_start, c.beta_end, c.num_train_timesteps, c.trained_betas)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if c.set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.timesteps = torch.from_numpy(np.arange(0, c.num_train_timesteps)[::-1].copy().astype(np.int64))
+        self._timesteps_host = self.timesteps.numpy()
+        self._eta = None
+
+    def _get_variance(self, timestep, prev_timestep):
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t = 1 - a_t
+        b_prev = 1 - a_prev
+        return (b_prev / b_t) * (1 - a_t / a_prev)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        c = self.config
+        if num_inference_steps > c.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                             f"`self.config.train_timesteps`: {c.num_train_timesteps} as the unet model trained with "
+                             f"this scheduler can only handle maximal {c.num_train_timesteps} timesteps.")
+        self.num_inference_steps = num_inference_steps
+        n_train = c.num_train_timesteps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, n_train - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            ratio = n_train // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+            ts += c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ratio = n_train / num_inference_steps
+            ts = np.round(np.arange(n_train, 0, -ratio)).astype(np.int64)
+            ts -= 1
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported. Please make sure to choose one of 'leading' or "
+                             "'trailing'.")
+        self.timesteps = torch.from_numpy(ts).to(device)
+        self._timesteps_host = ts
+        self._step_index = None
+        self._device_req = device
+        self._eta = None
+        self._table = None
+
+    def _build(self, eta: float):
+        c = self.config
+        ts = self._timesteps_host
+        n = len(ts)
+        rows = np.zeros((n, 8), dtype=np.float32)
+        for i, t in enumerate(ts):
+            t = int(t)
+            prev_t = t - c.num_train_timesteps // self.num_inference_steps
+            a_t = self.alphas_cumprod[t]
+            a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+            b_t = 1 - a_t
+            variance = self._get_variance(t, prev_t)
+            std = eta * variance ** 0.5
+            rows[i, 0] = float(b_t ** 0.5)
+            rows[i, 1] = float(a_t ** 0.5)
+            rows[i, 2] = float(a_prev ** 0.5)
+            rows[i, 3] = float((1 - a_prev - std ** 2) ** 0.5)
+            rows[i, 4] = 0.0
+            rows[i, 5] = float(std) if eta > 0 else 0.0
+            rows[i, 6] = float(c.clip_sample_range) if c.clip_sample else 0.0
+            rows[i, 7] = float(t)
+        self._upload(rows, self._device_req)
+        self._eta = eta
+
+    def _ensure(self, eta, timestep):
+        if self._table is None or self._eta != eta:
+            keep = self._step_index
+            self._build(eta)
+            self._step_index = keep
+            if keep is not None:
+                self._sync_device_step()
+        if self._step_index is None:
+            self._init_step_index(timestep)
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output: bool = False,
+             generator=None, variance_noise=None, return_dict: bool = True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating "
+                             "the scheduler")
+        if use_clipped_model_output:
+            raise NotImplementedError("use_clipped_model_output is not on the hot path")
+        self._ensure(eta, timestep)
+        # DDIM is stateless in the reference (indexed by timestep): honour out-of-order calls
+        idx = self.index_for_timestep(timestep)
+        if idx != self._step_index:
+            self._step_index = idx
+            self._sync_device_step()
+        noise = None
+        if eta > 0:
+            if variance_noise is not None and generator is not None:
+                raise ValueError("Cannot pass both generator and variance_noise. Please make sure that either "
+                                 "`generator` or `variance_noise` stays `None`.")
+            if variance_noise is None:
+                gdev = generator.device if generator is not None else model_output.device
+                variance_noise = torch.randn(model_output.shape, generator=generator, device=gdev,
+                                             dtype=model_output.dtype).to(model_output.device)
+            noise = variance_noise
+        prev = ops.x0_linear_step(model_output, sample, noise, self._table, self._step_dev, cfg=False, guidance=0.0)
+        self._advance()
+        if not return_dict:
+            return (prev, None)
+        return SchedulerOutput(prev_sample=prev)
+
+    def step_cfg(self, model_output_2b, sample, guidance_scale: float, eta: float = 0.0, out=None):
+        self._ensure(eta, self.timesteps[0])
+        if eta > 0:
+            raise NotImplementedError("step_cfg with eta > 0")
+        prev = ops.x0_linear_step(model_output_2b, sample, None, self._table, self._step_dev, cfg=True,
+                                  guidance=float(guidance_scale), out=out)
+        self._advance()
+        return prev
+
+    @property
+    def device_table(self):
+        if self._table is None:
+            self._build(0.0)
+        return self._table
+
+    @property
+    def device_step(self):
+        if self._table is None:
+            self._build(0.0)
+        return self._step_dev
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class DDPMScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                     trained_betas=None, variance_type="fixed_small", clip_sample=True, prediction_type="epsilon",
+                     thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0,
+                     sample_max_value=1.0, timestep_spacing="leading", steps_offset=0, rescale_betas_zero_snr=False)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        c = self.config
+        if c.prediction_type != "epsilon" or c.thresholding or c.rescale_betas_zero_snr:
+            raise NotImplementedError("DDPMScheduler: only epsilon prediction without thresholding")
+        if c.variance_type not in ("fixed_small", "fixed_large"):
+            raise NotImplementedError("DDPMScheduler: only fixed_small / fixed_large variance")
+        self.betas = _betas(c.beta_schedule, c.beta_start, c.beta_end, c.num_train_timesteps, c.trained_betas)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.one = torch.tensor(1.0)
+        self.init_noise_sigma = 1.0
+        self.custom_timesteps = False
+        self.timesteps = torch.from_numpy(np.arange(0, c.num_train_timesteps)[::-1].copy())
+        self._timesteps_host = self.timesteps.numpy()
+        self.variance_type = c.variance_type
+
+    def set_timesteps(self, num_inference_steps: int = None, device=None, timesteps=None):
+        c = self.config
+        if timesteps is not None:
+            raise NotImplementedError("custom timesteps are not supported by the HIP DDPMScheduler")
+        if num_inference_steps > c.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                             f"`self.config.train_timesteps`: {c.num_train_timesteps}")
+        self.num_inference_steps = num_inference_steps
+        n_train = c.num_train_timesteps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, n_train - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            ratio = n_train // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+            ts += c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ratio = n_train / num_inference_steps
+            ts = np.round(np.arange(n_train, 0, -ratio)).astype(np.int64)
+            ts -= 1
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported.")
+        self.timesteps = torch.from_numpy(ts).to(device)
+        self._timesteps_host = ts
+        self._step_index = None
+        rows = np.zeros((len(ts), 8), dtype=np.float32)
+        for i, t in enumerate(ts):
+            t = int(t)
+            prev_t = t - n_train // num_inference_steps
+            a_t = self.alphas_cumprod[t]
+            a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+            b_t = 1 - a_t
+            b_prev = 1 - a_prev
+            cur_a = a_t / a_prev
+            cur_b = 1 - cur_a
+            k0 = (a_prev ** 0.5 * cur_b) / b_t
+            kx = cur_a ** 0.5 * b_prev / b_t
+            var = (1 - a_prev) / (1 - a_t) * cur_b
+            var = torch.clamp(var, min=1e-20)
+            if self.variance_type == "fixed_large":
+                var = cur_b
+            rows[i, 0] = float(b_t ** 0.5)
+            rows[i, 1] = float(a_t ** 0.5)
+            rows[i, 2] = float(k0)
+            rows[i, 3] = 0.0
+            rows[i, 4] = float(kx)
+            rows[i, 5] = float(var ** 0.5) if t > 0 else 0.0
+            rows[i, 6] = float(c.clip_sample_range) if c.clip_sample else 0.0
+            rows[i, 7] = float(t)
+        self._upload(rows, device)
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict: bool = True):
+        idx = self.index_for_timestep(timestep)
+        if idx != self._step_index:
+            self._step_index = idx
+            self._sync_device_step()
+        t = int(self._timesteps_host[idx])
+        noise = None
+        if t > 0:
+            gdev = generator.device if generator is not None else model_output.device
+            noise = torch.randn(model_output.shape, generator=generator, device=gdev,
+                                dtype=model_output.dtype).to(model_output.device)
+        prev = ops.x0_linear_step(model_output, sample, noise, self._table, self._step_dev, cfg=False, guidance=0.0)
+        self._advance()
+        if not return_dict:
+            return (prev, None)
+        return SchedulerOutput(prev_sample=prev)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class FlowMatchEulerDiscreteScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, shift=1.0, use_dynamic_shifting=False, base_shift=0.5, max_shift=1.15,
+                     base_image_seq_len=256, max_image_seq_len=4096, invert_sigmas=False, shift_terminal=None,
+                     use_karras_sigmas=False, use_exponential_sigmas=False, use_beta_sigmas=False,
+                     time_shift_type="exponential", stochastic_sampling=False)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        c = self.config
+        if c.use_karras_sigmas or c.use_exponential_sigmas or c.use_beta_sigmas or c.invert_sigmas \
+                or c.shift_terminal or c.stochastic_sampling:
+            raise NotImplementedError("FlowMatchEulerDiscreteScheduler: option not on the hot path")
+        if c.time_shift_type not in {"exponential", "linear"}:
+            raise ValueError("`time_shift_type` must either be 'exponential' or 'linear'.")
+        ts = np.linspace(1, c.num_train_timesteps, c.num_train_timesteps, dtype=np.float32)[::-1].copy()
+        ts = torch.from_numpy(ts).to(dtype=torch.float32)
+        sig = ts / c.num_train_timesteps
+        if not c.use_dynamic_shifting:
+            sig = c.shift * sig / (1 + (c.shift - 1) * sig)
+        self.timesteps = sig * c.num_train_timesteps
+        self._timesteps_host = self.timesteps.numpy()
+        self._shift = c.shift
+        self.sigmas = sig
+        self.sigma_min = self.sigmas[-1].item()
+        self.sigma_max = self.sigmas[0].item()
+        self.init_noise_sigma = 1.0
+
+    @property
+    def shift(self):
+        return self._shift
+
+    def set_shift(self, shift: float):
+        self._shift = shift
+
+    def time_shift(self, mu: float, sigma: float, t):
+        if self.config.time_shift_type == "exponential":
+            return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+        return mu / (mu + (1 / t - 1) ** sigma)
+
+    def set_timesteps(self, num_inference_steps: int = None, device=None, sigmas: Optional[List[float]] = None,
+                      mu: Optional[float] = None, timesteps: Optional[List[float]] = None):
+        c = self.config
+        if c.use_dynamic_shifting and mu is None:
+            raise ValueError("`mu` must be passed when `use_dynamic_shifting` is set to be `True`")
+        if timesteps is not None:
+            raise NotImplementedError("custom timesteps are not supported by the HIP FlowMatch scheduler")
+        if sigmas is not None and num_inference_steps is not None and len(sigmas) != num_inference_steps:
+            raise ValueError("`sigmas` and `timesteps` should have the same length as num_inference_steps, if "
+                             "`num_inference_steps` is provided")
+        if num_inference_steps is None:
+            num_inference_steps = len(sigmas)
+        self.num_inference_steps = num_inference_steps
+        if sigmas is None:
+            ts = np.linspace(self.sigma_max * c.num_train_timesteps, self.sigma_min * c.num_train_timesteps,
+                             num_inference_steps)
+            sig = ts / c.num_train_timesteps
+        else:
+            sig = np.array(sigmas).astype(np.float32)
+        if c.use_dynamic_shifting:
+            sig = self.time_shift(mu, 1.0, sig)
+        else:
+            sig = self.shift * sig / (1 + (self.shift - 1) * sig)
+        sig_t = torch.from_numpy(np.asarray(sig)).to(dtype=torch.float32)
+        ts_t = sig_t * c.num_train_timesteps
+        sig_t = torch.cat([sig_t, torch.zeros(1)])
+        self.timesteps = ts_t.to(device)
+        self._timesteps_host = ts_t.numpy()
+        self.sigmas = sig_t.to(device)
+        self._step_index = None
+        self._begin_index = None
+        rows = np.zeros((num_inference_steps, 8), dtype=np.float32)
+        for i in range(num_inference_steps):
+            s, s_next = sig_t[i], sig_t[i + 1]
+            rows[i, 0] = float(s)
+            rows[i, 1] = float(s_next)
+            rows[i, 2] = float(s_next - s)
+            rows[i, 7] = float(ts_t[i])
+        self._upload(rows, device)
+
+    def step(self, model_output, timestep, sample, s_churn: float = 0.0, s_tmin: float = 0.0,
+             s_tmax: float = float("inf"), s_noise: float = 1.0, generator=None, per_token_timesteps=None,
+             return_dict: bool = True):
+        if isinstance(timestep, int) or (torch.is_tensor(timestep) and timestep.dtype in (torch.int32, torch.int64)):
+            raise ValueError("Passing integer indices (e.g. from `enumerate(timesteps)`) as timesteps to "
+                             "`FlowMatchEulerDiscreteScheduler.step()` is not supported. Make sure to pass one of the "
+                             "`scheduler.timesteps` as a timestep.")
+        if per_token_timesteps is not None:
+            raise NotImplementedError("per_token_timesteps is not on the hot path")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        prev = ops.flowmatch_step(model_output, sample, self._table, self._step_dev)
+        self._advance()
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev_sample=prev)
+
+    def step_cfg(self, model_output_2b, sample, guidance_scale: float, out=None):
+        if self._step_index is None:
+            self._init_step_index(self.timesteps[0])
+        prev = ops.flowmatch_step(model_output_2b, sample, self._table, self._step_dev, cfg=True,
+                                  guidance=float(guidance_scale), out=out)
+        self._advance()
+        return prev

@@ -1,0 +1,303 @@
+"""UNet2DConditionModel on the gfx950 kernels.
+
+Mirrors the reference class (models/unets/unet_2d_condition.py:979-1235) for the configurations the BASELINE names
+(SD1.5 and SDXL): same constructor kwargs, same ``state_dict`` key names / shapes, same ``forward`` arguments and
+NCHW in/out tensors, same ``ValueError``s for unsupported arguments.  Inside, activations are channels-last bf16 and every op is
+a hand-written HIP kernel (see layers.py / csrc/).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .layers import (Conv3x3, Downsample2D, GroupNorm, Linear, ResnetBlock2D, TimestepEmbedding, Transformer2DModel,
+                     Upsample2D, Weights, pad_encoder_states)
+
+bf16 = torch.bfloat16
+
+
+@dataclass
+class UNet2DConditionOutput:
+    sample: torch.Tensor
+
+
+class FrozenConfig(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+_DEFAULTS = dict(
+    sample_size=None, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    mid_block_type="UNetMidBlock2DCrossAttn",
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    only_cross_attention=False, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, downsample_padding=1,
+    mid_block_scale_factor=1, dropout=0.0, act_fn="silu", norm_num_groups=32, norm_eps=1e-5,
+    cross_attention_dim=1280, transformer_layers_per_block=1, reverse_transformer_layers_per_block=None,
+    encoder_hid_dim=None, encoder_hid_dim_type=None, attention_head_dim=8, num_attention_heads=None,
+    dual_cross_attention=False, use_linear_projection=False, class_embed_type=None, addition_embed_type=None,
+    addition_time_embed_dim=None, num_class_embeds=None, upcast_attention=False, resnet_time_scale_shift="default",
+    resnet_skip_time_act=False, resnet_out_scale_factor=1.0, time_embedding_type="positional",
+    time_embedding_dim=None, time_embedding_act_fn=None, timestep_post_act=None, time_cond_proj_dim=None,
+    conv_in_kernel=3, conv_out_kernel=3, projection_class_embeddings_input_dim=None, attention_type="default",
+    class_embeddings_concat=False, mid_block_only_cross_attention=None, cross_attention_norm=None,
+    addition_embed_type_num_heads=64,
+)
+
+
+def _tup(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+class _CrossAttnStage:
+    """resnet -> transformer pairs (CrossAttnDownBlock2D / CrossAttnUpBlock2D / mid), unet_2d_blocks.py:1239-1291."""
+
+
+class UNet2DConditionModel:
+    """Drop-in for the reference ``UNet2DConditionModel`` (inference, bf16, HIP device only)."""
+
+    def __init__(self, **kwargs):
+        unknown = set(kwargs) - set(_DEFAULTS)
+        if unknown:
+            raise TypeError(f"UNet2DConditionModel: unexpected config keys {sorted(unknown)}")
+        cfg = dict(_DEFAULTS)
+        cfg.update(kwargs)
+        self.config = FrozenConfig(cfg)
+        c = self.config
+        # -- what the engine implements; everything else is refused loudly rather than silently approximated --
+        if c.act_fn != "silu" or c.resnet_time_scale_shift != "default" or c.time_embedding_type != "positional":
+            raise ValueError("diffusers_amd UNet2DConditionModel supports act_fn='silu', default time scale shift")
+        if c.class_embed_type is not None or c.num_class_embeds is not None or c.encoder_hid_dim_type is not None:
+            raise ValueError("class / encoder_hid embeddings are not on the BASELINE hot path")
+        if c.addition_embed_type not in (None, "text_time"):
+            raise ValueError(f"addition_embed_type={c.addition_embed_type!r} is not supported")
+        if c.dual_cross_attention or c.only_cross_attention or c.attention_type != "default" or c.upcast_attention:
+            raise ValueError("unsupported attention variant")
+        if c.conv_in_kernel != 3 or c.conv_out_kernel != 3 or c.time_cond_proj_dim is not None:
+            raise ValueError("unsupported conv_in/out kernel or time_cond_proj_dim")
+        if len(c.down_block_types) != len(c.up_block_types) or len(c.block_out_channels) != len(c.down_block_types):
+            raise ValueError("Must provide the same number of `down_block_types`, `up_block_types`, `block_out_channels`.")
+        for t in c.down_block_types:
+            if t not in ("CrossAttnDownBlock2D", "DownBlock2D"):
+                raise ValueError(f"{t} does not exist.")
+        for t in c.up_block_types:
+            if t not in ("CrossAttnUpBlock2D", "UpBlock2D"):
+                raise ValueError(f"{t} does not exist.")
+        if c.mid_block_type != "UNetMidBlock2DCrossAttn":
+            raise ValueError(f"unknown mid_block_type : {c.mid_block_type}")
+        self.dtype = bf16
+        self.device = None
+        self._built = False
+
+    # ------------------------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], device="cuda", strict: bool = True):
+        """Pack a reference-format state_dict (keys as ``reference_unet.state_dict()``) onto ``device``."""
+        c = self.config
+        w = Weights(state_dict, device)
+        self.device = torch.device(device)
+        n = len(c.block_out_channels)
+        boc = tuple(c.block_out_channels)
+        groups, eps = c.norm_num_groups, c.norm_eps
+        heads = _tup(c.num_attention_heads or c.attention_head_dim, n)
+        lpb = _tup(c.layers_per_block, n)
+        tlpb = _tup(c.transformer_layers_per_block, n)
+        temb_dim = boc[0] * 4
+
+        # conv_in stays in torch layout [Cout][Cin][3][3] -> [Cout][9*Cin] for the thin-input kernel
+        self.conv_in_w = ops.pack_conv_weight(w.get("conv_in.weight"))
+        self.conv_in_b = w.get("conv_in.bias")
+        self.time_embedding = TimestepEmbedding(w, "time_embedding")
+        self.add_embedding = TimestepEmbedding(w, "add_embedding") if c.addition_embed_type == "text_time" else None
+
+        self.down = []
+        for i, btype in enumerate(c.down_block_types):
+            pre = f"down_blocks.{i}"
+            stage = {"resnets": [], "attns": [], "down": None}
+            for j in range(lpb[i]):
+                stage["resnets"].append(ResnetBlock2D(w, f"{pre}.resnets.{j}", groups, eps))
+                if btype == "CrossAttnDownBlock2D":
+                    stage["attns"].append(Transformer2DModel(w, f"{pre}.attentions.{j}", heads[i], tlpb[i], groups))
+            if i != n - 1:
+                stage["down"] = Downsample2D(w, f"{pre}.downsamplers.0")
+            self.down.append(stage)
+
+        self.mid = {
+            "resnets": [ResnetBlock2D(w, "mid_block.resnets.0", groups, eps, c.mid_block_scale_factor),
+                        ResnetBlock2D(w, "mid_block.resnets.1", groups, eps, c.mid_block_scale_factor)],
+            "attns": [Transformer2DModel(w, "mid_block.attentions.0", heads[-1], tlpb[-1], groups)],
+        }
+
+        rheads = tuple(reversed(heads))
+        rlpb = tuple(reversed(lpb))
+        rtlpb = tuple(reversed(tlpb)) if c.reverse_transformer_layers_per_block is None \
+            else _tup(c.reverse_transformer_layers_per_block, n)
+        self.up = []
+        for i, btype in enumerate(c.up_block_types):
+            pre = f"up_blocks.{i}"
+            stage = {"resnets": [], "attns": [], "up": None}
+            for j in range(rlpb[i] + 1):
+                stage["resnets"].append(ResnetBlock2D(w, f"{pre}.resnets.{j}", groups, eps))
+                if btype == "CrossAttnUpBlock2D":
+                    stage["attns"].append(Transformer2DModel(w, f"{pre}.attentions.{j}", rheads[i], rtlpb[i], groups))
+            if i != n - 1:
+                stage["up"] = Upsample2D(w, f"{pre}.upsamplers.0")
+            self.up.append(stage)
+
+        self.conv_norm_out = GroupNorm(w, "conv_norm_out", groups, eps)
+        self.conv_out_w = ops.pack_conv_weight(w.get("conv_out.weight"))
+        self.conv_out_b = w.get("conv_out.bias")
+        if strict and w.unused():
+            raise RuntimeError(f"unexpected keys in state_dict: {w.unused()[:8]} ...")
+        self._temb_dim = temb_dim
+        self._built = True
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------------------------------------------------
+    # step-invariant work (hoisted): cross-attention K / V^T of every transformer block, SDXL text_time embedding
+    # ------------------------------------------------------------------------------------------------------------
+    def _transformers(self) -> List[Transformer2DModel]:
+        out = []
+        for st in self.down:
+            out += st["attns"]
+        out += self.mid["attns"]
+        for st in self.up:
+            out += st["attns"]
+        return out
+
+    def precompute_conditioning(self, encoder_hidden_states: torch.Tensor,
+                                added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, Any]:
+        """Everything in forward() that does not depend on the timestep or the latents."""
+        if encoder_hidden_states.dtype != bf16 or not encoder_hidden_states.is_cuda:
+            raise ValueError("encoder_hidden_states must be a bf16 HIP tensor")
+        B = encoder_hidden_states.shape[0]
+        ehs_pad, skv, skv_alloc = pad_encoder_states(encoder_hidden_states.contiguous())
+        kvs = [tr.precompute_kv(ehs_pad, B, skv, skv_alloc) for tr in self._transformers()]
+        aug = None
+        if self.config.addition_embed_type == "text_time":
+            aug = self._text_time_embedding(added_cond_kwargs, B)
+        return {"kvs": kvs, "aug_emb": aug, "batch": B, "ehs_ptr": encoder_hidden_states.data_ptr()}
+
+    def _text_time_embedding(self, added_cond_kwargs, B):
+        # unet_2d_condition.py:906-922
+        if added_cond_kwargs is None or "text_embeds" not in added_cond_kwargs:
+            raise ValueError(f"{self.__class__} has the config param `addition_embed_type` set to 'text_time' which "
+                             "requires the keyword argument `text_embeds` to be passed in `added_cond_kwargs`")
+        if "time_ids" not in added_cond_kwargs:
+            raise ValueError(f"{self.__class__} has the config param `addition_embed_type` set to 'text_time' which "
+                             "requires the keyword argument `time_ids` to be passed in `added_cond_kwargs`")
+        text_embeds = added_cond_kwargs["text_embeds"].to(device=self.device, dtype=bf16).contiguous()
+        time_ids = added_cond_kwargs["time_ids"].to(device=self.device, dtype=torch.float32).contiguous()
+        c = self.config
+        n_ids = time_ids.shape[1]
+        te = ops.timestep_embedding(time_ids.reshape(-1), c.addition_time_embed_dim, batch=B * n_ids,
+                                    flip_sin_to_cos=c.flip_sin_to_cos, shift=float(c.freq_shift))
+        te = te.view(B, n_ids * c.addition_time_embed_dim)
+        add = torch.cat([text_embeds, te], dim=-1).contiguous()  # tiny host-side glue: (B, 2816)
+        return self.add_embedding(add)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------------------
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, class_labels=None,
+                timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None,
+                down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict: bool = True,
+                conditioning: Optional[Dict[str, Any]] = None, sampler_table=None, step_idx=None):
+        """Same signature as the reference forward (unet_2d_condition.py:979-994) plus two engine extensions:
+        ``conditioning`` (result of :meth:`precompute_conditioning`) and ``sampler_table``/``step_idx`` (read the
+        timestep from the device-resident sampler table so the call is HIP-graph replayable)."""
+        if not self._built:
+            raise RuntimeError("UNet2DConditionModel: call load_state_dict() first")
+        for name, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond),
+                        ("attention_mask", attention_mask), ("cross_attention_kwargs", cross_attention_kwargs),
+                        ("down_block_additional_residuals", down_block_additional_residuals),
+                        ("mid_block_additional_residual", mid_block_additional_residual),
+                        ("down_intrablock_additional_residuals", down_intrablock_additional_residuals),
+                        ("encoder_attention_mask", encoder_attention_mask)):
+            if v is not None:
+                raise ValueError(f"diffusers_amd UNet2DConditionModel.forward: `{name}` is not supported on the HIP path")
+        if sample.dtype != bf16 or not sample.is_cuda:
+            raise ValueError("sample must be a bf16 HIP tensor (there is no CPU / fp32 fallback)")
+        c = self.config
+        B, Cin, H, W_ = sample.shape
+        n_up = len(c.block_out_channels) - 1
+        if H % (2 ** n_up) or W_ % (2 ** n_up):
+            raise ValueError("sample height/width must be divisible by 2**(num_upsamplers)")
+        if conditioning is None:
+            conditioning = self.precompute_conditioning(encoder_hidden_states, added_cond_kwargs)
+        if conditioning["batch"] != B:
+            raise ValueError("conditioning batch does not match sample batch")
+        kvs = conditioning["kvs"]
+
+        # 1. time embedding (unet_2d_condition.py:852-872, :1081-1098)
+        if sampler_table is not None:
+            t_emb = ops.timestep_embedding(None, c.block_out_channels[0], batch=B, flip_sin_to_cos=c.flip_sin_to_cos,
+                                           shift=float(c.freq_shift), table=sampler_table, step_idx=step_idx)
+        else:
+            if not torch.is_tensor(timestep):
+                timestep = torch.tensor([float(timestep)], dtype=torch.float32)
+            t = timestep.to(device=self.device, dtype=torch.float32).reshape(-1)
+            if t.numel() == 1:
+                t = t.expand(B)
+            t_emb = ops.timestep_embedding(t.contiguous(), c.block_out_channels[0], batch=B,
+                                           flip_sin_to_cos=c.flip_sin_to_cos, shift=float(c.freq_shift))
+        emb = self.time_embedding(t_emb, residual=conditioning["aug_emb"])  # emb + aug_emb fused as residual
+
+        # 2. conv_in: NCHW -> channels-last
+        x = ops.conv_thin_in(sample.contiguous(), self.conv_in_w, self.conv_in_b, ksize=3, in_nchw=True)
+
+        # 3. down
+        ki = 0
+        skips = [x]
+        for st in self.down:
+            for j, rn in enumerate(st["resnets"]):
+                x = rn(x, emb)
+                if st["attns"]:
+                    x = st["attns"][j](x, kvs[ki])
+                    ki += 1
+                skips.append(x)
+            if st["down"] is not None:
+                x = st["down"](x)
+                skips.append(x)
+
+        # 4. mid
+        x = self.mid["resnets"][0](x, emb)
+        x = self.mid["attns"][0](x, kvs[ki])
+        ki += 1
+        x = self.mid["resnets"][1](x, emb)
+
+        # 5. up (skip concat fused into the resnets)
+        for st in self.up:
+            for j, rn in enumerate(st["resnets"]):
+                skip = skips.pop()
+                x = rn(x, emb, skip=skip)
+                if st["attns"]:
+                    x = st["attns"][j](x, kvs[ki])
+                    ki += 1
+            if st["up"] is not None:
+                x = st["up"](x)
+
+        # 6. out: GroupNorm + SiLU + conv_out, channels-last -> NCHW
+        x = self.conv_norm_out(x, silu=True)
+        out = ops.conv_thin_out(x, self.conv_out_w, self.conv_out_b)
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)

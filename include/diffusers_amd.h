@@ -1,0 +1,183 @@
+/*
+ * diffusers_amd -- C ABI of the MI355X (gfx950) denoising hot path.
+ *
+ * The reference (huggingface/diffusers, 100 % Python) has no FFI: its "operator API" is the set of torch calls its
+ * nn.Modules make.  Every entry point below replaces one such call site (cited per function as file:line under the
+ * reference's src/diffusers/) with a hand-written HIP kernel.  The boundary is plain C: device pointers, sizes and a
+ * hipStream_t passed as void*.  The library never allocates, never synchronises and keeps no mutable global state, so
+ * every call can be captured into a HIP graph on the caller's stream.
+ *
+ * Conventions
+ *   - all tensors are bf16 (uint16_t bit patterns) unless a parameter says otherwise; accumulation is fp32
+ *   - activations are channels-last: an image tensor is [B][H][W][C], a token tensor [B*S][C]
+ *   - return value: 0 = DA_OK, otherwise a DA_ERR_* code (the Python binding raises RuntimeError)
+ */
+#ifndef DIFFUSERS_AMD_H
+#define DIFFUSERS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DA_OK 0
+#define DA_ERR_INVALID 1
+#define DA_ERR_LAUNCH 2
+#define DA_ERR_UNSUPPORTED 3
+
+/* epilogue activations of da_gemm_bf16 */
+#define DA_ACT_NONE 0
+#define DA_ACT_GEGLU 1     /* out[m][j] = h * gelu_erf(g), weight rows packed [32 h | 32 g] per 64 (activations.py:93-124) */
+#define DA_ACT_GELU_TANH 2 /* activations.py:60-90 (approximate="tanh"), Flux / Wan feed-forward */
+#define DA_ACT_SILU 3
+#define DA_ACT_GELU_ERF 4
+
+#define DA_TILE_AUTO 0
+#define DA_TILE_128x128 1
+#define DA_TILE_64x128 2
+#define DA_TILE_128x64 3
+#define DA_TILE_64x64 4
+
+#define DA_STAGE_REGISTER 0   /* global_load_dwordx4 -> ds_write_b128 */
+#define DA_STAGE_LDS_DIRECT 1 /* global_load_lds_dwordx4 (LDS-DMA) */
+
+int da_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * da_gemm_bf16: C[M][N] = epilogue( alpha * A[M][K] . W[N][K]^T )
+ *   conv == 0  nn.Linear: A is [M][lda].  Replaces F.linear at attention_processor.py:2743-2777 (to_q/k/v/out),
+ *              activations.py:113-124 (GEGLU proj), attention.py:1717-1742 (FeedForward), transformer_2d.py:466-512
+ *              (proj_in / proj_out), embeddings.py:1262-1308 (TimestepEmbedding, large-M case), resnet.py:345-349.
+ *   conv == 3  nn.Conv2d(k=3, pad, stride 1|2) on channels-last input, as an implicit GEMM with K = 9*(C1+C2)
+ *              (conv == 1: the 1x1 shortcut conv of resnet.py:373 over the same two-source gather):
+ *              A  = source 1 [B][Hin][Win][C1], A2 = optional source 2 [B][Hin][Win][C2] (fused torch.cat on channels,
+ *              unet_2d_blocks.py:2444/:2561), W = [N][3][3][C1+C2]; up == 1 fuses F.interpolate(scale 2, nearest)
+ *              (upsampling.py:177-190); stride 2 = Downsample2D (downsampling.py:130-147).  M = B*Hout*Wout.
+ *              Replaces resnet.py:340/:365/:373, unet_2d_condition.py:1108/:1230, vae.py:286/:309.
+ *   epilogue   + bias[N] + rowvec[m / rows_per_batch][N] (time-embedding injection, resnet.py:345-349), activation,
+ *              + residual[M][ldr] (resnet.py:375, attention.py:1034-1080, transformer_2d.py:499-512), * out_scale.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct da_gemm_params {
+  const void* A;
+  const void* A2;
+  const void* W;
+  void* C;
+  const void* bias;     /* [N] or NULL */
+  const void* rowvec;   /* [M / rows_per_batch][ld_rowvec] or NULL */
+  const void* residual; /* [M][ldr] or NULL */
+  int M, N, K;
+  int lda, ldw, ldc, ldr, ld_rowvec;
+  int rows_per_batch;
+  float alpha;     /* 0 -> 1 */
+  float out_scale; /* 0 -> 1 */
+  int act;         /* DA_ACT_* */
+  int out_f32;     /* 1: C is float [M][ldc] */
+  int conv;        /* 0 linear; 1 or 3 = implicit-GEMM conv with that kernel size (pad given by `pad`) */
+  int Hin, Win, C1, C2, Hout, Wout, stride, up, pad;
+  int tile;    /* DA_TILE_* */
+  int staging; /* DA_STAGE_* */
+} da_gemm_params;
+
+int da_gemm_bf16(const da_gemm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * da_attention_bf16: out = softmax(scale * Q K^T) V, flash-style (no S x S tensor), no mask / dropout / causal.
+ *   Replaces F.scaled_dot_product_attention at attention_processor.py:2767 (AttnProcessor2_0) and
+ *   attention_dispatch.py:3709 (_native_attention: Flux / Wan).
+ *   q   element (b, s, h, d) at q  + b*q_batch_stride + s*q_row_stride + h*D + d
+ *   k   element (b, s, h, d) at k  + b*k_batch_stride + s*k_row_stride + h*D + d
+ *   vt  element (b, s, h, d) at vt + (h*D + d)*vt_ld + b*vt_batch_stride + s        (V transposed: keys contiguous)
+ *   out element (b, s, h, d) at out + b*o_batch_stride + s*o_row_stride + h*D + d
+ *   Skv = number of keys attended; Skv_alloc (multiple of 8, >= Skv) = keys present in memory per batch.
+ *   D in {64, 128}.  All strides in elements, multiples of 8 (o: 4).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct da_attention_params {
+  const void* q;
+  const void* k;
+  const void* vt;
+  void* out;
+  int B, H, Sq, Skv, Skv_alloc, D;
+  long long q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride;
+  int q_row_stride, k_row_stride, vt_ld, o_row_stride;
+  float scale;
+} da_attention_params;
+
+int da_attention_bf16(const da_attention_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Normalisation (norm.hip)
+ *   da_groupnorm_nhwc_bf16   nn.GroupNorm(G, C, eps) [+ SiLU when act == DA_ACT_SILU] on channels-last [B][HW][C].
+ *                            Replaces resnet.py:326-327,:350,:362, transformer_2d.py:466, unet_2d_condition.py:1228-1229,
+ *                            vae.py:305-308, attention_processor.py:2740.  workspace: da_groupnorm_workspace_bytes().
+ *                            x2 != NULL: channels [0,C1) come from x and [C1,C) from x2 (fused skip concat,
+ *                            unet_2d_blocks.py:2444).
+ *   da_layernorm_bf16        nn.LayerNorm(C, eps) over rows of [M][ldx] (gamma/beta may be NULL = no affine), optional
+ *                            AdaLN modulation y = LN(x) * (1 + mod_scale[b]) + mod_shift[b], b = row / rows_per_batch.
+ *                            Replaces attention.py:986,:1030,:1056 and normalization.py:157-170,:194-202,:346-351.
+ *   da_softmax_rows_f32_bf16 row softmax of fp32 scores -> bf16 (single-head D=512 VAE mid-block attention,
+ *                            attention_processor.py:2767 via vae.py / unet_2d_blocks.py:736-748).
+ * ------------------------------------------------------------------------------------------------------------------ */
+size_t da_groupnorm_workspace_bytes(int B, int HW, int C, int G);
+int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const void* gamma, const void* beta, void* y,
+                           void* workspace, int B, int HW, int C, int G, float eps, int act, void* stream);
+int da_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, const void* mod_scale,
+                      const void* mod_shift, int mod_ld, int rows_per_batch, int M, int C, int ldx, int ldy, float eps,
+                      void* stream);
+int da_softmax_rows_f32_bf16(const void* scores, void* probs, int M, int N, long long ld, long long ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Sampler (sampler.hip): fused classifier-free-guidance combine + scheduler.step.
+ *   `table` is a device array of 8 floats per step, `step_idx` a device int (graph-replay safe).  When cfg != 0 the
+ *   model output holds [uncond | cond] halves of n elements each and noise_pred = u + guidance * (c - u)
+ *   (pipeline_stable_diffusion.py:1054-1055).  dtype selects bf16 or fp32 tensors.
+ *   da_euler_scale_model_input  scheduling_euler_discrete.py:326-348, output replicated `rep` times (torch.cat([x]*2))
+ *                               row = [sigma, sigma_next, dt, sqrt(sigma^2+1), -, -, -, timestep]
+ *   da_euler_step               scheduling_euler_discrete.py:685-800 (epsilon prediction, gamma = 0)
+ *   da_x0_linear_step           scheduling_ddim.py:384-514 and scheduling_ddpm.py:461-567 (epsilon prediction)
+ *                               row = [sqrt(beta_t), sqrt(alpha_t), k0, ke, kx, kn, clip_range, timestep]
+ *   da_flowmatch_step           scheduling_flow_match_euler_discrete.py:423-523 ; row = [sigma, sigma_next, dt, ...]
+ *   da_advance_step             the reference's `self._step_index += 1`
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define DA_DTYPE_BF16 0
+#define DA_DTYPE_F32 1
+int da_euler_scale_model_input(const void* x, void* out, const float* table, const int* step_idx, int rep, long long n,
+                               int dtype, void* stream);
+int da_euler_step(const void* eps, const void* x, void* out, const float* table, const int* step_idx, int cfg,
+                  float guidance, long long n, int dtype, void* stream);
+int da_x0_linear_step(const void* eps, const void* x, const void* noise, void* out, const float* table,
+                      const int* step_idx, int cfg, float guidance, long long n, int dtype, void* stream);
+int da_flowmatch_step(const void* v, const void* x, void* out, const float* table, const int* step_idx, int cfg,
+                      float guidance, long long n, int dtype, void* stream);
+int da_advance_step(int* step_idx, void* stream);
+/* out = x * s in the tensor dtype: latents * scheduler.init_noise_sigma (pipeline_stable_diffusion.py:713) */
+int da_mul_scalar(const void* x, void* out, float s, long long n, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Misc (misc.hip)
+ *   da_timestep_embedding   get_timestep_embedding, embeddings.py:27-78.  t[B] (device floats) or table/step_idx
+ *                           (column 7 of the sampler table).  Output [B][dim] bf16 or fp32.
+ *   da_linear_small_m_bf16  M <= 8 Linear with optional SiLU on the input and SiLU/GELU on the output and a residual:
+ *                           TimestepEmbedding (embeddings.py:1262-1308), add_embedding (unet_2d_condition.py:906-922),
+ *                           time_emb_proj(SiLU(temb)) (resnet.py:345-349), AdaLN linears (normalization.py:157-202).
+ *   da_conv_thin_in_bf16    Conv2d with Cin <= 16, k in {1,3}: conv_in (unet_2d_condition.py:1108, vae.py:286),
+ *                           post_quant_conv (autoencoder_kl.py:204).  Input NCHW or NHWC, output NHWC.
+ *                           in_div != 1: input is first divided by it in bf16 (latents / scaling_factor,
+ *                           pipeline_stable_diffusion_xl.py:1283).
+ *   da_conv_thin_out_bf16   Conv2d 3x3 with Cout in {3,4,8,16}: conv_out (unet_2d_condition.py:1230, vae.py:309).
+ *                           Input NHWC, output NCHW (bf16 or fp32).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int da_timestep_embedding(const float* t, const float* table, const int* step_idx, void* out, int B, int dim,
+                          int flip_sin_to_cos, float shift, float scale, float max_period, int out_f32, void* stream);
+int da_linear_small_m_bf16(const void* x, const void* W, const void* bias, const void* res, void* out, int M, int N,
+                           int K, int ldx, int ldo, int ldr, int act_in, int act_out, void* stream);
+int da_conv_thin_in_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                         int ksize, int in_nchw, float in_div, void* stream);
+int da_conv_thin_out_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
+                          int Cout, int out_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
