@@ -1,0 +1,56 @@
+"""Build engine models / pipelines from canonical configs with seeded random weights (no checkpoints exist offline)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import init as dinit
+from .autoencoder_kl import AutoencoderKL
+from .pipelines import StableDiffusionPipeline, StableDiffusionXLPipeline
+from .schedulers import DDIMScheduler, EulerDiscreteScheduler
+from .unet_2d_condition import UNet2DConditionModel
+
+SDXL_SCHEDULER = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                      timestep_spacing="leading")
+SD15_SCHEDULER = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                      set_alpha_to_one=False, steps_offset=1)
+
+
+def build_unet(cfg: dict, seed: int = 0, device="cuda", init_device: Optional[str] = None, state_dict=None):
+    unet = UNet2DConditionModel(**cfg)
+    if state_dict is None:
+        shapes = dinit.unet_param_shapes(unet.config)
+        state_dict = dinit.random_state_dict(shapes, seed=seed, device=init_device or "cpu")
+    unet.load_state_dict(state_dict, device=device)
+    return unet, state_dict
+
+
+def build_vae(cfg: dict, seed: int = 1, device="cuda", init_device: Optional[str] = None, state_dict=None):
+    vae = AutoencoderKL(**cfg)
+    if state_dict is None:
+        shapes = dinit.vae_decoder_param_shapes(vae.config)
+        state_dict = dinit.random_state_dict(shapes, seed=seed, device=init_device or "cpu")
+    vae.load_state_dict(state_dict, device=device)
+    return vae, state_dict
+
+
+def build_sdxl_pipeline(device="cuda", tiny: bool = False, seed: int = 0, init_device: Optional[str] = None):
+    """SDXL-base (BASELINE config 3) or its tiny sibling.  Full size: weights are generated on ``init_device``
+    (default: the HIP device, ~2.6 B parameters in seconds) and freed after packing."""
+    ucfg = dinit.TINY_SDXL_UNET if tiny else dinit.SDXL_UNET
+    vcfg = dinit.TINY_VAE if tiny else dinit.SDXL_VAE
+    idev = init_device or ("cpu" if tiny else str(device))
+    unet, _ = build_unet(ucfg, seed=seed, device=device, init_device=idev)
+    vae, _ = build_vae(vcfg, seed=seed + 1, device=device, init_device=idev)
+    sch = EulerDiscreteScheduler(**SDXL_SCHEDULER)
+    return StableDiffusionXLPipeline(vae=vae, unet=unet, scheduler=sch)
+
+
+def build_sd15_pipeline(device="cuda", tiny: bool = False, seed: int = 0, init_device: Optional[str] = None):
+    ucfg = dinit.TINY_SD15_UNET if tiny else dinit.SD15_UNET
+    vcfg = dinit.TINY_VAE if tiny else dinit.SD_VAE
+    idev = init_device or ("cpu" if tiny else str(device))
+    unet, _ = build_unet(ucfg, seed=seed, device=device, init_device=idev)
+    vae, _ = build_vae(vcfg, seed=seed + 1, device=device, init_device=idev)
+    return StableDiffusionPipeline(vae=vae, unet=unet, scheduler=DDIMScheduler(**SD15_SCHEDULER))

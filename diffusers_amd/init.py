@@ -1,0 +1,219 @@
+"""Parameter inventories (reference ``state_dict`` key -> shape) and deterministic seeded initialisation.
+
+No checkpoints exist offline, so parity tests and the benchmark use seeded random weights.  The inventories are derived
+from the config exactly as the reference constructors derive them (unet_2d_condition.py:179-560, unet_2d_blocks.py,
+vae.py:180-278); ``oracle/make_golden.py`` checks them against the reference's own ``state_dict()`` key/shape set.
+"""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import torch
+
+
+def _tup(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+def _resnet(sh, p, cin, cout, temb):
+    sh[f"{p}.norm1.weight"] = (cin,)
+    sh[f"{p}.norm1.bias"] = (cin,)
+    sh[f"{p}.conv1.weight"] = (cout, cin, 3, 3)
+    sh[f"{p}.conv1.bias"] = (cout,)
+    if temb:
+        sh[f"{p}.time_emb_proj.weight"] = (cout, temb)
+        sh[f"{p}.time_emb_proj.bias"] = (cout,)
+    sh[f"{p}.norm2.weight"] = (cout,)
+    sh[f"{p}.norm2.bias"] = (cout,)
+    sh[f"{p}.conv2.weight"] = (cout, cout, 3, 3)
+    sh[f"{p}.conv2.bias"] = (cout,)
+    if cin != cout:
+        sh[f"{p}.conv_shortcut.weight"] = (cout, cin, 1, 1)
+        sh[f"{p}.conv_shortcut.bias"] = (cout,)
+
+
+def _transformer(sh, p, c, cross, layers, linear_proj):
+    sh[f"{p}.norm.weight"] = (c,)
+    sh[f"{p}.norm.bias"] = (c,)
+    proj = (c, c) if linear_proj else (c, c, 1, 1)
+    sh[f"{p}.proj_in.weight"] = proj
+    sh[f"{p}.proj_in.bias"] = (c,)
+    for k in range(layers):
+        b = f"{p}.transformer_blocks.{k}"
+        for nm in ("norm1", "norm2", "norm3"):
+            sh[f"{b}.{nm}.weight"] = (c,)
+            sh[f"{b}.{nm}.bias"] = (c,)
+        for a, kd in (("attn1", c), ("attn2", cross)):
+            sh[f"{b}.{a}.to_q.weight"] = (c, c)
+            sh[f"{b}.{a}.to_k.weight"] = (c, kd)
+            sh[f"{b}.{a}.to_v.weight"] = (c, kd)
+            sh[f"{b}.{a}.to_out.0.weight"] = (c, c)
+            sh[f"{b}.{a}.to_out.0.bias"] = (c,)
+        sh[f"{b}.ff.net.0.proj.weight"] = (8 * c, c)
+        sh[f"{b}.ff.net.0.proj.bias"] = (8 * c,)
+        sh[f"{b}.ff.net.2.weight"] = (c, 4 * c)
+        sh[f"{b}.ff.net.2.bias"] = (c,)
+    sh[f"{p}.proj_out.weight"] = proj
+    sh[f"{p}.proj_out.bias"] = (c,)
+
+
+def unet_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict inventory of UNet2DConditionModel for the supported configs (SD1.5 / SDXL families)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    boc = tuple(cfg["block_out_channels"])
+    n = len(boc)
+    temb = boc[0] * 4
+    lpb = _tup(cfg["layers_per_block"], n)
+    tlpb = _tup(cfg["transformer_layers_per_block"], n)
+    cross = _tup(cfg["cross_attention_dim"], n)
+    lin = cfg["use_linear_projection"]
+    sh["conv_in.weight"] = (boc[0], cfg["in_channels"], 3, 3)
+    sh["conv_in.bias"] = (boc[0],)
+    sh["time_embedding.linear_1.weight"] = (temb, boc[0])
+    sh["time_embedding.linear_1.bias"] = (temb,)
+    sh["time_embedding.linear_2.weight"] = (temb, temb)
+    sh["time_embedding.linear_2.bias"] = (temb,)
+    if cfg["addition_embed_type"] == "text_time":
+        sh["add_embedding.linear_1.weight"] = (temb, cfg["projection_class_embeddings_input_dim"])
+        sh["add_embedding.linear_1.bias"] = (temb,)
+        sh["add_embedding.linear_2.weight"] = (temb, temb)
+        sh["add_embedding.linear_2.bias"] = (temb,)
+    out_c = boc[0]
+    for i, bt in enumerate(cfg["down_block_types"]):
+        in_c, out_c = out_c, boc[i]
+        for j in range(lpb[i]):
+            _resnet(sh, f"down_blocks.{i}.resnets.{j}", in_c if j == 0 else out_c, out_c, temb)
+            if bt == "CrossAttnDownBlock2D":
+                _transformer(sh, f"down_blocks.{i}.attentions.{j}", out_c, cross[i], tlpb[i], lin)
+        if i != n - 1:
+            sh[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            sh[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (out_c,)
+    mid = boc[-1]
+    _resnet(sh, "mid_block.resnets.0", mid, mid, temb)
+    _transformer(sh, "mid_block.attentions.0", mid, cross[-1], tlpb[-1], lin)
+    _resnet(sh, "mid_block.resnets.1", mid, mid, temb)
+    rboc = tuple(reversed(boc))
+    rlpb = tuple(reversed(lpb))
+    rcross = tuple(reversed(cross))
+    rt = cfg.get("reverse_transformer_layers_per_block")
+    rtlpb = tuple(reversed(tlpb)) if rt is None else _tup(rt, n)
+    out_c = rboc[0]
+    for i, bt in enumerate(cfg["up_block_types"]):
+        prev_out = out_c
+        out_c = rboc[i]
+        in_c = rboc[min(i + 1, n - 1)]
+        nl = rlpb[i] + 1
+        for j in range(nl):
+            skip_c = in_c if j == nl - 1 else out_c
+            res_in = prev_out if j == 0 else out_c
+            _resnet(sh, f"up_blocks.{i}.resnets.{j}", res_in + skip_c, out_c, temb)
+            if bt == "CrossAttnUpBlock2D":
+                _transformer(sh, f"up_blocks.{i}.attentions.{j}", out_c, rcross[i], rtlpb[i], lin)
+        if i != n - 1:
+            sh[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            sh[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (out_c,)
+    sh["conv_norm_out.weight"] = (boc[0],)
+    sh["conv_norm_out.bias"] = (boc[0],)
+    sh["conv_out.weight"] = (cfg["out_channels"], boc[0], 3, 3)
+    sh["conv_out.bias"] = (cfg["out_channels"],)
+    return sh
+
+
+def vae_decoder_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Decoder half (+ post_quant_conv) of AutoencoderKL's state_dict."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    boc = tuple(cfg["block_out_channels"])
+    lat = cfg["latent_channels"]
+    if cfg["use_post_quant_conv"]:
+        sh["post_quant_conv.weight"] = (lat, lat, 1, 1)
+        sh["post_quant_conv.bias"] = (lat,)
+    top = boc[-1]
+    sh["decoder.conv_in.weight"] = (top, lat, 3, 3)
+    sh["decoder.conv_in.bias"] = (top,)
+    _resnet(sh, "decoder.mid_block.resnets.0", top, top, 0)
+    if cfg["mid_block_add_attention"]:
+        a = "decoder.mid_block.attentions.0"
+        sh[f"{a}.group_norm.weight"] = (top,)
+        sh[f"{a}.group_norm.bias"] = (top,)
+        for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+            sh[f"{a}.{nm}.weight"] = (top, top)
+            sh[f"{a}.{nm}.bias"] = (top,)
+    _resnet(sh, "decoder.mid_block.resnets.1", top, top, 0)
+    rboc = tuple(reversed(boc))
+    out_c = rboc[0]
+    for i in range(len(boc)):
+        prev, out_c = out_c, rboc[i]
+        for j in range(cfg["layers_per_block"] + 1):
+            _resnet(sh, f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else out_c, out_c, 0)
+        if i != len(boc) - 1:
+            sh[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            sh[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"] = (out_c,)
+    sh["decoder.conv_norm_out.weight"] = (boc[0],)
+    sh["decoder.conv_norm_out.bias"] = (boc[0],)
+    sh["decoder.conv_out.weight"] = (cfg["out_channels"], boc[0], 3, 3)
+    sh["decoder.conv_out.bias"] = (cfg["out_channels"],)
+    return sh
+
+
+def _seed_for(name: str, seed: int) -> int:
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    return int.from_bytes(h[:7], "little")
+
+
+def random_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, device="cpu",
+                      dtype=torch.bfloat16) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic per-tensor init (independent of enumeration order): weights ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)),
+    norm scales ~ 1 + 0.1 N(0,1), biases ~ 0.1 N(0,1)... scaled by 1/sqrt(fan_in) of their layer.  Values are drawn in
+    fp32 then rounded to ``dtype`` so every consumer (engine, oracle, reference) sees bit-identical weights."""
+    dev = torch.device(device)
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in shapes.items():
+        g = torch.Generator(device=dev)
+        g.manual_seed(_seed_for(name, seed))
+        is_norm = ".norm" in name or "norm." in name or "group_norm" in name or name.startswith("conv_norm_out") \
+            or "conv_norm_out" in name
+        if is_norm and name.endswith(".weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=dev, dtype=torch.float32)
+        elif name.endswith(".bias"):
+            t = 0.05 * torch.randn(shape, generator=g, device=dev, dtype=torch.float32)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            b = 1.0 / (fan_in ** 0.5)
+            t = (torch.rand(shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1) * b
+        out[name] = t.to(dtype)
+    return out
+
+
+# ---- canonical configs of the BASELINE ----
+SDXL_UNET = dict(sample_size=128, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280),
+                 layers_per_block=2, cross_attention_dim=2048, attention_head_dim=(5, 10, 20),
+                 down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                 up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                 transformer_layers_per_block=(1, 2, 10), use_linear_projection=True, addition_embed_type="text_time",
+                 addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816)
+SD15_UNET = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+                 layers_per_block=2, cross_attention_dim=768, attention_head_dim=8,
+                 down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
+                 up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3)
+SD_VAE = dict(in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+              down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4,
+              latent_channels=4, sample_size=512, scaling_factor=0.18215)
+SDXL_VAE = dict(SD_VAE, sample_size=1024, scaling_factor=0.13025)
+# tiny members of the same families (every channel count a multiple of 64, head dim 64) for parity tests
+TINY_SDXL_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(64, 128),
+                      layers_per_block=1, cross_attention_dim=64, attention_head_dim=(1, 2),
+                      down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"),
+                      up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"), transformer_layers_per_block=(1, 2),
+                      use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=32,
+                      projection_class_embeddings_input_dim=256)
+TINY_SD15_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(64, 128),
+                      layers_per_block=1, cross_attention_dim=64, attention_head_dim=(1, 2),
+                      down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                      up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+TINY_VAE = dict(in_channels=3, out_channels=3, block_out_channels=(64, 128), layers_per_block=1,
+                down_block_types=("DownEncoderBlock2D",) * 2, up_block_types=("UpDecoderBlock2D",) * 2,
+                latent_channels=4, sample_size=32, scaling_factor=0.13025)

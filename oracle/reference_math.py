@@ -1,0 +1,228 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product package ``diffusers_amd``.
+
+CPU restatement (plain PyTorch, fp32 by default) of the reference's algorithm for the denoising hot path, written as
+functions over a reference-format ``state_dict``.  Every function cites the reference lines it follows (paths under
+/root/reference/src/diffusers/).  Parity status: PINNED -- ``oracle/make_golden.py`` runs the real reference classes in
+the build container on the same seeded weights/inputs and ``tests/test_oracle_vs_golden.py`` checks this restatement
+against those committed outputs (tests/golden/*.npz), plus the reference's own known-answer vectors for the schedulers
+(tests/schedulers/test_scheduler_{ddim,euler,ddpm}.py full-loop sums).
+
+The arithmetic (conv, matmul, softmax ...) is delegated to torch CPU ops exactly as the reference delegates it to torch
+(the reference has no kernels of its own; its third-party arithmetic dependency is torch>=2.6, here
+torch 2.10.0).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def _tup(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# op-level references
+# --------------------------------------------------------------------------------------------------------------------
+def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool, shift: float, scale: float = 1.0,
+                       max_period: float = 10000.0) -> torch.Tensor:
+    """models/embeddings.py:27-78 (get_timestep_embedding), fp32."""
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32)
+    exponent = exponent / (half - shift)
+    emb = torch.exp(exponent)
+    emb = t[:, None].float() * emb[None, :]
+    emb = scale * emb
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+def geglu(x, w, b):
+    """models/activations.py:93-124: proj -> chunk(2) -> hidden * gelu(gate)."""
+    h = F.linear(x, w, b)
+    h, gate = h.chunk(2, dim=-1)
+    return h * F.gelu(gate)
+
+
+def attention(q, k, v, heads: int, scale: Optional[float] = None):
+    """models/attention_processor.py:2753-2773: (B,S,H*D) -> heads -> softmax(q k^T / sqrt(D)) v -> (B,S,H*D)."""
+    B, Sq, C = q.shape
+    D = C // heads
+    qh = q.view(B, Sq, heads, D).transpose(1, 2)
+    kh = k.view(B, -1, heads, D).transpose(1, 2)
+    vh = v.view(B, -1, heads, D).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * (D ** -0.5 if scale is None else scale)
+    p = torch.softmax(s, dim=-1)
+    o = p @ vh
+    return o.transpose(1, 2).reshape(B, Sq, C)
+
+
+def resnet_block(sd: Dict[str, torch.Tensor], p: str, x, temb, groups: int, eps: float, out_scale: float = 1.0):
+    """models/resnet.py:319-377 (default time scale shift, SiLU)."""
+    h = F.group_norm(x, groups, sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"], eps)
+    h = F.silu(h)
+    h = F.conv2d(h, sd[f"{p}.conv1.weight"], sd[f"{p}.conv1.bias"], padding=1)
+    if temb is not None and f"{p}.time_emb_proj.weight" in sd:
+        t = F.linear(F.silu(temb), sd[f"{p}.time_emb_proj.weight"], sd[f"{p}.time_emb_proj.bias"])
+        h = h + t[:, :, None, None]
+    h = F.group_norm(h, groups, sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"], eps)
+    h = F.silu(h)
+    h = F.conv2d(h, sd[f"{p}.conv2.weight"], sd[f"{p}.conv2.bias"], padding=1)
+    if f"{p}.conv_shortcut.weight" in sd:
+        x = F.conv2d(x, sd[f"{p}.conv_shortcut.weight"], sd[f"{p}.conv_shortcut.bias"])
+    return (x + h) / out_scale
+
+
+def basic_transformer_block(sd, p: str, x, ctx, heads: int):
+    """models/attention.py:960-1080 (layer_norm variant) + AttnProcessor2_0 + FeedForward(geglu)."""
+    def attn(a, h, c):
+        q = F.linear(h, sd[f"{p}.{a}.to_q.weight"])
+        k = F.linear(c, sd[f"{p}.{a}.to_k.weight"])
+        v = F.linear(c, sd[f"{p}.{a}.to_v.weight"])
+        o = attention(q, k, v, heads)
+        return F.linear(o, sd[f"{p}.{a}.to_out.0.weight"], sd[f"{p}.{a}.to_out.0.bias"])
+
+    C = x.shape[-1]
+    h = F.layer_norm(x, (C,), sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"], 1e-5)
+    x = x + attn("attn1", h, h)
+    h = F.layer_norm(x, (C,), sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"], 1e-5)
+    x = x + attn("attn2", h, ctx)
+    h = F.layer_norm(x, (C,), sd[f"{p}.norm3.weight"], sd[f"{p}.norm3.bias"], 1e-5)
+    ff = geglu(h, sd[f"{p}.ff.net.0.proj.weight"], sd[f"{p}.ff.net.0.proj.bias"])
+    ff = F.linear(ff, sd[f"{p}.ff.net.2.weight"], sd[f"{p}.ff.net.2.bias"])
+    return x + ff
+
+
+def transformer_2d(sd, p: str, x, ctx, heads: int, layers: int, groups: int, linear_proj: bool):
+    """models/transformers/transformer_2d.py:324-512 (continuous)."""
+    B, C, H, W = x.shape
+    res = x
+    h = F.group_norm(x, groups, sd[f"{p}.norm.weight"], sd[f"{p}.norm.bias"], 1e-6)
+    if linear_proj:
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        h = F.linear(h, sd[f"{p}.proj_in.weight"], sd[f"{p}.proj_in.bias"])
+    else:
+        h = F.conv2d(h, sd[f"{p}.proj_in.weight"], sd[f"{p}.proj_in.bias"])
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    for k in range(layers):
+        h = basic_transformer_block(sd, f"{p}.transformer_blocks.{k}", h, ctx, heads)
+    if linear_proj:
+        h = F.linear(h, sd[f"{p}.proj_out.weight"], sd[f"{p}.proj_out.bias"])
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    else:
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        h = F.conv2d(h, sd[f"{p}.proj_out.weight"], sd[f"{p}.proj_out.bias"])
+    return h + res
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# UNet2DConditionModel.forward  (models/unets/unet_2d_condition.py:979-1235)
+# --------------------------------------------------------------------------------------------------------------------
+def unet_forward(sd: Dict[str, torch.Tensor], cfg: dict, sample, timestep, encoder_hidden_states,
+                 added_cond_kwargs: Optional[dict] = None):
+    boc = tuple(cfg["block_out_channels"])
+    n = len(boc)
+    groups, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    heads = _tup(cfg.get("num_attention_heads") or cfg["attention_head_dim"], n)
+    lpb = _tup(cfg["layers_per_block"], n)
+    tlpb = _tup(cfg["transformer_layers_per_block"], n)
+    lin = cfg["use_linear_projection"]
+    B = sample.shape[0]
+    dt = sample.dtype
+
+    t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1)
+    if t.numel() == 1:
+        t = t.expand(B)
+    t_emb = timestep_embedding(t, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"]).to(dt)          # :852-872
+    emb = F.linear(t_emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
+    emb = F.linear(F.silu(emb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    if cfg["addition_embed_type"] == "text_time":                                                   # :906-922
+        te = added_cond_kwargs["text_embeds"]
+        ids = added_cond_kwargs["time_ids"]
+        tid = timestep_embedding(ids.flatten().float(), cfg["addition_time_embed_dim"], cfg["flip_sin_to_cos"],
+                                 cfg["freq_shift"])
+        tid = tid.reshape(te.shape[0], -1)
+        add = torch.cat([te.float(), tid], dim=-1).to(dt)
+        aug = F.linear(add, sd["add_embedding.linear_1.weight"], sd["add_embedding.linear_1.bias"])
+        aug = F.linear(F.silu(aug), sd["add_embedding.linear_2.weight"], sd["add_embedding.linear_2.bias"])
+        emb = emb + aug
+
+    x = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)                       # :1108
+    skips = [x]
+    for i, bt in enumerate(cfg["down_block_types"]):                                                # :1136
+        for j in range(lpb[i]):
+            x = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", x, emb, groups, eps)
+            if bt == "CrossAttnDownBlock2D":
+                x = transformer_2d(sd, f"down_blocks.{i}.attentions.{j}", x, encoder_hidden_states, heads[i], tlpb[i],
+                                   groups, lin)
+            skips.append(x)
+        if i != n - 1:
+            p = f"down_blocks.{i}.downsamplers.0.conv"
+            x = F.conv2d(x, sd[f"{p}.weight"], sd[f"{p}.bias"], stride=2, padding=1)
+            skips.append(x)
+    x = resnet_block(sd, "mid_block.resnets.0", x, emb, groups, eps, cfg["mid_block_scale_factor"])  # :1171
+    x = transformer_2d(sd, "mid_block.attentions.0", x, encoder_hidden_states, heads[-1], tlpb[-1], groups, lin)
+    x = resnet_block(sd, "mid_block.resnets.1", x, emb, groups, eps, cfg["mid_block_scale_factor"])
+    rheads = tuple(reversed(heads))
+    rlpb = tuple(reversed(lpb))
+    rt = cfg.get("reverse_transformer_layers_per_block")
+    rtlpb = tuple(reversed(tlpb)) if rt is None else _tup(rt, n)
+    for i, bt in enumerate(cfg["up_block_types"]):                                                  # :1196
+        for j in range(rlpb[i] + 1):
+            x = torch.cat([x, skips.pop()], dim=1)                                                  # blocks.py:2444
+            x = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", x, emb, groups, eps)
+            if bt == "CrossAttnUpBlock2D":
+                x = transformer_2d(sd, f"up_blocks.{i}.attentions.{j}", x, encoder_hidden_states, rheads[i], rtlpb[i],
+                                   groups, lin)
+        if i != n - 1:
+            p = f"up_blocks.{i}.upsamplers.0.conv"
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")                                  # upsampling.py:177
+            x = F.conv2d(x, sd[f"{p}.weight"], sd[f"{p}.bias"], padding=1)
+    x = F.group_norm(x, groups, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps)          # :1227-1230
+    x = F.silu(x)
+    return F.conv2d(x, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# AutoencoderKL.decode  (autoencoder_kl.py:199-240, vae.py:279-311, unet_2d_blocks.py:736-748,:2637-2645)
+# --------------------------------------------------------------------------------------------------------------------
+def vae_attention(sd, p: str, x, groups: int, eps: float):
+    """Legacy 4-D Attention (attention_processor.py:2705-2787): GN, q/k/v with bias, 1 head, + residual."""
+    B, C, H, W = x.shape
+    res = x
+    h = F.group_norm(x, groups, sd[f"{p}.group_norm.weight"], sd[f"{p}.group_norm.bias"], eps)
+    h = h.view(B, C, H * W).transpose(1, 2)
+    q = F.linear(h, sd[f"{p}.to_q.weight"], sd[f"{p}.to_q.bias"])
+    k = F.linear(h, sd[f"{p}.to_k.weight"], sd[f"{p}.to_k.bias"])
+    v = F.linear(h, sd[f"{p}.to_v.weight"], sd[f"{p}.to_v.bias"])
+    o = attention(q, k, v, heads=1)
+    o = F.linear(o, sd[f"{p}.to_out.0.weight"], sd[f"{p}.to_out.0.bias"])
+    o = o.transpose(1, 2).reshape(B, C, H, W)
+    return o + res
+
+
+def vae_decode(sd: Dict[str, torch.Tensor], cfg: dict, z):
+    groups, eps = cfg["norm_num_groups"], 1e-6
+    boc = tuple(cfg["block_out_channels"])
+    if cfg["use_post_quant_conv"]:
+        z = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+    x = F.conv2d(z, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
+    x = resnet_block(sd, "decoder.mid_block.resnets.0", x, None, groups, eps)
+    if cfg["mid_block_add_attention"]:
+        x = vae_attention(sd, "decoder.mid_block.attentions.0", x, groups, eps)
+    x = resnet_block(sd, "decoder.mid_block.resnets.1", x, None, groups, eps)
+    for i in range(len(boc)):
+        for j in range(cfg["layers_per_block"] + 1):
+            x = resnet_block(sd, f"decoder.up_blocks.{i}.resnets.{j}", x, None, groups, eps)
+        if i != len(boc) - 1:
+            p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = F.conv2d(x, sd[f"{p}.weight"], sd[f"{p}.bias"], padding=1)
+    x = F.group_norm(x, groups, sd["decoder.conv_norm_out.weight"], sd["decoder.conv_norm_out.bias"], eps)
+    x = F.silu(x)
+    return F.conv2d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)

@@ -1,0 +1,206 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference schedulers' per-step math.
+
+Follows (paths under /root/reference/src/diffusers/):
+  Euler      schedulers/scheduling_euler_discrete.py:203-276 (tables), :350-481 (set_timesteps), :326-348, :685-800
+  DDIM       schedulers/scheduling_ddim.py:212-236, :334-382, :384-514
+  DDPM       schedulers/scheduling_ddpm.py:348-416, :461-567
+  FlowMatch  schedulers/scheduling_flow_match_euler_discrete.py:283-382, :423-523
+  CFG        pipelines/stable_diffusion/pipeline_stable_diffusion.py:1054-1055
+
+Pinned against the reference's own known-answer vectors (tests/schedulers/test_scheduler_euler.py:129-137 -> 10.0807 /
+0.0131; test_scheduler_ddim.py:114-150 -> 172.0067, 149.8295, 149.0784; test_scheduler_ddpm.py:75-104 -> 258.9606) in
+tests/test_oracle_schedulers.py, and against live reference runs frozen in tests/golden/schedulers.npz.
+Tensor ops are torch CPU ops, so dtype promotion / rounding points are the reference's by construction.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+def make_betas(schedule: str, beta_start: float, beta_end: float, n: int) -> torch.Tensor:
+    if schedule == "linear":
+        return torch.linspace(beta_start, beta_end, n, dtype=torch.float32)
+    if schedule == "scaled_linear":
+        return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    raise NotImplementedError(schedule)
+
+
+def spaced_timesteps(spacing: str, n_train: int, n_inf: int, steps_offset: int, as_float: bool) -> np.ndarray:
+    if spacing == "linspace":
+        if as_float:
+            return np.linspace(0, n_train - 1, n_inf, dtype=np.float32)[::-1].copy()
+        return np.linspace(0, n_train - 1, n_inf).round()[::-1].copy().astype(np.int64)
+    if spacing == "leading":
+        ratio = n_train // n_inf
+        ts = (np.arange(0, n_inf) * ratio).round()[::-1].copy()
+        ts = ts.astype(np.float32 if as_float else np.int64)
+        return ts + steps_offset
+    if spacing == "trailing":
+        ratio = n_train / n_inf
+        ts = np.round(np.arange(n_train, 0, -ratio))
+        ts = ts.astype(np.float32 if as_float else np.int64)
+        return ts - 1
+    raise ValueError(spacing)
+
+
+def cfg_combine(uncond: torch.Tensor, cond: torch.Tensor, g: float) -> torch.Tensor:
+    return uncond + g * (cond - uncond)
+
+
+class EulerOracle:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 timestep_spacing="linspace", steps_offset=0):
+        self.n_train = num_train_timesteps
+        self.spacing, self.offset = timestep_spacing, steps_offset
+        betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).flip(0)
+        self.sigmas = torch.cat([sig, torch.zeros(1)])
+        self.step_index = 0
+
+    @property
+    def init_noise_sigma(self):
+        m = self.sigmas.max()
+        return m if self.spacing in ("linspace", "trailing") else (m ** 2 + 1) ** 0.5
+
+    def set_timesteps(self, n):
+        ts = spaced_timesteps(self.spacing, self.n_train, n, self.offset, as_float=True)
+        base = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sig = np.interp(ts, np.arange(0, len(base)), base)
+        sig = np.concatenate([sig, [0]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sig)
+        self.timesteps = torch.from_numpy(ts.astype(np.float32))
+        self.step_index = 0
+
+    def scale_model_input(self, sample):
+        sigma = self.sigmas[self.step_index]
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def step(self, model_output, sample):
+        sample = sample.to(torch.float32)
+        sigma = self.sigmas[self.step_index]
+        sigma_hat = sigma * (0.0 + 1)
+        pred_original = sample - sigma_hat * model_output
+        derivative = (sample - pred_original) / sigma_hat
+        dt = self.sigmas[self.step_index + 1] - sigma_hat
+        prev = sample + derivative * dt
+        self.step_index += 1
+        return prev.to(model_output.dtype)
+
+
+class DDIMOracle:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 clip_sample=True, set_alpha_to_one=True, steps_offset=0, timestep_spacing="leading",
+                 clip_sample_range=1.0):
+        self.n_train = num_train_timesteps
+        betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.clip, self.clip_range = clip_sample, clip_sample_range
+        self.spacing, self.offset = timestep_spacing, steps_offset
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n):
+        self.n_inf = n
+        self.timesteps = torch.from_numpy(spaced_timesteps(self.spacing, self.n_train, n, self.offset, as_float=False))
+
+    def step(self, model_output, timestep, sample, eta=0.0, variance_noise=None):
+        t = int(timestep)
+        prev_t = t - self.n_train // self.n_inf
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        b_t = 1 - a_t
+        x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+        if self.clip:
+            x0 = x0.clamp(-self.clip_range, self.clip_range)
+        variance = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
+        std = eta * variance ** 0.5
+        direction = (1 - a_prev - std ** 2) ** 0.5 * model_output
+        prev = a_prev ** 0.5 * x0 + direction
+        if eta > 0:
+            prev = prev + std * variance_noise
+        return prev
+
+
+class DDPMOracle:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 variance_type="fixed_small", clip_sample=True, clip_sample_range=1.0, timestep_spacing="leading",
+                 steps_offset=0):
+        self.n_train = num_train_timesteps
+        betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.one = torch.tensor(1.0)
+        self.variance_type = variance_type
+        self.clip, self.clip_range = clip_sample, clip_sample_range
+        self.spacing, self.offset = timestep_spacing, steps_offset
+        self.n_inf = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy())
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n):
+        self.n_inf = n
+        self.timesteps = torch.from_numpy(spaced_timesteps(self.spacing, self.n_train, n, self.offset, as_float=False))
+
+    def _prev(self, t):
+        return t - self.n_train // self.n_inf if self.n_inf else t - 1
+
+    def step(self, model_output, timestep, sample, generator=None, noise=None):
+        t = int(timestep)
+        prev_t = self._prev(t)
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        cur_a = a_t / a_prev
+        cur_b = 1 - cur_a
+        x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+        if self.clip:
+            x0 = x0.clamp(-self.clip_range, self.clip_range)
+        k0 = (a_prev ** 0.5 * cur_b) / b_t
+        kx = cur_a ** 0.5 * b_prev / b_t
+        prev = k0 * x0 + kx * sample
+        variance = 0
+        if t > 0:
+            if noise is None:
+                noise = torch.randn(model_output.shape, generator=generator, dtype=model_output.dtype)
+            var = torch.clamp((1 - a_prev) / (1 - a_t) * cur_b, min=1e-20)
+            if self.variance_type == "fixed_large":
+                var = cur_b
+            variance = (var ** 0.5) * noise
+        return prev + variance
+
+
+class FlowMatchOracle:
+    def __init__(self, num_train_timesteps=1000, shift=1.0, use_dynamic_shifting=False):
+        self.n_train = num_train_timesteps
+        self.shift, self.dynamic = shift, use_dynamic_shifting
+        ts = torch.from_numpy(np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy())
+        sig = ts / num_train_timesteps
+        if not use_dynamic_shifting:
+            sig = shift * sig / (1 + (shift - 1) * sig)
+        self.sigma_min, self.sigma_max = sig[-1].item(), sig[0].item()
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n=None, sigmas=None, mu=None):
+        if sigmas is None:
+            ts = np.linspace(self.sigma_max * self.n_train, self.sigma_min * self.n_train, n)
+            sig = ts / self.n_train
+        else:
+            sig = np.array(sigmas).astype(np.float32)
+        if self.dynamic:
+            sig = math.exp(mu) / (math.exp(mu) + (1 / sig - 1) ** 1.0)
+        else:
+            sig = self.shift * sig / (1 + (self.shift - 1) * sig)
+        sig = torch.from_numpy(np.asarray(sig)).to(torch.float32)
+        self.timesteps = sig * self.n_train
+        self.sigmas = torch.cat([sig, torch.zeros(1)])
+        self.step_index = 0
+
+    def step(self, model_output, sample):
+        sample = sample.to(torch.float32)
+        dt = self.sigmas[self.step_index + 1] - self.sigmas[self.step_index]
+        prev = sample + dt * model_output
+        self.step_index += 1
+        return prev.to(model_output.dtype)

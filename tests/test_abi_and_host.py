@@ -1,0 +1,155 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/diffusers_amd.h declares; host-side logic of the
+product (schedule tables, parameter inventories, weight packing, argument validation) -- no kernel is launched."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _header_functions():
+    src = (ROOT / "include" / "diffusers_amd.h").read_text()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(da_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from diffusers_amd import _lib as L
+    from diffusers_amd.build import build_extension
+    build_extension()
+    lib = L.load()
+    declared = _header_functions()
+    assert "da_gemm_bf16" in declared and "da_attention_bf16" in declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/diffusers_amd.h but not exported"
+    assert sorted(L.SIGNATURES) == declared, "ctypes signature table and header disagree"
+    assert lib.da_version() >= 1
+
+
+def test_struct_layout_matches_header_field_order():
+    from diffusers_amd import _lib as L
+    src = (ROOT / "include" / "diffusers_amd.h").read_text()
+    for cname, cls in (("da_gemm_params", L.GemmParams), ("da_attention_params", L.AttentionParams)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            parts = decl.replace("*", " ").split(",")
+            first = parts[0].split()
+            names.append(first[-1])
+            names += [p.strip() for p in parts[1:]]
+        assert names == [f[0] for f in cls._fields_], cname
+
+
+def test_ops_refuse_cpu_tensors():
+    from diffusers_amd import ops
+    x = torch.zeros((64, 64), dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.linear(x, x)
+
+
+def test_scheduler_tables_match_reference(golden):
+    """Host-side schedule construction of the product schedulers vs tables produced by the reference classes."""
+    from diffusers_amd import schedulers as S
+    gz = golden("schedulers")
+    e = S.EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                                 timestep_spacing="leading")
+    e.set_timesteps(50, device="cpu")
+    assert np.array_equal(e.timesteps.numpy(), gz["euler50_timesteps"])
+    assert np.array_equal(e.sigmas.numpy(), gz["euler50_sigmas"])
+    assert float(e.init_noise_sigma) == float(gz["euler50_init_sigma"])
+    tab = e.device_table.numpy()
+    assert tab.shape == (50, 8)
+    assert np.array_equal(tab[:, 0], gz["euler50_sigmas"][:-1]) and np.array_equal(tab[:, 1], gz["euler50_sigmas"][1:])
+    assert np.array_equal(tab[:, 7], gz["euler50_timesteps"])
+    d = S.DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                        set_alpha_to_one=False, steps_offset=1)
+    d.set_timesteps(50, device="cpu")
+    assert np.array_equal(d.timesteps.numpy(), gz["ddim50_timesteps"])
+    f = S.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    f.set_timesteps(sigmas=np.linspace(1.0, 1 / 4, 4), device="cpu")
+    assert np.array_equal(f.timesteps.numpy(), gz["flow4_timesteps"])
+    assert np.array_equal(f.sigmas.numpy(), gz["flow4_sigmas"])
+    fd = S.FlowMatchEulerDiscreteScheduler(shift=3.0, use_dynamic_shifting=True)
+    fd.set_timesteps(sigmas=np.linspace(1.0, 1 / 28, 28), mu=1.15, device="cpu")
+    assert np.array_equal(fd.sigmas.numpy(), gz["flowdyn28_sigmas"])
+    with pytest.raises(ValueError, match="mu"):
+        fd.set_timesteps(num_inference_steps=4, device="cpu")
+    p = S.DDPMScheduler()
+    p.set_timesteps(5, device="cpu")
+    assert p.timesteps.tolist() == [800, 600, 400, 200, 0]
+    d2 = S.DDIMScheduler(steps_offset=1)
+    d2.set_timesteps(5, device="cpu")
+    assert d2.timesteps.tolist() == [801, 601, 401, 201, 1]  # reference tests/schedulers/test_scheduler_ddim.py:46-54
+
+
+def test_scheduler_error_behaviour():
+    from diffusers_amd import schedulers as S
+    e = S.EulerDiscreteScheduler()
+    with pytest.raises(ValueError, match="exactly one"):
+        e.set_timesteps(None)
+    e.set_timesteps(4, device="cpu")
+    with pytest.raises(ValueError, match="integer indices"):
+        e.step(torch.zeros(1), 0, torch.zeros(1))
+    with pytest.raises(TypeError):
+        S.EulerDiscreteScheduler(bogus=1)
+    with pytest.raises(NotImplementedError):
+        S.EulerDiscreteScheduler(use_karras_sigmas=True)
+
+
+def test_param_inventory_counts():
+    """Parameter counts of the canonical configs (859.52 M, 2567.46 M, decoder 49.49 M)."""
+    from diffusers_amd import init as dinit
+    from diffusers_amd.autoencoder_kl import _DEFAULTS as VD
+    from diffusers_amd.unet_2d_condition import _DEFAULTS as UD
+
+    def count(shapes):
+        return sum(int(np.prod(s)) for s in shapes.values())
+
+    sdxl = dict(UD)
+    sdxl.update(dinit.SDXL_UNET)
+    sd15 = dict(UD)
+    sd15.update(dinit.SD15_UNET)
+    vae = dict(VD)
+    vae.update(dinit.SDXL_VAE)
+    assert abs(count(dinit.unet_param_shapes(sdxl)) / 1e6 - 2567.46) < 0.01
+    assert abs(count(dinit.unet_param_shapes(sd15)) / 1e6 - 859.52) < 0.01
+    assert abs(count(dinit.vae_decoder_param_shapes(vae)) / 1e6 - 49.49) < 0.01
+
+
+def test_weight_packing_roundtrip():
+    from diffusers_amd import ops
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = ops.pack_conv_weight(w)
+    assert p.shape == (2, 27)
+    assert p[1, (2 * 3 + 1) * 3 + 2] == w[1, 2, 2, 1]  # K index = (kh*3+kw)*Cin + c
+    wg = torch.arange(256 * 4, dtype=torch.float32).reshape(256, 4)
+    bg = torch.arange(256, dtype=torch.float32)
+    wp, bp = ops.pack_geglu(wg, bg)
+    # group 1 (rows 64..127 of the packed matrix) = value rows 32..63 then gate rows 128+32..128+63
+    assert torch.equal(bp[64:96], bg[32:64]) and torch.equal(bp[96:128], bg[160:192])
+    assert torch.equal(wp[96], wg[160])
+
+
+def test_model_config_validation():
+    from diffusers_amd.autoencoder_kl import AutoencoderKL
+    from diffusers_amd.unet_2d_condition import UNet2DConditionModel
+    with pytest.raises(ValueError, match="does not exist"):
+        UNet2DConditionModel(down_block_types=("Bogus",) * 4)
+    with pytest.raises(ValueError, match="same number"):
+        UNet2DConditionModel(block_out_channels=(64, 128))
+    with pytest.raises(TypeError):
+        UNet2DConditionModel(not_a_key=1)
+    m = UNet2DConditionModel()
+    assert m.config.cross_attention_dim == 1280 and m.config["norm_num_groups"] == 32
+    with pytest.raises(RuntimeError, match="load_state_dict"):
+        m.forward(torch.zeros(1), 1, torch.zeros(1))
+    with pytest.raises(NotImplementedError):
+        AutoencoderKL().encode(None)

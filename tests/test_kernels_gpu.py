@@ -1,0 +1,365 @@
+"""GPU parity tests of every HIP kernel, called through the C ABI (diffusers_amd.ops -> ctypes -> libdiffusers_amd.so)
+and checked against plain PyTorch fp32 references of the same op / the oracle restatement / the golden vectors."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close_bf16, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+DEV = "cuda"
+
+
+def _ops():
+    from diffusers_amd import _lib as L
+    from diffusers_amd import ops
+    return ops, L
+
+
+def rnd(shape, seed, scale=1.0, dtype=bf16):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(256, 256, 256), (154, 1280, 2048), (2048, 1280, 1280), (1000, 324, 320), (128, 64, 64), (8192, 640, 640),
+               (96, 132, 192)]
+
+
+@pytest.mark.parametrize("staging", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_plain(M, N, K, tile, staging):
+    ops, L = _ops()
+    x = rnd((M, K), 1)
+    w = rnd((N, K), 2, scale=K ** -0.5)
+    y = ops.linear(x, w, tile=tile, staging=staging)
+    ref = x.float() @ w.float().t()
+    assert y.shape == (M, N)
+    assert_close_bf16(y, ref, f"gemm {M}x{N}x{K} tile={tile} stage={staging}", rtol=8e-3, atol_rms=4e-3)
+
+
+@pytest.mark.parametrize("staging", [0, 1])
+def test_gemm_epilogues(staging):
+    ops, L = _ops()
+    M, N, K = 520, 384, 448
+    x, w = rnd((M, K), 3), rnd((N, K), 4, scale=K ** -0.5)
+    bias, res = rnd((N,), 5), rnd((M, N), 6)
+    rowvec = rnd((4, N), 7)
+    y = ops.linear(x, w, bias, residual=res, rowvec=rowvec, rows_per_batch=130, out_scale=0.5, staging=staging)
+    ref = x.float() @ w.float().t() + bias.float() + rowvec.float().repeat_interleave(130, 0) + res.float()
+    assert_close_bf16(y, ref * 0.5, "gemm bias+rowvec+residual+scale", rtol=8e-3, atol_rms=4e-3)
+    # fp32 output with alpha (attention scores)
+    s = ops.linear(x, w, alpha=0.125, out_f32=True, staging=staging)
+    assert s.dtype == torch.float32
+    assert_close_bf16(s, 0.125 * (x.float() @ w.float().t()), "gemm f32 out + alpha", rtol=1e-4, atol_rms=1e-4)
+    # activations
+    for act, fn in ((L.ACT_SILU, F.silu), (L.ACT_GELU_TANH, lambda t: F.gelu(t, approximate="tanh")),
+                    (L.ACT_GELU_ERF, F.gelu)):
+        y = ops.linear(x, w, bias, act=act, staging=staging)
+        assert_close_bf16(y, fn(x.float() @ w.float().t() + bias.float()), f"gemm act {act}", rtol=1.6e-2, atol_rms=8e-3)
+
+
+@pytest.mark.parametrize("staging", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_gemm_geglu(tile, staging):
+    ops, L = _ops()
+    M, C = 300, 128
+    x = rnd((M, C), 8)
+    w = rnd((8 * C, C), 9, scale=C ** -0.5)
+    b = rnd((8 * C,), 10, scale=0.1)
+    wp, bp = ops.pack_geglu(w, b)
+    y = ops.linear(x, wp, bp, act=L.ACT_GEGLU, tile=tile, staging=staging)
+    h = x.float() @ w.float().t() + b.float()
+    hv, gate = h.chunk(2, dim=-1)
+    assert y.shape == (M, 4 * C)
+    assert_close_bf16(y, hv * F.gelu(gate), f"geglu tile={tile}", rtol=1.6e-2, atol_rms=8e-3)
+
+
+def test_gemm_strided_views_and_transposed_v():
+    """Exactly the call patterns of layers.Attention: fused QK output consumed through column views, V^T = W_v . X^T."""
+    ops, L = _ops()
+    M, C = 512, 128
+    x = rnd((M, C), 11)
+    wv = rnd((C, C), 12, scale=C ** -0.5)
+    vt = ops.linear(wv, x)  # [C][M]
+    assert_close_bf16(vt, wv.float() @ x.float().t(), "V^T gemm", rtol=8e-3, atol_rms=4e-3)
+    big = rnd((M, 2 * C), 13)
+    y = ops.linear(big[:, C:], wv)  # row stride 2C, offset C
+    assert_close_bf16(y, big[:, C:].float() @ wv.float().t(), "gemm on strided view", rtol=8e-3, atol_rms=4e-3)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# implicit-GEMM conv
+# ----------------------------------------------------------------------------------------------------------------------
+def _conv_ref(x_nhwc, w_oihw, bias, stride=1, up=False, pad=1):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if up:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(x, w_oihw.float(), bias.float() if bias is not None else None, stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("staging", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [
+    (2, 16, 16, 64, 128, 1, False), (1, 13, 9, 128, 64, 1, False), (2, 16, 16, 64, 64, 2, False),
+    (2, 8, 8, 128, 128, 1, True), (1, 32, 32, 320, 320, 1, False), (1, 17, 17, 64, 68, 2, False)])
+def test_conv3x3(B, H, W, Cin, Cout, stride, up, staging):
+    ops, L = _ops()
+    x = rnd((B, H, W, Cin), 20)
+    w = rnd((Cout, Cin, 3, 3), 21, scale=(9 * Cin) ** -0.5)
+    b = rnd((Cout,), 22, scale=0.1)
+    for tile in (0, 1, 4):
+        y = ops.conv2d_nhwc(x, ops.pack_conv_weight(w), b, ksize=3, stride=stride, up=up, tile=tile, staging=staging)
+        ref = _conv_ref(x, w, b, stride, up)
+        assert y.shape == ref.shape
+        assert_close_bf16(y, ref, f"conv3x3 {B}x{H}x{W}x{Cin}->{Cout} s{stride} up{up} tile{tile}", rtol=8e-3, atol_rms=4e-3)
+
+
+@pytest.mark.parametrize("staging", [0, 1])
+def test_conv_concat_rowvec_residual(staging):
+    ops, L = _ops()
+    B, H, W, C1, C2, Cout = 2, 12, 12, 128, 64, 128
+    x1, x2 = rnd((B, H, W, C1), 23), rnd((B, H, W, C2), 24)
+    w = rnd((Cout, C1 + C2, 3, 3), 25, scale=(9 * (C1 + C2)) ** -0.5)
+    b, tv = rnd((Cout,), 26, scale=0.1), rnd((B, Cout), 27)
+    res = rnd((B, H, W, Cout), 28)
+    y = ops.conv2d_nhwc(x1, ops.pack_conv_weight(w), b, ksize=3, x2=x2, rowvec=tv, residual=res, out_scale=0.5,
+                        staging=staging)
+    ref = _conv_ref(torch.cat([x1, x2], -1), w, b) + tv.float()[:, None, None, :] + res.float()
+    assert_close_bf16(y, ref * 0.5, "conv3x3 concat+temb+residual", rtol=8e-3, atol_rms=4e-3)
+    # 1x1 shortcut over the same two sources
+    w1 = rnd((Cout, C1 + C2, 1, 1), 29, scale=(C1 + C2) ** -0.5)
+    y1 = ops.conv2d_nhwc(x1, w1.reshape(Cout, -1).contiguous(), b, ksize=1, x2=x2, staging=staging)
+    ref1 = _conv_ref(torch.cat([x1, x2], -1), w1, b, pad=0)
+    assert_close_bf16(y1, ref1, "conv1x1 concat", rtol=8e-3, atol_rms=4e-3)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, H):
+    from oracle.reference_math import attention
+    return attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), H)
+
+
+@pytest.mark.parametrize("B,H,D,Sq,Skv", [(2, 3, 64, 256, 256), (1, 2, 64, 200, 200), (2, 2, 64, 128, 77),
+                                         (1, 5, 64, 1024, 1024), (1, 2, 128, 192, 320), (2, 1, 128, 64, 77)])
+def test_flash_attention(B, H, D, Sq, Skv):
+    ops, L = _ops()
+    C = H * D
+    q, k, v = rnd((B, Sq, C), 30), rnd((B, Skv, C), 31), rnd((B, Skv, C), 32)
+    skv_alloc = ((Skv + 15) // 16) * 16
+    kp = torch.zeros((B, skv_alloc, C), device=DEV, dtype=bf16)
+    kp[:, :Skv] = k
+    vt = torch.zeros((C, B * skv_alloc), device=DEV, dtype=bf16)
+    vt.view(C, B, skv_alloc)[:, :, :Skv] = v.permute(2, 0, 1)
+    o = ops.attention(q.view(B * Sq, C), kp.view(B * skv_alloc, C), vt, B=B, H=H, D=D, Sq=Sq, Skv=Skv,
+                      Skv_alloc=skv_alloc, q_row_stride=C, k_row_stride=C, q_batch_stride=Sq * C,
+                      k_batch_stride=skv_alloc * C, vt_ld=B * skv_alloc, vt_batch_stride=skv_alloc)
+    ref = _attn_ref(q, k, v, H).view(B * Sq, C)
+    assert_close_bf16(o, ref, f"flash attn B{B} H{H} D{D} Sq{Sq} Skv{Skv}", rtol=1.6e-2, atol_rms=1.6e-2)
+
+
+def test_flash_attention_rescale_branch():
+    """Force the online-softmax running max to jump late: one key matches one query far more than the others."""
+    ops, L = _ops()
+    B, H, D, S = 1, 1, 64, 512
+    q, k, v = rnd((B, S, D), 33), rnd((B, S, D), 34), rnd((B, S, D), 35)
+    k[0, 400] = q[0, 17] * 4.0
+    k[0, 3] = q[0, 100] * 3.0
+    vt = v.permute(2, 0, 1).reshape(D, B * S).contiguous()
+    o = ops.attention(q.view(S, D), k.view(S, D), vt, B=B, H=H, D=D, Sq=S, Skv=S, Skv_alloc=S, q_row_stride=D,
+                      k_row_stride=D, q_batch_stride=S * D, k_batch_stride=S * D, vt_ld=S, vt_batch_stride=S)
+    assert_close_bf16(o, _attn_ref(q, k, v, H).view(S, D), "flash attn spiked keys", rtol=1.6e-2, atol_rms=1.6e-2)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# norms
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 64, True), (2, 1024, 320, True), (1, 4096, 128, False),
+                                        (2, 64, 1280, True), (1, 100, 960, True), (2, 16, 2560, False)])
+def test_groupnorm(B, HW, C, silu):
+    ops, L = _ops()
+    x = rnd((B, HW, C), 40, scale=2.0) + 0.5
+    g, b = rnd((C,), 41) * 0.1 + 1.0, rnd((C,), 42, scale=0.1)
+    y = ops.group_norm_nhwc(x, g, b, 32, 1e-5, silu=silu)
+    ref = F.group_norm(x.float().transpose(1, 2), 32, g.float(), b.float(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    assert_close_bf16(y, ref.transpose(1, 2), f"groupnorm B{B} HW{HW} C{C} silu{silu}", rtol=1.6e-2, atol_rms=8e-3)
+
+
+def test_groupnorm_two_sources():
+    ops, L = _ops()
+    B, HW, C1, C2 = 2, 144, 640, 320
+    x1, x2 = rnd((B, HW, C1), 43), rnd((B, HW, C2), 44, scale=3.0)
+    g, b = rnd((C1 + C2,), 45) * 0.1 + 1.0, rnd((C1 + C2,), 46, scale=0.1)
+    y = ops.group_norm_nhwc(x1, g, b, 32, 1e-5, silu=True, x2=x2)
+    ref = F.silu(F.group_norm(torch.cat([x1, x2], -1).float().transpose(1, 2), 32, g.float(), b.float(), 1e-5))
+    assert_close_bf16(y, ref.transpose(1, 2), "groupnorm fused concat", rtol=1.6e-2, atol_rms=8e-3)
+
+
+@pytest.mark.parametrize("M,C", [(100, 320), (2048, 640), (513, 1280), (64, 3072), (7, 1536), (33, 64)])
+def test_layernorm(M, C):
+    ops, L = _ops()
+    x = rnd((M, C), 47, scale=1.5) + 0.3
+    g, b = rnd((C,), 48) * 0.1 + 1.0, rnd((C,), 49, scale=0.1)
+    y = ops.layer_norm(x, g, b, 1e-5)
+    assert_close_bf16(y, F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5), f"layernorm {M}x{C}", rtol=8e-3, atol_rms=4e-3)
+    sc, sh = rnd((2, C), 50, scale=0.3), rnd((2, C), 51, scale=0.3)
+    if M % 2 == 0:
+        y2 = ops.layer_norm(x, None, None, 1e-6, mod_scale=sc, mod_shift=sh, rows_per_batch=M // 2)
+        ln = F.layer_norm(x.float(), (C,), None, None, 1e-6)
+        ref = ln * (1 + sc.float().repeat_interleave(M // 2, 0)) + sh.float().repeat_interleave(M // 2, 0)
+        assert_close_bf16(y2, ref, f"adaLN {M}x{C}", rtol=1.6e-2, atol_rms=8e-3)
+
+
+def test_softmax_rows():
+    ops, L = _ops()
+    s = (torch.randn((300, 4096), generator=torch.Generator().manual_seed(52)) * 3).to(DEV)
+    p = ops.softmax_rows(s)
+    assert_close_bf16(p, torch.softmax(s.float(), -1), "softmax rows", rtol=8e-3, atol_rms=1e-3)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sampler: bit-exact against trajectories produced by the real reference schedulers (tests/golden/schedulers.npz)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+def test_sampler_bit_exact_vs_reference(golden, dt_name):
+    from diffusers_amd import schedulers as S
+    ops, L = _ops()
+    gz = golden("schedulers")
+    dt = torch.float32 if dt_name == "f32" else bf16
+    x0 = torch.from_numpy(gz[f"x0_{dt_name}"]).to(dt).to(DEV)
+    eps = torch.from_numpy(gz[f"eps_{dt_name}"]).to(dt).to(DEV)
+
+    def check(traj, name):
+        ref = torch.from_numpy(gz[name]).to(dt)
+        got = torch.stack([t.cpu() for t in traj])
+        nbad = int((got.view(torch.int16 if dt == bf16 else torch.int32) != ref.view(torch.int16 if dt == bf16 else torch.int32)).sum())
+        print(f"[parity] {name}: mismatching elements = {nbad}/{got.numel()} max_abs={float((got.float()-ref.float()).abs().max()):.3e}")
+        assert nbad == 0, f"{name}: {nbad} elements differ from the reference trajectory"
+
+    e = S.EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                                 timestep_spacing="leading")
+    e.set_timesteps(5, device=DEV)
+    x = ops.mul_scalar(x0, float(e.init_noise_sigma))
+    check([x], f"euler_start_{dt_name}") if False else None
+    traj, scaled = [], []
+    for i, t in enumerate(e.timesteps):
+        scaled.append(e.scale_model_input(x, t))
+        x = e.step(eps[i], t, x).prev_sample
+        traj.append(x)
+    check(scaled, f"euler_scaled_{dt_name}")
+    check(traj, f"euler_traj_{dt_name}")
+
+    d = S.DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                        set_alpha_to_one=False, steps_offset=1)
+    d.set_timesteps(5, device=DEV)
+    x, traj = x0.clone(), []
+    for i, t in enumerate(d.timesteps):
+        x = d.step(eps[i], t, x).prev_sample
+        traj.append(x)
+    check(traj, f"ddim_traj_{dt_name}")
+
+    p = S.DDPMScheduler(beta_start=0.0001, beta_end=0.02, beta_schedule="linear", variance_type="fixed_small",
+                        clip_sample=True)
+    p.set_timesteps(5, device=DEV)
+    gg = torch.Generator("cpu").manual_seed(9)
+    x, traj = x0.clone(), []
+    for i, t in enumerate(p.timesteps):
+        x = p.step(eps[i], t, x, generator=gg).prev_sample
+        traj.append(x)
+    check(traj, f"ddpm_traj_{dt_name}")
+
+    f = S.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    f.set_timesteps(sigmas=np.linspace(1.0, 1 / 5, 5), device=DEV)
+    x, traj = x0.clone(), []
+    for i, t in enumerate(f.timesteps):
+        x = f.step(eps[i], t, x).prev_sample
+        traj.append(x)
+    check(traj, f"flow_traj_{dt_name}")
+
+
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+def test_fused_cfg_step_equals_unfused(golden, dt_name):
+    """step_cfg([u;c]) == step(u + g*(c-u)) bit for bit, and the CFG combine matches the reference's."""
+    from diffusers_amd import schedulers as S
+    from oracle.samplers import EulerOracle, cfg_combine
+    gz = golden("schedulers")
+    dt = torch.float32 if dt_name == "f32" else bf16
+    eps = torch.from_numpy(gz[f"eps_{dt_name}"]).to(dt)
+    x0 = torch.from_numpy(gz[f"x0_{dt_name}"]).to(dt)
+    u, c = eps[0], eps[1]
+    comb = cfg_combine(u, c, 7.5)
+    assert torch.equal(comb.float(), torch.from_numpy(gz[f"cfg_{dt_name}"]))
+    o = EulerOracle(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="leading",
+                    steps_offset=1)
+    o.set_timesteps(5)
+    want = o.step(comb, x0)
+    e = S.EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                                 timestep_spacing="leading")
+    e.set_timesteps(5, device=DEV)
+    got = e.step_cfg(torch.cat([u, c], 0).to(DEV), x0.to(DEV), 7.5)
+    assert torch.equal(got.cpu(), want), "fused CFG+Euler differs from reference order of operations"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# misc
+# ----------------------------------------------------------------------------------------------------------------------
+def test_timestep_embedding():
+    from oracle.reference_math import timestep_embedding as ref_te
+    ops, L = _ops()
+    t = torch.tensor([981.0, 1.0, 500.5, 0.0])
+    for dim, flip, shift in ((320, True, 0.0), (256, True, 0.0), (128, False, 1.0)):
+        got = ops.timestep_embedding(t.to(DEV), dim, batch=4, flip_sin_to_cos=flip, shift=shift, out_f32=True)
+        ref = ref_te(t, dim, flip, shift)
+        err = float((got.cpu() - ref).abs().max())
+        print(f"[parity] timestep_embedding dim={dim}: max_abs={err:.3e}")
+        assert err < 2e-3  # sin/cos of arguments up to 1e3: fp32 argument rounding differs by ulps between libms
+        got16 = ops.timestep_embedding(t.to(DEV), dim, batch=4, flip_sin_to_cos=flip, shift=shift)
+        assert float((got16.float().cpu() - ref).abs().max()) < 6e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(2, 1280, 320), (2, 1280, 2816), (1, 320, 1280), (6, 64, 256), (8, 132, 64)])
+def test_linear_small_m(M, N, K):
+    ops, L = _ops()
+    x, w, b = rnd((M, K), 60), rnd((N, K), 61, scale=K ** -0.5), rnd((N,), 62, scale=0.1)
+    res = rnd((M, N), 63)
+    y = ops.linear_small_m(x, w, b)
+    assert_close_bf16(y, x.float() @ w.float().t() + b.float(), f"small-M linear {M}x{N}x{K}", rtol=8e-3, atol_rms=4e-3)
+    y = ops.linear_small_m(x, w, b, act_in=L.ACT_SILU)
+    assert_close_bf16(y, F.silu(x.float()).to(bf16).float() @ w.float().t() + b.float(), "small-M silu-in", rtol=8e-3, atol_rms=4e-3)
+    y = ops.linear_small_m(x, w, b, act_out=L.ACT_SILU, residual=res)
+    assert_close_bf16(y, F.silu(x.float() @ w.float().t() + b.float()) + res.float(), "small-M silu-out+res", rtol=1.6e-2, atol_rms=8e-3)
+
+
+def test_conv_thin_in_out():
+    ops, L = _ops()
+    B, Cin, H, W, Cout = 2, 4, 16, 16, 64
+    x = rnd((B, Cin, H, W), 64)
+    w, b = rnd((Cout, Cin, 3, 3), 65, scale=(9 * Cin) ** -0.5), rnd((Cout,), 66, scale=0.1)
+    y = ops.conv_thin_in(x, ops.pack_conv_weight(w), b, ksize=3, in_nchw=True)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    assert_close_bf16(y, ref, "conv_thin_in 3x3 nchw", rtol=8e-3, atol_rms=4e-3)
+    y = ops.conv_thin_in(x, ops.pack_conv_weight(w), b, ksize=3, in_nchw=True, in_div=0.13025)
+    ref = F.conv2d((x.float() / 0.13025).to(bf16).float(), w.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    assert_close_bf16(y, ref, "conv_thin_in with latents/scaling_factor", rtol=8e-3, atol_rms=4e-3)
+    w1 = rnd((8, Cin, 1, 1), 67, scale=0.5)
+    y = ops.conv_thin_in(x, w1.reshape(8, Cin).contiguous(), None, ksize=1, in_nchw=True)
+    assert_close_bf16(y, F.conv2d(x.float(), w1.float()).permute(0, 2, 3, 1), "conv_thin_in 1x1", rtol=8e-3, atol_rms=4e-3)
+    xh = rnd((B, H, W, 128), 68)
+    for co in (3, 4):
+        wo, bo = rnd((co, 128, 3, 3), 69, scale=(9 * 128) ** -0.5), rnd((co,), 70, scale=0.1)
+        y = ops.conv_thin_out(xh, ops.pack_conv_weight(wo), bo)
+        ref = F.conv2d(xh.float().permute(0, 3, 1, 2), wo.float(), bo.float(), padding=1)
+        assert y.shape == ref.shape
+        assert_close_bf16(y, ref, f"conv_thin_out Cout={co}", rtol=8e-3, atol_rms=4e-3)
