@@ -50,6 +50,7 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "da_version": (_i, []),
+    "da_last_error": (C.c_char_p, []),
     "da_gemm_bf16": (_i, [C.POINTER(GemmParams), _vp]),
     "da_attention_bf16": (_i, [C.POINTER(AttentionParams), _vp]),
     "da_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
@@ -81,6 +82,11 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m diffusers_amd.build` "
             "(or __graft_entry__.build()). diffusers_amd has no CPU / PyTorch fallback path."
         )
+    # PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7) and must be the HIP runtime of the process:
+    # device pointers and streams handed to the C ABI are its objects.  Importing torch first makes the dynamic loader
+    # resolve this library's libamdhip64.so.7 dependency to the runtime torch already mapped (loading ours first would
+    # map /opt/rocm's copy as a second, device-less runtime -> hipErrorNoDevice on every launch).
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
@@ -92,4 +98,7 @@ def load() -> C.CDLL:
 
 def check(status: int, what: str) -> None:
     if status != DA_OK:
-        raise RuntimeError(f"{what} failed: {ERRORS.get(status, status)}")
+        detail = ""
+        if status == 2 and _lib is not None:
+            detail = f" ({_lib.da_last_error().decode()})"
+        raise RuntimeError(f"{what} failed: {ERRORS.get(status, status)}{detail}")

@@ -249,7 +249,7 @@ int launch_attn(const da_attention_params& p, hipStream_t s) {
     }
   }
   dim3 grid((p.Sq + 127) / 128, p.H, p.B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  DA_LAUNCH(kern, grid, dim3(256), lds, s, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

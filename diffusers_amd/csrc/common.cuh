@@ -11,10 +11,22 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 
+// hipGetLastError() is per-thread and sticky: PyTorch's allocator leaves benign hipErrorNotReady results from
+// hipEventQuery behind, so the error slot is cleared right before every launch and read right after it.
+#define DA_LAUNCH(...)                                      \
+  do {                                                      \
+    (void)hipGetLastError();                                \
+    hipLaunchKernelGGL(__VA_ARGS__);                        \
+  } while (0)
+
+extern "C" void da_set_last_error(int hip_error);  // version.hip: remembered for da_last_error()
 #define DA_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \
-    if (e__ != hipSuccess) return DA_ERR_LAUNCH;            \
+    if (e__ != hipSuccess) {                                \
+      da_set_last_error((int)e__);                          \
+      return DA_ERR_LAUNCH;                                 \
+    }                                                       \
   } while (0)
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

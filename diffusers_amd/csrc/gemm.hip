@@ -332,7 +332,7 @@ int launch(const da_gemm_params& p, hipStream_t s) {
       attr_set = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, p);
+  DA_LAUNCH(kern, dim3(tiles), dim3(256), lds, s, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -184,7 +184,7 @@ extern "C" int da_timestep_embedding(const float* t, const float* table, const i
   if ((!t && !table) || !out || B <= 0 || dim <= 0 || (dim & 1)) return DA_ERR_INVALID;
   if (table && !step_idx) return DA_ERR_INVALID;
   const int total = B * (dim / 2);
-  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, table,
+  DA_LAUNCH(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, table,
                      step_idx, out, B, dim, flip_sin_to_cos, shift, scale, max_period, out_f32);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -197,11 +197,11 @@ extern "C" int da_linear_small_m_bf16(const void* x, const void* W, const void* 
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((N + 3) / 4), block(256);
   if (M <= 2)
-    hipLaunchKernelGGL(linear_small_m_kernel<2>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)W,
+    DA_LAUNCH(linear_small_m_kernel<2>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)W,
                        (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)out, M, N, K, ldx, ldo, ldr, act_in,
                        act_out);
   else
-    hipLaunchKernelGGL(linear_small_m_kernel<8>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)W,
+    DA_LAUNCH(linear_small_m_kernel<8>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)W,
                        (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)out, M, N, K, ldx, ldo, ldr, act_in,
                        act_out);
   DA_CHECK_LAUNCH();
@@ -225,7 +225,7 @@ extern "C" int da_conv_thin_in_bf16(const void* x, const void* w, const void* bi
   size_t total = (size_t)B * H * W * (Cout / 8);
   size_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x,
+  DA_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x,
                      (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)y, B, H, W, Cin, Cout, ksize, in_nchw,
                      in_div);
   DA_CHECK_LAUNCH();
@@ -252,7 +252,7 @@ extern "C" int da_conv_thin_out_bf16(const void* x, const void* w, const void* b
         return DA_ERR_LAUNCH;                                                                                         \
       lds_enabled = 150 * 1024;                                                                                       \
     }                                                                                                                 \
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, (const uint16_t*)x, (const uint16_t*)w,       \
+    DA_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, s, (const uint16_t*)x, (const uint16_t*)w,       \
                        (const uint16_t*)bias, y, B, H, W, Cin, out_f32);                                              \
   } while (0)
   switch (Cout) {

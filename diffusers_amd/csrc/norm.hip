@@ -283,10 +283,10 @@ extern "C" int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)g.krows * C * 2 * sizeof(float);
   if (lds > 64 * 1024) return DA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(g.nblk, B), dim3(g.threads), lds, s, (const uint16_t*)x, (const uint16_t*)x2,
+  DA_LAUNCH(gn_stats_kernel, dim3(g.nblk, B), dim3(g.threads), lds, s, (const uint16_t*)x, (const uint16_t*)x2,
                      C1, (float*)workspace, HW, C, G, g.pix_per_blk, g.krows);
   DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(g.nblk, B), dim3(g.threads), 0, s, (const uint16_t*)x,
+  DA_LAUNCH(gn_apply_kernel, dim3(g.nblk, B), dim3(g.threads), 0, s, (const uint16_t*)x,
                      (const uint16_t*)x2, C1, (const uint16_t*)gamma, (const uint16_t*)beta, (uint16_t*)y, (const float*)workspace, g.nblk, HW,
                      C, G, eps, act, g.pix_per_blk, g.krows);
   DA_CHECK_LAUNCH();
@@ -304,7 +304,7 @@ extern "C" int da_layernorm_bf16(const void* x, const void* gamma, const void* b
   const int nch = (C / 8 + 63) / 64;
   dim3 grid((M + 3) / 4), block(256);
 #define DA_LN(N)                                                                                                  \
-  hipLaunchKernelGGL(layernorm_kernel<N>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)gamma,          \
+  DA_LAUNCH(layernorm_kernel<N>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)gamma,          \
                      (const uint16_t*)beta, (uint16_t*)y, (const uint16_t*)mod_scale, (const uint16_t*)mod_shift, \
                      mod_ld, rows_per_batch, M, C, ldx, ldy, eps)
   if (nch <= 1) DA_LN(1);
@@ -322,7 +322,7 @@ extern "C" int da_layernorm_bf16(const void* x, const void* gamma, const void* b
 extern "C" int da_softmax_rows_f32_bf16(const void* scores, void* probs, int M, int N, long long ld, long long ldo,
                                         void* stream) {
   if (!scores || !probs || M <= 0 || N <= 0 || (N & 3) || (ld & 3) || (ldo & 3)) return DA_ERR_INVALID;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)scores,
+  DA_LAUNCH(softmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)scores,
                      (uint16_t*)probs, N, ld, ldo);
   DA_CHECK_LAUNCH();
   return DA_OK;

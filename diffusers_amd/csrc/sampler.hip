@@ -138,11 +138,11 @@ extern "C" int da_euler_step(const void* eps, const void* x, void* out, const fl
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DA_DTYPE_BF16) {
-    if (cfg) hipLaunchKernelGGL((euler_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
-    else hipLaunchKernelGGL((euler_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
+    if (cfg) DA_LAUNCH((euler_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
+    else DA_LAUNCH((euler_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
   } else if (dtype == DA_DTYPE_F32) {
-    if (cfg) hipLaunchKernelGGL((euler_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (float*)out, table, step_idx, guidance, n);
-    else hipLaunchKernelGGL((euler_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (float*)out, table, step_idx, guidance, n);
+    if (cfg) DA_LAUNCH((euler_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (float*)out, table, step_idx, guidance, n);
+    else DA_LAUNCH((euler_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (float*)out, table, step_idx, guidance, n);
   } else {
     return DA_ERR_UNSUPPORTED;
   }
@@ -156,9 +156,9 @@ extern "C" int da_euler_scale_model_input(const void* x, void* out, const float*
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DA_DTYPE_BF16)
-    hipLaunchKernelGGL((euler_scale_input_kernel<uint16_t>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)out, table, step_idx, rep, n);
+    DA_LAUNCH((euler_scale_input_kernel<uint16_t>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)out, table, step_idx, rep, n);
   else if (dtype == DA_DTYPE_F32)
-    hipLaunchKernelGGL((euler_scale_input_kernel<float>), ew_grid(n), dim3(256), 0, s, (const float*)x, (float*)out, table, step_idx, rep, n);
+    DA_LAUNCH((euler_scale_input_kernel<float>), ew_grid(n), dim3(256), 0, s, (const float*)x, (float*)out, table, step_idx, rep, n);
   else
     return DA_ERR_UNSUPPORTED;
   DA_CHECK_LAUNCH();
@@ -171,11 +171,11 @@ extern "C" int da_x0_linear_step(const void* eps, const void* x, const void* noi
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DA_DTYPE_BF16) {
-    if (cfg) hipLaunchKernelGGL((x0_linear_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n);
-    else hipLaunchKernelGGL((x0_linear_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n);
+    if (cfg) DA_LAUNCH((x0_linear_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n);
+    else DA_LAUNCH((x0_linear_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n);
   } else if (dtype == DA_DTYPE_F32) {
-    if (cfg) hipLaunchKernelGGL((x0_linear_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n);
-    else hipLaunchKernelGGL((x0_linear_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n);
+    if (cfg) DA_LAUNCH((x0_linear_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n);
+    else DA_LAUNCH((x0_linear_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n);
   } else {
     return DA_ERR_UNSUPPORTED;
   }
@@ -189,11 +189,11 @@ extern "C" int da_flowmatch_step(const void* v, const void* x, void* out, const 
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DA_DTYPE_BF16) {
-    if (cfg) hipLaunchKernelGGL((flowmatch_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)v, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
-    else hipLaunchKernelGGL((flowmatch_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)v, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
+    if (cfg) DA_LAUNCH((flowmatch_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)v, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
+    else DA_LAUNCH((flowmatch_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)v, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
   } else if (dtype == DA_DTYPE_F32) {
-    if (cfg) hipLaunchKernelGGL((flowmatch_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)v, (const float*)x, (float*)out, table, step_idx, guidance, n);
-    else hipLaunchKernelGGL((flowmatch_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)v, (const float*)x, (float*)out, table, step_idx, guidance, n);
+    if (cfg) DA_LAUNCH((flowmatch_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)v, (const float*)x, (float*)out, table, step_idx, guidance, n);
+    else DA_LAUNCH((flowmatch_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)v, (const float*)x, (float*)out, table, step_idx, guidance, n);
   } else {
     return DA_ERR_UNSUPPORTED;
   }
@@ -203,7 +203,7 @@ extern "C" int da_flowmatch_step(const void* v, const void* x, void* out, const 
 
 extern "C" int da_advance_step(int* step_idx, void* stream) {
   if (!step_idx) return DA_ERR_INVALID;
-  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_idx);
+  DA_LAUNCH(advance_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_idx);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -213,9 +213,9 @@ extern "C" int da_mul_scalar(const void* x, void* out, float sc, long long n_, i
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DA_DTYPE_BF16)
-    hipLaunchKernelGGL((mul_scalar_kernel<uint16_t>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)out, sc, n);
+    DA_LAUNCH((mul_scalar_kernel<uint16_t>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)out, sc, n);
   else if (dtype == DA_DTYPE_F32)
-    hipLaunchKernelGGL((mul_scalar_kernel<float>), ew_grid(n), dim3(256), 0, s, (const float*)x, (float*)out, sc, n);
+    DA_LAUNCH((mul_scalar_kernel<float>), ew_grid(n), dim3(256), 0, s, (const float*)x, (float*)out, sc, n);
   else
     return DA_ERR_UNSUPPORTED;
   DA_CHECK_LAUNCH();

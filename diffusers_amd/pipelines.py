@@ -68,7 +68,8 @@ class _LatentDiffusionBase:
             for _ in range(num_steps):
                 self._step(latents, cond, guidance_scale, do_cfg)
             return latents
-        key = (tuple(latents.shape), float(guidance_scale), cond["kvs"][0][0].skv if cond["kvs"] else 0)
+        key = (tuple(latents.shape), float(guidance_scale), cond["kvs"][0][0].skv if cond["kvs"] else 0,
+               sch.device_table.data_ptr(), sch.device_step.data_ptr())
         if self._graph is None or self._graph_key != key:
             # warm-up on a side stream (lazy one-time driver calls must not happen during capture), then capture
             saved = latents.clone()
@@ -157,8 +158,8 @@ class StableDiffusionXLPipeline(_LatentDiffusionBase):
         if latents is None:
             gdev = generator.device if generator is not None else torch.device("cpu")
             latents = torch.randn(shape, generator=generator, device=gdev, dtype=bf16)
-        if tuple(latents.shape) != shape:
-            raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {shape}")
+        # (like the reference's prepare_latents, user-supplied latents are taken as they are: no shape check,
+        #  pipeline_stable_diffusion_xl.py:707-727)
         latents = latents.to(device=dev, dtype=bf16).contiguous()
         latents = ops.mul_scalar(latents, float(self.scheduler.init_noise_sigma))
 

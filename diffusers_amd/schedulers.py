@@ -86,9 +86,17 @@ class _SchedulerBase:
             self._step_dev.fill_(int(self._step_index))
 
     def _upload(self, rows: np.ndarray, device):
-        self._device = torch.device(device) if device is not None else torch.device("cuda")
-        self._table = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(self._device)
-        self._step_dev = torch.zeros((), dtype=torch.int32, device=self._device)
+        dev = torch.device(device) if device is not None else torch.device("cuda")
+        host = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32))
+        if (self._table is not None and self._device == dev and tuple(self._table.shape) == tuple(host.shape)):
+            # same schedule length as before: refresh IN PLACE so that HIP graphs that captured these two device
+            # addresses (the pipelines' per-step graph) stay valid across set_timesteps() calls
+            self._table.copy_(host)
+            self._step_dev.zero_()
+            return
+        self._device = dev
+        self._table = host.to(dev)
+        self._step_dev = torch.zeros((), dtype=torch.int32, device=dev)
 
     def _advance(self):
         self._step_index += 1
@@ -165,7 +173,7 @@ class EulerDiscreteScheduler(_SchedulerBase):
         else:
             raise ValueError(f"{c.timestep_spacing} is not supported. Please make sure to choose one of 'linspace', "
                              "'leading' or 'trailing'.")
-        base = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        base = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sig = np.interp(ts, np.arange(0, len(base)), base)
         if c.final_sigmas_type == "sigma_min":
             last = float(((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5)
@@ -275,8 +283,7 @@ class DDIMScheduler(_SchedulerBase):
         self._timesteps_host = ts
         self._step_index = None
         self._device_req = device
-        self._eta = None
-        self._table = None
+        self._eta = None   # table rows are rebuilt lazily for the eta of the first step(); buffers are reused in place
 
     def _build(self, eta: float):
         c = self.config
@@ -352,13 +359,13 @@ class DDIMScheduler(_SchedulerBase):
 
     @property
     def device_table(self):
-        if self._table is None:
+        if self._table is None or self._eta is None:
             self._build(0.0)
         return self._table
 
     @property
     def device_step(self):
-        if self._table is None:
+        if self._table is None or self._eta is None:
             self._build(0.0)
         return self._step_dev
 

@@ -44,6 +44,8 @@ extern "C" {
 #define DA_STAGE_LDS_DIRECT 1 /* global_load_lds_dwordx4 (LDS-DMA) */
 
 int da_version(void);
+/* name of the HIP runtime error behind this thread's most recent DA_ERR_LAUNCH (diagnostics only) */
+const char* da_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * da_gemm_bf16: C[M][N] = epilogue( alpha * A[M][K] . W[N][K]^T )

@@ -11,6 +11,12 @@ Pinned against the reference's own known-answer vectors (tests/schedulers/test_s
 0.0131; test_scheduler_ddim.py:114-150 -> 172.0067, 149.8295, 149.0784; test_scheduler_ddpm.py:75-104 -> 258.9606) in
 tests/test_oracle_schedulers.py, and against live reference runs frozen in tests/golden/schedulers.npz.
 Tensor ops are torch CPU ops, so dtype promotion / rounding points are the reference's by construction.
+
+One torch quirk matters for bf16 latents: ``scalar_tensor * bf16_tensor`` (0-d fp32 scalar FIRST) rounds the scalar to
+bf16 on torch's CPU kernels, while torch's device kernels (``opmath_symmetric_gpu_kernel_with_scalars``) keep it in
+fp32 in either operand order.  Every oracle class therefore takes ``device_scalars``: False (default) = the reference
+as it runs on CPU (what tests/golden/schedulers.npz froze), True = the reference as it runs on a GPU (fp32 scalars),
+which is the behaviour the HIP kernels implement bit for bit.  For fp32 latents both modes are identical.
 """
 from __future__ import annotations
 
@@ -46,14 +52,22 @@ def spaced_timesteps(spacing: str, n_train: int, n_inf: int, steps_offset: int, 
     raise ValueError(spacing)
 
 
+def smul(scalar, tensor: torch.Tensor, device_scalars: bool) -> torch.Tensor:
+    """``scalar * tensor`` with the scalar first, as the reference writes it (see the module docstring)."""
+    if device_scalars and tensor.dtype in (torch.bfloat16, torch.float16):
+        return (tensor.float() * scalar).to(tensor.dtype)
+    return scalar * tensor
+
+
 def cfg_combine(uncond: torch.Tensor, cond: torch.Tensor, g: float) -> torch.Tensor:
     return uncond + g * (cond - uncond)
 
 
 class EulerOracle:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
-                 timestep_spacing="linspace", steps_offset=0):
+                 timestep_spacing="linspace", steps_offset=0, device_scalars=False):
         self.n_train = num_train_timesteps
+        self.dev = device_scalars
         self.spacing, self.offset = timestep_spacing, steps_offset
         betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
@@ -68,7 +82,7 @@ class EulerOracle:
 
     def set_timesteps(self, n):
         ts = spaced_timesteps(self.spacing, self.n_train, n, self.offset, as_float=True)
-        base = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        base = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sig = np.interp(ts, np.arange(0, len(base)), base)
         sig = np.concatenate([sig, [0]]).astype(np.float32)
         self.sigmas = torch.from_numpy(sig)
@@ -83,7 +97,7 @@ class EulerOracle:
         sample = sample.to(torch.float32)
         sigma = self.sigmas[self.step_index]
         sigma_hat = sigma * (0.0 + 1)
-        pred_original = sample - sigma_hat * model_output
+        pred_original = sample - smul(sigma_hat, model_output, self.dev)
         derivative = (sample - pred_original) / sigma_hat
         dt = self.sigmas[self.step_index + 1] - sigma_hat
         prev = sample + derivative * dt
@@ -94,8 +108,9 @@ class EulerOracle:
 class DDIMOracle:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  clip_sample=True, set_alpha_to_one=True, steps_offset=0, timestep_spacing="leading",
-                 clip_sample_range=1.0):
+                 clip_sample_range=1.0, device_scalars=False):
         self.n_train = num_train_timesteps
+        self.dev = device_scalars
         betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
@@ -113,23 +128,24 @@ class DDIMOracle:
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         b_t = 1 - a_t
-        x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+        x0 = (sample - smul(b_t ** 0.5, model_output, self.dev)) / a_t ** 0.5
         if self.clip:
             x0 = x0.clamp(-self.clip_range, self.clip_range)
         variance = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
         std = eta * variance ** 0.5
-        direction = (1 - a_prev - std ** 2) ** 0.5 * model_output
-        prev = a_prev ** 0.5 * x0 + direction
+        direction = smul((1 - a_prev - std ** 2) ** 0.5, model_output, self.dev)
+        prev = smul(a_prev ** 0.5, x0, self.dev) + direction
         if eta > 0:
-            prev = prev + std * variance_noise
+            prev = prev + smul(std, variance_noise, self.dev)
         return prev
 
 
 class DDPMOracle:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  variance_type="fixed_small", clip_sample=True, clip_sample_range=1.0, timestep_spacing="leading",
-                 steps_offset=0):
+                 steps_offset=0, device_scalars=False):
         self.n_train = num_train_timesteps
+        self.dev = device_scalars
         betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.one = torch.tensor(1.0)
@@ -155,12 +171,12 @@ class DDPMOracle:
         b_t, b_prev = 1 - a_t, 1 - a_prev
         cur_a = a_t / a_prev
         cur_b = 1 - cur_a
-        x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+        x0 = (sample - smul(b_t ** 0.5, model_output, self.dev)) / a_t ** 0.5
         if self.clip:
             x0 = x0.clamp(-self.clip_range, self.clip_range)
         k0 = (a_prev ** 0.5 * cur_b) / b_t
         kx = cur_a ** 0.5 * b_prev / b_t
-        prev = k0 * x0 + kx * sample
+        prev = smul(k0, x0, self.dev) + smul(kx, sample, self.dev)
         variance = 0
         if t > 0:
             if noise is None:
@@ -168,13 +184,14 @@ class DDPMOracle:
             var = torch.clamp((1 - a_prev) / (1 - a_t) * cur_b, min=1e-20)
             if self.variance_type == "fixed_large":
                 var = cur_b
-            variance = (var ** 0.5) * noise
+            variance = smul(var ** 0.5, noise, self.dev)
         return prev + variance
 
 
 class FlowMatchOracle:
-    def __init__(self, num_train_timesteps=1000, shift=1.0, use_dynamic_shifting=False):
+    def __init__(self, num_train_timesteps=1000, shift=1.0, use_dynamic_shifting=False, device_scalars=False):
         self.n_train = num_train_timesteps
+        self.dev = device_scalars
         self.shift, self.dynamic = shift, use_dynamic_shifting
         ts = torch.from_numpy(np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy())
         sig = ts / num_train_timesteps
@@ -201,6 +218,6 @@ class FlowMatchOracle:
     def step(self, model_output, sample):
         sample = sample.to(torch.float32)
         dt = self.sigmas[self.step_index + 1] - self.sigmas[self.step_index]
-        prev = sample + dt * model_output
+        prev = sample + smul(dt, model_output, self.dev)
         self.step_index += 1
         return prev.to(model_output.dtype)
