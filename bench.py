@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--save-tuning", default=None, help="write the GEMM variant table measured during warm-up here")
     return ap.parse_args()
 
 
@@ -92,35 +93,48 @@ def instrumented_gemm_pass(pipe, run_one_step):
     return len(recs), sum(r[0] for r in recs), sum(r[1] for r in recs)
 
 
+# CFG-batched (B=2) SDXL U-Net forward at 32x32 latents, from the 128x128 op census of SURVEY.md 8a: conv 3.246/16,
+# linear (8.709 - 0.105)/16 + 0.105 (the cross-attention K/V projections see 154 text rows at any resolution),
+# attention 1.503/256 (self, quadratic in tokens) + 0.0646/16 (cross)
+CPU_SAMPLE_TFLOP = 3.246 / 16 + (8.709 - 0.105) / 16 + 0.105 + 1.503 / 256 + 0.0646 / 16
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(unet_sd, cfg_full, budget_s=25.0):
     """CPU leg (rank 0, N=1): the oracle restatement of the U-Net forward (oracle/reference_math.py, kind "port") on the
-    host cores, on a bounded sample: CFG-batched forward of the FULL SDXL architecture at 32x32 latents (1/16 of the
-    bench's 128x128 pixels), fp32.  images/s is scaled by algorithmic FLOPs (sample FLOPs counted, 686.6 TFLOP/image)."""
-    from torch.utils.flop_counter import FlopCounterMode
+    host cores this process may run on, on a bounded sample: CFG-batched forward of the FULL SDXL architecture at 32x32
+    latents, fp32.  images/s is scaled by algorithmic FLOPs (CPU_SAMPLE_TFLOP per sample, 686.6 TFLOP per image)."""
     from oracle import reference_math as R
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
     sd = {k: v.detach().to("cpu", torch.float32) for k, v in unet_sd.items()}
     g = torch.Generator("cpu").manual_seed(7)
     sample = torch.randn((2, 4, 32, 32), generator=g)
     ehs = torch.randn((2, 77, 2048), generator=g)
     added = {"text_embeds": torch.randn((2, 1280), generator=g),
              "time_ids": torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]]).repeat(2, 1)}
+    reps, tot = 0, 0.0
     with torch.no_grad():
-        with FlopCounterMode(display=False) as fc:
+        while True:
             t0 = time.perf_counter()
             R.unet_forward(sd, cfg_full, sample, 961.0, ehs, added)
             dt = time.perf_counter() - t0
-        flops = float(fc.get_total_flops())
-        reps, tot = 1, dt
-        while tot < 10.0 and tot + dt < budget_s:
-            t0 = time.perf_counter()
-            R.unet_forward(sd, cfg_full, sample, 961.0, ehs, added)
-            tot += time.perf_counter() - t0
+            tot += dt
             reps += 1
-    tflops = flops * reps / tot / 1e12
-    return {"value": tflops / TFLOP_PER_IMAGE, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps}x oracle fp32 CFG-batched SDXL U-Net forward at 32x32 latents ({flops / 1e12:.3f} TFLOP "
-                      f"each, {tot:.1f} s); scaled by FLOPs to 686.6 TFLOP/image",
+            log(f"cpu_baseline: oracle forward {reps} took {dt:.1f} s on {threads} threads")
+            if tot >= 10.0 or tot + dt > budget_s:
+                break
+    tflops = CPU_SAMPLE_TFLOP * reps / tot
+    return {"value": tflops / TFLOP_PER_IMAGE, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{reps}x oracle fp32 CFG-batched SDXL U-Net forward at 32x32 latents ({CPU_SAMPLE_TFLOP:.3f} "
+                      f"TFLOP each, {tot:.1f} s); scaled by FLOPs to 686.6 TFLOP/image",
             "cpu_tflops": tflops}
 
 
@@ -140,6 +154,7 @@ def main():
     from diffusers_amd.unet_2d_condition import _DEFAULTS as UD
     ucfg = dinit.TINY_SDXL_UNET if args.tiny else dinit.SDXL_UNET
     vcfg = dinit.TINY_VAE if args.tiny else dinit.SDXL_VAE
+    log(f"rank {rank}/{world}: building models on {dev}")
     unet, unet_sd = factory.build_unet(ucfg, seed=0, device=dev, init_device=str(dev))
     vae, _ = factory.build_vae(vcfg, seed=1, device=dev, init_device=str(dev))
     from diffusers_amd.pipelines import StableDiffusionXLPipeline
@@ -161,9 +176,11 @@ def main():
                     latents=mine["latents"].clone(), num_inference_steps=args.denoise_steps, guidance_scale=5.0,
                     height=hw, width=hw, output_type="raw", use_graph=not args.no_graph).images
 
+    log("warm-up (tunes GEMM variants for unseen shapes, captures the denoising-step HIP graph)")
     for _ in range(args.warmup):
         img = one_image()
     torch.cuda.synchronize()
+    log("timed region")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -176,6 +193,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     finite = bool(torch.isfinite(img.float()).all())
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} image(s) per GPU")
+    if args.save_tuning and rank == 0:
+        from diffusers_amd import tuning
+        tuning.save(args.save_tuning)
 
     result = {
         "metric": "images/sec @ SDXL-base 1024x1024 50-step EulerDiscrete CFG bf16",
@@ -199,6 +220,7 @@ def main():
             def one_step():
                 sch.reset(0)
                 pipe._step(lat, cond, 5.0, True)
+            log("roofline leg: one eager denoising step with HIP events around every igemm launch")
             one_step()  # untimed warm pass
             n, ms, fl = instrumented_gemm_pass(pipe, one_step)
             ach = fl / (ms * 1e-3) / 1e12
@@ -211,7 +233,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             full = dict(UD)
             full.update(ucfg)
-            result["cpu_baseline"] = cpu_baseline(unet_sd, full)
+            log("cpu_baseline leg")
+            import signal
+
+            def _alarm(signum, frame):
+                raise TimeoutError("cpu_baseline exceeded its wall-clock bound")
+            signal.signal(signal.SIGALRM, _alarm)
+            signal.alarm(150)
+            try:
+                result["cpu_baseline"] = cpu_baseline(unet_sd, full)
+            except TimeoutError as e:
+                result["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": None, "kind": "port",
+                                          "sample": f"not measured: {e}"}
+            finally:
+                signal.alarm(0)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

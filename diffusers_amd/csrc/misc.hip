@@ -91,9 +91,14 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const uint16_t* __res
                                                            const uint16_t* __restrict__ bias,
                                                            uint16_t* __restrict__ y, int B, int H, int W, int Cin,
                                                            int Cout, int ks, int in_nchw, float in_div) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [Cout][ks*ks*Cin] as float
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [ks*ks*Cin][Cout] as float (transposed in LDS)
   const int kk = ks * ks * Cin;
-  for (int i = threadIdx.x; i < Cout * kk; i += blockDim.x) wsm[i] = bf2f(w[i]);
+  // k-major image: the 8 output channels a thread owns are 32 contiguous bytes (two ds_read_b128), and the lanes of a
+  // wave (consecutive channel groups of one pixel) read consecutive addresses instead of one bank
+  for (int i = threadIdx.x; i < Cout * kk; i += blockDim.x) {
+    const int co = i / kk, k = i - co * kk;
+    wsm[k * Cout + co] = bf2f(w[i]);
+  }
   __syncthreads();
   const int cgroups = Cout >> 3;
   const size_t total = (size_t)B * H * W * cgroups;
@@ -117,9 +122,10 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const uint16_t* __res
           const size_t off = in_nchw ? (((size_t)b * Cin + c) * H + iy) * W + ix : (((size_t)b * H + iy) * W + ix) * Cin + c;
           float xv = bf2f(x[off]);
           if (in_div != 1.0f) xv = bf2f(f2bf(__fdiv_rn(xv, in_div)));  // e.g. latents / vae.config.scaling_factor
-          const float* wp = wsm + (size_t)(cg * 8) * kk + (kh * ks + kw) * Cin + c;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] += xv * wp[(size_t)e * kk];
+          const float* wp = wsm + (size_t)((kh * ks + kw) * Cin + c) * Cout + cg * 8;
+          const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
+          acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
+          acc[4] += xv * w1.x; acc[5] += xv * w1.y; acc[6] += xv * w1.z; acc[7] += xv * w1.w;
         }
       }
     }

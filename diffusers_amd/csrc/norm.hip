@@ -32,14 +32,22 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* 
   const bool second = (cc * 8 >= C1);
   const int Cs = second ? (C - C1) : C1;
   const uint16_t* xb = (second ? x2 + (size_t)(cc * 8 - C1) : x + (size_t)cc * 8) + (size_t)b * HW * Cs;
-  for (int pix = p0 + prow; pix < p1; pix += krows) {
-    const uint4 v = *(const uint4*)(xb + (size_t)pix * Cs);
-    float f[8];
-    unpack8(v, f);
+  for (int pix = p0 + prow; pix < p1; pix += 4 * krows) {  // 4 independent 16-byte loads in flight per lane
+    uint4 v[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      s[e] += f[e];
-      q[e] += f[e] * f[e];
+    for (int u = 0; u < 4; ++u) {
+      const int pu = pix + u * krows;
+      v[u] = (pu < p1) ? *(const uint4*)(xb + (size_t)pu * Cs) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float f[8];
+      unpack8(v[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s[e] += f[e];
+        q[e] += f[e] * f[e];
+      }
     }
   }
   float* my = sm + ((size_t)prow * C + cc * 8) * 2;
@@ -72,16 +80,34 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
                                 const float* __restrict__ ws, int nblk_stats, int HW, int C, int G, float eps, int act,
                                 int pix_per_blk, int krows) {
   __shared__ float s_mean[64], s_rstd[64];
+  __shared__ double s_part[8][64][2];
   const int cpr = C >> 3;
   const int t = threadIdx.x;
   const int cc = t % cpr, prow = t / cpr;
   const int b = blockIdx.y, blk = blockIdx.x;
+  // Every block folds the statistics partials itself (they are L2-resident); the fold is spread over SL slices of G
+  // threads so no thread walks more than nblk_stats / SL entries, always in the same order (deterministic).
+  int SL = (int)blockDim.x / G;
+  if (SL > 8) SL = 8;
+  if (SL < 1) SL = 1;
+  if (t < G * SL) {
+    const int g = t % G, sl = t / G;
+    double ts = 0.0, tq = 0.0;
+    const float* w = ws + ((size_t)b * nblk_stats * G + g) * 2;
+    for (int i = sl; i < nblk_stats; i += SL) {
+      const float2 pq = *(const float2*)(w + (size_t)i * G * 2);
+      ts += (double)pq.x;
+      tq += (double)pq.y;
+    }
+    s_part[sl][g][0] = ts;
+    s_part[sl][g][1] = tq;
+  }
+  __syncthreads();
   if (t < G) {
     double ts = 0.0, tq = 0.0;
-    const float* w = ws + ((size_t)b * nblk_stats * G + t) * 2;
-    for (int i = 0; i < nblk_stats; ++i) {
-      ts += (double)w[(size_t)i * G * 2];
-      tq += (double)w[(size_t)i * G * 2 + 1];
+    for (int sl = 0; sl < SL; ++sl) {
+      ts += s_part[sl][t][0];
+      tq += s_part[sl][t][1];
     }
     const double n = (double)HW * (double)(C / G);
     const double mean = ts / n;
@@ -110,20 +136,30 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
   const bool second = (cc * 8 >= C1);
   const int Cs = second ? (C - C1) : C1;
   const uint16_t* xb = (second ? x2 + (size_t)(cc * 8 - C1) : x + (size_t)cc * 8) + (size_t)b * HW * Cs;
-  for (int pix = p0 + prow; pix < p1; pix += krows) {
-    const uint4 v = *(const uint4*)(xb + (size_t)pix * Cs);
-    float f[8];
-    unpack8(v, f);
+  for (int pix = p0 + prow; pix < p1; pix += 4 * krows) {  // 4 independent 16-byte loads in flight per lane
+    uint4 v[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float o = f[e] * a[e] + c[e];
-      if (act) {
-        o = bf2f(f2bf(o));  // reference rounds the GroupNorm output to bf16 before SiLU
-        o = silu_f(o);
-      }
-      f[e] = o;
+    for (int u = 0; u < 4; ++u) {
+      const int pu = pix + u * krows;
+      v[u] = (pu < p1) ? *(const uint4*)(xb + (size_t)pu * Cs) : make_uint4(0, 0, 0, 0);
     }
-    *(uint4*)(y + base + (size_t)pix * C) = pack8(f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pu = pix + u * krows;
+      if (pu >= p1) break;
+      float f[8];
+      unpack8(v[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float o = f[e] * a[e] + c[e];
+        if (act) {
+          o = bf2f(f2bf(o));  // reference rounds the GroupNorm output to bf16 before SiLU
+          o = silu_f(o);
+        }
+        f[e] = o;
+      }
+      *(uint4*)(y + base + (size_t)pu * C) = pack8(f);
+    }
   }
 }
 
@@ -251,11 +287,11 @@ GnPlan gn_plan(int B, int HW, int C) {
   while (k > 1 && cpr * k > 512) --k;
   g.krows = k;
   g.threads = cpr * k;
-  int nblk = 2048 / (B > 0 ? B : 1);
-  const int max_blk = (HW + 4 * k - 1) / (4 * k);  // at least 4 pixels per thread row
-  if (nblk > max_blk) nblk = max_blk;
+  int nblk = (HW + 8 * k - 1) / (8 * k);  // at least 8 pixels per thread row (two rounds of 4 loads in flight)
+  const int cap = 2048 / (B > 0 ? B : 1);
+  if (nblk > cap) nblk = cap;
+  if (nblk > 512) nblk = 512;
   if (nblk < 1) nblk = 1;
-  if (nblk > 256) nblk = 256;
   int ppb = (HW + nblk - 1) / nblk;
   ppb = ((ppb + k - 1) / k) * k;
   g.pix_per_blk = ppb;

@@ -11,12 +11,23 @@ from typing import Optional
 import torch
 
 from . import _lib as L
+from . import tuning
 
 bf16 = torch.bfloat16
 
 # Global knobs (tests / bench flip these to A/B the staging paths).
 DEFAULT_STAGING = L.STAGE_LDS_DIRECT
 DEFAULT_TILE = L.TILE_AUTO
+TUNING = True  # per-shape (tile, staging) from diffusers_amd.tuning when the caller does not pin them
+
+
+def _select_variant(p: "L.GemmParams", tile: Optional[int], staging: Optional[int], stream: int) -> None:
+    if (TUNING and tile is None and staging is None and DEFAULT_TILE == L.TILE_AUTO
+            and DEFAULT_STAGING == L.STAGE_LDS_DIRECT):
+        p.tile, p.staging = tuning.lookup(p, stream)
+    else:
+        p.tile = DEFAULT_TILE if tile is None else tile
+        p.staging = DEFAULT_STAGING if staging is None else staging
 
 
 def _stream() -> int:
@@ -71,9 +82,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     p.ld_rowvec = _rows2d(rowvec, "rowvec") if rowvec is not None else 0
     p.rows_per_batch = rows_per_batch
     p.alpha, p.out_scale, p.act, p.out_f32, p.conv = alpha, out_scale, act, int(out_f32), 0
-    p.tile = DEFAULT_TILE if tile is None else tile
-    p.staging = DEFAULT_STAGING if staging is None else staging
-    L.check(L.load().da_gemm_bf16(C.byref(p), _stream()), "da_gemm_bf16(linear)")
+    st = _stream()
+    _select_variant(p, tile, staging, st)
+    L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(linear)")
     return out
 
 
@@ -121,9 +132,9 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     p.alpha, p.out_scale, p.act, p.out_f32, p.conv = 1.0, out_scale, act, 0, ksize
     p.Hin, p.Win, p.C1, p.C2, p.Hout, p.Wout = H, W_, C1, C2, Hout, Wout
     p.stride, p.up, p.pad = stride, int(up), pad
-    p.tile = DEFAULT_TILE if tile is None else tile
-    p.staging = DEFAULT_STAGING if staging is None else staging
-    L.check(L.load().da_gemm_bf16(C.byref(p), _stream()), "da_gemm_bf16(conv)")
+    st = _stream()
+    _select_variant(p, tile, staging, st)
+    L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(conv)")
     return out
 
 

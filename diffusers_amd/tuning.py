@@ -1,0 +1,91 @@
+"""Per-shape kernel selection for ``da_gemm_bf16`` (Linear + implicit-GEMM Conv2d).
+
+The reference leaves this choice to the vendor libraries behind ``F.linear`` / ``F.conv2d`` (hipBLASLt heuristics, MIOpen
+find-db).  Here the C ABI exposes every (tile, staging) variant of the one hand-written kernel plus ``da_gemm_tune``,
+which times them on the caller's stream; this module owns the resulting table:
+
+  * ``lookup(p)``   -> (tile, staging) for a problem, from the table, else tuned live (outside graph capture), else the
+                      library's untuned heuristic (tile = AUTO).
+  * the table is keyed by problem shape only, is plain JSON (``tuned/gfx950.json`` ships the shapes of the BASELINE
+    configs measured on an MI355X) and can be extended / saved with ``save()``.
+
+All variants produce bit-identical outputs (same K order, same MFMA), so the table affects speed only.
+Env: ``DIFFUSERS_AMD_TUNE=0`` disables live tuning, ``DIFFUSERS_AMD_TUNE_DB=<path>`` overrides the table location.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+_PKG = Path(__file__).resolve().parent
+DB_PATH = Path(os.environ.get("DIFFUSERS_AMD_TUNE_DB", _PKG / "tuned" / "gfx950.json"))
+LIVE = os.environ.get("DIFFUSERS_AMD_TUNE", "1") != "0"
+ITERS = 3
+
+_table: Dict[str, Tuple[int, int, float]] = {}
+_loaded = False
+_dirty = False
+
+
+def key_of(p: "L.GemmParams") -> str:
+    """Shape key: everything that changes the kernel's work or its memory pattern, nothing that is a pointer."""
+    if p.conv:
+        return (f"conv{p.conv}:M{p.M}:N{p.N}:C{p.C1}+{p.C2}:H{p.Hin}x{p.Win}:s{p.stride}:u{p.up}:a{p.act}"
+                f":r{int(bool(p.residual))}")
+    return f"lin:M{p.M}:N{p.N}:K{p.K}:a{p.act}:f{p.out_f32}:r{int(bool(p.residual))}"
+
+
+def _load() -> None:
+    global _loaded
+    _loaded = True
+    if DB_PATH.exists():
+        try:
+            raw = json.loads(DB_PATH.read_text())
+            for k, v in raw.get("entries", {}).items():
+                _table[k] = (int(v[0]), int(v[1]), float(v[2]))
+        except (ValueError, KeyError, TypeError) as e:  # a corrupt table must not break inference
+            raise RuntimeError(f"diffusers_amd: unreadable tuning table {DB_PATH}: {e}") from e
+
+
+def table() -> Dict[str, Tuple[int, int, float]]:
+    if not _loaded:
+        _load()
+    return _table
+
+
+def save(path: Optional[os.PathLike] = None) -> Path:
+    path = Path(path) if path is not None else DB_PATH
+    path.parent.mkdir(parents=True, exist_ok=True)
+    ent = {k: [v[0], v[1], round(v[2], 2)] for k, v in sorted(table().items())}
+    path.write_text(json.dumps({"arch": "gfx950", "format": "key -> [tile, staging, microseconds]",
+                                "tiles": list(L.TILE_NAMES), "entries": ent}, indent=0))
+    return path
+
+
+def tune(p: "L.GemmParams", stream: int) -> Tuple[int, int, float]:
+    """Run da_gemm_tune for this problem (synchronises the stream) and remember the winner."""
+    global _dirty
+    bt, bs, us = C.c_int(0), C.c_int(0), C.c_float(0.0)
+    L.check(L.load().da_gemm_tune(C.byref(p), stream, ITERS, C.byref(bt), C.byref(bs), C.byref(us)), "da_gemm_tune")
+    ent = (bt.value, bs.value, us.value)
+    table()[key_of(p)] = ent
+    _dirty = True
+    return ent
+
+
+def lookup(p: "L.GemmParams", stream: int) -> Tuple[int, int]:
+    """(tile, staging) to launch this problem with."""
+    ent = table().get(key_of(p))
+    if ent is None:
+        if LIVE and not torch.cuda.is_current_stream_capturing():
+            ent = tune(p, stream)
+        else:
+            return L.TILE_AUTO, L.STAGE_LDS_DIRECT
+    return ent[0], ent[1]

@@ -39,9 +39,13 @@ extern "C" {
 #define DA_TILE_64x128 2
 #define DA_TILE_128x64 3
 #define DA_TILE_64x64 4
+#define DA_TILE_256x128 5 /* 8 waves (4x2); LDS-direct staging only */
+#define DA_TILE_128x256 6 /* 8 waves (2x4); LDS-direct staging only */
+#define DA_TILE_256x256 7 /* 8 waves (2x4), 128x64 per wave; LDS-direct, 2-stage only */
 
 #define DA_STAGE_REGISTER 0   /* global_load_dwordx4 -> ds_write_b128 */
-#define DA_STAGE_LDS_DIRECT 1 /* global_load_lds_dwordx4 (LDS-DMA) */
+#define DA_STAGE_LDS_DIRECT 1 /* global_load_lds_dwordx4 (LDS-DMA), 2-slot ring: prefetch distance 1 */
+#define DA_STAGE_LDS_DIRECT3 2 /* LDS-DMA, 3-slot ring: prefetch distance 2, counted vmcnt across the barrier */
 
 int da_version(void);
 /* name of the HIP runtime error behind this thread's most recent DA_ERR_LAUNCH (diagnostics only) */
@@ -83,6 +87,14 @@ typedef struct da_gemm_params {
 } da_gemm_params;
 
 int da_gemm_bf16(const da_gemm_params* p, void* stream);
+
+/* Times every (tile, staging) variant able to run *p on `stream` (HIP events; one warm launch + min of `iters` timed
+ * launches each) and returns the fastest in *best_tile / *best_staging (and its time in *best_us, may be NULL).
+ * Every variant walks K in the same order with the same MFMA, so all of them write bit-identical C: the choice
+ * changes speed only.  The library keeps no tuning state: the caller owns the table (diffusers_amd/tuning.py keeps
+ * it per problem shape, the role torch's cublasLt/hipblasLt heuristic cache plays for F.linear / F.conv2d in the
+ * reference).  Synchronises the stream; must not be called while the stream is being captured into a graph. */
+int da_gemm_tune(const da_gemm_params* p, void* stream, int iters, int* best_tile, int* best_staging, float* best_us);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * da_attention_bf16: out = softmax(scale * Q K^T) V, flash-style (no S x S tensor), no mask / dropout / causal.

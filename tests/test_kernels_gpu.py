@@ -46,6 +46,90 @@ def test_gemm_plain(M, N, K, tile, staging):
     assert_close_bf16(y, ref, f"gemm {M}x{N}x{K} tile={tile} stage={staging}", rtol=8e-3, atol_rms=4e-3)
 
 
+# every (tile, staging) variant the C ABI exposes: (1..4 x register) + (1..7 x LDS-direct) + (1..6 x LDS-direct 3-stage)
+ALL_VARIANTS = [(t, 0) for t in (1, 2, 3, 4)] + [(t, 1) for t in range(1, 8)] + [(t, 2) for t in range(1, 7)]
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 320, 192), (2048, 1280, 1280), (520, 132, 64), (777, 640, 1152)])
+def test_gemm_all_variants_bit_identical(M, N, K):
+    """All variants walk K in the same order with the same MFMA: outputs must be BIT-identical (and right)."""
+    ops, L = _ops()
+    x = rnd((M, K), 21)
+    w = rnd((N, K), 22, scale=K ** -0.5)
+    bias, res = rnd((N,), 23), rnd((M, N), 24)
+    ref = x.float() @ w.float().t() + bias.float() + res.float()
+    base = None
+    for tile, staging in ALL_VARIANTS:
+        y = ops.linear(x, w, bias, residual=res, tile=tile, staging=staging)
+        if base is None:
+            base = y
+            assert_close_bf16(y, ref, f"gemm {M}x{N}x{K} variant ({tile},{staging})", rtol=8e-3, atol_rms=4e-3)
+        else:
+            assert torch.equal(y, base), f"variant (tile={tile}, staging={staging}) differs from (1, 0) at {M}x{N}x{K}"
+
+
+def test_conv_all_variants_bit_identical():
+    ops, L = _ops()
+    B, H, W, C1, C2, Cout = 2, 24, 20, 64, 128, 192
+    x1, x2 = rnd((B, H, W, C1), 31), rnd((B, H, W, C2), 32)
+    w = rnd((Cout, C1 + C2, 3, 3), 33, scale=(9 * (C1 + C2)) ** -0.5)
+    b = rnd((Cout,), 34)
+    wp = ops.pack_conv_weight(w)
+    xcat = torch.cat([x1, x2], -1).permute(0, 3, 1, 2).float()
+    for stride, up in ((1, False), (2, False), (1, True)):
+        xin = F.interpolate(xcat, scale_factor=2.0, mode="nearest") if up else xcat
+        ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=1).permute(0, 2, 3, 1)
+        base = None
+        for tile, staging in ALL_VARIANTS:
+            y = ops.conv2d_nhwc(x1, wp, b, ksize=3, x2=x2, stride=stride, up=up, tile=tile, staging=staging)
+            if base is None:
+                base = y
+                assert_close_bf16(y, ref, f"conv s{stride} up{up} variant ({tile},{staging})", rtol=8e-3, atol_rms=4e-3)
+            else:
+                assert torch.equal(y, base), f"conv variant (tile={tile}, staging={staging}) differs, s{stride} up{up}"
+
+
+def test_geglu_all_variants_bit_identical():
+    ops, L = _ops()
+    M, Cc = 700, 256
+    x = rnd((M, Cc), 41)
+    w = rnd((8 * Cc, Cc), 42, scale=Cc ** -0.5)
+    b = rnd((8 * Cc,), 43, scale=0.1)
+    wp, bp = ops.pack_geglu(w, b)
+    h = (x.float() @ w.float().t() + b.float()).to(bf16).float()
+    hv, gate = h.chunk(2, -1)
+    base = None
+    for tile, staging in ALL_VARIANTS:
+        if tile in (L.TILE_128x64, L.TILE_64x64):
+            with pytest.raises(RuntimeError):
+                ops.linear(x, wp, bp, act=L.ACT_GEGLU, tile=tile, staging=staging)
+            continue
+        y = ops.linear(x, wp, bp, act=L.ACT_GEGLU, tile=tile, staging=staging)
+        if base is None:
+            base = y
+            assert_close_bf16(y, hv * F.gelu(gate), f"geglu variant ({tile},{staging})", rtol=1.6e-2, atol_rms=8e-3)
+        else:
+            assert torch.equal(y, base), f"geglu variant (tile={tile}, staging={staging}) differs"
+
+
+def test_gemm_tuner_picks_a_valid_variant(tmp_path, monkeypatch):
+    """da_gemm_tune through diffusers_amd.tuning: the chosen variant is recorded, reused, and changes no bit."""
+    ops, L = _ops()
+    from diffusers_amd import tuning
+    monkeypatch.setattr(tuning, "_table", {})
+    monkeypatch.setattr(tuning, "_loaded", True)
+    x, w = rnd((2048, 640), 51), rnd((1280, 640), 52, scale=640 ** -0.5)
+    y_ref = ops.linear(x, w, tile=L.TILE_128x128, staging=L.STAGE_REGISTER)
+    y = ops.linear(x, w)  # tunes live
+    assert torch.equal(y, y_ref)
+    (key, (tile, staging, us)), = tuning.table().items()
+    assert 1 <= tile <= 7 and staging in (1, 2) and us > 0
+    print(f"[tune] {key} -> tile {L.TILE_NAMES[tile]} staging {staging}: {us:.1f} us")
+    assert torch.equal(ops.linear(x, w), y_ref)  # table hit
+    out = tuning.save(tmp_path / "t.json")
+    assert "lin:M2048:N1280:K640" in out.read_text()
+
+
 @pytest.mark.parametrize("staging", [0, 1])
 def test_gemm_epilogues(staging):
     ops, L = _ops()

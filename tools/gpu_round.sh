@@ -1,0 +1,33 @@
+#!/bin/bash
+# One gpurun call: GPU parity tests, smoke, kernel microbenchmarks, bench line, rocprofv3 kernel stats.
+# Everything lands in gpurun_out/.   usage: gpu_round.sh "test smoke kernels bench prof"
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+WHAT=${1:-test smoke kernels bench prof}
+if [[ $WHAT == *test* ]]; then
+  timeout 900 python -m pytest tests -m gpu -q --timeout 300 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
+  grep -E "^\[tune\]|passed|failed|FAILED|Error" $O/pytest_gpu.log | tail -25
+fi
+if [[ $WHAT == *smoke* ]]; then
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/smoke.log
+  tail -3 $O/smoke.log
+fi
+if [[ $WHAT == *kernels* ]]; then
+  timeout 600 python tools/bench_kernels.py > $O/kernels.log 2>&1; echo "kernels rc=$?"
+  grep -E '"op": "(linear|conv3x3).best"|"op": "(attention|groupnorm_silu|layernorm)"' $O/kernels.log | cut -c1-220
+fi
+if [[ $WHAT == *bench* ]]; then
+  timeout 600 python bench.py --steps 3 --warmup 1 --save-tuning $O/tuned_gfx950.json > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+  cat $O/bench.json; grep "^\[bench" $O/bench.err | tail -12
+fi
+if [[ $WHAT == *prof* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/prof
+  DIFFUSERS_AMD_TUNE_DB=$O/tuned_gfx950.json timeout 420 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o sdxl -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof.log 2>&1; echo "prof rc=$?"
+  grep '"metric"' $O/prof.log | cut -c1-200
+  find $O/prof -type f | head
+  find $O/prof -name '*kernel_trace*' -size +30M -delete
+  cd $R
+fi
