@@ -16,7 +16,8 @@ ERRORS = {1: "DA_ERR_INVALID", 2: "DA_ERR_LAUNCH", 3: "DA_ERR_UNSUPPORTED"}
 ACT_NONE, ACT_GEGLU, ACT_GELU_TANH, ACT_SILU, ACT_GELU_ERF = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64, TILE_256x128, TILE_128x256, TILE_256x256 = range(8)
 TILE_NAMES = ("auto", "128x128", "64x128", "128x64", "64x64", "256x128", "128x256", "256x256")
-STAGE_REGISTER, STAGE_LDS_DIRECT, STAGE_LDS_DIRECT3 = 0, 1, 2
+STAGE_REGISTER, STAGE_LDS_DIRECT, STAGE_LDS_DIRECT3, STAGE_LDS_DIRECT4, STAGE_LDS_DIRECT6, STAGE_LDS_DIRECT8 = range(6)
+RING_SLOTS = (2, 2, 3, 4, 6, 8)  # LDS ring depth per staging code
 DTYPE_BF16, DTYPE_F32 = 0, 1
 
 
@@ -53,7 +54,8 @@ SIGNATURES = {
     "da_version": (_i, []),
     "da_last_error": (C.c_char_p, []),
     "da_gemm_bf16": (_i, [C.POINTER(GemmParams), _vp]),
-    "da_gemm_tune": (_i, [C.POINTER(GemmParams), _vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "da_gemm_tune": (_i, [C.POINTER(GemmParams), _vp, _i, _vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                          C.POINTER(C.c_float)]),
     "da_attention_bf16": (_i, [C.POINTER(AttentionParams), _vp]),
     "da_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "da_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

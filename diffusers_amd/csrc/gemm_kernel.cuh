@@ -1,0 +1,449 @@
+// Shared kernel template of the bf16 MFMA GEMM / implicit-GEMM conv (instantiated by gemm.hip for nn.Linear and by
+// gemm_conv.hip for nn.Conv2d so the two halves compile in parallel).  See gemm.hip for the design notes.
+#pragma once
+#include "common.cuh"
+#include "diffusers_amd.h"
+
+namespace da_gemm {
+
+static __device__ uint4 g_zero_line[8];  // 128 B of zeros: source for out-of-bounds rows in the direct-to-LDS path
+
+struct RowInfo {      // per staged activation row (implicit GEMM gather state)
+  int base;           // linear: row index (or -1 if out of range); conv: b*Hin
+  int oy, ox;         // conv: oy*stride - pad, ox*stride - pad
+};
+
+// WM x WN waves, each wave owns MT x NT MFMA tiles of 32x32  ->  block tile (32*MT*WM) x (32*NT*WN), K slices of 64.
+// STAGES = LDS ring depth, prefetch distance PD = STAGES - 1: PD K slices are in flight while one is multiplied.  The
+// operands of these GEMMs stream from HBM / the Infinity Cache (weights are read once per denoising step, activations
+// were written by the previous kernel), i.e. at ~2 k cycles of latency, so the sustained fill rate of a CU is
+// (bytes in flight) / latency: the ring is made as deep as the 160 KiB of LDS allow and the wait before each
+// rendezvous is a COUNTED s_waitcnt vmcnt((PD-1)*LOADS), never 0, so PD-1 slices stay in flight across every barrier.
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, bool GLDS>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_params p) {
+  constexpr int NW = WM * WN, NTHR = 64 * NW, RP = NTHR / 8;  // RP = tile rows staged per pass (one 1 KiB piece per wave)
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  constexpr int XR = BM / RP, WR = BN / RP;  // staged rows per thread
+  constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
+  constexpr int PD = STAGES - 1;             // prefetch distance
+  constexpr int LOADS = XR + WR;             // LDS-DMA instructions per wave per K slice
+  static_assert(XR >= 1 && XR <= 4 && WR >= 1 && WR <= 4, "tile / thread-count combination not stageable");
+  static_assert(GLDS || (STAGES == 2 && NW == 4), "register staging exists for the 4-wave 2-stage tiles only");
+  static_assert(STAGES >= 2 && STAGES <= 8 && (PD - 1) * LOADS <= 63, "vmcnt is a 6-bit counter");
+  static_assert(STAGES * STAGE <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of tiles ----
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const uint16_t* __restrict__ A = (const uint16_t*)p.A;
+  const uint16_t* __restrict__ A2 = (const uint16_t*)p.A2;
+  const uint16_t* __restrict__ Wt = (const uint16_t*)p.W;
+
+  // ---- staging assignment: thread t stages LDS slot (row = (t>>3)+RP*i, pos = t&7) from source chunk sc ----
+  const int srow = t >> 3;
+  const int spos = t & 7;
+  const int sc = spos ^ ((t >> 4) & 7);  // (row>>1)&7 == (t>>4)&7 for every i (RP is a multiple of 16)
+
+  RowInfo xr[XR];
+  const int Hv = CONV ? (p.Hin << p.up) : 0, Wv = CONV ? (p.Win << p.up) : 0;
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    const int m = m0 + srow + RP * i;
+    if (CONV) {
+      if (m < p.M) {
+        const int hw = p.Hout * p.Wout;
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int oy = rem / p.Wout;
+        const int ox = rem - oy * p.Wout;
+        xr[i].base = b * p.Hin;
+        xr[i].oy = oy * p.stride - p.pad;
+        xr[i].ox = ox * p.stride - p.pad;
+      } else {
+        xr[i].base = 0;
+        xr[i].oy = -100000;  // never in range
+        xr[i].ox = -100000;
+      }
+    } else {
+      xr[i].base = (m < p.M) ? m : -1;
+      xr[i].oy = 0;
+      xr[i].ox = 0;
+    }
+  }
+  int wrow[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int n = n0 + srow + RP * i;
+    wrow[i] = (n < p.N) ? n : -1;
+  }
+
+  const int nk = p.K >> 6;
+  const int Ctot = CONV ? (p.C1 + p.C2) : 0;
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 xg0, xg1, xg2, xg3, wg0, wg1, wg2, wg3;  // named (not arrays) so they never land in scratch
+  xg0 = xg1 = xg2 = xg3 = wg0 = wg1 = wg2 = wg3 = make_uint4(0, 0, 0, 0);
+
+  // K-slice cursor of the NEXT slice to issue.  Slices are issued strictly in order, so the (tap, channel) position
+  // of the implicit GEMM advances incrementally (no integer division in the loop): K index = tap * Ctot + c.
+  int is_kh = 0, is_kw = 0, is_c0 = 0;  // conv: kernel row / column of the tap, first channel of the slice
+  size_t is_k = 0;                      // linear / weights: element offset of the slice inside a row
+
+  // source pointer of activation row i for the cursor slice (a 128-byte line of zeros when the slot must be zero,
+  // so every staging load is unconditional and the compiler keeps them all in flight)
+  const uint16_t* zline = (const uint16_t*)g_zero_line;
+  auto x_src = [&](int i) -> const uint16_t* {
+    if (CONV) {
+      const int iy = xr[i].oy + is_kh, ix = xr[i].ox + is_kw;
+      if ((unsigned)iy >= (unsigned)Hv || (unsigned)ix >= (unsigned)Wv) return zline;
+      const int sy = iy >> p.up, sx = ix >> p.up;
+      const size_t pix = (size_t)(xr[i].base + sy) * p.Win + sx;
+      if (is_c0 < p.C1) return A + pix * p.C1 + is_c0 + sc * 8;
+      return A2 + pix * p.C2 + (is_c0 - p.C1) + sc * 8;
+    } else {
+      if (xr[i].base < 0) return zline;
+      return A + (size_t)xr[i].base * p.lda + is_k + sc * 8;
+    }
+  };
+  auto w_src = [&](int i) -> const uint16_t* {
+    if (wrow[i] < 0) return zline;
+    return Wt + (size_t)wrow[i] * p.ldw + is_k + sc * 8;
+  };
+
+  // Staging is written as macros (not lambdas) so the staged registers stay in VGPRs.
+#define DA_STAGE_ISSUE(BUF)                                                                                            \
+  do {                                                                                                                 \
+    if (GLDS) {                                                                                                        \
+      unsigned char* xb_ = smem + (BUF) * STAGE;                                                                       \
+      unsigned char* wb_ = xb_ + XBYTES;                                                                               \
+      _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                                                 \
+        const uint16_t* s_ = x_src(i);                                                                                 \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,                            \
+                                         (__attribute__((address_space(3))) void*)(xb_ + (i * NW + wave) * 1024), 16,  \
+                                         0, 0);                                                                        \
+      }                                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < WR; ++i) {                                                                 \
+        const uint16_t* s_ = w_src(i);                                                                                 \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,                            \
+                                         (__attribute__((address_space(3))) void*)(wb_ + (i * NW + wave) * 1024), 16,  \
+                                         0, 0);                                                                        \
+      }                                                                                                                \
+    } else {                                                                                                           \
+      xg0 = *(const uint4*)x_src(0);                                                                                   \
+      xg1 = *(const uint4*)x_src(XR > 1 ? 1 : 0);                                                                      \
+      if constexpr (XR > 2) {                                                                                          \
+        xg2 = *(const uint4*)x_src(2);                                                                                 \
+        xg3 = *(const uint4*)x_src(3);                                                                                 \
+      }                                                                                                                \
+      wg0 = *(const uint4*)w_src(0);                                                                                   \
+      wg1 = *(const uint4*)w_src(WR > 1 ? 1 : 0);                                                                      \
+      if constexpr (WR > 2) {                                                                                          \
+        wg2 = *(const uint4*)w_src(2);                                                                                 \
+        wg3 = *(const uint4*)w_src(3);                                                                                 \
+      }                                                                                                                \
+    }                                                                                                                  \
+    /* advance the cursor to the next K slice */                                                                       \
+    is_k += 64;                                                                                                        \
+    if (CONV) {                                                                                                        \
+      is_c0 += 64;                                                                                                     \
+      if (is_c0 >= Ctot) {                                                                                             \
+        is_c0 = 0;                                                                                                     \
+        if (++is_kw >= p.conv) {                                                                                       \
+          is_kw = 0;                                                                                                   \
+          ++is_kh;                                                                                                     \
+        }                                                                                                              \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+#define DA_STAGE_COMMIT(BUF)                                                                                           \
+  do {                                                                                                                 \
+    if (!GLDS) {                                                                                                       \
+      unsigned char* xb_ = smem + (BUF) * STAGE;                                                                       \
+      unsigned char* wb_ = xb_ + XBYTES;                                                                               \
+      unsigned char* xs_ = xb_ + srow * 128 + spos * 16;                                                               \
+      unsigned char* ws_ = wb_ + srow * 128 + spos * 16;                                                               \
+      *(uint4*)(xs_) = xg0;                                                                                            \
+      if constexpr (XR > 1) *(uint4*)(xs_ + RP * 128) = xg1;                                                           \
+      if constexpr (XR > 2) {                                                                                          \
+        *(uint4*)(xs_ + 2 * RP * 128) = xg2;                                                                           \
+        *(uint4*)(xs_ + 3 * RP * 128) = xg3;                                                                           \
+      }                                                                                                                \
+      *(uint4*)(ws_) = wg0;                                                                                            \
+      if constexpr (WR > 1) *(uint4*)(ws_ + RP * 128) = wg1;                                                           \
+      if constexpr (WR > 2) {                                                                                          \
+        *(uint4*)(ws_ + 2 * RP * 128) = wg2;                                                                           \
+        *(uint4*)(ws_ + 3 * RP * 128) = wg3;                                                                           \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+  // Wait until at most G later slices of THIS wave's LDS-DMA are still in flight, then rendezvous.  The raw s_barrier
+  // (not __syncthreads, whose fence would drain vmcnt to 0) lets those slices stay in flight across the barrier; the
+  // asm "memory" clobbers keep the compiler from moving LDS accesses across the rendezvous.  G is wave-uniform.
+#define DA_VMCNT_CASE(G_) \
+  case G_: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G_) * LOADS <= 63 ? (G_) * LOADS : 63) : "memory"); break;
+#define DA_STAGE_WAIT(G)                                                                                               \
+  do {                                                                                                                 \
+    if (GLDS) {                                                                                                        \
+      switch (G) {                                                                                                     \
+        DA_VMCNT_CASE(1) DA_VMCNT_CASE(2) DA_VMCNT_CASE(3) DA_VMCNT_CASE(4) DA_VMCNT_CASE(5) DA_VMCNT_CASE(6)          \
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;                                    \
+      }                                                                                                                \
+      __builtin_amdgcn_s_barrier();                                                                                    \
+      asm volatile("" ::: "memory");                                                                                   \
+    } else {                                                                                                           \
+      __syncthreads();                                                                                                 \
+    }                                                                                                                  \
+  } while (0)
+
+  // fragment read offsets (bytes) inside a tile: row (l31) * 128 + ((2*ks+hi) ^ ((l31>>1)&7)) * 16
+  const int fsw = (l31 >> 1) & 7;
+  const int frow = l31 * 128;
+
+  auto compute = [&](int buf) {
+    const unsigned char* xb = smem + buf * STAGE + (wm * MT * 32) * 128 + frow;
+    const unsigned char* wb = smem + buf * STAGE + XBYTES + (wn * NT * 32) * 128 + frow;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = ((2 * ks + hi) ^ fsw) << 4;
+      bf16x8_t wf[NT], xf[MT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8_t*)(wb + j * 32 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *(const bf16x8_t*)(xb + i * 32 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: LDS ring of STAGES slices, one rendezvous per K slice ----
+  // prologue: slices 0 .. min(PD, nk) - 1 go to ring slots 0 .. ; then slice 0 must have landed
+#pragma unroll
+  for (int s = 0; s < PD; ++s) {
+    if (s < nk) {
+      DA_STAGE_ISSUE(s);
+      if (s == 0) DA_STAGE_COMMIT(0);
+    }
+  }
+  {
+    const int g0 = min(nk, PD) - 1;  // slices still allowed in flight once slice 0 is needed
+    DA_STAGE_WAIT(g0);
+  }
+  int cur = 0;          // ring slot of slice kt
+  int nxt = PD;         // ring slot the next issued slice goes to (STAGES == PD + 1)
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + PD < nk);
+    if (more) DA_STAGE_ISSUE(nxt);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in flight under this slice's MFMAs
+    compute(cur);
+    if (kt + 1 < nk) {
+      if (more) DA_STAGE_COMMIT(nxt);
+      // issued so far: min(nk, kt + PD + 1) slices; slices 0 .. kt+1 must have landed before the next iteration
+      const int g = min(nk - kt - 2, PD - 1);
+      DA_STAGE_WAIT(g);
+    }
+    cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+    nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+  }
+#undef DA_STAGE_ISSUE
+#undef DA_STAGE_COMMIT
+#undef DA_STAGE_WAIT
+#undef DA_VMCNT_CASE
+
+  // ---- epilogue: lane holds, for output row m (= lane&31 within the 32-tile), channels 8*(r>>2)+4*hi+(r&3) ----
+  const uint16_t* __restrict__ bias = (const uint16_t*)p.bias;
+  const uint16_t* __restrict__ rowvec = (const uint16_t*)p.rowvec;
+  const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
+  const bool geglu = (p.act == DA_ACT_GEGLU);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + (wm * MT + i) * 32 + l31;
+    if (m >= p.M) continue;
+    const int bidx = (rowvec != nullptr) ? (m / p.rows_per_batch) : 0;
+    if (geglu) {
+      // packed weight rows: per 64 rows = [32 value rows | 32 gate rows]; tile pair (2jp, 2jp+1) = (value, gate)
+      if constexpr ((NT & 1) == 0) {
+#pragma unroll
+        for (int jp = 0; jp < NT / 2; ++jp) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cin = 8 * g + 4 * hi;                                   // channel inside the 32-wide half
+            const int nv = n0 + (wn * NT + 2 * jp) * 32 + cin;                // packed row of value
+            const int no = (n0 >> 1) + (wn * (NT / 2) + jp) * 32 + cin;       // output column
+            if (nv >= p.N) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float hv = acc[i][2 * jp][4 * g + e] * p.alpha;
+              float gv = acc[i][2 * jp + 1][4 * g + e] * p.alpha;
+              if (bias) {
+                hv += bf2f(bias[nv + e]);
+                gv += bf2f(bias[nv + 32 + e]);
+              }
+              // reference rounds the projection to bf16 before chunk/gelu/mul (activations.py:113-124)
+              hv = bf2f(f2bf(hv));
+              gv = bf2f(f2bf(gv));
+              o[e] = hv * bf2f(f2bf(gelu_erf_f(gv)));
+            }
+            uint2 pk;
+            pk.x = pack_bf2(o[0], o[1]);
+            pk.y = pack_bf2(o[2], o[3]);
+            *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + no) = pk;
+          }
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + (wn * NT + j) * 32 + 8 * g + 4 * hi;
+        if (n >= p.N) continue;  // N is a multiple of 4 (checked on the host)
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * p.alpha;
+        if (bias) {
+          const uint2 bv = *(const uint2*)(bias + n);
+          o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y);
+        }
+        if (rowvec) {
+          const uint2 rv = *(const uint2*)(rowvec + (size_t)bidx * p.ld_rowvec + n);
+          o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
+        }
+        if (p.act == DA_ACT_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = gelu_tanh_f(bf2f(f2bf(o[e])));
+        } else if (p.act == DA_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = silu_f(bf2f(f2bf(o[e])));
+        } else if (p.act == DA_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(bf2f(f2bf(o[e])));
+        }
+        if (resid) {
+          const uint2 rv = *(const uint2*)(resid + (size_t)m * p.ldr + n);
+          o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
+        }
+        if (p.out_scale != 1.0f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= p.out_scale;
+        }
+        if (p.out_f32) {
+          *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          uint2 pk;
+          pk.x = pack_bf2(o[0], o[1]);
+          pk.y = pack_bf2(o[2], o[3]);
+          *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + n) = pk;
+        }
+      }
+    }
+  }
+}
+
+
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, bool GLDS>
+int launch(const da_gemm_params& p, hipStream_t s) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const size_t lds = (size_t)(BM + BN) * 128 * STAGES;
+  auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, GLDS>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DA_ERR_LAUNCH;
+      attr_set = true;
+    }
+  }
+  DA_LAUNCH(kern, dim3(tiles), dim3(64 * WM * WN), lds, s, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+
+// (tile, staging) -> kernel instantiation.  staging: 0 register staged (2 slots); 1..5 LDS-DMA with 2/3/4/6/8 ring slots.
+template <bool CONV>
+int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
+#define DA_V(WM_, WN_, MT_, NT_, ST_, G_) return launch<WM_, WN_, MT_, NT_, ST_, CONV, G_>(p, s)
+  switch (staging) {
+    case DA_STAGE_REGISTER:
+      switch (tile) {
+        case DA_TILE_128x128: DA_V(2, 2, 2, 2, 2, false);
+        case DA_TILE_64x128: DA_V(2, 2, 1, 2, 2, false);
+        case DA_TILE_128x64: DA_V(2, 2, 2, 1, 2, false);
+        case DA_TILE_64x64: DA_V(2, 2, 1, 1, 2, false);
+      }
+      return DA_ERR_UNSUPPORTED;
+    case DA_STAGE_LDS_DIRECT:
+      switch (tile) {
+        case DA_TILE_128x128: DA_V(2, 2, 2, 2, 2, true);
+        case DA_TILE_64x128: DA_V(2, 2, 1, 2, 2, true);
+        case DA_TILE_128x64: DA_V(2, 2, 2, 1, 2, true);
+        case DA_TILE_64x64: DA_V(2, 2, 1, 1, 2, true);
+        case DA_TILE_256x128: DA_V(4, 2, 2, 2, 2, true);
+        case DA_TILE_128x256: DA_V(2, 4, 2, 2, 2, true);
+        case DA_TILE_256x256: DA_V(2, 4, 4, 2, 2, true);
+      }
+      return DA_ERR_UNSUPPORTED;
+    case DA_STAGE_LDS_DIRECT3:
+      switch (tile) {
+        case DA_TILE_128x128: DA_V(2, 2, 2, 2, 3, true);
+        case DA_TILE_64x128: DA_V(2, 2, 1, 2, 3, true);
+        case DA_TILE_128x64: DA_V(2, 2, 2, 1, 3, true);
+        case DA_TILE_64x64: DA_V(2, 2, 1, 1, 3, true);
+        case DA_TILE_256x128: DA_V(4, 2, 2, 2, 3, true);
+        case DA_TILE_128x256: DA_V(2, 4, 2, 2, 3, true);
+      }
+      return DA_ERR_UNSUPPORTED;  // 256x256 x 3 slots would need 192 KiB of LDS
+    case DA_STAGE_LDS_DIRECT4:
+      switch (tile) {
+        case DA_TILE_128x128: DA_V(2, 2, 2, 2, 4, true);
+        case DA_TILE_64x128: DA_V(2, 2, 1, 2, 4, true);
+        case DA_TILE_128x64: DA_V(2, 2, 2, 1, 4, true);
+        case DA_TILE_64x64: DA_V(2, 2, 1, 1, 4, true);
+      }
+      return DA_ERR_UNSUPPORTED;
+    case DA_STAGE_LDS_DIRECT6:
+      switch (tile) {
+        case DA_TILE_64x128: DA_V(2, 2, 1, 2, 6, true);
+        case DA_TILE_128x64: DA_V(2, 2, 2, 1, 6, true);
+        case DA_TILE_64x64: DA_V(2, 2, 1, 1, 6, true);
+      }
+      return DA_ERR_UNSUPPORTED;
+    case DA_STAGE_LDS_DIRECT8:
+      switch (tile) {
+        case DA_TILE_64x64: DA_V(2, 2, 1, 1, 8, true);
+      }
+      return DA_ERR_UNSUPPORTED;
+  }
+#undef DA_V
+  return DA_ERR_INVALID;
+}
+
+}  // namespace da_gemm

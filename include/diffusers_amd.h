@@ -46,6 +46,9 @@ extern "C" {
 #define DA_STAGE_REGISTER 0   /* global_load_dwordx4 -> ds_write_b128 */
 #define DA_STAGE_LDS_DIRECT 1 /* global_load_lds_dwordx4 (LDS-DMA), 2-slot ring: prefetch distance 1 */
 #define DA_STAGE_LDS_DIRECT3 2 /* LDS-DMA, 3-slot ring: prefetch distance 2, counted vmcnt across the barrier */
+#define DA_STAGE_LDS_DIRECT4 3 /* LDS-DMA, 4-slot ring (tiles up to 128x128) */
+#define DA_STAGE_LDS_DIRECT6 4 /* LDS-DMA, 6-slot ring (64x128, 128x64, 64x64) */
+#define DA_STAGE_LDS_DIRECT8 5 /* LDS-DMA, 8-slot ring (64x64): 112 KiB in flight per CU */
 
 int da_version(void);
 /* name of the HIP runtime error behind this thread's most recent DA_ERR_LAUNCH (diagnostics only) */
@@ -90,11 +93,14 @@ int da_gemm_bf16(const da_gemm_params* p, void* stream);
 
 /* Times every (tile, staging) variant able to run *p on `stream` (HIP events; one warm launch + min of `iters` timed
  * launches each) and returns the fastest in *best_tile / *best_staging (and its time in *best_us, may be NULL).
+ * `scratch` (may be NULL) is a caller-owned device buffer, ideally larger than the 256 MiB Infinity Cache, that is
+ * memset before every timed launch so the operands are fetched from HBM as they are inside the denoising loop.
  * Every variant walks K in the same order with the same MFMA, so all of them write bit-identical C: the choice
  * changes speed only.  The library keeps no tuning state: the caller owns the table (diffusers_amd/tuning.py keeps
  * it per problem shape, the role torch's cublasLt/hipblasLt heuristic cache plays for F.linear / F.conv2d in the
  * reference).  Synchronises the stream; must not be called while the stream is being captured into a graph. */
-int da_gemm_tune(const da_gemm_params* p, void* stream, int iters, int* best_tile, int* best_staging, float* best_us);
+int da_gemm_tune(const da_gemm_params* p, void* stream, int iters, void* scratch, size_t scratch_bytes, int* best_tile,
+                 int* best_staging, float* best_us);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * da_attention_bf16: out = softmax(scale * Q K^T) V, flash-style (no S x S tensor), no mask / dropout / causal.

@@ -31,3 +31,19 @@ if [[ $WHAT == *prof* ]]; then
   find $O/prof -name '*kernel_trace*' -size +30M -delete
   cd $R
 fi
+if [[ $WHAT == *pmc* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 -L > $O/counters_list.txt 2>&1
+  rm -rf $O/pmc; mkdir -p $O/pmc
+  timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -f csv -d $O/pmc/sq -o focus -- python $R/tools/bench_focus.py > $O/pmc/sq.log 2>&1; echo "pmc sq rc=$?"
+  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -f csv -d $O/pmc/fetch -o focus -- python $R/tools/bench_focus.py > $O/pmc/fetch.log 2>&1; echo "pmc fetch rc=$?"
+  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -f csv -d $O/pmc/write -o focus -- python $R/tools/bench_focus.py > $O/pmc/write.log 2>&1; echo "pmc write rc=$?"
+  export DIFFUSERS_AMD_TUNE_DB=$O/tuned_gfx950.json
+  timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc/bench_fetch -o sdxl -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $O/pmc/bench_fetch.log 2>&1; echo "pmc bench fetch rc=$?"
+  timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc/bench_write -o sdxl -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $O/pmc/bench_write.log 2>&1; echo "pmc bench write rc=$?"
+  for d in sq fetch write bench_fetch bench_write; do python $R/tools/pmc_agg.py $O/pmc/$d > $O/pmc/$d.summary.csv 2>> $O/pmc/agg.err; done
+  find $O/pmc -name '*kernel_trace*' -delete
+  find $O/pmc -name '*counter_collection.csv' -size +8M -delete
+  ls -la $O/pmc/*
+  cd $R
+fi
