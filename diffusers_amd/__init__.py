@@ -14,6 +14,8 @@ __version__ = "0.1.0"
 _EXPORTS = {
     "UNet2DConditionModel": "unet_2d_condition",
     "AutoencoderKL": "autoencoder_kl",
+    "FluxTransformer2DModel": "transformer_flux",
+    "FluxPipeline": "pipelines",
     "EulerDiscreteScheduler": "schedulers",
     "DDIMScheduler": "schedulers",
     "DDPMScheduler": "schedulers",

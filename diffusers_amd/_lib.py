@@ -25,8 +25,10 @@ class GemmParams(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
         ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("residual", C.c_void_p),
+        ("bias_rows", C.c_void_p), ("gate", C.c_void_p),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int), ("ld_rowvec", C.c_int),
+        ("ld_gate", C.c_int),
         ("rows_per_batch", C.c_int),
         ("alpha", C.c_float), ("out_scale", C.c_float),
         ("act", C.c_int), ("out_f32", C.c_int), ("conv", C.c_int),
@@ -60,6 +62,8 @@ SIGNATURES = {
     "da_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "da_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "da_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "da_rmsnorm_rope_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_void_p), _f, _vp, _vp,
+                                  _i, _i, _vp]),
     "da_softmax_rows_f32_bf16": (_i, [_vp, _vp, _i, _i, _ll, _ll, _vp]),
     "da_euler_scale_model_input": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
     "da_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
@@ -69,7 +73,7 @@ SIGNATURES = {
     "da_mul_scalar": (_i, [_vp, _vp, _f, _ll, _i, _vp]),
     "da_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp]),
     "da_linear_small_m_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "da_conv_thin_in_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "da_conv_thin_in_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "da_conv_thin_out_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
 }
 

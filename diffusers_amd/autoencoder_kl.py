@@ -173,19 +173,22 @@ class AutoencoderKL:
     def encode(self, *a, **k):
         raise NotImplementedError("diffusers_amd.AutoencoderKL implements the decode hot path only")
 
-    def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None, *, latents_div: float = 1.0):
-        """autoencoder_kl.py:214-240.  ``latents_div`` fuses the pipeline's ``latents / scaling_factor``
-        (pipeline_stable_diffusion_xl.py:1283) into the first conv's input read."""
+    def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None, *, latents_div: float = 1.0,
+               latents_add: float = 0.0):
+        """autoencoder_kl.py:214-240.  ``latents_div`` / ``latents_add`` fuse the pipeline's
+        ``latents / scaling_factor (+ shift_factor)`` (pipeline_stable_diffusion_xl.py:1283, pipeline_flux.py:960) into
+        the first conv's input read."""
         if not self._built:
             raise RuntimeError("AutoencoderKL: call load_state_dict() first")
         if z.dtype != bf16 or not z.is_cuda:
             raise ValueError("z must be a bf16 HIP tensor (there is no CPU / fp32 fallback)")
         z = z.contiguous()
         if self.post_quant_conv:
-            x = ops.conv_thin_in(z, self.pqc_w, self.pqc_b, ksize=1, in_nchw=True, in_div=latents_div)
+            x = ops.conv_thin_in(z, self.pqc_w, self.pqc_b, ksize=1, in_nchw=True, in_div=latents_div, in_add=latents_add)
             x = ops.conv_thin_in(x, self.conv_in_w, self.conv_in_b, ksize=3, in_nchw=False)
         else:
-            x = ops.conv_thin_in(z, self.conv_in_w, self.conv_in_b, ksize=3, in_nchw=True, in_div=latents_div)
+            x = ops.conv_thin_in(z, self.conv_in_w, self.conv_in_b, ksize=3, in_nchw=True, in_div=latents_div,
+                                 in_add=latents_add)
         x = self.mid_res0(x)
         if self.mid_attn is not None:
             x = self.mid_attn(x)

@@ -53,6 +53,7 @@ int validate(da_gemm_params& p) {
   if (!p.A || !p.W || !p.C) return DA_ERR_INVALID;
   if (p.residual && (p.ldr & 3)) return DA_ERR_UNSUPPORTED;
   if (p.rowvec && (p.rows_per_batch <= 0 || (p.ld_rowvec & 3))) return DA_ERR_INVALID;
+  if (p.gate && (p.rows_per_batch <= 0 || (p.ld_gate & 3))) return DA_ERR_INVALID;
   if (p.alpha == 0.0f) p.alpha = 1.0f;
   if (p.out_scale == 0.0f) p.out_scale = 1.0f;
   if (p.conv) {
@@ -67,7 +68,8 @@ int validate(da_gemm_params& p) {
   } else {
     if ((p.lda & 7) || (p.ldw & 7)) return DA_ERR_UNSUPPORTED;
   }
-  if (p.act == DA_ACT_GEGLU && ((p.N & 127) || p.out_f32 || p.residual || p.rowvec)) return DA_ERR_UNSUPPORTED;
+  if (p.act == DA_ACT_GEGLU && ((p.N & 127) || p.out_f32 || p.residual || p.rowvec || p.gate || p.bias_rows))
+    return DA_ERR_UNSUPPORTED;
   return DA_OK;
 }
 

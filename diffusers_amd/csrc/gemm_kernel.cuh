@@ -278,12 +278,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   const uint16_t* __restrict__ bias = (const uint16_t*)p.bias;
   const uint16_t* __restrict__ rowvec = (const uint16_t*)p.rowvec;
   const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
+  const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
+  const uint16_t* __restrict__ gate = (const uint16_t*)p.gate;
   const bool geglu = (p.act == DA_ACT_GEGLU);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + (wm * MT + i) * 32 + l31;
     if (m >= p.M) continue;
-    const int bidx = (rowvec != nullptr) ? (m / p.rows_per_batch) : 0;
+    const int bidx = (rowvec != nullptr || gate != nullptr) ? (m / p.rows_per_batch) : 0;
+    const float brow = bias_rows ? bf2f(bias_rows[m]) : 0.f;
     if (geglu) {
       // packed weight rows: per 64 rows = [32 value rows | 32 gate rows]; tile pair (2jp, 2jp+1) = (value, gate)
       if constexpr ((NT & 1) == 0) {
@@ -331,6 +334,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
           const uint2 bv = *(const uint2*)(bias + n);
           o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y);
         }
+        if (bias_rows) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += brow;
+        }
         if (rowvec) {
           const uint2 rv = *(const uint2*)(rowvec + (size_t)bidx * p.ld_rowvec + n);
           o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
@@ -344,6 +351,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         } else if (p.act == DA_ACT_GELU_ERF) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(bf2f(f2bf(o[e])));
+        }
+        if (gate) {
+          // reference: y = Linear(x) (bf16) ; g = gate * y (bf16) ; out = residual + g
+          const uint2 gv = *(const uint2*)(gate + (size_t)bidx * p.ld_gate + n);
+          o[0] = bf2f(f2bf(bf2f(f2bf(o[0])) * bf_lo(gv.x)));
+          o[1] = bf2f(f2bf(bf2f(f2bf(o[1])) * bf_hi(gv.x)));
+          o[2] = bf2f(f2bf(bf2f(f2bf(o[2])) * bf_lo(gv.y)));
+          o[3] = bf2f(f2bf(bf2f(f2bf(o[3])) * bf_hi(gv.y)));
         }
         if (resid) {
           const uint2 rv = *(const uint2*)(resid + (size_t)m * p.ldr + n);

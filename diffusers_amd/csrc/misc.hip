@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const uint16_t* __res
                                                            const uint16_t* __restrict__ w,
                                                            const uint16_t* __restrict__ bias,
                                                            uint16_t* __restrict__ y, int B, int H, int W, int Cin,
-                                                           int Cout, int ks, int in_nchw, float in_div) {
+                                                           int Cout, int ks, int in_nchw, float in_div, float in_add) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];  // [ks*ks*Cin][Cout] as float (transposed in LDS)
   const int kk = ks * ks * Cin;
   // k-major image: the 8 output channels a thread owns are 32 contiguous bytes (two ds_read_b128), and the lanes of a
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const uint16_t* __res
           const size_t off = in_nchw ? (((size_t)b * Cin + c) * H + iy) * W + ix : (((size_t)b * H + iy) * W + ix) * Cin + c;
           float xv = bf2f(x[off]);
           if (in_div != 1.0f) xv = bf2f(f2bf(__fdiv_rn(xv, in_div)));  // e.g. latents / vae.config.scaling_factor
+          if (in_add != 0.0f) xv = bf2f(f2bf(__fadd_rn(xv, in_add)));  // + vae.config.shift_factor (Flux)
           const float* wp = wsm + (size_t)((kh * ks + kw) * Cin + c) * Cout + cg * 8;
           const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
           acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
@@ -215,7 +216,7 @@ extern "C" int da_linear_small_m_bf16(const void* x, const void* W, const void* 
 }
 
 extern "C" int da_conv_thin_in_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W,
-                                    int Cin, int Cout, int ksize, int in_nchw, float in_div, void* stream) {
+                                    int Cin, int Cout, int ksize, int in_nchw, float in_div, float in_add, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return DA_ERR_INVALID;
   if (Cin <= 0 || Cin > 16 || Cout <= 0 || (Cout & 7) || (ksize != 1 && ksize != 3)) return DA_ERR_UNSUPPORTED;
   const size_t lds = (size_t)Cout * ksize * ksize * Cin * sizeof(float);
@@ -233,7 +234,7 @@ extern "C" int da_conv_thin_in_bf16(const void* x, const void* w, const void* bi
   if (blocks > 4096) blocks = 4096;
   DA_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x,
                      (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)y, B, H, W, Cin, Cout, ksize, in_nchw,
-                     in_div);
+                     in_div, in_add);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

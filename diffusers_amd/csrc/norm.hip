@@ -242,6 +242,96 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// RMSNorm over the head dim (torch.nn.RMSNorm(head_dim): Flux q/k norm) or over all heads ("rms_norm_across_heads":
+// Wan) followed by the interleaved-pair rotary embedding, IN PLACE on `parts` column blocks (q, k) of a token-major
+// buffer.  One wave per (row, part): lane l owns 8-channel chunks l, l+64, ...; a head of D channels is D/8
+// consecutive lanes, so the per-head mean square is a shuffle reduction inside aligned lane groups.
+//   norm:  y = bf16( x * rsqrt(mean(x^2) + eps) * w )                  (normalization.py:510-569 / torch.nn.RMSNorm)
+//   rope:  out[2i] = y[2i] cos[2i] - y[2i+1] sin[2i] ; out[2i+1] = y[2i+1] cos[2i+1] + y[2i] sin[2i+1]   (fp32 math,
+//          embeddings.py:1216-1232 with use_real_unbind_dim = -1)
+// ------------------------------------------------------------------------------------------------------------------
+struct RopeParts {
+  int col_off[4];
+  const uint16_t* weight[4];
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(uint16_t* __restrict__ x, int ld, int rows,
+                                                           int rows_per_batch, int heads, int D, int parts,
+                                                           RopeParts pp, float eps, const float* __restrict__ cosT,
+                                                           const float* __restrict__ sinT, int rope_row0, int do_norm) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= rows * parts) return;
+  const int row = item / parts, part = item - row * parts;
+  const int C = heads * D, nchunks = C >> 3, cph = D >> 3;  // chunks per head
+  uint16_t* xr = x + (size_t)row * ld + pp.col_off[part];
+  float v[NCH][8];
+  float ss[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    ss[i] = 0.f;
+    if (ch < nchunks) {
+      unpack8(*(const uint4*)(xr + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss[i] += v[i][e] * v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  if (do_norm == 1) {  // per head: reduce over the cph consecutive lanes of a head
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      for (int o = cph >> 1; o > 0; o >>= 1) ss[i] += __shfl_xor(ss[i], o, 64);
+      ss[i] = rsqrtf(ss[i] / (float)D + eps);
+    }
+  } else if (do_norm == 2) {  // across heads: one statistic for the whole row
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) t += ss[i];
+    t = wave_sum(t);
+    const float r = rsqrtf(t / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) ss[i] = r;
+  }
+  const uint16_t* w = pp.weight[part];
+  const float* cr = cosT ? cosT + (size_t)(rope_row0 + row % rows_per_batch) * D : nullptr;
+  const float* sr = sinT ? sinT + (size_t)(rope_row0 + row % rows_per_batch) * D : nullptr;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch >= nchunks) continue;
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = v[i][e];
+    if (do_norm) {
+      float wf[8];
+      if (w) unpack8(*(const uint4*)(w + (do_norm == 1 ? (ch % cph) * 8 : ch * 8)), wf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = bf2f(f2bf(y[e] * ss[i] * (w ? wf[e] : 1.0f)));
+    }
+    if (cr) {
+      const int d0 = (ch % cph) * 8;
+      const float4 c0 = *(const float4*)(cr + d0), c1 = *(const float4*)(cr + d0 + 4);
+      const float4 s0 = *(const float4*)(sr + d0), s1 = *(const float4*)(sr + d0 + 4);
+      const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        o[e] = y[e] * cc[e] - y[e + 1] * sn[e];
+        o[e + 1] = y[e + 1] * cc[e + 1] + y[e] * sn[e + 1];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = o[e];
+    }
+    *(uint4*)(xr + ch * 8) = pack8(y);
+  }
+}
+
 // Row softmax: fp32 scores [M][ld] -> bf16 probabilities [M][ldo]; one block per row (N up to 2^20).
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, uint16_t* __restrict__ pr,
                                                            int N, long long ld, long long ldo) {
@@ -351,6 +441,38 @@ extern "C" int da_layernorm_bf16(const void* x, const void* gamma, const void* b
   else if (nch <= 8) DA_LN(8);
   else return DA_ERR_UNSUPPORTED;
 #undef DA_LN
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_rmsnorm_rope_bf16(void* x, int ld, int rows, int rows_per_batch, int heads, int D, int parts,
+                                    const int* col_off, const void* const* weight, float eps, const float* cosT,
+                                    const float* sinT, int rope_row0, int do_norm, void* stream) {
+  if (!x || !col_off || rows <= 0 || heads <= 0 || parts <= 0 || parts > 4) return DA_ERR_INVALID;
+  if ((cosT == nullptr) != (sinT == nullptr)) return DA_ERR_INVALID;
+  if (D != 64 && D != 128) return DA_ERR_UNSUPPORTED;
+  if ((ld & 7) || do_norm < 0 || do_norm > 2) return DA_ERR_UNSUPPORTED;
+  if (rows_per_batch <= 0) rows_per_batch = rows;
+  RopeParts pp;
+  for (int j = 0; j < 4; ++j) {
+    pp.col_off[j] = j < parts ? col_off[j] : 0;
+    pp.weight[j] = (j < parts && weight) ? (const uint16_t*)weight[j] : nullptr;
+    if (j < parts && (col_off[j] & 7)) return DA_ERR_UNSUPPORTED;
+  }
+  const int nch = (heads * D / 8 + 63) / 64;
+  dim3 grid((rows * parts + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DA_RR(N)                                                                                                   \
+  DA_LAUNCH(rmsnorm_rope_kernel<N>, grid, block, 0, s, (uint16_t*)x, ld, rows, rows_per_batch, heads, D, parts, pp, \
+            eps, cosT, sinT, rope_row0, do_norm)
+  if (nch <= 1) DA_RR(1);
+  else if (nch <= 2) DA_RR(2);
+  else if (nch <= 3) DA_RR(3);
+  else if (nch <= 4) DA_RR(4);
+  else if (nch <= 6) DA_RR(6);
+  else if (nch <= 8) DA_RR(8);
+  else return DA_ERR_UNSUPPORTED;
+#undef DA_RR
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -7,8 +7,9 @@ import torch
 
 from . import init as dinit
 from .autoencoder_kl import AutoencoderKL
-from .pipelines import StableDiffusionPipeline, StableDiffusionXLPipeline
-from .schedulers import DDIMScheduler, EulerDiscreteScheduler
+from .pipelines import FluxPipeline, StableDiffusionPipeline, StableDiffusionXLPipeline
+from .schedulers import DDIMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
+from .transformer_flux import FluxTransformer2DModel
 from .unet_2d_condition import UNet2DConditionModel
 
 SDXL_SCHEDULER = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
@@ -54,3 +55,22 @@ def build_sd15_pipeline(device="cuda", tiny: bool = False, seed: int = 0, init_d
     unet, _ = build_unet(ucfg, seed=seed, device=device, init_device=idev)
     vae, _ = build_vae(vcfg, seed=seed + 1, device=device, init_device=idev)
     return StableDiffusionPipeline(vae=vae, unet=unet, scheduler=DDIMScheduler(**SD15_SCHEDULER))
+
+
+def build_flux_transformer(cfg: dict, seed: int = 5, device="cuda", init_device: Optional[str] = None, state_dict=None):
+    tr = FluxTransformer2DModel(**cfg)
+    if state_dict is None:
+        state_dict = dinit.random_state_dict(dinit.flux_param_shapes(tr.config), seed=seed, device=init_device or "cpu")
+    tr.load_state_dict(state_dict, device=device)
+    return tr, state_dict
+
+
+def build_flux_pipeline(device="cuda", tiny: bool = False, seed: int = 5, init_device: Optional[str] = None):
+    """FLUX.1-schnell (BASELINE config 4) or its tiny sibling: transformer + 16-channel VAE + FlowMatch-Euler (shift 1)."""
+    tcfg = dinit.TINY_FLUX if tiny else dinit.FLUX_SCHNELL
+    vcfg = dinit.TINY_FLUX_VAE if tiny else dinit.FLUX_VAE
+    idev = init_device or ("cpu" if tiny else str(device))
+    tr, _ = build_flux_transformer(tcfg, seed=seed, device=device, init_device=idev)
+    vae, _ = build_vae(vcfg, seed=seed + 1, device=device, init_device=idev)
+    sch = FlowMatchEulerDiscreteScheduler(shift=1.0, use_dynamic_shifting=False)
+    return FluxPipeline(scheduler=sch, vae=vae, transformer=tr)

@@ -157,6 +157,59 @@ def vae_decoder_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
     return sh
 
 
+def _lin(sh, p, n_out, n_in, bias=True):
+    sh[f"{p}.weight"] = (n_out, n_in)
+    if bias:
+        sh[f"{p}.bias"] = (n_out,)
+
+
+def flux_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict inventory of FluxTransformer2DModel (transformer_flux.py:613-669) with guidance_embeds=False."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    D = cfg["attention_head_dim"]
+    inner = cfg["num_attention_heads"] * D
+    _lin(sh, "time_text_embed.timestep_embedder.linear_1", inner, 256)
+    _lin(sh, "time_text_embed.timestep_embedder.linear_2", inner, inner)
+    if cfg.get("guidance_embeds"):
+        _lin(sh, "time_text_embed.guidance_embedder.linear_1", inner, 256)
+        _lin(sh, "time_text_embed.guidance_embedder.linear_2", inner, inner)
+    _lin(sh, "time_text_embed.text_embedder.linear_1", inner, cfg["pooled_projection_dim"])
+    _lin(sh, "time_text_embed.text_embedder.linear_2", inner, inner)
+    _lin(sh, "context_embedder", inner, cfg["joint_attention_dim"])
+    _lin(sh, "x_embedder", inner, cfg["in_channels"])
+    for i in range(cfg["num_layers"]):
+        b = f"transformer_blocks.{i}"
+        _lin(sh, f"{b}.norm1.linear", 6 * inner, inner)
+        _lin(sh, f"{b}.norm1_context.linear", 6 * inner, inner)
+        sh[f"{b}.attn.norm_q.weight"] = (D,)
+        sh[f"{b}.attn.norm_k.weight"] = (D,)
+        for nm in ("to_q", "to_k", "to_v"):
+            _lin(sh, f"{b}.attn.{nm}", inner, inner)
+        _lin(sh, f"{b}.attn.to_out.0", inner, inner)
+        sh[f"{b}.attn.norm_added_q.weight"] = (D,)
+        sh[f"{b}.attn.norm_added_k.weight"] = (D,)
+        for nm in ("add_q_proj", "add_k_proj", "add_v_proj"):
+            _lin(sh, f"{b}.attn.{nm}", inner, inner)
+        _lin(sh, f"{b}.attn.to_add_out", inner, inner)
+        _lin(sh, f"{b}.ff.net.0.proj", 4 * inner, inner)
+        _lin(sh, f"{b}.ff.net.2", inner, 4 * inner)
+        _lin(sh, f"{b}.ff_context.net.0.proj", 4 * inner, inner)
+        _lin(sh, f"{b}.ff_context.net.2", inner, 4 * inner)
+    for i in range(cfg["num_single_layers"]):
+        b = f"single_transformer_blocks.{i}"
+        _lin(sh, f"{b}.norm.linear", 3 * inner, inner)
+        _lin(sh, f"{b}.proj_mlp", 4 * inner, inner)
+        _lin(sh, f"{b}.proj_out", inner, 5 * inner)
+        sh[f"{b}.attn.norm_q.weight"] = (D,)
+        sh[f"{b}.attn.norm_k.weight"] = (D,)
+        for nm in ("to_q", "to_k", "to_v"):
+            _lin(sh, f"{b}.attn.{nm}", inner, inner)
+    _lin(sh, "norm_out.linear", 2 * inner, inner)
+    out_c = cfg.get("out_channels") or cfg["in_channels"]
+    _lin(sh, "proj_out", cfg.get("patch_size", 1) ** 2 * out_c, inner)
+    return sh
+
+
 def _seed_for(name: str, seed: int) -> int:
     h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
     return int.from_bytes(h[:7], "little")
@@ -172,8 +225,8 @@ def random_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, device=
     for name, shape in shapes.items():
         g = torch.Generator(device=dev)
         g.manual_seed(_seed_for(name, seed))
-        is_norm = ".norm" in name or "norm." in name or "group_norm" in name or name.startswith("conv_norm_out") \
-            or "conv_norm_out" in name
+        is_norm = (".norm" in name or "norm." in name or "group_norm" in name or name.startswith("conv_norm_out")
+                   or "conv_norm_out" in name) and ".linear." not in name
         if is_norm and name.endswith(".weight"):
             t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=dev, dtype=torch.float32)
         elif name.endswith(".bias"):
@@ -203,6 +256,18 @@ SD_VAE = dict(in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 
               down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4,
               latent_channels=4, sample_size=512, scaling_factor=0.18215)
 SDXL_VAE = dict(SD_VAE, sample_size=1024, scaling_factor=0.13025)
+FLUX_SCHNELL = dict(patch_size=1, in_channels=64, out_channels=None, num_layers=19, num_single_layers=38,
+                    attention_head_dim=128, num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768,
+                    guidance_embeds=False, axes_dims_rope=(16, 56, 56))
+FLUX_VAE = dict(SD_VAE, latent_channels=16, sample_size=1024, use_quant_conv=False, use_post_quant_conv=False,
+                scaling_factor=0.3611, shift_factor=0.1159)
+TINY_FLUX = dict(patch_size=1, in_channels=64, out_channels=None, num_layers=2, num_single_layers=2,
+                 attention_head_dim=64, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=64,
+                 guidance_embeds=False, axes_dims_rope=(8, 28, 28))
+TINY_FLUX_VAE = dict(in_channels=3, out_channels=3, block_out_channels=(64, 128), layers_per_block=1,
+                     down_block_types=("DownEncoderBlock2D",) * 2, up_block_types=("UpDecoderBlock2D",) * 2,
+                     latent_channels=16, sample_size=32, use_quant_conv=False, use_post_quant_conv=False,
+                     scaling_factor=0.3611, shift_factor=0.1159)
 # tiny members of the same families (every channel count a multiple of 64, head dim 64) for parity tests
 TINY_SDXL_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(64, 128),
                       layers_per_block=1, cross_attention_dim=64, attention_head_dim=(1, 2),

@@ -59,6 +59,7 @@ def _rows2d(t: torch.Tensor, name: str) -> int:
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
            residual: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
            alpha: float = 1.0, out_scale: float = 1.0, out: Optional[torch.Tensor] = None, out_f32: bool = False,
+           bias_rows: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
            tile: Optional[int] = None, staging: Optional[int] = None) -> torch.Tensor:
     """out[M][N] = epilogue(alpha * x[M][K] @ w[N][K]^T).  For act == GEGLU, w/bias are in the packed layout of
     :func:`pack_geglu` and the output has N/2 columns."""
@@ -69,7 +70,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         raise ValueError(f"linear: K mismatch {K} vs {Kw}")
     n_out = N // 2 if act == L.ACT_GEGLU else N
     if M <= 8 and act in (L.ACT_NONE, L.ACT_SILU, L.ACT_GELU_TANH) and rowvec is None and not out_f32 \
-            and alpha == 1.0 and out_scale == 1.0:
+            and alpha == 1.0 and out_scale == 1.0 and bias_rows is None and gate is None:
         return linear_small_m(x, w, bias, act_out=act, residual=residual, out=out)
     if out is None:
         out = torch.empty((M, n_out), device=x.device, dtype=torch.float32 if out_f32 else bf16)
@@ -80,6 +81,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     p.lda, p.ldw, p.ldc = _rows2d(x, "x"), _rows2d(w, "w"), _rows2d(out, "out")
     p.ldr = _rows2d(residual, "residual") if residual is not None else 0
     p.ld_rowvec = _rows2d(rowvec, "rowvec") if rowvec is not None else 0
+    p.bias_rows, p.gate = _ptr(bias_rows), _ptr(gate)
+    p.ld_gate = _rows2d(gate, "gate") if gate is not None else 0
+    if out.data_ptr() == (residual.data_ptr() if residual is not None else -1):
+        raise ValueError("linear: `out` must not alias `residual` (variant tuning re-runs the launch)")
     p.rows_per_batch = rows_per_batch
     p.alpha, p.out_scale, p.act, p.out_f32, p.conv = alpha, out_scale, act, int(out_f32), 0
     st = _stream()
@@ -186,12 +191,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: 
     _req(q, "q"), _req(k, "k"), _req(vt, "vt")
     if out is None:
         out = torch.empty((B * Sq, H * D), device=q.device, dtype=bf16)
+    o_row_stride = _rows2d(out, "out")  # `out` may be a column block of a wider buffer (fused torch.cat on channels)
     p = L.AttentionParams()
     p.q, p.k, p.vt, p.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
     p.B, p.H, p.Sq, p.Skv, p.Skv_alloc, p.D = B, H, Sq, Skv, Skv_alloc, D
     p.q_batch_stride, p.k_batch_stride, p.vt_batch_stride = q_batch_stride, k_batch_stride, vt_batch_stride
-    p.o_batch_stride = Sq * H * D
-    p.q_row_stride, p.k_row_stride, p.vt_ld, p.o_row_stride = q_row_stride, k_row_stride, vt_ld, H * D
+    p.o_batch_stride = Sq * o_row_stride
+    p.q_row_stride, p.k_row_stride, p.vt_ld, p.o_row_stride = q_row_stride, k_row_stride, vt_ld, o_row_stride
     p.scale = (D ** -0.5) if scale is None else scale
     L.check(L.load().da_attention_bf16(C.byref(p), _stream()), "da_attention_bf16")
     return out
@@ -243,6 +249,33 @@ def layer_norm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[to
                                        _ptr(mod_shift), mod_ld, rows_per_batch, M, Cc, _rows2d(x, "x"), Cc, eps,
                                        _stream()), "da_layernorm_bf16")
     return y
+
+
+def rmsnorm_rope_(x: torch.Tensor, *, heads: int, head_dim: int, col_offsets, weights=None, eps: float = 1e-6,
+                  cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None, rope_row0: int = 0,
+                  rows_per_batch: int = 0, norm: str = "per_head") -> torch.Tensor:
+    """IN PLACE per-head RMSNorm (+ weight) and rotary embedding on column blocks (e.g. the q and k thirds of a fused
+    QKV projection) of the token-major buffer x [rows][ld].  cos / sin: fp32 [>= rope_row0 + rows_per_batch][head_dim]."""
+    _req(x, "x")
+    rows = x.shape[0]
+    ld = _rows2d(x, "x")
+    parts = len(col_offsets)
+    offs = (C.c_int * parts)(*[int(o) for o in col_offsets])
+    wptr = None
+    if weights is not None:
+        for w_ in weights:
+            if w_ is not None:
+                _req(w_, "weight")
+        wptr = (C.c_void_p * parts)(*[(w_.data_ptr() if w_ is not None else None) for w_ in weights])
+    if cos is not None:
+        _req(cos, "cos", torch.float32), _req(sin, "sin", torch.float32)
+        if cos.shape[-1] != head_dim or not cos.is_contiguous() or not sin.is_contiguous():
+            raise ValueError("rmsnorm_rope_: cos / sin must be contiguous [rows][head_dim] fp32")
+    mode = {"none": 0, "per_head": 1, "across_heads": 2}[norm]
+    L.check(L.load().da_rmsnorm_rope_bf16(x.data_ptr(), ld, rows, rows_per_batch or rows, heads, head_dim, parts, offs,
+                                          wptr, eps, _ptr(cos), _ptr(sin), rope_row0, mode, _stream()),
+            "da_rmsnorm_rope_bf16")
+    return x
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -331,7 +364,7 @@ def timestep_embedding(t: Optional[torch.Tensor], dim: int, *, batch: int, flip_
 
 
 def conv_thin_in(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ksize: int, in_nchw: bool,
-                 in_div: float = 1.0) -> torch.Tensor:
+                 in_div: float = 1.0, in_add: float = 0.0) -> torch.Tensor:
     """Conv2d with Cin <= 16.  x: NCHW [B][Cin][H][W] or NHWC; w: [Cout][k*k*Cin]; returns NHWC [B][H][W][Cout]."""
     _req(x, "x"), _req(w, "w")
     if not x.is_contiguous():
@@ -343,7 +376,7 @@ def conv_thin_in(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     Cout = w.shape[0]
     y = torch.empty((B, H, W_, Cout), device=x.device, dtype=bf16)
     L.check(L.load().da_conv_thin_in_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, H, W_, Cin, Cout,
-                                          ksize, int(in_nchw), in_div, _stream()), "da_conv_thin_in_bf16")
+                                          ksize, int(in_nchw), in_div, in_add, _stream()), "da_conv_thin_in_bf16")
     return y
 
 

@@ -15,11 +15,13 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import ops
 from .autoencoder_kl import AutoencoderKL
-from .schedulers import DDIMScheduler, EulerDiscreteScheduler
+from .schedulers import DDIMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
+from .transformer_flux import FluxTransformer2DModel
 from .unet_2d_condition import UNet2DConditionModel
 
 bf16 = torch.bfloat16
@@ -215,6 +217,165 @@ class StableDiffusionPipeline(_LatentDiffusionBase):
         cond = self.unet.precompute_conditioning(pe.contiguous(), None)
         latents = self._denoise(latents, cond, num_inference_steps, guidance_scale, do_cfg, use_graph)
         images = self._decode(latents, output_type)
+        if not return_dict:
+            return (images,)
+        return PipelineOutput(images=images)
+
+
+def calculate_shift(image_seq_len, base_seq_len: int = 256, max_seq_len: int = 4096, base_shift: float = 0.5,
+                    max_shift: float = 1.15):
+    """pipelines/flux/pipeline_flux.py:73-84."""
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    b = base_shift - m * base_seq_len
+    return image_seq_len * m + b
+
+
+class FluxPipeline:
+    """pipelines/flux/pipeline_flux.py:654-980 for pre-computed prompt embeddings (FLUX.1-schnell protocol: no true-CFG,
+    no guidance embedding).  The step body -- transformer forward + FlowMatch-Euler update -- is captured once in a HIP
+    graph and replayed; latents stay in the packed (B, (h/2)(w/2), 64) layout of the reference throughout the loop."""
+
+    def __init__(self, scheduler: FlowMatchEulerDiscreteScheduler, vae: AutoencoderKL, text_encoder=None, tokenizer=None,
+                 text_encoder_2=None, tokenizer_2=None, transformer: FluxTransformer2DModel = None, image_encoder=None,
+                 feature_extractor=None):
+        self.scheduler, self.vae, self.transformer = scheduler, vae, transformer
+        self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
+        self.default_sample_size = 128
+        self._graph = None
+        self._graph_key = None
+        self._static = {}
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    def set_progress_bar_config(self, **kw):
+        pass
+
+    @staticmethod
+    def _prepare_latent_image_ids(height, width):
+        ids = torch.zeros(height, width, 3)
+        ids[..., 1] = ids[..., 1] + torch.arange(height)[:, None]
+        ids[..., 2] = ids[..., 2] + torch.arange(width)[None, :]
+        return ids.reshape(height * width, 3)
+
+    @staticmethod
+    def _pack_latents(latents, batch_size, num_channels_latents, height, width):
+        latents = latents.view(batch_size, num_channels_latents, height // 2, 2, width // 2, 2)
+        latents = latents.permute(0, 2, 4, 1, 3, 5)
+        return latents.reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+    @staticmethod
+    def _unpack_latents(latents, height, width, vae_scale_factor):
+        batch_size, num_patches, channels = latents.shape
+        height = 2 * (int(height) // (vae_scale_factor * 2))
+        width = 2 * (int(width) // (vae_scale_factor * 2))
+        latents = latents.view(batch_size, height // 2, width // 2, channels // 4, 2, 2)
+        latents = latents.permute(0, 3, 1, 4, 2, 5)
+        return latents.reshape(batch_size, channels // (2 * 2), height, width)
+
+    def _step(self, latents, pe, cond):
+        sch = self.scheduler
+        v = self.transformer(latents, encoder_hidden_states=pe, conditioning=cond, sampler_table=sch.device_table,
+                             step_idx=sch.device_step, return_dict=False)[0]
+        sch.step_inplace(v, latents)
+        return latents
+
+    def _denoise(self, latents, pe, cond, num_steps, use_graph):
+        sch = self.scheduler
+        sch.reset(0)
+        if not use_graph:
+            for _ in range(num_steps):
+                self._step(latents, pe, cond)
+            return latents
+        key = (tuple(latents.shape), tuple(pe.shape), sch.device_table.data_ptr(), sch.device_step.data_ptr())
+        if self._graph is None or self._graph_key != key:
+            saved = latents.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._step(latents, pe, cond)      # warm-up: variant tuning + lazy one-time driver calls
+            torch.cuda.current_stream().wait_stream(s)
+            latents.copy_(saved)
+            sch.reset(0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step(latents, pe, cond)
+            self._graph, self._graph_key = g, key
+            self._static = {"latents": latents, "pe": pe, "cond": cond}
+            latents.copy_(saved)
+            sch.reset(0)
+        else:
+            st = self._static
+            st["latents"].copy_(latents)
+            st["pe"].copy_(pe)
+            st["cond"]["pooled_emb"].copy_(cond["pooled_emb"])
+            if st["cond"]["cos"].data_ptr() != cond["cos"].data_ptr():
+                st["cond"]["cos"].copy_(cond["cos"])
+                st["cond"]["sin"].copy_(cond["sin"])
+            latents = st["latents"]
+        for _ in range(num_steps):
+            self._graph.replay()
+        sch._step_index = num_steps
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, prompt_2=None, negative_prompt=None, negative_prompt_2=None, true_cfg_scale: float = 1.0,
+                 height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 28, sigmas=None,
+                 guidance_scale: float = 3.5, num_images_per_prompt: int = 1, generator=None,
+                 latents: Optional[torch.Tensor] = None, prompt_embeds=None, pooled_prompt_embeds=None,
+                 negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, output_type: str = "pt",
+                 return_dict: bool = True, max_sequence_length: int = 512, use_graph: bool = True):
+        if prompt is not None or prompt_2 is not None:
+            raise ValueError("text encoders are outside the HIP hot path: pass `prompt_embeds`/`pooled_prompt_embeds`")
+        if prompt_embeds is None or pooled_prompt_embeds is None:
+            raise ValueError("Provide `prompt_embeds` and `pooled_prompt_embeds`.")
+        if negative_prompt_embeds is not None or negative_pooled_prompt_embeds is not None or negative_prompt is not None:
+            raise NotImplementedError("true-CFG (negative prompts) is not on the FLUX.1-schnell hot path")
+        dev = self.device
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        if height % (self.vae_scale_factor * 2) or width % (self.vae_scale_factor * 2):
+            raise ValueError(f"`height` and `width` have to be divisible by {self.vae_scale_factor * 2}")
+        B = prompt_embeds.shape[0]
+        lh = 2 * (int(height) // (self.vae_scale_factor * 2))
+        lw = 2 * (int(width) // (self.vae_scale_factor * 2))
+        nch = self.transformer.config.in_channels // 4
+        if latents is None:
+            gdev = generator.device if generator is not None else torch.device("cpu")
+            raw = torch.randn((B, nch, lh, lw), generator=generator, device=gdev, dtype=bf16)
+            latents = self._pack_latents(raw, B, nch, lh, lw)
+        latents = latents.to(device=dev, dtype=bf16).contiguous().clone()
+        img_ids = self._prepare_latent_image_ids(lh // 2, lw // 2)
+        txt_ids = torch.zeros(prompt_embeds.shape[1], 3)
+
+        n = num_inference_steps
+        sig = np.linspace(1.0, 1 / n, n) if sigmas is None else sigmas
+        sc = self.scheduler.config
+        mu = calculate_shift(latents.shape[1], sc.get("base_image_seq_len", 256), sc.get("max_image_seq_len", 4096),
+                             sc.get("base_shift", 0.5), sc.get("max_shift", 1.15))
+        self.scheduler.set_timesteps(sigmas=sig, device=dev, mu=mu)
+        # what the transformer's sinusoid sees: timestep -> latents dtype, / 1000 (pipeline), * 1000 (model), all in bf16
+        t_model = ((self.scheduler.timesteps.to("cpu", bf16) / 1000).to(bf16) * 1000).float()
+        self.scheduler.set_model_timesteps(t_model)
+        self.scheduler.set_begin_index(0)
+
+        pe = prompt_embeds.to(device=dev, dtype=bf16).contiguous()
+        cond = self.transformer.precompute_conditioning(pooled_prompt_embeds.to(device=dev, dtype=bf16), img_ids, txt_ids)
+        latents = self._denoise(latents, pe, cond, len(self.scheduler.timesteps), use_graph)
+        if output_type == "latent":
+            images = latents
+        else:
+            unp = self._unpack_latents(latents, height, width, self.vae_scale_factor).contiguous()
+            vc = self.vae.config
+            img = self.vae.decode(unp, return_dict=False, latents_div=float(vc.scaling_factor),
+                                  latents_add=float(vc.shift_factor or 0.0))[0]
+            if output_type == "raw":
+                images = img
+            elif output_type == "pt":
+                images = (img.float() * 0.5 + 0.5).clamp(0, 1)
+            else:
+                raise ValueError(f"output_type={output_type!r}: use 'pt', 'raw' or 'latent'")
         if not return_dict:
             return (images,)
         return PipelineOutput(images=images)

@@ -111,6 +111,15 @@ class _SchedulerBase:
     def device_step(self):
         return self._step_dev
 
+    def set_model_timesteps(self, values) -> None:
+        """Engine extension: overwrite column 7 of the device table (what the denoiser's sinusoidal embedding reads in
+        the graph-replayed step) with the pipeline's own transform of ``timesteps`` -- e.g. Flux feeds
+        ``bf16(bf16(t) / 1000) * 1000`` (pipeline_flux.py:902-907, transformer_flux.py:725)."""
+        v = torch.as_tensor(values, dtype=torch.float32).reshape(-1)
+        if self._table is None or v.numel() != self._table.shape[0]:
+            raise ValueError("set_model_timesteps: call set_timesteps() first; one value per step")
+        self._table[:, 7].copy_(v.to(self._table.device))
+
     def reset(self, index: int = 0):
         """Rewind to step ``index`` (host mirror + device counter)."""
         self._step_index = index
@@ -558,6 +567,14 @@ class FlowMatchEulerDiscreteScheduler(_SchedulerBase):
         if not return_dict:
             return (prev,)
         return SchedulerOutput(prev_sample=prev)
+
+    def step_inplace(self, model_output, sample):
+        """Engine extension: the update written over ``sample`` (same buffer every HIP-graph replay)."""
+        if self._step_index is None:
+            self._init_step_index(self.timesteps[0])
+        ops.flowmatch_step(model_output, sample, self._table, self._step_dev, out=sample)
+        self._advance()
+        return sample
 
     def step_cfg(self, model_output_2b, sample, guidance_scale: float, out=None):
         if self._step_index is None:

@@ -65,8 +65,12 @@ const char* da_last_error(void);
  *              unet_2d_blocks.py:2444/:2561), W = [N][3][3][C1+C2]; up == 1 fuses F.interpolate(scale 2, nearest)
  *              (upsampling.py:177-190); stride 2 = Downsample2D (downsampling.py:130-147).  M = B*Hout*Wout.
  *              Replaces resnet.py:340/:365/:373, unet_2d_condition.py:1108/:1230, vae.py:286/:309.
- *   epilogue   + bias[N] + rowvec[m / rows_per_batch][N] (time-embedding injection, resnet.py:345-349), activation,
- *              + residual[M][ldr] (resnet.py:375, attention.py:1034-1080, transformer_2d.py:499-512), * out_scale.
+ *   epilogue   + bias[N] + bias_rows[M] + rowvec[m / rows_per_batch][N] (time-embedding injection, resnet.py:345-349),
+ *              activation, * gate[m / rows_per_batch][N] (adaLN-Zero gates, transformer_flux.py:400-405,:470-494;
+ *              transformer_wan.py:488-502), + residual[M][ldr] (resnet.py:375, attention.py:1034-1080,
+ *              transformer_2d.py:499-512), * out_scale.  bias_rows is the bias of a SWAPPED product (V^T = W_v . X^T:
+ *              the Linear's bias runs along M).  With a gate the linear output and the gated value are each rounded to
+ *              bf16 first, as the reference's separate torch ops round them.
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct da_gemm_params {
   const void* A;
@@ -76,8 +80,10 @@ typedef struct da_gemm_params {
   const void* bias;     /* [N] or NULL */
   const void* rowvec;   /* [M / rows_per_batch][ld_rowvec] or NULL */
   const void* residual; /* [M][ldr] or NULL */
+  const void* bias_rows; /* [M] or NULL */
+  const void* gate;      /* [M / rows_per_batch][ld_gate] or NULL */
   int M, N, K;
-  int lda, ldw, ldc, ldr, ld_rowvec;
+  int lda, ldw, ldc, ldr, ld_rowvec, ld_gate;
   int rows_per_batch;
   float alpha;     /* 0 -> 1 */
   float out_scale; /* 0 -> 1 */
@@ -136,6 +142,13 @@ int da_attention_bf16(const da_attention_params* p, void* stream);
  *   da_layernorm_bf16        nn.LayerNorm(C, eps) over rows of [M][ldx] (gamma/beta may be NULL = no affine), optional
  *                            AdaLN modulation y = LN(x) * (1 + mod_scale[b]) + mod_shift[b], b = row / rows_per_batch.
  *                            Replaces attention.py:986,:1030,:1056 and normalization.py:157-170,:194-202,:346-351.
+ *   da_rmsnorm_rope_bf16     per-head RMSNorm (torch.nn.RMSNorm(head_dim), transformer_flux.py:316-317,:101-102 ;
+ *                            "rms_norm_across_heads" when heads == 1, transformer_wan.py:83-84) followed by rotary
+ *                            position embedding (apply_rotary_emb, embeddings.py:1187-1230, interleaved pairs) IN PLACE
+ *                            on `parts` column blocks (query, key) of a token-major buffer x[rows][ld]:
+ *                            block j starts at column col_off[j] and holds heads*D channels, weight[j] is its [D]
+ *                            scale (NULL = none).  cos/sin are fp32 [>= rope_row0 + rows][D] tables (NULL = no
+ *                            rotation); row r of x uses table row rope_row0 + (r % rows_per_batch).
  *   da_softmax_rows_f32_bf16 row softmax of fp32 scores -> bf16 (single-head D=512 VAE mid-block attention,
  *                            attention_processor.py:2767 via vae.py / unet_2d_blocks.py:736-748).
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -145,6 +158,9 @@ int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const void* ga
 int da_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, const void* mod_scale,
                       const void* mod_shift, int mod_ld, int rows_per_batch, int M, int C, int ldx, int ldy, float eps,
                       void* stream);
+int da_rmsnorm_rope_bf16(void* x, int ld, int rows, int rows_per_batch, int heads, int D, int parts, const int* col_off,
+                         const void* const* weight, float eps, const float* cos, const float* sin, int rope_row0,
+                         int do_norm, void* stream);
 int da_softmax_rows_f32_bf16(const void* scores, void* probs, int M, int N, long long ld, long long ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -184,7 +200,8 @@ int da_mul_scalar(const void* x, void* out, float s, long long n, int dtype, voi
  *   da_conv_thin_in_bf16    Conv2d with Cin <= 16, k in {1,3}: conv_in (unet_2d_condition.py:1108, vae.py:286),
  *                           post_quant_conv (autoencoder_kl.py:204).  Input NCHW or NHWC, output NHWC.
  *                           in_div != 1: input is first divided by it in bf16 (latents / scaling_factor,
- *                           pipeline_stable_diffusion_xl.py:1283).
+ *                           pipeline_stable_diffusion_xl.py:1283), then in_add is added in bf16 (+ shift_factor,
+ *                           pipeline_flux.py:960).
  *   da_conv_thin_out_bf16   Conv2d 3x3 with Cout in {3,4,8,16}: conv_out (unet_2d_condition.py:1230, vae.py:309).
  *                           Input NHWC, output NCHW (bf16 or fp32).
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -193,7 +210,7 @@ int da_timestep_embedding(const float* t, const float* table, const int* step_id
 int da_linear_small_m_bf16(const void* x, const void* W, const void* bias, const void* res, void* out, int M, int N,
                            int K, int ldx, int ldo, int ldr, int act_in, int act_out, void* stream);
 int da_conv_thin_in_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
-                         int ksize, int in_nchw, float in_div, void* stream);
+                         int ksize, int in_nchw, float in_div, float in_add, void* stream);
 int da_conv_thin_out_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
                           int Cout, int out_f32, void* stream);
 

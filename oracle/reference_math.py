@@ -226,3 +226,137 @@ def vae_decode(sd: Dict[str, torch.Tensor], cfg: dict, z):
     x = F.group_norm(x, groups, sd["decoder.conv_norm_out.weight"], sd["decoder.conv_norm_out.bias"], eps)
     x = F.silu(x)
     return F.conv2d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Flux (models/transformers/transformer_flux.py)
+# --------------------------------------------------------------------------------------------------------------------
+def rope_tables(ids: torch.Tensor, axes_dim, theta: float = 10000.0):
+    """FluxPosEmbed.forward + get_1d_rotary_pos_embed(use_real=True, repeat_interleave_real=True, float64 freqs)
+    (transformer_flux.py:500-526, embeddings.py:1120-1184): returns (cos, sin) fp32 [S][sum(axes_dim)]."""
+    pos = ids.float()
+    cos_out, sin_out = [], []
+    for i, dim in enumerate(axes_dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64) / dim))
+        f = torch.outer(pos[:, i], freqs)          # float32 pos x float64 freqs -> float64
+        cos_out.append(f.cos().repeat_interleave(2, dim=1).float())
+        sin_out.append(f.sin().repeat_interleave(2, dim=1).float())
+    return torch.cat(cos_out, dim=-1), torch.cat(sin_out, dim=-1)
+
+
+def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """apply_rotary_emb(use_real=True, use_real_unbind_dim=-1, sequence_dim=1), embeddings.py:1187-1232.
+    x: (B, S, H, D); cos/sin: (S, D)."""
+    c = cos[None, :, None, :]
+    s = sin[None, :, None, :]
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return (x.float() * c + rot.float() * s).to(x.dtype)
+
+
+def _rms(x, w, eps):
+    """torch.nn.RMSNorm(head_dim, eps) (transformer_flux.py:316-317)."""
+    return F.rms_norm(x, (x.shape[-1],), w, eps)
+
+
+def _flux_attention(q, k, v, heads):
+    """dispatch_attention_fn native backend on (B, S, H, D) tensors (attention_dispatch.py:3709)."""
+    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+    return o.transpose(1, 2).flatten(2, 3)
+
+
+def _ada_chunks(sd, p, temb, n):
+    return F.linear(F.silu(temb), sd[f"{p}.weight"], sd[f"{p}.bias"]).chunk(n, dim=1)
+
+
+def flux_double_block(sd, p, x, ctx, temb, cos, sin, heads, D):
+    """FluxTransformerBlock.forward (transformer_flux.py:443-497) + FluxAttnProcessor (:76-142)."""
+    C = x.shape[-1]
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = _ada_chunks(sd, f"{p}.norm1.linear", temb, 6)
+    csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = _ada_chunks(sd, f"{p}.norm1_context.linear", temb, 6)
+    nx = F.layer_norm(x, (C,), None, None, 1e-6) * (1 + sc_a[:, None]) + sh_a[:, None]
+    nc = F.layer_norm(ctx, (C,), None, None, 1e-6) * (1 + csc_a[:, None]) + csh_a[:, None]
+
+    def proj(h, nm):
+        return F.linear(h, sd[f"{p}.attn.{nm}.weight"], sd[f"{p}.attn.{nm}.bias"]).unflatten(-1, (heads, D))
+    q, k, v = proj(nx, "to_q"), proj(nx, "to_k"), proj(nx, "to_v")
+    q = _rms(q, sd[f"{p}.attn.norm_q.weight"], 1e-6)
+    k = _rms(k, sd[f"{p}.attn.norm_k.weight"], 1e-6)
+    eq, ek, ev = proj(nc, "add_q_proj"), proj(nc, "add_k_proj"), proj(nc, "add_v_proj")
+    eq = _rms(eq, sd[f"{p}.attn.norm_added_q.weight"], 1e-6)
+    ek = _rms(ek, sd[f"{p}.attn.norm_added_k.weight"], 1e-6)
+    q = apply_rope(torch.cat([eq, q], dim=1), cos, sin)
+    k = apply_rope(torch.cat([ek, k], dim=1), cos, sin)
+    v = torch.cat([ev, v], dim=1)
+    o = _flux_attention(q, k, v, heads)
+    St = ctx.shape[1]
+    o_ctx, o_x = o[:, :St], o[:, St:]
+    o_x = F.linear(o_x, sd[f"{p}.attn.to_out.0.weight"], sd[f"{p}.attn.to_out.0.bias"])
+    o_ctx = F.linear(o_ctx, sd[f"{p}.attn.to_add_out.weight"], sd[f"{p}.attn.to_add_out.bias"])
+
+    x = x + g_a[:, None] * o_x
+    n2 = F.layer_norm(x, (C,), None, None, 1e-6) * (1 + sc_m[:, None]) + sh_m[:, None]
+    ff = F.gelu(F.linear(n2, sd[f"{p}.ff.net.0.proj.weight"], sd[f"{p}.ff.net.0.proj.bias"]), approximate="tanh")
+    ff = F.linear(ff, sd[f"{p}.ff.net.2.weight"], sd[f"{p}.ff.net.2.bias"])
+    x = x + g_m[:, None] * ff
+
+    ctx = ctx + cg_a[:, None] * o_ctx
+    n2c = F.layer_norm(ctx, (C,), None, None, 1e-6) * (1 + csc_m[:, None]) + csh_m[:, None]
+    ffc = F.gelu(F.linear(n2c, sd[f"{p}.ff_context.net.0.proj.weight"], sd[f"{p}.ff_context.net.0.proj.bias"]),
+                 approximate="tanh")
+    ffc = F.linear(ffc, sd[f"{p}.ff_context.net.2.weight"], sd[f"{p}.ff_context.net.2.bias"])
+    ctx = ctx + cg_m[:, None] * ffc
+    return ctx, x
+
+
+def flux_single_block(sd, p, x, ctx, temb, cos, sin, heads, D):
+    """FluxSingleTransformerBlock.forward (transformer_flux.py:383-412)."""
+    St = ctx.shape[1]
+    h = torch.cat([ctx, x], dim=1)
+    C = h.shape[-1]
+    res = h
+    sh, sc, g = _ada_chunks(sd, f"{p}.norm.linear", temb, 3)
+    n = F.layer_norm(h, (C,), None, None, 1e-6) * (1 + sc[:, None]) + sh[:, None]
+    mlp = F.gelu(F.linear(n, sd[f"{p}.proj_mlp.weight"], sd[f"{p}.proj_mlp.bias"]), approximate="tanh")
+
+    def proj(nm):
+        return F.linear(n, sd[f"{p}.attn.{nm}.weight"], sd[f"{p}.attn.{nm}.bias"]).unflatten(-1, (heads, D))
+    q = apply_rope(_rms(proj("to_q"), sd[f"{p}.attn.norm_q.weight"], 1e-6), cos, sin)
+    k = apply_rope(_rms(proj("to_k"), sd[f"{p}.attn.norm_k.weight"], 1e-6), cos, sin)
+    o = _flux_attention(q, k, proj("to_v"), heads)
+    out = F.linear(torch.cat([o, mlp], dim=2), sd[f"{p}.proj_out.weight"], sd[f"{p}.proj_out.bias"])
+    h = res + g[:, None] * out
+    return h[:, :St], h[:, St:]
+
+
+def flux_forward(sd: Dict[str, torch.Tensor], cfg: dict, hidden_states, encoder_hidden_states, pooled_projections,
+                 timestep, img_ids, txt_ids):
+    """FluxTransformer2DModel.forward (transformer_flux.py:671-821), guidance_embeds=False.
+    hidden_states (B, S_img, in_channels) packed latents; timestep (B,) in [0, 1]."""
+    heads, D = cfg["num_attention_heads"], cfg["attention_head_dim"]
+    dt = hidden_states.dtype
+    x = F.linear(hidden_states, sd["x_embedder.weight"], sd["x_embedder.bias"])
+    t = timestep.to(dt) * 1000
+    # CombinedTimestepTextProjEmbeddings (embeddings.py:1585-1601)
+    tp = timestep_embedding(t, 256, flip_sin_to_cos=True, shift=0.0).to(dt)
+    te = F.linear(tp, sd["time_text_embed.timestep_embedder.linear_1.weight"],
+                  sd["time_text_embed.timestep_embedder.linear_1.bias"])
+    te = F.linear(F.silu(te), sd["time_text_embed.timestep_embedder.linear_2.weight"],
+                  sd["time_text_embed.timestep_embedder.linear_2.bias"])
+    pe = F.linear(pooled_projections, sd["time_text_embed.text_embedder.linear_1.weight"],
+                  sd["time_text_embed.text_embedder.linear_1.bias"])
+    pe = F.linear(F.silu(pe), sd["time_text_embed.text_embedder.linear_2.weight"],
+                  sd["time_text_embed.text_embedder.linear_2.bias"])
+    temb = te + pe
+    ctx = F.linear(encoder_hidden_states, sd["context_embedder.weight"], sd["context_embedder.bias"])
+    cos, sin = rope_tables(torch.cat((txt_ids, img_ids), dim=0), cfg["axes_dims_rope"])
+    for i in range(cfg["num_layers"]):
+        ctx, x = flux_double_block(sd, f"transformer_blocks.{i}", x, ctx, temb, cos, sin, heads, D)
+    for i in range(cfg["num_single_layers"]):
+        ctx, x = flux_single_block(sd, f"single_transformer_blocks.{i}", x, ctx, temb, cos, sin, heads, D)
+    # AdaLayerNormContinuous (normalization.py:307-351): scale first, then shift
+    emb = F.linear(F.silu(temb), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"])
+    scale, shift = emb.chunk(2, dim=1)
+    C = x.shape[-1]
+    x = F.layer_norm(x, (C,), None, None, 1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
+    return F.linear(x, sd["proj_out.weight"], sd["proj_out.bias"])

@@ -153,3 +153,36 @@ def test_model_config_validation():
         m.forward(torch.zeros(1), 1, torch.zeros(1))
     with pytest.raises(NotImplementedError):
         AutoencoderKL().encode(None)
+
+
+def test_flux_host_logic():
+    """Host-side pieces of the Flux path: latent packing, the dynamic-shift formula, RoPE tables, config validation."""
+    from diffusers_amd import init as dinit
+    from diffusers_amd.pipelines import FluxPipeline, calculate_shift
+    from diffusers_amd.transformer_flux import FluxTransformer2DModel, rope_tables
+    from oracle import reference_math as R
+    x = torch.arange(2 * 16 * 8 * 6, dtype=torch.float32).view(2, 16, 8, 6)
+    packed = FluxPipeline._pack_latents(x, 2, 16, 8, 6)
+    assert packed.shape == (2, 12, 64)
+    assert torch.equal(FluxPipeline._unpack_latents(packed, 8 * 8, 6 * 8, 8), x)
+    assert abs(calculate_shift(4096) - 1.15) < 1e-9 and abs(calculate_shift(256) - 0.5) < 1e-9
+    ids = torch.cat([torch.zeros(16, 3), FluxPipeline._prepare_latent_image_ids(8, 8)], 0)
+    c1, s1 = rope_tables(ids, (8, 28, 28))
+    c2, s2 = R.rope_tables(ids, (8, 28, 28))
+    assert torch.equal(c1, c2) and torch.equal(s1, s2) and c1.shape == (80, 64) and c1.dtype == torch.float32
+    assert FluxTransformer2DModel(**dinit.FLUX_SCHNELL).inner_dim == 3072
+    with pytest.raises(ValueError):
+        FluxTransformer2DModel(guidance_embeds=True)
+    with pytest.raises(ValueError):
+        FluxTransformer2DModel(attention_head_dim=96, axes_dims_rope=(16, 40, 40))
+    with pytest.raises(TypeError):
+        FluxTransformer2DModel(not_a_key=1)
+    n = sum(int(np.prod(s)) for s in dinit.flux_param_shapes(dinit.FLUX_SCHNELL).values())
+    assert n == 11_891_178_560
+
+
+def test_flowmatch_model_timestep_column():
+    from diffusers_amd import schedulers as S
+    sch = S.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    with pytest.raises(ValueError):
+        sch.set_model_timesteps([1.0])

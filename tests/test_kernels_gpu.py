@@ -493,3 +493,74 @@ def test_conv_thin_in_out():
         ref = F.conv2d(xh.float().permute(0, 3, 1, 2), wo.float(), bo.float(), padding=1)
         assert y.shape == ref.shape
         assert_close_bf16(y, ref, f"conv_thin_out Cout={co}", rtol=8e-3, atol_rms=4e-3)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Flux-side kernels: gate / row-bias GEMM epilogues, RMSNorm + RoPE
+# ----------------------------------------------------------------------------------------------------------------------
+def test_gemm_gate_and_row_bias_epilogues():
+    ops, L = _ops()
+    M, N, K, B = 640, 384, 256, 2
+    x, w = rnd((M, K), 61), rnd((N, K), 62, scale=K ** -0.5)
+    bias, res, gate = rnd((N,), 63), rnd((M, N), 64), rnd((B, 3 * N), 65)
+    g = gate[:, N:2 * N]                                    # a column chunk of the adaLN projection (ld = 3N)
+    y = ops.linear(x, w, bias, gate=g, rows_per_batch=M // B, residual=res)
+    lin = (x.float() @ w.float().t() + bias.float()).to(bf16).float()
+    gated = (lin * g.float().repeat_interleave(M // B, 0)).to(bf16).float()
+    assert_close_bf16(y, res.float() + gated, "gemm gate*(xW+b)+residual", rtol=8e-3, atol_rms=4e-3)
+    # swapped product with the Linear's bias along M (V^T = W_v . X^T + b_v 1^T), written into a column block
+    bm = rnd((M,), 66)
+    wide = torch.zeros((M, 2 * N), device=DEV, dtype=bf16)
+    ops.linear(x, w, bias_rows=bm, out=wide[:, N:])
+    assert_close_bf16(wide[:, N:], x.float() @ w.float().t() + bm.float()[:, None], "gemm row bias", rtol=8e-3, atol_rms=4e-3)
+    assert float(wide[:, :N].float().abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        ops.linear(x, w, residual=res, out=res)          # aliasing out / residual is refused
+
+
+@pytest.mark.parametrize("D,heads", [(64, 2), (128, 24)])
+def test_rmsnorm_rope_per_head(D, heads):
+    ops, L = _ops()
+    rows, St = 80, 16
+    Cc = heads * D
+    x = rnd((rows, 3 * Cc), 71)
+    wq, wk = rnd((D,), 72, scale=0.2) + 1, rnd((D,), 73, scale=0.2) + 1
+    gcpu = torch.Generator("cpu").manual_seed(74)
+    ang = torch.rand((rows, D // 2), generator=gcpu) * 6.0
+    cos = ang.cos().repeat_interleave(2, 1).contiguous().to(DEV)
+    sin = ang.sin().repeat_interleave(2, 1).contiguous().to(DEV)
+    ref = x.float().clone()
+
+    def ref_part(block, w_, lo, hi):
+        v = block.view(-1, heads, D)
+        v = F.rms_norm(v, (D,), w_.float(), 1e-6).to(bf16).float()
+        c, s = cos[lo:hi].float().cpu()[:, None, :], sin[lo:hi].float().cpu()[:, None, :]
+        xr, xi = v.reshape(*v.shape[:-1], -1, 2).unbind(-1)
+        rot = torch.stack([-xi, xr], -1).flatten(2)
+        return (v * c + rot * s).reshape(-1, Cc)
+    xc = x.float().cpu()
+    want_q = ref_part(xc[St:, :Cc], wq.cpu(), St, rows)
+    want_k = ref_part(xc[St:, Cc:2 * Cc], wk.cpu(), St, rows)
+    y = x.clone()
+    ops.rmsnorm_rope_(y[St:], heads=heads, head_dim=D, col_offsets=(0, Cc), weights=(wq, wk), eps=1e-6, cos=cos, sin=sin,
+                      rope_row0=St)
+    assert torch.equal(y[:St], x[:St]) and torch.equal(y[:, 2 * Cc:], x[:, 2 * Cc:]), "rows / columns outside the view changed"
+    assert_close_bf16(y[St:, :Cc], want_q, f"rmsnorm+rope q D={D}", rtol=1.6e-2, atol_rms=8e-3)
+    assert_close_bf16(y[St:, Cc:2 * Cc], want_k, f"rmsnorm+rope k D={D}", rtol=1.6e-2, atol_rms=8e-3)
+    # norm only / rope only
+    y2 = x.clone()
+    ops.rmsnorm_rope_(y2, heads=heads, head_dim=D, col_offsets=(0,), weights=(wq,), eps=1e-6)
+    want = F.rms_norm(xc[:, :Cc].view(-1, heads, D), (D,), wq.float().cpu(), 1e-6).reshape(-1, Cc)
+    assert_close_bf16(y2[:, :Cc], want, "rmsnorm only", rtol=1.6e-2, atol_rms=8e-3)
+
+
+def test_rmsnorm_across_heads():
+    ops, L = _ops()
+    rows, heads, D = 70, 12, 128
+    Cc = heads * D
+    x = rnd((rows, Cc), 81)
+    w = rnd((Cc,), 82, scale=0.2) + 1
+    y = x.clone()
+    ops.rmsnorm_rope_(y, heads=heads, head_dim=D, col_offsets=(0,), weights=(w,), eps=1e-6, norm="across_heads")
+    want = F.rms_norm(x.float().cpu(), (Cc,), w.float().cpu(), 1e-6)
+    assert_close_bf16(y, want, "rmsnorm across heads", rtol=1.6e-2, atol_rms=8e-3)

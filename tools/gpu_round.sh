@@ -7,8 +7,8 @@ mkdir -p $O
 cd $R
 WHAT=${1:-test smoke kernels bench prof}
 if [[ $WHAT == *test* ]]; then
-  timeout 900 python -m pytest tests -m gpu -q --timeout 300 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
-  grep -E "^\[tune\]|passed|failed|FAILED|Error" $O/pytest_gpu.log | tail -25
+  timeout 900 python -m pytest tests -m gpu -q -s --timeout 300 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
+  grep -E "^\[tune\]|passed|failed|FAILED|Error|\[parity\]" $O/pytest_gpu.log | tail -40
 fi
 if [[ $WHAT == *smoke* ]]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/smoke.log
@@ -17,6 +17,10 @@ fi
 if [[ $WHAT == *kernels* ]]; then
   timeout 600 python tools/bench_kernels.py > $O/kernels.log 2>&1; echo "kernels rc=$?"
   grep -E '"op": "(linear|conv3x3).best"|"op": "(attention|groupnorm_silu|layernorm)"' $O/kernels.log | cut -c1-220
+fi
+if [[ $WHAT == *flux* ]]; then
+  timeout 600 python tools/bench_flux.py > $O/flux.log 2>&1; echo "flux rc=$?"
+  tail -4 $O/flux.log | cut -c1-300
 fi
 if [[ $WHAT == *bench* ]]; then
   timeout 600 python bench.py --steps 3 --warmup 1 --save-tuning $O/tuned_gfx950.json > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
