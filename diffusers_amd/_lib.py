@@ -70,7 +70,7 @@ SIGNATURES = {
     "da_x0_linear_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
     "da_flowmatch_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
     "da_advance_step": (_i, [_vp, _vp]),
-    "da_mul_scalar": (_i, [_vp, _vp, _f, _ll, _i, _vp]),
+    "da_mul_scalar": (_i, [_vp, _vp, _f, _i, _ll, _i, _vp]),
     "da_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp]),
     "da_linear_small_m_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_conv_thin_in_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),

@@ -30,13 +30,20 @@ struct AttnCfg {
   static constexpr int VCH = (D * 8) / 256;      // V^T chunks staged per thread
 };
 
+// 16-byte-slot XOR applied to a K row so the 16 rows of a ds_read_b128 lane group spread over the LDS bank row.  The XOR
+// must keep a chunk inside its row (CPR = D/8 chunks): D = 64 / 128 have power-of-two rows (conflict free); D = 96 (SD1.5
+// head_dim 80, zero padded) can only permute the low two bits; D = 160 (SD1.5 head_dim 160, sequence <= 256: negligible
+// share of a step) stays linear.
 template <int D>
 __device__ __forceinline__ int k_swz(int row) {
-  return (D == 64) ? ((row >> 1) & 7) : (row & 15);
+  if (D == 64) return (row >> 1) & 7;
+  if (D == 128) return row & 15;
+  if (D == 96) return (row >> 2) & 3;
+  return 0;
 }
 
 template <int D>
-__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
+__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
   using C = AttnCfg<D>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -268,7 +275,9 @@ extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   switch (p.D) {
     case 64: return launch_attn<64>(p, s);
+    case 96: return launch_attn<96>(p, s);
     case 128: return launch_attn<128>(p, s);
+    case 160: return launch_attn<160>(p, s);
   }
   return DA_ERR_UNSUPPORTED;
 }

@@ -85,22 +85,26 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const uint16_t* __r
 }
 
 // Thin-input conv: Cin <= 16, k in {1,3}, stride 1, pad (k-1)/2.  Input NCHW or NHWC, output NHWC [B][H][W][Cout].
-// Thread = (pixel, 8 output channels).  weights: [Cout][k][k][Cin] bf16.  `batch_mod`: input batch index = b % batch_mod
+// Thread = (pixel, 8 output channels).  weights: [Cout][k][k][Cin] bf16.  blockIdx.y selects a chunk of `coc` output
+// channels whose weights are staged in LDS as float, k-major ([k*k*Cin][coc]): the 8 channels a thread owns are 32
+// contiguous bytes (two ds_read_b128) and the lanes of a wave (consecutive channel groups of one pixel) read
+// consecutive addresses instead of one bank.
 __global__ __launch_bounds__(256) void conv_thin_in_kernel(const uint16_t* __restrict__ x,
                                                            const uint16_t* __restrict__ w,
                                                            const uint16_t* __restrict__ bias,
                                                            uint16_t* __restrict__ y, int B, int H, int W, int Cin,
-                                                           int Cout, int ks, int in_nchw, float in_div, float in_add) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [ks*ks*Cin][Cout] as float (transposed in LDS)
+                                                           int Cout, int ks, int in_nchw, float in_div, float in_add,
+                                                           int coc) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [ks*ks*Cin][coc]
   const int kk = ks * ks * Cin;
-  // k-major image: the 8 output channels a thread owns are 32 contiguous bytes (two ds_read_b128), and the lanes of a
-  // wave (consecutive channel groups of one pixel) read consecutive addresses instead of one bank
-  for (int i = threadIdx.x; i < Cout * kk; i += blockDim.x) {
+  const int co0 = blockIdx.y * coc;
+  const int ncoc = min(coc, Cout - co0);
+  for (int i = threadIdx.x; i < ncoc * kk; i += blockDim.x) {
     const int co = i / kk, k = i - co * kk;
-    wsm[k * Cout + co] = bf2f(w[i]);
+    wsm[k * coc + co] = bf2f(w[(size_t)(co0 + co) * kk + k]);
   }
   __syncthreads();
-  const int cgroups = Cout >> 3;
+  const int cgroups = ncoc >> 3;
   const size_t total = (size_t)B * H * W * cgroups;
   const int pad = (ks - 1) / 2;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const uint16_t* __res
     const int b = (int)(pix / ((size_t)W * H));
     float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bias ? bf2f(bias[cg * 8 + e]) : 0.f;
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bf2f(bias[co0 + cg * 8 + e]) : 0.f;
     for (int kh = 0; kh < ks; ++kh) {
       const int iy = yh + kh - pad;
       if ((unsigned)iy >= (unsigned)H) continue;
@@ -123,14 +127,14 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const uint16_t* __res
           float xv = bf2f(x[off]);
           if (in_div != 1.0f) xv = bf2f(f2bf(__fdiv_rn(xv, in_div)));  // e.g. latents / vae.config.scaling_factor
           if (in_add != 0.0f) xv = bf2f(f2bf(__fadd_rn(xv, in_add)));  // + vae.config.shift_factor (Flux)
-          const float* wp = wsm + (size_t)((kh * ks + kw) * Cin + c) * Cout + cg * 8;
+          const float* wp = wsm + (size_t)((kh * ks + kw) * Cin + c) * coc + cg * 8;
           const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
           acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
           acc[4] += xv * w1.x; acc[5] += xv * w1.y; acc[6] += xv * w1.z; acc[7] += xv * w1.w;
         }
       }
     }
-    *(uint4*)(y + pix * Cout + cg * 8) = pack8(acc);
+    *(uint4*)(y + pix * Cout + co0 + cg * 8) = pack8(acc);
   }
 }
 
@@ -219,22 +223,21 @@ extern "C" int da_conv_thin_in_bf16(const void* x, const void* w, const void* bi
                                     int Cin, int Cout, int ksize, int in_nchw, float in_div, float in_add, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return DA_ERR_INVALID;
   if (Cin <= 0 || Cin > 16 || Cout <= 0 || (Cout & 7) || (ksize != 1 && ksize != 3)) return DA_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)Cout * ksize * ksize * Cin * sizeof(float);
-  if (lds > 150 * 1024) return DA_ERR_UNSUPPORTED;
   if (in_div == 0.f) in_div = 1.f;
-  auto kern = conv_thin_in_kernel;
-  static size_t lds_enabled = 48 * 1024;  // raise the dynamic-LDS cap once (not during graph capture)
-  if (lds > lds_enabled) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-      return DA_ERR_LAUNCH;
-    lds_enabled = 150 * 1024;
-  }
-  size_t total = (size_t)B * H * W * (Cout / 8);
+  // output channels per block column: as many as fit 64 KiB of LDS (no opt-in attribute, two blocks per CU)
+  const int kk = ksize * ksize * Cin;
+  int coc = ((64 * 1024) / (kk * (int)sizeof(float))) & ~7;
+  if (coc > Cout) coc = Cout;
+  if (coc < 8) return DA_ERR_UNSUPPORTED;
+  const int nchunk = (Cout + coc - 1) / coc;
+  const size_t lds = (size_t)coc * kk * sizeof(float);
+  size_t total = (size_t)B * H * W * (coc / 8);
   size_t blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  DA_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x,
-                     (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)y, B, H, W, Cin, Cout, ksize, in_nchw,
-                     in_div, in_add);
+  const size_t cap = 4096 / nchunk > 0 ? 4096 / nchunk : 1;
+  if (blocks > cap) blocks = cap;
+  DA_LAUNCH(conv_thin_in_kernel, dim3((unsigned)blocks, (unsigned)nchunk), dim3(256), lds, (hipStream_t)stream,
+            (const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)y, B, H, W, Cin, Cout, ksize,
+            in_nchw, in_div, in_add, coc);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -118,9 +118,11 @@ __global__ void advance_step_kernel(int* step_idx) { *step_idx += 1; }
 
 // out = x * s in the tensor dtype (latents * init_noise_sigma, pipeline_stable_diffusion.py:713)
 template <typename T>
-__global__ void mul_scalar_kernel(const T* __restrict__ x, T* __restrict__ out, float sc, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    IO<T>::st(out, i, __fmul_rn(IO<T>::ld(x, i), sc));
+__global__ void mul_scalar_kernel(const T* __restrict__ x, T* __restrict__ out, float sc, int rep, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = __fmul_rn(IO<T>::ld(x, i), sc);
+    for (int r = 0; r < rep; ++r) IO<T>::st(out, (size_t)r * n + i, v);  // rep > 1: torch.cat([x] * rep) fused
+  }
 }
 
 inline dim3 ew_grid(size_t n) {
@@ -208,14 +210,14 @@ extern "C" int da_advance_step(int* step_idx, void* stream) {
   return DA_OK;
 }
 
-extern "C" int da_mul_scalar(const void* x, void* out, float sc, long long n_, int dtype, void* stream) {
-  if (!x || !out || n_ <= 0) return DA_ERR_INVALID;
+extern "C" int da_mul_scalar(const void* x, void* out, float sc, int rep, long long n_, int dtype, void* stream) {
+  if (!x || !out || n_ <= 0 || rep <= 0) return DA_ERR_INVALID;
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DA_DTYPE_BF16)
-    DA_LAUNCH((mul_scalar_kernel<uint16_t>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)out, sc, n);
+    DA_LAUNCH((mul_scalar_kernel<uint16_t>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)out, sc, rep, n);
   else if (dtype == DA_DTYPE_F32)
-    DA_LAUNCH((mul_scalar_kernel<float>), ew_grid(n), dim3(256), 0, s, (const float*)x, (float*)out, sc, n);
+    DA_LAUNCH((mul_scalar_kernel<float>), ew_grid(n), dim3(256), 0, s, (const float*)x, (float*)out, sc, rep, n);
   else
     return DA_ERR_UNSUPPORTED;
   DA_CHECK_LAUNCH();

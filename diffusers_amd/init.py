@@ -279,6 +279,10 @@ TINY_SD15_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_c
                       layers_per_block=1, cross_attention_dim=64, attention_head_dim=(1, 2),
                       down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
                       up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+# SD1.5's head geometry (attention_head_dim=8 means 8 HEADS: head dims 40 / 80 / 160) on a small spatial size
+SMALL_SD15_UNET = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280),
+                       layers_per_block=1, cross_attention_dim=64, attention_head_dim=8,
+                       down_block_types=("CrossAttnDownBlock2D",) * 3, up_block_types=("CrossAttnUpBlock2D",) * 3)
 TINY_VAE = dict(in_channels=3, out_channels=3, block_out_channels=(64, 128), layers_per_block=1,
                 down_block_types=("DownEncoderBlock2D",) * 2, up_block_types=("UpDecoderBlock2D",) * 2,
                 latent_channels=4, sample_size=32, scaling_factor=0.13025)

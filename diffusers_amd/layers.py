@@ -163,10 +163,40 @@ class CrossKV:
         self.k, self.vt, self.skv, self.skv_alloc, self.batch = k, vt, skv, skv_alloc, batch
 
 
+KERNEL_HEAD_DIMS = (64, 96, 128, 160)  # head sizes of the flash kernel (csrc/attention.hip)
+
+
+def kernel_head_dim(d: int) -> int:
+    for k in KERNEL_HEAD_DIMS:
+        if d <= k:
+            return k
+    raise ValueError(f"attention head_dim {d} exceeds the largest flash-kernel head size {KERNEL_HEAD_DIMS[-1]}")
+
+
+def pad_head_rows(w: torch.Tensor, heads: int, d: int, dp: int) -> torch.Tensor:
+    """[heads*d][K] projection rows -> [heads*dp][K] with zero rows after each head (SD1.5 head dims 40 / 80 run on the
+    64 / 96 wide kernels: zero q/k channels add nothing to q.k, zero v channels produce zero outputs)."""
+    if d == dp:
+        return w
+    out = torch.zeros((heads, dp) + tuple(w.shape[1:]), device=w.device, dtype=w.dtype)
+    out[:, :d] = w.view((heads, d) + tuple(w.shape[1:]))
+    return out.view((heads * dp,) + tuple(w.shape[1:])).contiguous()
+
+
+def pad_head_cols(w: torch.Tensor, heads: int, d: int, dp: int) -> torch.Tensor:
+    """[N][heads*d] to_out weight -> [N][heads*dp] with zero columns at the padded channels."""
+    if d == dp:
+        return w
+    out = torch.zeros((w.shape[0], heads, dp), device=w.device, dtype=w.dtype)
+    out[:, :, :d] = w.view(w.shape[0], heads, d)
+    return out.view(w.shape[0], heads * dp).contiguous()
+
+
 class Attention:
     """models/attention_processor.py:52-309 + AttnProcessor2_0 (:2696-2787): to_q/to_k/to_v (no bias), SDPA, to_out[0].
     Self-attention fuses Q and K into one GEMM and produces V already transposed (out^T = W_v . X^T) for the flash
-    kernel; cross-attention K / V^T depend only on the text embeddings and come from :meth:`precompute_kv`."""
+    kernel; cross-attention K / V^T depend only on the text embeddings and come from :meth:`precompute_kv`.
+    Head dims that are not a kernel size (SD1.5: 40, 80) are zero-padded once, in the packed weights."""
 
     def __init__(self, w: Weights, prefix: str, heads: int, cross: bool):
         self.heads = heads
@@ -174,14 +204,19 @@ class Attention:
         wq = w.get(prefix + ".to_q.weight")
         wk = w.get(prefix + ".to_k.weight")
         wv = w.get(prefix + ".to_v.weight")
-        self.inner = wq.shape[0]
-        self.head_dim = self.inner // heads
+        inner = wq.shape[0]
+        self.head_dim = inner // heads
+        self.kdim = kernel_head_dim(self.head_dim)
+        self.inner = heads * self.kdim                      # width of the (padded) q / k / v activations
+        d, dp = self.head_dim, self.kdim
+        wq, wk, wv = (pad_head_rows(t, heads, d, dp) for t in (wq, wk, wv))
         if cross:
             self.wq, self.wk, self.wv = wq, wk, wv
         else:
             self.wqk = torch.cat([wq, wk], dim=0).contiguous()
             self.wv = wv
         self.to_out = Linear(w, prefix + ".to_out.0")
+        self.to_out.weight = pad_head_cols(self.to_out.weight, heads, d, dp)
         self.scale = self.head_dim ** -0.5
 
     def precompute_kv(self, ehs_pad: torch.Tensor, batch: int, skv: int, skv_alloc: int) -> CrossKV:
@@ -192,7 +227,7 @@ class Attention:
 
     def __call__(self, x, batch: int, seq: int, residual, kv: Optional[CrossKV] = None):
         """x: [batch*seq][C] (already normalised); returns to_out(attn) + residual."""
-        Hh, D = self.heads, self.head_dim
+        Hh, D = self.heads, self.kdim
         if self.cross:
             q = ops.linear(x, self.wq)
             o = ops.attention(q, kv.k, kv.vt, B=batch, H=Hh, D=D, Sq=seq, Skv=kv.skv, Skv_alloc=kv.skv_alloc,

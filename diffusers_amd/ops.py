@@ -334,10 +334,11 @@ def flowmatch_step(v: torch.Tensor, x: torch.Tensor, table: torch.Tensor, step_i
     return out
 
 
-def mul_scalar(x: torch.Tensor, s: float) -> torch.Tensor:
+def mul_scalar(x: torch.Tensor, s: float, rep: int = 1) -> torch.Tensor:
+    """x * s (in the tensor dtype), replicated ``rep`` times along the batch dim (fused torch.cat([x] * rep))."""
     _req(x, "x", None)
-    out = torch.empty_like(x)
-    L.check(L.load().da_mul_scalar(x.data_ptr(), out.data_ptr(), float(s), x.numel(), _dt(x), _stream()),
+    out = torch.empty((rep * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+    L.check(L.load().da_mul_scalar(x.data_ptr(), out.data_ptr(), float(s), rep, x.numel(), _dt(x), _stream()),
             "da_mul_scalar")
     return out
 

@@ -54,7 +54,7 @@ class _LatentDiffusionBase:
         if isinstance(sch, EulerDiscreteScheduler):
             x_in = sch.scale_model_input(latents, sch.timesteps[0], rep=rep)
         else:
-            x_in = torch.cat([latents] * rep) if rep > 1 else latents  # DDIM: scale_model_input is the identity
+            x_in = ops.mul_scalar(latents, 1.0, rep=rep) if rep > 1 else latents  # DDIM: scale_model_input = identity
         eps = self.unet(x_in, None, None, conditioning=cond, sampler_table=sch.device_table,
                         step_idx=sch.device_step, return_dict=False)[0]
         if do_cfg:

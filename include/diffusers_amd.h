@@ -117,7 +117,8 @@ int da_gemm_tune(const da_gemm_params* p, void* stream, int iters, void* scratch
  *   vt  element (b, s, h, d) at vt + (h*D + d)*vt_ld + b*vt_batch_stride + s        (V transposed: keys contiguous)
  *   out element (b, s, h, d) at out + b*o_batch_stride + s*o_row_stride + h*D + d
  *   Skv = number of keys attended; Skv_alloc (multiple of 8, >= Skv) = keys present in memory per batch.
- *   D in {64, 128}.  All strides in elements, multiples of 8 (o: 4).
+ *   D in {64, 96, 128, 160} (SD1.5's head dims 40 / 80 are zero-padded to 64 / 96 by the host-side weight packing).
+ *   All strides in elements, multiples of 8 (o: 4).
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct da_attention_params {
   const void* q;
@@ -187,8 +188,9 @@ int da_x0_linear_step(const void* eps, const void* x, const void* noise, void* o
 int da_flowmatch_step(const void* v, const void* x, void* out, const float* table, const int* step_idx, int cfg,
                       float guidance, long long n, int dtype, void* stream);
 int da_advance_step(int* step_idx, void* stream);
-/* out = x * s in the tensor dtype: latents * scheduler.init_noise_sigma (pipeline_stable_diffusion.py:713) */
-int da_mul_scalar(const void* x, void* out, float s, long long n, int dtype, void* stream);
+/* out[r][:] = x * s in the tensor dtype for r < rep: latents * scheduler.init_noise_sigma
+ * (pipeline_stable_diffusion.py:713); rep = 2, s = 1 is the CFG batch doubling torch.cat([latents] * 2) (:1037) */
+int da_mul_scalar(const void* x, void* out, float s, int rep, long long n, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Misc (misc.hip)

@@ -186,3 +186,26 @@ def test_flowmatch_model_timestep_column():
     sch = S.FlowMatchEulerDiscreteScheduler(shift=1.0)
     with pytest.raises(ValueError):
         sch.set_model_timesteps([1.0])
+
+
+def test_head_dim_padding_is_exact():
+    """Zero-padding heads to a kernel size must not change q.k or the to_out product (SD1.5: 40 -> 64, 80 -> 96)."""
+    from diffusers_amd.layers import kernel_head_dim, pad_head_cols, pad_head_rows
+    assert [kernel_head_dim(d) for d in (8, 40, 64, 80, 96, 128, 160)] == [64, 64, 64, 96, 96, 128, 160]
+    with pytest.raises(ValueError):
+        kernel_head_dim(192)
+    g = torch.Generator().manual_seed(0)
+    heads, d, dp, C = 8, 40, 64, 48
+    wq, wk, wv = (torch.randn((heads * d, C), generator=g) for _ in range(3))
+    wo = torch.randn((C, heads * d), generator=g)
+    x = torch.randn((5, C), generator=g)
+
+    def attn(wq_, wk_, wv_, wo_, dd):
+        q, k, v = (x @ w_.t() for w_ in (wq_, wk_, wv_))
+        q, k, v = (t_.view(5, heads, dd).transpose(0, 1) for t_ in (q, k, v))
+        p = torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, -1)
+        return (p @ v).transpose(0, 1).reshape(5, heads * dd) @ wo_.t()
+    a = attn(wq, wk, wv, wo, d)
+    b = attn(pad_head_rows(wq, heads, d, dp), pad_head_rows(wk, heads, d, dp), pad_head_rows(wv, heads, d, dp),
+             pad_head_cols(wo, heads, d, dp), dp)
+    assert torch.allclose(a, b, atol=1e-5)

@@ -486,6 +486,13 @@ def test_conv_thin_in_out():
     w1 = rnd((8, Cin, 1, 1), 67, scale=0.5)
     y = ops.conv_thin_in(x, w1.reshape(8, Cin).contiguous(), None, ksize=1, in_nchw=True)
     assert_close_bf16(y, F.conv2d(x.float(), w1.float()).permute(0, 2, 3, 1), "conv_thin_in 1x1", rtol=8e-3, atol_rms=4e-3)
+    # 16 latent channels -> 512 (Flux VAE conv_in): output channels are processed in LDS-sized chunks (+ shift_factor)
+    x16 = rnd((1, 16, 12, 10), 91)
+    w16, b16 = rnd((512, 16, 3, 3), 92, scale=(9 * 16) ** -0.5), rnd((512,), 93, scale=0.1)
+    y = ops.conv_thin_in(x16, ops.pack_conv_weight(w16), b16, ksize=3, in_nchw=True, in_div=0.3611, in_add=0.1159)
+    xin = ((x16.float() / 0.3611).to(bf16).float() + 0.1159).to(bf16).float()
+    assert_close_bf16(y, F.conv2d(xin, w16.float(), b16.float(), padding=1).permute(0, 2, 3, 1),
+                      "conv_thin_in 16->512 chunked, /scale + shift", rtol=8e-3, atol_rms=4e-3)
     xh = rnd((B, H, W, 128), 68)
     for co in (3, 4):
         wo, bo = rnd((co, 128, 3, 3), 69, scale=(9 * 128) ** -0.5), rnd((co,), 70, scale=0.1)
@@ -552,6 +559,30 @@ def test_rmsnorm_rope_per_head(D, heads):
     ops.rmsnorm_rope_(y2, heads=heads, head_dim=D, col_offsets=(0,), weights=(wq,), eps=1e-6)
     want = F.rms_norm(xc[:, :Cc].view(-1, heads, D), (D,), wq.float().cpu(), 1e-6).reshape(-1, Cc)
     assert_close_bf16(y2[:, :Cc], want, "rmsnorm only", rtol=1.6e-2, atol_rms=8e-3)
+
+
+@pytest.mark.parametrize("D,S,Skv", [(96, 320, 320), (160, 256, 256), (160, 64, 77), (96, 1024, 77)])
+def test_attention_sd15_head_sizes(D, S, Skv):
+    """D = 96 / 160 kernels (SD1.5 head dims 80 -> 96 zero padded, 160) against fp32 SDPA."""
+    ops, L = _ops()
+    B, H = 2, 8
+    inner = H * D
+    sa = ((Skv + 15) // 16) * 16
+    q = rnd((B * S, inner), 95)
+    k = torch.zeros((B * sa, inner), device=DEV, dtype=bf16)
+    v = torch.zeros((B * sa, inner), device=DEV, dtype=bf16)
+    kk, vv = rnd((B, Skv, inner), 96), rnd((B, Skv, inner), 97)
+    k.view(B, sa, inner)[:, :Skv] = kk
+    v.view(B, sa, inner)[:, :Skv] = vv
+    vt = v.t().contiguous()
+    o = ops.attention(q, k, vt, B=B, H=H, D=D, Sq=S, Skv=Skv, Skv_alloc=sa, q_row_stride=inner, k_row_stride=inner,
+                      q_batch_stride=S * inner, k_batch_stride=sa * inner, vt_ld=B * sa, vt_batch_stride=sa,
+                      scale=80 ** -0.5)
+    qh = q.float().view(B, S, H, D).transpose(1, 2)
+    kh = kk.float().view(B, Skv, H, D).transpose(1, 2)
+    vh = vv.float().view(B, Skv, H, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh.cpu(), kh.cpu(), vh.cpu(), scale=80 ** -0.5).transpose(1, 2).reshape(B * S, inner)
+    assert_close_bf16(o, ref, f"attention D={D} S={S} Skv={Skv}", rtol=1.6e-2, atol_rms=1.6e-2)
 
 
 def test_rmsnorm_across_heads():

@@ -168,3 +168,19 @@ def test_tiny_flux_pipeline_vs_reference(golden):
     print(f"[parity] tiny Flux pipeline: latents rel_rms={rr:.3e}  image PSNR vs reference fp32 = {ps:.1f} dB")
     assert rr < 4e-2
     assert ps >= 35.0
+
+
+def test_sd15_head_geometry_vs_reference(golden):
+    """8 heads of 40 / 80 / 160 channels (SD1.5, unet_2d_condition.py:248-254): 40 and 80 run zero-padded on the 64 / 96
+    wide flash kernels, 160 on its own; 409 M parameters, vs the real reference's fp32 output."""
+    from diffusers_amd import factory, init as dinit
+    g = golden("small_unet_sd15_heads")
+    unet, _ = factory.build_unet(dinit.SMALL_SD15_UNET, seed=7, device=DEV)
+    kd = sorted({tr.blocks[0].attn1.kdim for tr in unet._transformers()})
+    assert kd == [64, 96, 160]
+    y = unet(t(g, "sample"), torch.tensor(float(g["t"])), t(g, "ehs")).sample
+    ref = torch.from_numpy(g["out"])
+    rr = rel_rms(y, ref)
+    print(f"[parity] SD1.5 head geometry (40/80/160): rel_rms vs reference fp32 = {rr:.3e}")
+    assert y.shape == ref.shape and torch.isfinite(y.float()).all()
+    assert rr < MODEL_REL_RMS

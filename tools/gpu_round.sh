@@ -22,6 +22,10 @@ if [[ $WHAT == *flux* ]]; then
   timeout 600 python tools/bench_flux.py > $O/flux.log 2>&1; echo "flux rc=$?"
   tail -4 $O/flux.log | cut -c1-300
 fi
+if [[ $WHAT == *sd15* ]]; then
+  timeout 600 python tools/bench_sd15.py > $O/sd15.log 2>&1; echo "sd15 rc=$?"
+  tail -3 $O/sd15.log | cut -c1-300
+fi
 if [[ $WHAT == *bench* ]]; then
   timeout 600 python bench.py --steps 3 --warmup 1 --save-tuning $O/tuned_gfx950.json > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
   cat $O/bench.json; grep "^\[bench" $O/bench.err | tail -12
