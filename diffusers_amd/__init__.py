@@ -16,6 +16,8 @@ _EXPORTS = {
     "AutoencoderKL": "autoencoder_kl",
     "FluxTransformer2DModel": "transformer_flux",
     "FluxPipeline": "pipelines",
+    "WanTransformer3DModel": "transformer_wan",
+    "WanPipeline": "pipelines",
     "EulerDiscreteScheduler": "schedulers",
     "DDIMScheduler": "schedulers",
     "DDPMScheduler": "schedulers",

@@ -34,7 +34,7 @@ class GemmParams(C.Structure):
         ("act", C.c_int), ("out_f32", C.c_int), ("conv", C.c_int),
         ("Hin", C.c_int), ("Win", C.c_int), ("C1", C.c_int), ("C2", C.c_int),
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("pad", C.c_int),
-        ("tile", C.c_int), ("staging", C.c_int),
+        ("tile", C.c_int), ("staging", C.c_int), ("gate_f32", C.c_int),
     ]
 
 
@@ -61,7 +61,7 @@ SIGNATURES = {
     "da_attention_bf16": (_i, [C.POINTER(AttentionParams), _vp]),
     "da_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "da_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
-    "da_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "da_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "da_rmsnorm_rope_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_void_p), _f, _vp, _vp,
                                   _i, _i, _vp]),
     "da_softmax_rows_f32_bf16": (_i, [_vp, _vp, _i, _i, _ll, _ll, _vp]),
@@ -71,6 +71,9 @@ SIGNATURES = {
     "da_flowmatch_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
     "da_advance_step": (_i, [_vp, _vp]),
     "da_mul_scalar": (_i, [_vp, _vp, _f, _i, _ll, _i, _vp]),
+    "da_bcast_add_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "da_patchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "da_unpatchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp]),
     "da_linear_small_m_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_conv_thin_in_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),

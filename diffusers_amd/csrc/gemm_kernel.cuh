@@ -352,7 +352,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(bf2f(f2bf(o[e])));
         }
-        if (gate) {
+        if (gate && p.gate_f32) {
+          // WanTransformerBlock: hidden.float() + Linear(x) (bf16) * gate (fp32), rounded once at the store
+          const float4 gv = *(const float4*)((const float*)p.gate + (size_t)bidx * p.ld_gate + n);
+          o[0] = bf2f(f2bf(o[0])) * gv.x; o[1] = bf2f(f2bf(o[1])) * gv.y;
+          o[2] = bf2f(f2bf(o[2])) * gv.z; o[3] = bf2f(f2bf(o[3])) * gv.w;
+        } else if (gate) {
           // reference: y = Linear(x) (bf16) ; g = gate * y (bf16) ; out = residual + g
           const uint2 gv = *(const uint2*)(gate + (size_t)bidx * p.ld_gate + n);
           o[0] = bf2f(f2bf(bf2f(f2bf(o[0])) * bf_lo(gv.x)));

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
                                                         const uint16_t* __restrict__ gamma,
                                                         const uint16_t* __restrict__ beta, uint16_t* __restrict__ y,
                                                         const uint16_t* __restrict__ mod_scale,
-                                                        const uint16_t* __restrict__ mod_shift, int mod_ld,
+                                                        const uint16_t* __restrict__ mod_shift, int mod_ld, int mod_f32,
                                                         int rows_per_batch, int M, int C, int ldx, int ldy, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -230,7 +230,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += bb[e];
       }
-      if (mod_scale) {
+      if (mod_scale && mod_f32) {
+        const float* scp = (const float*)mod_scale + (size_t)bidx * mod_ld + ch * 8;
+        const float* shp = (const float*)mod_shift + (size_t)bidx * mod_ld + ch * 8;
+        const float4 s0 = *(const float4*)scp, s1 = *(const float4*)(scp + 4);
+        const float4 h0 = *(const float4*)shp, h1 = *(const float4*)(shp + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
+      } else if (mod_scale) {
         float sc[8], sh[8];
         unpack8(*(const uint4*)(mod_scale + (size_t)bidx * mod_ld + ch * 8), sc);
         unpack8(*(const uint4*)(mod_shift + (size_t)bidx * mod_ld + ch * 8), sh);
@@ -420,8 +429,8 @@ extern "C" int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
 }
 
 extern "C" int da_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, const void* mod_scale,
-                                 const void* mod_shift, int mod_ld, int rows_per_batch, int M, int C, int ldx, int ldy,
-                                 float eps, void* stream) {
+                                 const void* mod_shift, int mod_ld, int mod_f32, int rows_per_batch, int M, int C,
+                                 int ldx, int ldy, float eps, void* stream) {
   if (!x || !y) return DA_ERR_INVALID;
   if (M <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7)) return DA_ERR_UNSUPPORTED;
   if ((mod_scale == nullptr) != (mod_shift == nullptr)) return DA_ERR_INVALID;
@@ -432,7 +441,7 @@ extern "C" int da_layernorm_bf16(const void* x, const void* gamma, const void* b
 #define DA_LN(N)                                                                                                  \
   DA_LAUNCH(layernorm_kernel<N>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)gamma,          \
                      (const uint16_t*)beta, (uint16_t*)y, (const uint16_t*)mod_scale, (const uint16_t*)mod_shift, \
-                     mod_ld, rows_per_batch, M, C, ldx, ldy, eps)
+                     mod_ld, mod_f32, rows_per_batch, M, C, ldx, ldy, eps)
   if (nch <= 1) DA_LN(1);
   else if (nch <= 2) DA_LN(2);
   else if (nch <= 3) DA_LN(3);

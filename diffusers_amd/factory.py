@@ -7,7 +7,8 @@ import torch
 
 from . import init as dinit
 from .autoencoder_kl import AutoencoderKL
-from .pipelines import FluxPipeline, StableDiffusionPipeline, StableDiffusionXLPipeline
+from .pipelines import FluxPipeline, StableDiffusionPipeline, StableDiffusionXLPipeline, WanPipeline
+from .transformer_wan import WanTransformer3DModel
 from .schedulers import DDIMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
 from .transformer_flux import FluxTransformer2DModel
 from .unet_2d_condition import UNet2DConditionModel
@@ -74,3 +75,21 @@ def build_flux_pipeline(device="cuda", tiny: bool = False, seed: int = 5, init_d
     vae, _ = build_vae(vcfg, seed=seed + 1, device=device, init_device=idev)
     sch = FlowMatchEulerDiscreteScheduler(shift=1.0, use_dynamic_shifting=False)
     return FluxPipeline(scheduler=sch, vae=vae, transformer=tr)
+
+
+def build_wan_transformer(cfg: dict, seed: int = 9, device="cuda", init_device: Optional[str] = None, state_dict=None):
+    tr = WanTransformer3DModel(**cfg)
+    if state_dict is None:
+        state_dict = dinit.random_state_dict(dinit.wan_param_shapes(tr.config), seed=seed, device=init_device or "cpu")
+    tr.load_state_dict(state_dict, device=device)
+    return tr, state_dict
+
+
+def build_wan_pipeline(device="cuda", tiny: bool = False, seed: int = 9, init_device: Optional[str] = None,
+                       flow_shift: float = 3.0):
+    """Wan2.1-T2V-1.3B (BASELINE config 5) or its tiny sibling with the FlowMatch-Euler scheduler of SURVEY.md 8d."""
+    cfg = dinit.TINY_WAN if tiny else dinit.WAN_1_3B
+    idev = init_device or ("cpu" if tiny else str(device))
+    tr, _ = build_wan_transformer(cfg, seed=seed, device=device, init_device=idev)
+    sch = FlowMatchEulerDiscreteScheduler(shift=flow_shift, use_dynamic_shifting=False)
+    return WanPipeline(scheduler=sch, transformer=tr)

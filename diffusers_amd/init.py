@@ -210,6 +210,36 @@ def flux_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
     return sh
 
 
+def wan_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict inventory of WanTransformer3DModel (transformer_wan.py:571-627), T2V (no image branch)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    inner = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    pt, ph, pw = cfg["patch_size"]
+    sh["patch_embedding.weight"] = (inner, cfg["in_channels"], pt, ph, pw)
+    sh["patch_embedding.bias"] = (inner,)
+    _lin(sh, "condition_embedder.time_embedder.linear_1", inner, cfg["freq_dim"])
+    _lin(sh, "condition_embedder.time_embedder.linear_2", inner, inner)
+    _lin(sh, "condition_embedder.time_proj", 6 * inner, inner)
+    _lin(sh, "condition_embedder.text_embedder.linear_1", inner, cfg["text_dim"])
+    _lin(sh, "condition_embedder.text_embedder.linear_2", inner, inner)
+    for i in range(cfg["num_layers"]):
+        b = f"blocks.{i}"
+        for a in ("attn1", "attn2"):
+            for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+                _lin(sh, f"{b}.{a}.{nm}", inner, inner)
+            sh[f"{b}.{a}.norm_q.weight"] = (inner,)
+            sh[f"{b}.{a}.norm_k.weight"] = (inner,)
+        if cfg.get("cross_attn_norm", True):
+            sh[f"{b}.norm2.weight"] = (inner,)
+            sh[f"{b}.norm2.bias"] = (inner,)
+        _lin(sh, f"{b}.ffn.net.0.proj", cfg["ffn_dim"], inner)
+        _lin(sh, f"{b}.ffn.net.2", inner, cfg["ffn_dim"])
+        sh[f"{b}.scale_shift_table"] = (1, 6, inner)
+    _lin(sh, "proj_out", cfg["out_channels"] * pt * ph * pw, inner)
+    sh["scale_shift_table"] = (1, 2, inner)
+    return sh
+
+
 def _seed_for(name: str, seed: int) -> int:
     h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
     return int.from_bytes(h[:7], "little")
@@ -279,6 +309,12 @@ TINY_SD15_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_c
                       layers_per_block=1, cross_attention_dim=64, attention_head_dim=(1, 2),
                       down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
                       up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+WAN_1_3B = dict(patch_size=(1, 2, 2), num_attention_heads=12, attention_head_dim=128, in_channels=16, out_channels=16,
+                text_dim=4096, freq_dim=256, ffn_dim=8960, num_layers=30, cross_attn_norm=True,
+                qk_norm="rms_norm_across_heads", eps=1e-6, image_dim=None, added_kv_proj_dim=None, rope_max_seq_len=1024,
+                pos_embed_seq_len=None)
+TINY_WAN = dict(WAN_1_3B, num_attention_heads=2, attention_head_dim=64, text_dim=64, ffn_dim=256, num_layers=2,
+                rope_max_seq_len=32)
 # SD1.5's head geometry (attention_head_dim=8 means 8 HEADS: head dims 40 / 80 / 160) on a small spatial size
 SMALL_SD15_UNET = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280),
                        layers_per_block=1, cross_attention_dim=64, attention_head_dim=8,

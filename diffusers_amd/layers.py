@@ -35,6 +35,13 @@ class Weights:
         self.used.add(name)
         return self.sd[name].detach().to(device=self.device, dtype=bf16).contiguous()
 
+    def get_f32(self, name: str) -> torch.Tensor:
+        """Parameters the reference keeps in fp32 (``_keep_in_fp32_modules``, e.g. Wan's scale_shift_table)."""
+        if name not in self.sd:
+            raise KeyError(f"missing weight '{name}' in state_dict")
+        self.used.add(name)
+        return self.sd[name].detach().to(device=self.device, dtype=torch.float32).contiguous()
+
     def opt(self, name: str) -> Optional[torch.Tensor]:
         return self.get(name) if name in self.sd else None
 

@@ -83,6 +83,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     p.ld_rowvec = _rows2d(rowvec, "rowvec") if rowvec is not None else 0
     p.bias_rows, p.gate = _ptr(bias_rows), _ptr(gate)
     p.ld_gate = _rows2d(gate, "gate") if gate is not None else 0
+    if gate is not None:
+        if gate.dtype not in (bf16, torch.float32):
+            raise TypeError("linear: gate must be bf16 (Flux rounding) or float32 (Wan rounding)")
+        p.gate_f32 = int(gate.dtype == torch.float32)
     if out.data_ptr() == (residual.data_ptr() if residual is not None else -1):
         raise ValueError("linear: `out` must not alias `residual` (variant tuning re-runs the launch)")
     p.rows_per_batch = rows_per_batch
@@ -245,9 +249,14 @@ def layer_norm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[to
     M, Cc = x.shape
     y = torch.empty((M, Cc), device=x.device, dtype=bf16)
     mod_ld = _rows2d(mod_scale, "mod_scale") if mod_scale is not None else 0
+    mod_f32 = 0
+    if mod_scale is not None:
+        if mod_scale.dtype != mod_shift.dtype or mod_scale.dtype not in (bf16, torch.float32):
+            raise TypeError("layer_norm: mod_scale / mod_shift must both be bf16 or both float32")
+        mod_f32 = int(mod_scale.dtype == torch.float32)
     L.check(L.load().da_layernorm_bf16(x.data_ptr(), _ptr(gamma), _ptr(beta), y.data_ptr(), _ptr(mod_scale),
-                                       _ptr(mod_shift), mod_ld, rows_per_batch, M, Cc, _rows2d(x, "x"), Cc, eps,
-                                       _stream()), "da_layernorm_bf16")
+                                       _ptr(mod_shift), mod_ld, mod_f32, rows_per_batch, M, Cc, _rows2d(x, "x"), Cc,
+                                       eps, _stream()), "da_layernorm_bf16")
     return y
 
 
@@ -362,6 +371,43 @@ def timestep_embedding(t: Optional[torch.Tensor], dim: int, *, batch: int, flip_
                                            int(flip_sin_to_cos), shift, scale, max_period, int(out_f32), _stream()),
             "da_timestep_embedding")
     return out
+
+
+def bcast_add_f32(a: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
+    """out[b] = a (fp32 [n]) + m[b] (bf16 [B][n]) in fp32."""
+    _req(a, "a", torch.float32), _req(m, "m")
+    B, n = m.shape
+    if a.numel() != n or not a.is_contiguous() or not m.is_contiguous():
+        raise ValueError("bcast_add_f32: a must be contiguous [n], m contiguous [B][n]")
+    out = torch.empty((B, n), device=m.device, dtype=torch.float32)
+    L.check(L.load().da_bcast_add_f32(a.data_ptr(), m.data_ptr(), out.data_ptr(), B, n, _stream()), "da_bcast_add_f32")
+    return out
+
+
+def patchify3d(x: torch.Tensor, patch) -> torch.Tensor:
+    """[B][C][F][H][W] -> tokens [B*f*h*w][C*pt*ph*pw] (feature order c, dt, dh, dw = Conv3d weight order)."""
+    _req(x, "x")
+    B, Cc, Fr, H, W_ = x.shape
+    pt, ph, pw = patch
+    if not x.is_contiguous():
+        raise ValueError("patchify3d: contiguous input required")
+    tok = torch.empty((B * (Fr // pt) * (H // ph) * (W_ // pw), Cc * pt * ph * pw), device=x.device, dtype=bf16)
+    L.check(L.load().da_patchify3d_bf16(x.data_ptr(), tok.data_ptr(), B, Cc, Fr, H, W_, pt, ph, pw, _stream()),
+            "da_patchify3d_bf16")
+    return tok
+
+
+def unpatchify3d(tok: torch.Tensor, shape, patch) -> torch.Tensor:
+    """tokens [B*f*h*w][pt*ph*pw*C] (feature order dt, dh, dw, c) -> [B][C][F][H][W]."""
+    _req(tok, "tok")
+    B, Cc, Fr, H, W_ = shape
+    pt, ph, pw = patch
+    if not tok.is_contiguous() or tok.numel() != B * Cc * Fr * H * W_:
+        raise ValueError("unpatchify3d: token buffer does not match the target shape")
+    x = torch.empty((B, Cc, Fr, H, W_), device=tok.device, dtype=bf16)
+    L.check(L.load().da_unpatchify3d_bf16(tok.data_ptr(), x.data_ptr(), B, Cc, Fr, H, W_, pt, ph, pw, _stream()),
+            "da_unpatchify3d_bf16")
+    return x
 
 
 def conv_thin_in(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ksize: int, in_nchw: bool,

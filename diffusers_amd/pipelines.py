@@ -22,6 +22,7 @@ from . import ops
 from .autoencoder_kl import AutoencoderKL
 from .schedulers import DDIMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
 from .transformer_flux import FluxTransformer2DModel
+from .transformer_wan import WanTransformer3DModel
 from .unet_2d_condition import UNet2DConditionModel
 
 bf16 = torch.bfloat16
@@ -379,3 +380,114 @@ class FluxPipeline:
         if not return_dict:
             return (images,)
         return PipelineOutput(images=images)
+
+
+class WanPipeline:
+    """pipelines/wan/pipeline_wan.py:380-700 (Wan 2.1 T2V) for pre-computed prompt embeddings: the denoising loop.
+    The reference runs the transformer twice per step (cond / uncond, :613-632); here the two are one batch-2 call
+    (identical arithmetic per sample, twice the GEMM M) and ``uncond + g (cond - uncond)`` is fused into the FlowMatch
+    update.  Decoding needs AutoencoderKLWan (a "next" row): ``output_type`` must be "latent"."""
+
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, scheduler: FlowMatchEulerDiscreteScheduler = None,
+                 transformer: WanTransformer3DModel = None, transformer_2=None, boundary_ratio=None,
+                 expand_timesteps: bool = False):
+        if transformer_2 is not None or boundary_ratio is not None or expand_timesteps:
+            raise NotImplementedError("Wan 2.2 two-stage / TI2V options are not on the BASELINE hot path")
+        self.scheduler, self.transformer, self.vae = scheduler, transformer, vae
+        self.vae_scale_factor_temporal, self.vae_scale_factor_spatial = 4, 8
+        self._graph = None
+        self._graph_key = None
+        self._static = {}
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    def set_progress_bar_config(self, **kw):
+        pass
+
+    def _step(self, latents, cond, guidance_scale, do_cfg):
+        sch = self.scheduler
+        x_in = ops.mul_scalar(latents, 1.0, rep=2) if do_cfg else latents       # cond / uncond share the latents
+        v = self.transformer(x_in, conditioning=cond, sampler_table=sch.device_table, step_idx=sch.device_step,
+                             return_dict=False)[0]
+        if do_cfg:
+            sch.step_cfg(v, latents, guidance_scale, out=latents)
+        else:
+            sch.step_inplace(v, latents)
+        return latents
+
+    def _denoise(self, latents, cond, num_steps, guidance_scale, do_cfg, use_graph):
+        sch = self.scheduler
+        sch.reset(0)
+        if not use_graph:
+            for _ in range(num_steps):
+                self._step(latents, cond, guidance_scale, do_cfg)
+            return latents
+        key = (tuple(latents.shape), float(guidance_scale), do_cfg, cond["St"], sch.device_table.data_ptr())
+        if self._graph is None or self._graph_key != key:
+            saved = latents.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._step(latents, cond, guidance_scale, do_cfg)
+            torch.cuda.current_stream().wait_stream(s)
+            latents.copy_(saved)
+            sch.reset(0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step(latents, cond, guidance_scale, do_cfg)
+            self._graph, self._graph_key = g, key
+            self._static = {"latents": latents, "cond": cond}
+            latents.copy_(saved)
+            sch.reset(0)
+        else:
+            st = self._static
+            st["latents"].copy_(latents)
+            for (k0, v0), (k1, v1) in zip(st["cond"]["kvs"], cond["kvs"]):
+                k0.copy_(k1)
+                v0.copy_(v1)
+            latents = st["latents"]
+        for _ in range(num_steps):
+            self._graph.replay()
+        sch._step_index = num_steps
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, negative_prompt=None, height: int = 480, width: int = 832, num_frames: int = 81,
+                 num_inference_steps: int = 50, guidance_scale: float = 5.0, num_videos_per_prompt: int = 1,
+                 generator=None, latents: Optional[torch.Tensor] = None, prompt_embeds=None,
+                 negative_prompt_embeds=None, output_type: str = "latent", return_dict: bool = True,
+                 use_graph: bool = True):
+        if prompt is not None or negative_prompt is not None:
+            raise ValueError("text encoders are outside the HIP hot path: pass `prompt_embeds`")
+        if prompt_embeds is None:
+            raise ValueError("Provide `prompt_embeds`.")
+        if output_type != "latent":
+            raise NotImplementedError("AutoencoderKLWan is a 'next' row (SURVEY.md 8f): use output_type='latent'")
+        do_cfg = guidance_scale > 1.0
+        if do_cfg and negative_prompt_embeds is None:
+            raise ValueError("classifier-free guidance needs `negative_prompt_embeds`")
+        if num_frames % self.vae_scale_factor_temporal != 1:
+            raise ValueError("`num_frames - 1` has to be divisible by 4")
+        dev = self.device
+        B = prompt_embeds.shape[0]
+        if B != 1:
+            raise NotImplementedError("one prompt per call (its cond / uncond pair forms the batch)")
+        c = self.transformer.config
+        shape = (B, c.in_channels, (num_frames - 1) // self.vae_scale_factor_temporal + 1,
+                 height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
+        if latents is None:
+            gdev = generator.device if generator is not None else torch.device("cpu")
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32)
+        latents = latents.to(device=dev, dtype=bf16).contiguous().clone()
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        self.scheduler.set_begin_index(0)
+        pe = prompt_embeds.to(device=dev, dtype=bf16)
+        if do_cfg:
+            pe = torch.cat([negative_prompt_embeds.to(device=dev, dtype=bf16), pe], dim=0)   # [uncond ; cond]
+        cond = self.transformer.precompute_conditioning(pe.contiguous())
+        latents = self._denoise(latents, cond, len(self.scheduler.timesteps), guidance_scale, do_cfg, use_graph)
+        if not return_dict:
+            return (latents,)
+        return PipelineOutput(images=latents)

@@ -81,7 +81,7 @@ typedef struct da_gemm_params {
   const void* rowvec;   /* [M / rows_per_batch][ld_rowvec] or NULL */
   const void* residual; /* [M][ldr] or NULL */
   const void* bias_rows; /* [M] or NULL */
-  const void* gate;      /* [M / rows_per_batch][ld_gate] or NULL */
+  const void* gate;      /* [M / rows_per_batch][ld_gate] or NULL (bf16, or fp32 when gate_f32) */
   int M, N, K;
   int lda, ldw, ldc, ldr, ld_rowvec, ld_gate;
   int rows_per_batch;
@@ -93,6 +93,8 @@ typedef struct da_gemm_params {
   int Hin, Win, C1, C2, Hout, Wout, stride, up, pad;
   int tile;    /* DA_TILE_* */
   int staging; /* DA_STAGE_* */
+  int gate_f32; /* 1: gate is float and out = residual + bf16(xW+b) * gate in fp32, rounded once
+                   (WanTransformerBlock, transformer_wan.py:491,:502); 0: Flux rounding (gate product rounded to bf16) */
 } da_gemm_params;
 
 int da_gemm_bf16(const da_gemm_params* p, void* stream);
@@ -142,6 +144,9 @@ int da_attention_bf16(const da_attention_params* p, void* stream);
  *                            unet_2d_blocks.py:2444).
  *   da_layernorm_bf16        nn.LayerNorm(C, eps) over rows of [M][ldx] (gamma/beta may be NULL = no affine), optional
  *                            AdaLN modulation y = LN(x) * (1 + mod_scale[b]) + mod_shift[b], b = row / rows_per_batch.
+ *                            mod_f32 == 0: bf16 vectors, LN(x) rounded to bf16 before the modulation (the reference's
+ *                            separate bf16 ops); mod_f32 == 1: fp32 vectors and fp32 math throughout (FP32LayerNorm +
+ *                            fp32 scale_shift_table, transformer_wan.py:488-502,:723).
  *                            Replaces attention.py:986,:1030,:1056 and normalization.py:157-170,:194-202,:346-351.
  *   da_rmsnorm_rope_bf16     per-head RMSNorm (torch.nn.RMSNorm(head_dim), transformer_flux.py:316-317,:101-102 ;
  *                            "rms_norm_across_heads" when heads == 1, transformer_wan.py:83-84) followed by rotary
@@ -157,8 +162,8 @@ size_t da_groupnorm_workspace_bytes(int B, int HW, int C, int G);
 int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const void* gamma, const void* beta, void* y,
                            void* workspace, int B, int HW, int C, int G, float eps, int act, void* stream);
 int da_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, const void* mod_scale,
-                      const void* mod_shift, int mod_ld, int rows_per_batch, int M, int C, int ldx, int ldy, float eps,
-                      void* stream);
+                      const void* mod_shift, int mod_ld, int mod_f32, int rows_per_batch, int M, int C, int ldx, int ldy,
+                      float eps, void* stream);
 int da_rmsnorm_rope_bf16(void* x, int ld, int rows, int rows_per_batch, int heads, int D, int parts, const int* col_off,
                          const void* const* weight, float eps, const float* cos, const float* sin, int rope_row0,
                          int do_norm, void* stream);
@@ -207,6 +212,13 @@ int da_mul_scalar(const void* x, void* out, float s, int rep, long long n, int d
  *   da_conv_thin_out_bf16   Conv2d 3x3 with Cout in {3,4,8,16}: conv_out (unet_2d_condition.py:1230, vae.py:309).
  *                           Input NHWC, output NCHW (bf16 or fp32).
  * ------------------------------------------------------------------------------------------------------------------ */
+/* out[b][i] = (float)a[i] + (float)m[b][i]: scale_shift_table + temb.float() (transformer_wan.py:483-485,:719) */
+int da_bcast_add_f32(const float* a, const void* m_bf16, float* out, int B, int n, void* stream);
+/* Conv3d patch embedding with kernel == stride as a gather + GEMM (transformer_wan.py:598,:663-664): tokens[b*f*h*w + ...]
+ * [c][dt][dh][dw] <- x[b][c][F][H][W]; and its inverse for the output (:727-731): x[b][c][F][H][W] <- tokens[..][dt][dh][dw][c] */
+int da_patchify3d_bf16(const void* x, void* tokens, int B, int C, int F, int H, int W, int pt, int ph, int pw, void* stream);
+int da_unpatchify3d_bf16(const void* tokens, void* x, int B, int C, int F, int H, int W, int pt, int ph, int pw,
+                         void* stream);
 int da_timestep_embedding(const float* t, const float* table, const int* step_idx, void* out, int B, int dim,
                           int flip_sin_to_cos, float shift, float scale, float max_period, int out_f32, void* stream);
 int da_linear_small_m_bf16(const void* x, const void* W, const void* bias, const void* res, void* out, int M, int N,

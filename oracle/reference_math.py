@@ -360,3 +360,105 @@ def flux_forward(sd: Dict[str, torch.Tensor], cfg: dict, hidden_states, encoder_
     C = x.shape[-1]
     x = F.layer_norm(x, (C,), None, None, 1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
     return F.linear(x, sd["proj_out.weight"], sd["proj_out.bias"])
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Wan 2.1 T2V (models/transformers/transformer_wan.py)
+# --------------------------------------------------------------------------------------------------------------------
+def wan_rope_tables(head_dim: int, frames: int, height: int, width: int, max_seq_len: int, theta: float = 10000.0):
+    """WanRotaryPosEmbed (transformer_wan.py:354-416) for a (frames, height, width) post-patch grid:
+    (cos, sin) fp32 [frames*height*width][head_dim], each frequency repeated for the pair it rotates."""
+    h_dim = w_dim = 2 * (head_dim // 6)
+    t_dim = head_dim - h_dim - w_dim
+    tabs = []
+    for dim in (t_dim, h_dim, w_dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64) / dim))
+        f = torch.outer(torch.arange(max_seq_len), freqs)
+        tabs.append((f.cos().repeat_interleave(2, dim=1).float(), f.sin().repeat_interleave(2, dim=1).float()))
+
+    def grid(i):
+        ct, st = tabs[0][i][:frames].view(frames, 1, 1, -1).expand(frames, height, width, -1), None
+        ch = tabs[1][i][:height].view(1, height, 1, -1).expand(frames, height, width, -1)
+        cw = tabs[2][i][:width].view(1, 1, width, -1).expand(frames, height, width, -1)
+        return torch.cat([ct, ch, cw], dim=-1).reshape(frames * height * width, head_dim)
+    return grid(0), grid(1)
+
+
+def wan_apply_rope(x, cos, sin):
+    """WanAttnProcessor.apply_rotary_emb (transformer_wan.py:103-116).  x: (B, S, H, D); cos/sin: (S, D)."""
+    x1, x2 = x.unflatten(-1, (-1, 2)).unbind(-1)
+    c = cos[None, :, None, 0::2]
+    s = sin[None, :, None, 1::2]
+    out = torch.empty_like(x)
+    out[..., 0::2] = x1 * c - x2 * s
+    out[..., 1::2] = x1 * s + x2 * c
+    return out.type_as(x)
+
+
+def _fp32_layer_norm(x, w, b, eps):
+    """FP32LayerNorm (normalization.py:429-444)."""
+    return F.layer_norm(x.float(), (x.shape[-1],), None if w is None else w.float(), None if b is None else b.float(),
+                        eps).to(x.dtype)
+
+
+def wan_attention(sd, p, x, ctx, heads, cos=None, sin=None, eps=1e-6):
+    """WanAttention + WanAttnProcessor (transformer_wan.py:68-162): q/k RMSNorm over ALL heads, RoPE, SDPA, to_out."""
+    src = x if ctx is None else ctx
+    q = F.linear(x, sd[f"{p}.to_q.weight"], sd[f"{p}.to_q.bias"])
+    k = F.linear(src, sd[f"{p}.to_k.weight"], sd[f"{p}.to_k.bias"])
+    v = F.linear(src, sd[f"{p}.to_v.weight"], sd[f"{p}.to_v.bias"])
+    q = F.rms_norm(q, (q.shape[-1],), sd[f"{p}.norm_q.weight"], eps)
+    k = F.rms_norm(k, (k.shape[-1],), sd[f"{p}.norm_k.weight"], eps)
+    q, k, v = (t.unflatten(2, (heads, -1)) for t in (q, k, v))
+    if cos is not None:
+        q, k = wan_apply_rope(q, cos, sin), wan_apply_rope(k, cos, sin)
+    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+    o = o.flatten(2, 3).type_as(q)
+    return F.linear(o, sd[f"{p}.to_out.0.weight"], sd[f"{p}.to_out.0.bias"])
+
+
+def wan_block(sd, p, x, ctx, tproj, cos, sin, heads, eps, cross_attn_norm):
+    """WanTransformerBlock.forward (transformer_wan.py:462-504), temb (B, 6, dim)."""
+    sh, sc, g, csh, csc, cg = (sd[f"{p}.scale_shift_table"].float() + tproj.float()).chunk(6, dim=1)
+    n = (_fp32_layer_norm(x.float(), None, None, eps) * (1 + sc) + sh).type_as(x)
+    a = wan_attention(sd, f"{p}.attn1", n, None, heads, cos, sin, eps)
+    x = (x.float() + a * g).type_as(x)
+    if cross_attn_norm:
+        n = _fp32_layer_norm(x.float(), sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"], eps).type_as(x)
+    else:
+        n = x
+    x = x + wan_attention(sd, f"{p}.attn2", n, ctx, heads, None, None, eps)
+    n = (_fp32_layer_norm(x.float(), None, None, eps) * (1 + csc) + csh).type_as(x)
+    ff = F.gelu(F.linear(n, sd[f"{p}.ffn.net.0.proj.weight"], sd[f"{p}.ffn.net.0.proj.bias"]), approximate="tanh")
+    ff = F.linear(ff, sd[f"{p}.ffn.net.2.weight"], sd[f"{p}.ffn.net.2.bias"])
+    return (x.float() + ff.float() * cg).type_as(x)
+
+
+def wan_forward(sd: Dict[str, torch.Tensor], cfg: dict, hidden_states, timestep, encoder_hidden_states):
+    """WanTransformer3DModel.forward (transformer_wan.py:629-735), T2V.  hidden_states (B, C, F, H, W)."""
+    heads, D, eps = cfg["num_attention_heads"], cfg["attention_head_dim"], cfg["eps"]
+    B, C, Fr, H, W = hidden_states.shape
+    pt, ph, pw = cfg["patch_size"]
+    f, h, w = Fr // pt, H // ph, W // pw
+    cos, sin = wan_rope_tables(D, f, h, w, cfg["rope_max_seq_len"])
+    x = F.conv3d(hidden_states, sd["patch_embedding.weight"], sd["patch_embedding.bias"], stride=(pt, ph, pw))
+    x = x.flatten(2).transpose(1, 2).contiguous()
+    # WanTimeTextImageEmbedding (transformer_wan.py:308-351)
+    tp = timestep_embedding(timestep, cfg["freq_dim"], flip_sin_to_cos=True, shift=0.0)
+    te = F.linear(tp.to(x.dtype), sd["condition_embedder.time_embedder.linear_1.weight"],
+                  sd["condition_embedder.time_embedder.linear_1.bias"])
+    temb = F.linear(F.silu(te), sd["condition_embedder.time_embedder.linear_2.weight"],
+                    sd["condition_embedder.time_embedder.linear_2.bias"]).type_as(encoder_hidden_states)
+    tproj = F.linear(F.silu(temb), sd["condition_embedder.time_proj.weight"], sd["condition_embedder.time_proj.bias"])
+    tproj = tproj.unflatten(1, (6, -1))
+    ctx = F.linear(encoder_hidden_states, sd["condition_embedder.text_embedder.linear_1.weight"],
+                   sd["condition_embedder.text_embedder.linear_1.bias"])
+    ctx = F.linear(F.gelu(ctx, approximate="tanh"), sd["condition_embedder.text_embedder.linear_2.weight"],
+                   sd["condition_embedder.text_embedder.linear_2.bias"])
+    for i in range(cfg["num_layers"]):
+        x = wan_block(sd, f"blocks.{i}", x, ctx, tproj, cos, sin, heads, eps, cfg.get("cross_attn_norm", True))
+    shift, scale = (sd["scale_shift_table"] + temb.unsqueeze(1)).chunk(2, dim=1)
+    x = (_fp32_layer_norm(x.float(), None, None, eps) * (1 + scale) + shift).type_as(x)
+    x = F.linear(x, sd["proj_out.weight"], sd["proj_out.bias"])
+    x = x.reshape(B, f, h, w, pt, ph, pw, -1).permute(0, 7, 1, 4, 2, 5, 3, 6)
+    return x.flatten(6, 7).flatten(4, 5).flatten(2, 3)

@@ -595,3 +595,42 @@ def test_rmsnorm_across_heads():
     ops.rmsnorm_rope_(y, heads=heads, head_dim=D, col_offsets=(0,), weights=(w,), eps=1e-6, norm="across_heads")
     want = F.rms_norm(x.float().cpu(), (Cc,), w.float().cpu(), 1e-6)
     assert_close_bf16(y, want, "rmsnorm across heads", rtol=1.6e-2, atol_rms=8e-3)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Wan-side kernels: patch gather / scatter, fp32 modulation + gate, broadcast add
+# ----------------------------------------------------------------------------------------------------------------------
+def test_patchify_unpatchify_3d():
+    ops, L = _ops()
+    B, Cc, Fr, H, W = 2, 16, 3, 8, 6
+    x = rnd((B, Cc, Fr, H, W), 101)
+    tok = ops.patchify3d(x, (1, 2, 2))
+    w = rnd((32, Cc, 1, 2, 2), 102, scale=0.1)
+    want = F.conv3d(x.float(), w.float(), stride=(1, 2, 2)).flatten(2).transpose(1, 2).reshape(-1, 32)
+    got = tok.float() @ w.float().reshape(32, -1).t()
+    assert torch.allclose(got.cpu(), want.cpu(), atol=1e-4), "patchify feature order != Conv3d weight order"
+    # unpatchify == the reference's reshape / permute / flatten (transformer_wan.py:727-731)
+    y = rnd((B * Fr * (H // 2) * (W // 2), 4 * Cc), 103)
+    ref = y.reshape(B, Fr, H // 2, W // 2, 1, 2, 2, -1).permute(0, 7, 1, 4, 2, 5, 3, 6).flatten(6, 7).flatten(4, 5).flatten(2, 3)
+    assert torch.equal(ops.unpatchify3d(y, (B, Cc, Fr, H, W), (1, 2, 2)), ref.contiguous())
+
+
+def test_fp32_modulation_gate_and_bcast_add():
+    ops, L = _ops()
+    M, Cc, B = 96, 256, 2
+    x = rnd((M, Cc), 111)
+    tab = torch.randn(6 * Cc, generator=torch.Generator("cpu").manual_seed(112)).to(DEV)
+    proj = rnd((B, 6 * Cc), 113, scale=0.3)
+    mod = ops.bcast_add_f32(tab, proj)
+    want_mod = tab[None, :] + proj.float()
+    assert mod.dtype == torch.float32 and torch.equal(mod, want_mod)
+    sc, sh, gt = mod[:, Cc:2 * Cc], mod[:, :Cc], mod[:, 2 * Cc:3 * Cc]
+    y = ops.layer_norm(x, None, None, 1e-6, mod_scale=sc, mod_shift=sh, rows_per_batch=M // B)
+    ln = F.layer_norm(x.float(), (Cc,), None, None, 1e-6)
+    ref = ln * (1 + sc.repeat_interleave(M // B, 0)) + sh.repeat_interleave(M // B, 0)
+    assert_close_bf16(y, ref, "fp32 LayerNorm * (1 + scale) + shift", rtol=8e-3, atol_rms=4e-3)
+    w, bias, res = rnd((Cc, Cc), 114, scale=Cc ** -0.5), rnd((Cc,), 115), rnd((M, Cc), 116)
+    z = ops.linear(x, w, bias, gate=gt, rows_per_batch=M // B, residual=res)
+    lin = (x.float() @ w.float().t() + bias.float()).to(bf16).float()
+    assert_close_bf16(z, res.float() + lin * gt.repeat_interleave(M // B, 0), "gemm fp32 gate + residual", rtol=8e-3,
+                      atol_rms=4e-3)

@@ -22,6 +22,10 @@ if [[ $WHAT == *flux* ]]; then
   timeout 600 python tools/bench_flux.py > $O/flux.log 2>&1; echo "flux rc=$?"
   tail -4 $O/flux.log | cut -c1-300
 fi
+if [[ $WHAT == *wan* ]]; then
+  timeout 900 python tools/bench_wan.py > $O/wan.log 2>&1; echo "wan rc=$?"
+  tail -3 $O/wan.log | cut -c1-400
+fi
 if [[ $WHAT == *sd15* ]]; then
   timeout 600 python tools/bench_sd15.py > $O/sd15.log 2>&1; echo "sd15 rc=$?"
   tail -3 $O/sd15.log | cut -c1-300
