@@ -15,10 +15,13 @@
 // lane^32 exchange, the online-softmax rescale is a per-lane scalar, and P never leaves registers: the MFMA K-index
 // permutation that the C/D layout imposes on P is simply applied to the V^T fragment reads as well.
 //
-// One block = 4 waves = 128 queries of one (batch, head); KV tiles of 64, double-buffered in LDS (register staged).
+// One block = 4 waves = 128 queries of one (batch, head); KV tiles of 64 in a 2-slot LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, the next tile streams in under this tile's MFMAs / softmax).
 #include "common.cuh"
 
 namespace {
+
+__device__ uint4 g_zero_chunk[1];  // 16 B of zeros: the source of every K / V^T chunk past the end of the sequence
 
 template <int D>
 struct AttnCfg {
@@ -70,53 +73,42 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
     }
   }
 
-  // ---- staging assignment ----
-  // K: chunk id = t + 256*i -> row = id / CPR, c = id % CPR ; V^T: id -> row d = id / 8, c = id % 8
-  uint4 kg[C::KCH], vg[C::VCH];
-
-  auto issue = [&](int tile) {
+  // ---- staging: LDS-DMA, one 1 KiB piece (64 lanes x 16 B) per wave instruction ----
+  // The LDS image is lane-linear, so the bank swizzles live on the SOURCE side: linear chunk p of the K tile is
+  // (row = p / CPR, slot = p % CPR) and receives global chunk slot ^ k_swz(row); chunk p of the V^T tile is
+  // (d = p / 8, slot = p % 8) and receives chunk slot ^ ((d >> 1) & 7).  Chunks past the end of the sequence are
+  // redirected to a line of zeros BEFORE the load (a pointer select: nothing ever waits on a loaded value here).
+  const uint16_t* zsrc = (const uint16_t*)g_zero_chunk;
+  auto issue = [&](int tile, int buf) {
     const int kv0 = tile * 64;
-#pragma unroll
-    for (int i = 0; i < C::KCH; ++i) {
-      const int id = t + 256 * i;
-      const int row = id / C::CPR, c = id % C::CPR;
-      const int kv = kv0 + row;
-      const bool ok = kv < p.Skv_alloc;
-      const uint16_t* src = K + (size_t)(ok ? kv : 0) * p.k_row_stride + c * 8;
-      uint4 v = *(const uint4*)src;
-      if (!ok) v = make_uint4(0, 0, 0, 0);
-      kg[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < C::VCH; ++i) {
-      const int id = t + 256 * i;
-      const int d = id >> 3, c = id & 7;
-      const int kv = kv0 + c * 8;
-      const bool ok = kv < p.Skv_alloc;  // Skv_alloc is a multiple of 8
-      const uint16_t* src = VT + (size_t)d * p.vt_ld + (ok ? kv : 0);
-      uint4 v = *(const uint4*)src;
-      if (!ok) v = make_uint4(0, 0, 0, 0);
-      vg[i] = v;
-    }
-  };
-  auto commit = [&](int buf) {
     unsigned char* kb = smem + buf * C::STAGE;
     unsigned char* vb = kb + C::KBYTES;
 #pragma unroll
     for (int i = 0; i < C::KCH; ++i) {
-      const int id = t + 256 * i;
-      const int row = id / C::CPR, c = id % C::CPR;
-      *(uint4*)(kb + row * (2 * D) + ((c ^ k_swz<D>(row)) << 4)) = kg[i];
+      const int pch = (i * 4 + wave) * 64 + lane;
+      const int row = pch / C::CPR, slot = pch % C::CPR;
+      const int c = slot ^ k_swz<D>(row);
+      const int kv = kv0 + row;
+      const uint16_t* src = (kv < p.Skv_alloc) ? K + (size_t)kv * p.k_row_stride + c * 8 : zsrc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(kb + (i * 4 + wave) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < C::VCH; ++i) {
-      const int id = t + 256 * i;
-      const int d = id >> 3, c = id & 7;
-      const int g = (d >> 1) & 15;  // 8-byte slot swizzle; slots (2c, 2c+1) -> (2c^g, (2c+1)^g)
-      uint4 v = vg[i];
-      if (g & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-      *(uint4*)(vb + d * 128 + ((c ^ (g >> 1)) << 4)) = v;
+      const int pch = (i * 4 + wave) * 64 + lane;
+      const int d = pch >> 3, slot = pch & 7;
+      const int c = slot ^ ((d >> 1) & 7);
+      const int kv = kv0 + c * 8;
+      const uint16_t* src = (kv < p.Skv_alloc) ? VT + (size_t)d * p.vt_ld + kv : zsrc;  // Skv_alloc % 8 == 0
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(vb + (i * 4 + wave) * 1024), 16, 0, 0);
     }
+  };
+  // all of this wave's LDS-DMA has landed and its LDS reads have retired, then rendezvous (raw barrier + compiler fence)
+  auto wait_all = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
   f32x16_t o[D / 32];
@@ -129,31 +121,36 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
 
   const int ntiles = (p.Skv + 63) >> 6;
   const int ksw = k_swz<D>(l31);           // K fragment swizzle of this lane's row
-  const int vsw = (l31 >> 1) & 15;         // V^T 8-byte slot swizzle of this lane's row
+  const int vsw = (l31 >> 1) & 7;          // V^T 16-byte chunk swizzle of this lane's row ((32*dt + l31) >> 1) & 7
 
-  issue(0);
-  commit(0);
-  __syncthreads();
+  issue(0, 0);
+  wait_all();
 
   for (int j = 0; j < ntiles; ++j) {
     const int cur = j & 1;
     const bool more = (j + 1 < ntiles);
-    if (more) issue(j + 1);
+    if (more) issue(j + 1, cur ^ 1);   // the other slot was last read in iteration j-1, behind that iteration's barrier
+    __builtin_amdgcn_sched_barrier(0);
 
     const unsigned char* kb = smem + cur * C::STAGE;
     const unsigned char* vb = kb + C::KBYTES;
 
-    // ---- S^T = K . Q^T : two 32-kv tiles ----
+    // ---- S^T = K . Q^T : two 32-kv tiles, interleaved so consecutive MFMAs hit independent accumulators ----
     f32x16_t s[2];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
-      const unsigned char* krow = kb + (32 * st + l31) * (2 * D);
+    {
+      const unsigned char* krow0 = kb + l31 * (2 * D);
+      const unsigned char* krow1 = kb + (32 + l31) * (2 * D);
 #pragma unroll
       for (int ks = 0; ks < D / 16; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(krow + (((2 * ks + hi) ^ ksw) << 4));
-        s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
+        const int off = ((2 * ks + hi) ^ ksw) << 4;
+        const bf16x8_t kf0 = *(const bf16x8_t*)(krow0 + off);
+        const bf16x8_t kf1 = *(const bf16x8_t*)(krow1 + off);
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s[0], 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s[1], 0, 0, 0);
       }
     }
 
@@ -208,20 +205,20 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
     }
 
     // ---- O^T += V^T . P^T ; V^T fragment of lane (d = 32*dt + l31, hi): kv 16u+4hi+{0..3} and 16u+8+4hi+{0..3} ----
+    // u outer / dt inner: the D/32 accumulators of one u are independent, so the MFMAs issue back to back
 #pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt) {
-      const unsigned char* vrow = vb + (32 * dt + l31) * 128;
+    for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint2 a0 = *(const uint2*)(vrow + (((4 * u + hi) ^ vsw) << 3));
-        const uint2 a1 = *(const uint2*)(vrow + (((4 * u + 2 + hi) ^ vsw) << 3));
+      for (int dt = 0; dt < D / 32; ++dt) {
+        const unsigned char* vrow = vb + (32 * dt + l31) * 128;
+        const uint2 a0 = *(const uint2*)(vrow + (((2 * u) ^ vsw) << 4) + 8 * hi);
+        const uint2 a1 = *(const uint2*)(vrow + (((2 * u + 1) ^ vsw) << 4) + 8 * hi);
         const uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), pf[u], o[dt], 0, 0, 0);
       }
     }
 
-    if (more) commit(cur ^ 1);
-    __syncthreads();
+    if (more) wait_all();
   }
 
   // ---- epilogue ----
