@@ -18,6 +18,8 @@ _EXPORTS = {
     "FluxPipeline": "pipelines",
     "WanTransformer3DModel": "transformer_wan",
     "WanPipeline": "pipelines",
+    "UNet2DModel": "unet_2d",
+    "DDPMPipeline": "pipelines",
     "EulerDiscreteScheduler": "schedulers",
     "DDIMScheduler": "schedulers",
     "DDPMScheduler": "schedulers",

@@ -35,7 +35,7 @@ _DEFAULTS = dict(
 class VaeAttention:
     """Legacy single-head Attention block of the VAE mid block (attention_processor.py:2696-2787 with a 4-D input:
     GroupNorm, to_q/k/v WITH bias, residual connection).  head_dim = channels (512 for SD/SDXL): handled as
-    scores = Q K^T (fp32) -> row softmax -> P V with the MFMA GEMM; head_dim in {64,128} uses the flash kernel.
+    scores = Q K^T (fp32) -> row softmax -> P V with the MFMA GEMM; a flash-kernel head size uses the flash kernel.
     The V bias is folded into the output bias (softmax rows sum to 1):  W_o (P (V + 1 b_v^T)) + b_o = W_o P V + (W_o b_v + b_o)."""
 
     def __init__(self, w: Weights, prefix: str, groups: int, eps: float, heads: int = 1):
@@ -68,7 +68,7 @@ class VaeAttention:
         h = self.group_norm(x).view(B * S, C)
         qk = ops.linear(h, self.wqk, self.bqk)      # [B*S][2C]
         vt = ops.linear(self.wv, h)                 # [C][B*S]  (bias folded into self.bo)
-        if self.head_dim in (64, 128) and not self.force_gemm_path:
+        if self.head_dim in (64, 96, 128, 160) and not self.force_gemm_path:
             o = ops.attention(qk, qk[:, self.inner:], vt, B=B, H=self.heads, D=self.head_dim, Sq=S, Skv=S, Skv_alloc=S,
                               q_row_stride=2 * self.inner, k_row_stride=2 * self.inner,
                               q_batch_stride=S * 2 * self.inner, k_batch_stride=S * 2 * self.inner,

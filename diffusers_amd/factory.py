@@ -7,7 +7,9 @@ import torch
 
 from . import init as dinit
 from .autoencoder_kl import AutoencoderKL
-from .pipelines import FluxPipeline, StableDiffusionPipeline, StableDiffusionXLPipeline, WanPipeline
+from .pipelines import DDPMPipeline, FluxPipeline, StableDiffusionPipeline, StableDiffusionXLPipeline, WanPipeline
+from .schedulers import DDPMScheduler
+from .unet_2d import UNet2DModel
 from .transformer_wan import WanTransformer3DModel
 from .schedulers import DDIMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
 from .transformer_flux import FluxTransformer2DModel
@@ -93,3 +95,19 @@ def build_wan_pipeline(device="cuda", tiny: bool = False, seed: int = 9, init_de
     tr, _ = build_wan_transformer(cfg, seed=seed, device=device, init_device=idev)
     sch = FlowMatchEulerDiscreteScheduler(shift=flow_shift, use_dynamic_shifting=False)
     return WanPipeline(scheduler=sch, transformer=tr)
+
+
+def build_unet2d(cfg: dict, seed: int = 0, device="cuda", init_device: Optional[str] = None, state_dict=None):
+    unet = UNet2DModel(**cfg)
+    if state_dict is None:
+        full = dict(unet.config)
+        state_dict = dinit.random_state_dict(dinit.unet2d_param_shapes(full), seed=seed, device=init_device or "cpu")
+    unet.load_state_dict(state_dict, device=device)
+    return unet, state_dict
+
+
+def build_ddpm_pipeline(device="cuda", tiny: bool = False, seed: int = 0, init_device: Optional[str] = None):
+    """google/ddpm-cat-256 (BASELINE config 1) or its tiny sibling."""
+    cfg = dinit.TINY_DDPM if tiny else dinit.DDPM_CAT
+    unet, _ = build_unet2d(cfg, seed=seed, device=device, init_device=init_device or ("cpu" if tiny else str(device)))
+    return DDPMPipeline(unet=unet, scheduler=DDPMScheduler(**dinit.DDPM_SCHEDULER))

@@ -240,6 +240,61 @@ def wan_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
     return sh
 
 
+def _attn_block(sh, p, c):
+    sh[f"{p}.group_norm.weight"] = (c,)
+    sh[f"{p}.group_norm.bias"] = (c,)
+    for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+        sh[f"{p}.{nm}.weight"] = (c, c)
+        sh[f"{p}.{nm}.bias"] = (c,)
+
+
+def unet2d_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict inventory of UNet2DModel (unet_2d.py:95-247) for the DDPM family (positional embedding, conv resampling)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    boc = tuple(cfg["block_out_channels"])
+    n = len(boc)
+    temb = cfg.get("time_embedding_dim") or boc[0] * 4
+    L_ = cfg["layers_per_block"]
+    sh["conv_in.weight"] = (boc[0], cfg["in_channels"], 3, 3)
+    sh["conv_in.bias"] = (boc[0],)
+    _lin(sh, "time_embedding.linear_1", temb, boc[0])
+    _lin(sh, "time_embedding.linear_2", temb, temb)
+    out_c = boc[0]
+    for i, bt in enumerate(cfg["down_block_types"]):
+        in_c, out_c = out_c, boc[i]
+        for j in range(L_):
+            _resnet(sh, f"down_blocks.{i}.resnets.{j}", in_c if j == 0 else out_c, out_c, temb)
+            if bt == "AttnDownBlock2D":
+                _attn_block(sh, f"down_blocks.{i}.attentions.{j}", out_c)
+        if i != n - 1:
+            sh[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            sh[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (out_c,)
+    mid = boc[-1]
+    _resnet(sh, "mid_block.resnets.0", mid, mid, temb)
+    if cfg.get("add_attention", True):
+        _attn_block(sh, "mid_block.attentions.0", mid)
+    _resnet(sh, "mid_block.resnets.1", mid, mid, temb)
+    rboc = tuple(reversed(boc))
+    out_c = rboc[0]
+    for i, bt in enumerate(cfg["up_block_types"]):
+        prev_out, out_c = out_c, rboc[i]
+        in_c = rboc[min(i + 1, n - 1)]
+        for j in range(L_ + 1):
+            skip_c = in_c if j == L_ else out_c
+            res_in = prev_out if j == 0 else out_c
+            _resnet(sh, f"up_blocks.{i}.resnets.{j}", res_in + skip_c, out_c, temb)
+            if bt == "AttnUpBlock2D":
+                _attn_block(sh, f"up_blocks.{i}.attentions.{j}", out_c)
+        if i != n - 1:
+            sh[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            sh[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (out_c,)
+    sh["conv_norm_out.weight"] = (boc[0],)
+    sh["conv_norm_out.bias"] = (boc[0],)
+    sh["conv_out.weight"] = (cfg["out_channels"], boc[0], 3, 3)
+    sh["conv_out.bias"] = (cfg["out_channels"],)
+    return sh
+
+
 def _seed_for(name: str, seed: int) -> int:
     h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
     return int.from_bytes(h[:7], "little")
@@ -309,6 +364,15 @@ TINY_SD15_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_c
                       layers_per_block=1, cross_attention_dim=64, attention_head_dim=(1, 2),
                       down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
                       up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+DDPM_CAT = dict(sample_size=256, in_channels=3, out_channels=3, block_out_channels=(128, 128, 256, 256, 512, 512),
+                layers_per_block=2, down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
+                up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4, attention_head_dim=None,
+                norm_eps=1e-6, downsample_padding=0, flip_sin_to_cos=False, freq_shift=1)
+DDPM_SCHEDULER = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                      variance_type="fixed_small", clip_sample=True)
+TINY_DDPM = dict(DDPM_CAT, sample_size=32, block_out_channels=(64, 64, 128), layers_per_block=1,
+                 down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D"),
+                 up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D"))
 WAN_1_3B = dict(patch_size=(1, 2, 2), num_attention_heads=12, attention_head_dim=128, in_channels=16, out_channels=16,
                 text_dim=4096, freq_dim=256, ffn_dim=8960, num_layers=30, cross_attn_norm=True,
                 qk_norm="rms_norm_across_heads", eps=1e-6, image_dim=None, added_kv_proj_dim=None, rope_max_seq_len=1024,

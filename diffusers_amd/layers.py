@@ -142,13 +142,19 @@ class ResnetBlock2D:
 
 
 class Downsample2D:
-    """models/downsampling.py:130-147 (use_conv=True, padding=1): conv3x3 stride 2."""
+    """models/downsampling.py:130-147 (use_conv=True): conv3x3 stride 2 with padding=1, or with padding=0 after a
+    (0, 1, 0, 1) zero pad (the DDPM U-Nets, ``downsample_padding=0``)."""
 
-    def __init__(self, w: Weights, prefix: str):
+    def __init__(self, w: Weights, prefix: str, padding: int = 1):
+        if padding not in (0, 1):
+            raise ValueError("Downsample2D: padding must be 0 or 1")
         self.conv = Conv3x3(w, prefix + ".conv")
+        self.padding = padding
 
     def __call__(self, x):
-        return self.conv(x, stride=2)
+        if self.padding == 1:
+            return self.conv(x, stride=2)
+        return self.conv(x, stride=2, pad=0, pad_after=1)
 
 
 class Upsample2D:

@@ -101,7 +101,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                 x2: Optional[torch.Tensor] = None, stride: int = 1, up: bool = False, pad: Optional[int] = None,
                 rowvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 out_scale: float = 1.0, act: int = L.ACT_NONE, tile: Optional[int] = None,
-                staging: Optional[int] = None) -> torch.Tensor:
+                staging: Optional[int] = None, pad_after: int = 0) -> torch.Tensor:
     """Implicit-GEMM Conv2d on channels-last tensors.  x: [B][H][W][C1] (x2: [B][H][W][C2] = fused channel concat),
     w: [Cout][k][k][C1+C2] flattened to [Cout][k*k*(C1+C2)].  up=True fuses a nearest 2x upsample of the input.
     rowvec [B][Cout] is added per batch (time embedding); residual is [B][Hout][Wout][Cout]."""
@@ -121,8 +121,10 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     if pad is None:
         pad = (ksize - 1) // 2
     Hv, Wv = (2 * H, 2 * W_) if up else (H, W_)
-    Hout = (Hv + 2 * pad - ksize) // stride + 1
-    Wout = (Wv + 2 * pad - ksize) // stride + 1
+    # pad_after: extra zero rows / columns on the bottom / right only (Downsample2D with padding=0 pads (0, 1, 0, 1),
+    # downsampling.py:139-141); out-of-range taps read zeros, so only the output extent changes
+    Hout = (Hv + 2 * pad + pad_after - ksize) // stride + 1
+    Wout = (Wv + 2 * pad + pad_after - ksize) // stride + 1
     out = torch.empty((B, Hout, Wout, Cout), device=x.device, dtype=bf16)
     p = L.GemmParams()
     p.A, p.A2, p.W, p.C = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()

@@ -20,9 +20,10 @@ import torch
 
 from . import ops
 from .autoencoder_kl import AutoencoderKL
-from .schedulers import DDIMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
+from .schedulers import DDIMScheduler, DDPMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
 from .transformer_flux import FluxTransformer2DModel
 from .transformer_wan import WanTransformer3DModel
+from .unet_2d import UNet2DModel
 from .unet_2d_condition import UNet2DConditionModel
 
 bf16 = torch.bfloat16
@@ -491,3 +492,44 @@ class WanPipeline:
         if not return_dict:
             return (latents,)
         return PipelineOutput(images=latents)
+
+
+class DDPMPipeline:
+    """pipelines/ddpm/pipeline_ddpm.py:40-130: unconditional ancestral sampling.  The initial image and the per-step
+    variance noise are drawn on the host from ``generator`` in fp32 in the reference's order (initial image first, then
+    one draw per step with t > 0) and rounded to bf16, so a seeded run consumes the same random stream as the
+    reference; each step is the U-Net forward plus ONE fused update kernel (da_x0_linear_step)."""
+
+    def __init__(self, unet: UNet2DModel, scheduler: DDPMScheduler):
+        self.unet, self.scheduler = unet, scheduler
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    def set_progress_bar_config(self, **kw):
+        pass
+
+    @torch.no_grad()
+    def __call__(self, batch_size: int = 1, generator=None, num_inference_steps: int = 1000, output_type: str = "np",
+                 return_dict: bool = True):
+        c = self.unet.config
+        ss = c.sample_size
+        shape = (batch_size, c.in_channels, ss, ss) if isinstance(ss, int) else (batch_size, c.in_channels, *ss)
+        dev = self.device
+        gdev = generator.device if generator is not None else torch.device("cpu")
+        image = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32).to(device=dev, dtype=bf16)
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        for t in self.scheduler.timesteps.tolist():
+            eps = self.unet(image, float(t), return_dict=False)[0]
+            image = self.scheduler.step(eps, t, image, generator=generator, return_dict=False)[0]
+        image = (image.float() / 2 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            out = image
+        elif output_type == "np":
+            out = image.cpu().permute(0, 2, 3, 1).numpy()
+        else:
+            raise ValueError(f"output_type={output_type!r}: use 'np' or 'pt' (PIL conversion is outside the hot path)")
+        if not return_dict:
+            return (out,)
+        return PipelineOutput(images=out)

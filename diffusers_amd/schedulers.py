@@ -461,9 +461,11 @@ class DDPMScheduler(_SchedulerBase):
         t = int(self._timesteps_host[idx])
         noise = None
         if t > 0:
+            # drawn in fp32 like the reference's fp32 pipeline (randn_tensor, utils/torch_utils.py:183-234) and then
+            # rounded: a bf16 draw from the same generator state yields a DIFFERENT sample arrangement
             gdev = generator.device if generator is not None else model_output.device
-            noise = torch.randn(model_output.shape, generator=generator, device=gdev,
-                                dtype=model_output.dtype).to(model_output.device)
+            noise = torch.randn(model_output.shape, generator=generator, device=gdev, dtype=torch.float32)
+            noise = noise.to(device=model_output.device, dtype=model_output.dtype)
         prev = ops.x0_linear_step(model_output, sample, noise, self._table, self._step_dev, cfg=False, guidance=0.0)
         self._advance()
         if not return_dict:

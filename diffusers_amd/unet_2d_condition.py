@@ -127,7 +127,7 @@ class UNet2DConditionModel:
                 if btype == "CrossAttnDownBlock2D":
                     stage["attns"].append(Transformer2DModel(w, f"{pre}.attentions.{j}", heads[i], tlpb[i], groups))
             if i != n - 1:
-                stage["down"] = Downsample2D(w, f"{pre}.downsamplers.0")
+                stage["down"] = Downsample2D(w, f"{pre}.downsamplers.0", padding=c.downsample_padding)
             self.down.append(stage)
 
         self.mid = {

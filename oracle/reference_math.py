@@ -462,3 +462,68 @@ def wan_forward(sd: Dict[str, torch.Tensor], cfg: dict, hidden_states, timestep,
     x = F.linear(x, sd["proj_out.weight"], sd["proj_out.bias"])
     x = x.reshape(B, f, h, w, pt, ph, pw, -1).permute(0, 7, 1, 4, 2, 5, 3, 6)
     return x.flatten(6, 7).flatten(4, 5).flatten(2, 3)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# UNet2DModel (models/unets/unet_2d.py) -- the DDPM pixel-space U-Net
+# --------------------------------------------------------------------------------------------------------------------
+def attn_block_2d(sd, p: str, x, groups: int, eps: float, heads: int):
+    """Legacy Attention on a 4-D input (attention_processor.py:2705-2787: GroupNorm, biased q/k/v, residual), as used by
+    AttnDownBlock2D / AttnUpBlock2D / UNetMidBlock2D (unet_2d_blocks.py:1018-1146, :2185-2313, :736-748)."""
+    B, C, H, W = x.shape
+    h = F.group_norm(x, groups, sd[f"{p}.group_norm.weight"], sd[f"{p}.group_norm.bias"], eps)
+    h = h.view(B, C, H * W).transpose(1, 2)
+    q = F.linear(h, sd[f"{p}.to_q.weight"], sd[f"{p}.to_q.bias"])
+    k = F.linear(h, sd[f"{p}.to_k.weight"], sd[f"{p}.to_k.bias"])
+    v = F.linear(h, sd[f"{p}.to_v.weight"], sd[f"{p}.to_v.bias"])
+    o = attention(q, k, v, heads)
+    o = F.linear(o, sd[f"{p}.to_out.0.weight"], sd[f"{p}.to_out.0.bias"])
+    return o.transpose(1, 2).reshape(B, C, H, W) + x
+
+
+def unet2d_forward(sd: Dict[str, torch.Tensor], cfg: dict, sample, timestep):
+    """UNet2DModel.forward (unet_2d.py:249-353), positional time embedding, conv down / up sampling."""
+    boc = tuple(cfg["block_out_channels"])
+    n = len(boc)
+    groups, eps, L_ = cfg["norm_num_groups"], cfg["norm_eps"], cfg["layers_per_block"]
+    hd = cfg["attention_head_dim"]
+    B = sample.shape[0]
+    t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).expand(B)
+    t_emb = timestep_embedding(t, boc[0], cfg["flip_sin_to_cos"], float(cfg["freq_shift"])).to(sample.dtype)
+    emb = F.linear(t_emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
+    emb = F.linear(F.silu(emb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    x = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    skips = [x]
+    for i, bt in enumerate(cfg["down_block_types"]):
+        heads = boc[i] // (hd if hd is not None else boc[i])
+        for j in range(L_):
+            x = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", x, emb, groups, eps)
+            if bt == "AttnDownBlock2D":
+                x = attn_block_2d(sd, f"down_blocks.{i}.attentions.{j}", x, groups, eps, heads)
+            skips.append(x)
+        if i != n - 1:
+            p = f"down_blocks.{i}.downsamplers.0.conv"
+            if cfg["downsample_padding"] == 0:   # downsampling.py:139-141
+                x = F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[f"{p}.weight"], sd[f"{p}.bias"], stride=2)
+            else:
+                x = F.conv2d(x, sd[f"{p}.weight"], sd[f"{p}.bias"], stride=2, padding=cfg["downsample_padding"])
+            skips.append(x)
+    mheads = boc[-1] // (hd if hd is not None else boc[-1])
+    x = resnet_block(sd, "mid_block.resnets.0", x, emb, groups, eps, cfg["mid_block_scale_factor"])
+    if cfg.get("add_attention", True):
+        x = attn_block_2d(sd, "mid_block.attentions.0", x, groups, eps, mheads)
+    x = resnet_block(sd, "mid_block.resnets.1", x, emb, groups, eps, cfg["mid_block_scale_factor"])
+    rboc = tuple(reversed(boc))
+    for i, bt in enumerate(cfg["up_block_types"]):
+        heads = rboc[i] // (hd if hd is not None else rboc[i])
+        for j in range(L_ + 1):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", x, emb, groups, eps)
+            if bt == "AttnUpBlock2D":
+                x = attn_block_2d(sd, f"up_blocks.{i}.attentions.{j}", x, groups, eps, heads)
+        if i != n - 1:
+            p = f"up_blocks.{i}.upsamplers.0.conv"
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = F.conv2d(x, sd[f"{p}.weight"], sd[f"{p}.bias"], padding=1)
+    x = F.group_norm(x, groups, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps)
+    return F.conv2d(F.silu(x), sd["conv_out.weight"], sd["conv_out.bias"], padding=1)

@@ -634,3 +634,15 @@ def test_fp32_modulation_gate_and_bcast_add():
     lin = (x.float() @ w.float().t() + bias.float()).to(bf16).float()
     assert_close_bf16(z, res.float() + lin * gt.repeat_interleave(M // B, 0), "gemm fp32 gate + residual", rtol=8e-3,
                       atol_rms=4e-3)
+
+
+def test_conv_downsample_asymmetric_pad():
+    """Downsample2D with padding=0: F.pad(x, (0, 1, 0, 1)) then conv3x3 stride 2 (downsampling.py:139-147)."""
+    ops, L = _ops()
+    B, H, W, Cc = 2, 16, 12, 64
+    x = rnd((B, H, W, Cc), 121)
+    w, b = rnd((128, Cc, 3, 3), 122, scale=(9 * Cc) ** -0.5), rnd((128,), 123, scale=0.1)
+    y = ops.conv2d_nhwc(x, ops.pack_conv_weight(w), b, ksize=3, stride=2, pad=0, pad_after=1)
+    ref = F.conv2d(F.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1)), w.float(), b.float(), stride=2).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape == (B, H // 2, W // 2, 128)
+    assert_close_bf16(y, ref, "conv3x3 stride 2, pad (0,1,0,1)", rtol=8e-3, atol_rms=4e-3)

@@ -222,3 +222,28 @@ def test_tiny_wan_pipeline_vs_reference(golden):
     print(f"[parity] tiny Wan CFG loop: latents rel_rms vs reference fp32 = {rr:.3e}")
     assert lat_eager.shape == (1, 16, 3, 8, 8)
     assert rr < 4e-2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# UNet2DModel + DDPM (BASELINE config 1) vs the reference goldens
+# ----------------------------------------------------------------------------------------------------------------------
+def test_tiny_ddpm_unet_and_pipeline_vs_reference(golden):
+    from diffusers_amd import factory, init as dinit
+    g = golden("tiny_ddpm")
+    unet, _ = factory.build_unet2d(dinit.TINY_DDPM, seed=11, device=DEV)
+    y = unet(t(g, "sample"), float(g["t"])).sample
+    ref = torch.from_numpy(g["out"])
+    rr = rel_rms(y, ref)
+    print(f"[parity] tiny UNet2DModel (asymmetric-pad downsample, 1-head attention): rel_rms vs reference fp32 = {rr:.3e}")
+    assert y.shape == ref.shape and torch.isfinite(y.float()).all()
+    assert rr < MODEL_REL_RMS
+    assert torch.equal(y, unet(t(g, "sample"), torch.tensor(float(g["t"])), return_dict=False)[0])
+    # DDPMPipeline: 5 ancestral steps, same seeded generator stream as the reference (fp32 draws, rounded to bf16)
+    pipe = factory.build_ddpm_pipeline(device=DEV, tiny=True, seed=11)
+    img = pipe(batch_size=1, generator=torch.Generator().manual_seed(0), num_inference_steps=5, output_type="np").images
+    want = g["pipeline_image"]
+    assert img.shape == want.shape
+    mse = float(((img - want) ** 2).mean())
+    ps = 10 * np.log10(1.0 / max(mse, 1e-12))
+    print(f"[parity] tiny DDPM pipeline (5 steps): image PSNR vs reference fp32 = {ps:.1f} dB, max abs {np.abs(img - want).max():.3f}")
+    assert ps >= 35.0

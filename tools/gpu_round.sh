@@ -26,6 +26,10 @@ if [[ $WHAT == *wan* ]]; then
   timeout 900 python tools/bench_wan.py > $O/wan.log 2>&1; echo "wan rc=$?"
   tail -3 $O/wan.log | cut -c1-400
 fi
+if [[ $WHAT == *ddpm* ]]; then
+  timeout 600 python tools/bench_ddpm.py > $O/ddpm.log 2>&1; echo "ddpm rc=$?"
+  tail -3 $O/ddpm.log | cut -c1-400
+fi
 if [[ $WHAT == *sd15* ]]; then
   timeout 600 python tools/bench_sd15.py > $O/sd15.log 2>&1; echo "sd15 rc=$?"
   tail -3 $O/sd15.log | cut -c1-300
