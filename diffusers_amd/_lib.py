@@ -67,13 +67,14 @@ SIGNATURES = {
     "da_softmax_rows_f32_bf16": (_i, [_vp, _vp, _i, _i, _ll, _ll, _vp]),
     "da_euler_scale_model_input": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
     "da_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
-    "da_x0_linear_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
+    "da_x0_linear_step": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
     "da_flowmatch_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
     "da_advance_step": (_i, [_vp, _vp]),
     "da_mul_scalar": (_i, [_vp, _vp, _f, _i, _ll, _i, _vp]),
     "da_bcast_add_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "da_patchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_unpatchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "da_transpose_bf16": (_i, [_vp, _vp, _i, _i, _ll, _ll, _vp]),
     "da_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp]),
     "da_linear_small_m_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_conv_thin_in_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),

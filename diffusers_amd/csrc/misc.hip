@@ -232,7 +232,33 @@ __global__ void unpatchify3d_kernel(const uint16_t* __restrict__ tok, uint16_t* 
   }
 }
 
+// out[c][r] = in[r][c] (bf16), 64x64 tiles through LDS (padded rows: conflict-free column reads).  Used to hand a
+// (B, S, H, D) value tensor to the flash kernel, which consumes V^T (keys contiguous).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                             int R, int Cc, long long ldi, long long ldo) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? in[(size_t)r * ldi + c] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) out[(size_t)c * ldo + r] = tile[tx][i];
+  }
+}
+
 }  // namespace
+
+extern "C" int da_transpose_bf16(const void* in, void* out, int R, int Cc, long long ldi, long long ldo, void* stream) {
+  if (!in || !out || R <= 0 || Cc <= 0 || ldi < Cc || ldo < R) return DA_ERR_INVALID;
+  DA_LAUNCH(transpose_bf16_kernel, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+            (const uint16_t*)in, (uint16_t*)out, R, Cc, ldi, ldo);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
 
 extern "C" int da_bcast_add_f32(const float* a, const void* m, float* out, int B, int n, void* stream) {
   if (!a || !m || !out || B <= 0 || n <= 0) return DA_ERR_INVALID;

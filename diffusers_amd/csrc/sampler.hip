@@ -82,8 +82,9 @@ __global__ void euler_scale_input_kernel(const T* __restrict__ x, T* __restrict_
 template <typename T, bool CFG>
 __global__ void x0_linear_step_kernel(const T* __restrict__ eps, const T* __restrict__ x, const T* __restrict__ noise,
                                       T* __restrict__ out, const float* __restrict__ table,
-                                      const int* __restrict__ step_idx, float g, size_t n) {
+                                      const int* __restrict__ step_idx, float g, size_t n, size_t noise_step_stride) {
   const float* row = table + (size_t)(*step_idx) * 8;
+  if (noise) noise += (size_t)(*step_idx) * noise_step_stride;  // pre-drawn per-step noise: graph-replay safe
   const float cb = row[0], ca = row[1], k0 = row[2], ke = row[3], kx = row[4], kn = row[5], clip = row[6];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float e = load_eps<T, CFG>(eps, i, n, g);
@@ -167,17 +168,18 @@ extern "C" int da_euler_scale_model_input(const void* x, void* out, const float*
   return DA_OK;
 }
 
-extern "C" int da_x0_linear_step(const void* eps, const void* x, const void* noise, void* out, const float* table,
-                                 const int* step_idx, int cfg, float guidance, long long n_, int dtype, void* stream) {
-  if (!eps || !x || !out || !table || !step_idx || n_ <= 0) return DA_ERR_INVALID;
+extern "C" int da_x0_linear_step(const void* eps, const void* x, const void* noise, long long noise_step_stride,
+                                 void* out, const float* table, const int* step_idx, int cfg, float guidance,
+                                 long long n_, int dtype, void* stream) {
+  if (!eps || !x || !out || !table || !step_idx || n_ <= 0 || noise_step_stride < 0) return DA_ERR_INVALID;
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DA_DTYPE_BF16) {
-    if (cfg) DA_LAUNCH((x0_linear_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n);
-    else DA_LAUNCH((x0_linear_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n);
+    if (cfg) DA_LAUNCH((x0_linear_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n, (size_t)noise_step_stride);
+    else DA_LAUNCH((x0_linear_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n, (size_t)noise_step_stride);
   } else if (dtype == DA_DTYPE_F32) {
-    if (cfg) DA_LAUNCH((x0_linear_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n);
-    else DA_LAUNCH((x0_linear_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n);
+    if (cfg) DA_LAUNCH((x0_linear_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n, (size_t)noise_step_stride);
+    else DA_LAUNCH((x0_linear_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n, (size_t)noise_step_stride);
   } else {
     return DA_ERR_UNSUPPORTED;
   }

@@ -322,13 +322,16 @@ def euler_step(eps: torch.Tensor, x: torch.Tensor, table: torch.Tensor, step_idx
 
 def x0_linear_step(eps: torch.Tensor, x: torch.Tensor, noise: Optional[torch.Tensor], table: torch.Tensor,
                    step_idx: torch.Tensor, *, cfg: bool, guidance: float,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, noise_step_stride: int = 0) -> torch.Tensor:
     _req(x, "x", None)
     if out is None:
         out = torch.empty_like(x)
     if eps.numel() != x.numel() * (2 if cfg else 1) or eps.dtype != x.dtype:
         raise ValueError("x0_linear_step: eps must be [2 x latents] with cfg, same dtype")
-    L.check(L.load().da_x0_linear_step(eps.data_ptr(), x.data_ptr(), _ptr(noise), out.data_ptr(), table.data_ptr(),
+    if noise is not None and noise.dtype != x.dtype:
+        raise ValueError("x0_linear_step: noise must have the dtype of the sample")
+    L.check(L.load().da_x0_linear_step(eps.data_ptr(), x.data_ptr(), _ptr(noise), noise_step_stride, out.data_ptr(),
+                                       table.data_ptr(),
                                        step_idx.data_ptr(), int(cfg), guidance, x.numel(), _dt(x), _stream()),
             "da_x0_linear_step")
     return out
@@ -372,6 +375,17 @@ def timestep_embedding(t: Optional[torch.Tensor], dim: int, *, batch: int, flip_
     L.check(L.load().da_timestep_embedding(_ptr(t), _ptr(table), _ptr(step_idx), out.data_ptr(), batch, dim,
                                            int(flip_sin_to_cos), shift, scale, max_period, int(out_f32), _stream()),
             "da_timestep_embedding")
+    return out
+
+
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[R][C] (row stride free) -> [C][R]."""
+    _req(x, "x")
+    R, Cc = x.shape
+    if out is None:
+        out = torch.empty((Cc, R), device=x.device, dtype=bf16)
+    L.check(L.load().da_transpose_bf16(x.data_ptr(), out.data_ptr(), R, Cc, _rows2d(x, "x"), _rows2d(out, "out"),
+                                       _stream()), "da_transpose_bf16")
     return out
 
 

@@ -510,19 +510,57 @@ class DDPMPipeline:
     def set_progress_bar_config(self, **kw):
         pass
 
+    def _step(self, image, noise_table):
+        sch = self.scheduler
+        eps = self.unet(image, None, sampler_table=sch.device_table, step_idx=sch.device_step, return_dict=False)[0]
+        sch.step_inplace(eps, image, noise_table)
+
     @torch.no_grad()
     def __call__(self, batch_size: int = 1, generator=None, num_inference_steps: int = 1000, output_type: str = "np",
-                 return_dict: bool = True):
+                 return_dict: bool = True, use_graph: bool = True):
         c = self.unet.config
         ss = c.sample_size
         shape = (batch_size, c.in_channels, ss, ss) if isinstance(ss, int) else (batch_size, c.in_channels, *ss)
         dev = self.device
+        sch = self.scheduler
         gdev = generator.device if generator is not None else torch.device("cpu")
+        sch.set_timesteps(num_inference_steps, device=dev)
+        ts = sch.timesteps.tolist()
+        # the reference's random stream (pipeline_ddpm.py:104-121): the initial image, then one draw per step with t > 0,
+        # all fp32 (its pipeline is fp32); drawn up front so the loop has no host work, then rounded to bf16
         image = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32).to(device=dev, dtype=bf16)
-        self.scheduler.set_timesteps(num_inference_steps, device=dev)
-        for t in self.scheduler.timesteps.tolist():
-            eps = self.unet(image, float(t), return_dict=False)[0]
-            image = self.scheduler.step(eps, t, image, generator=generator, return_dict=False)[0]
+        draws = [torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32) if t > 0 else
+                 torch.zeros(shape, dtype=torch.float32, device=gdev) for t in ts]
+        noise_table = torch.stack(draws).to(device=dev, dtype=bf16).contiguous()
+        sch.reset(0)
+        if not use_graph:
+            for _ in ts:
+                self._step(image, noise_table)
+        else:
+            key = (tuple(shape), len(ts), sch.device_table.data_ptr())
+            if getattr(self, "_graph_key", None) != key:
+                saved = image.clone()
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._step(image, noise_table)          # warm-up: variant tuning, lazy driver calls
+                torch.cuda.current_stream().wait_stream(s)
+                image.copy_(saved)
+                sch.reset(0)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step(image, noise_table)
+                self._graph, self._graph_key = g, key
+                self._static = {"image": image, "noise": noise_table}
+                image.copy_(saved)
+                sch.reset(0)
+            else:
+                self._static["image"].copy_(image)
+                self._static["noise"].copy_(noise_table)
+                image = self._static["image"]
+            for _ in ts:
+                self._graph.replay()
+            sch._step_index = len(ts)
         image = (image.float() / 2 + 0.5).clamp(0, 1)
         if output_type == "pt":
             out = image

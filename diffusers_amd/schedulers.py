@@ -453,24 +453,35 @@ class DDPMScheduler(_SchedulerBase):
             rows[i, 7] = float(t)
         self._upload(rows, device)
 
-    def step(self, model_output, timestep, sample, generator=None, return_dict: bool = True):
+    def step(self, model_output, timestep, sample, generator=None, return_dict: bool = True, noise=None):
+        """scheduling_ddpm.py:461-567.  ``noise`` (engine extension): this step's variance noise instead of a draw from
+        ``generator`` (which, like the reference's randn_tensor, draws in the dtype of ``model_output``)."""
         idx = self.index_for_timestep(timestep)
         if idx != self._step_index:
             self._step_index = idx
             self._sync_device_step()
         t = int(self._timesteps_host[idx])
-        noise = None
-        if t > 0:
-            # drawn in fp32 like the reference's fp32 pipeline (randn_tensor, utils/torch_utils.py:183-234) and then
-            # rounded: a bf16 draw from the same generator state yields a DIFFERENT sample arrangement
+        if t > 0 and noise is None:
             gdev = generator.device if generator is not None else model_output.device
-            noise = torch.randn(model_output.shape, generator=generator, device=gdev, dtype=torch.float32)
-            noise = noise.to(device=model_output.device, dtype=model_output.dtype)
-        prev = ops.x0_linear_step(model_output, sample, noise, self._table, self._step_dev, cfg=False, guidance=0.0)
+            noise = torch.randn(model_output.shape, generator=generator, device=gdev,
+                                dtype=model_output.dtype).to(model_output.device)
+        prev = ops.x0_linear_step(model_output, sample, noise if t > 0 else None, self._table, self._step_dev, cfg=False,
+                                  guidance=0.0)
         self._advance()
         if not return_dict:
             return (prev, None)
         return SchedulerOutput(prev_sample=prev)
+
+    def step_inplace(self, model_output, sample, noise_table):
+        """Engine extension for HIP-graph replay: the update written over ``sample``; ``noise_table`` [steps][numel]
+        holds every step's pre-drawn variance noise, the kernel picks row ``step`` (kn = 0 on the last step)."""
+        if self._step_index is None:
+            self._step_index = 0
+            self._sync_device_step()
+        ops.x0_linear_step(model_output, sample, noise_table, self._table, self._step_dev, cfg=False, guidance=0.0,
+                           out=sample, noise_step_stride=sample.numel())
+        self._advance()
+        return sample
 
 
 # ----------------------------------------------------------------------------------------------------------------------

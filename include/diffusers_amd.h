@@ -179,6 +179,8 @@ int da_softmax_rows_f32_bf16(const void* scores, void* probs, int M, int N, long
  *   da_euler_step               scheduling_euler_discrete.py:685-800 (epsilon prediction, gamma = 0)
  *   da_x0_linear_step           scheduling_ddim.py:384-514 and scheduling_ddpm.py:461-567 (epsilon prediction)
  *                               row = [sqrt(beta_t), sqrt(alpha_t), k0, ke, kx, kn, clip_range, timestep]
+ *                               noise (may be NULL) + step * noise_step_stride elements = this step's variance noise
+ *                               (stride 0: one buffer refilled by the host per step; > 0: all steps pre-drawn)
  *   da_flowmatch_step           scheduling_flow_match_euler_discrete.py:423-523 ; row = [sigma, sigma_next, dt, ...]
  *   da_advance_step             the reference's `self._step_index += 1`
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -188,8 +190,9 @@ int da_euler_scale_model_input(const void* x, void* out, const float* table, con
                                int dtype, void* stream);
 int da_euler_step(const void* eps, const void* x, void* out, const float* table, const int* step_idx, int cfg,
                   float guidance, long long n, int dtype, void* stream);
-int da_x0_linear_step(const void* eps, const void* x, const void* noise, void* out, const float* table,
-                      const int* step_idx, int cfg, float guidance, long long n, int dtype, void* stream);
+int da_x0_linear_step(const void* eps, const void* x, const void* noise, long long noise_step_stride, void* out,
+                      const float* table, const int* step_idx, int cfg, float guidance, long long n, int dtype,
+                      void* stream);
 int da_flowmatch_step(const void* v, const void* x, void* out, const float* table, const int* step_idx, int cfg,
                       float guidance, long long n, int dtype, void* stream);
 int da_advance_step(int* step_idx, void* stream);
@@ -219,6 +222,9 @@ int da_bcast_add_f32(const float* a, const void* m_bf16, float* out, int B, int 
 int da_patchify3d_bf16(const void* x, void* tokens, int B, int C, int F, int H, int W, int pt, int ph, int pw, void* stream);
 int da_unpatchify3d_bf16(const void* tokens, void* x, int B, int C, int F, int H, int W, int pt, int ph, int pw,
                          void* stream);
+/* out[c][r] = in[r][c]: turns a token-major value tensor into the V^T operand of da_attention_bf16 (attention backends
+ * that receive (B, S, H, D) tensors, attention_dispatch.py:494-515) */
+int da_transpose_bf16(const void* in, void* out, int R, int C, long long ldi, long long ldo, void* stream);
 int da_timestep_embedding(const float* t, const float* table, const int* step_idx, void* out, int B, int dim,
                           int flip_sin_to_cos, float shift, float scale, float max_period, int out_f32, void* stream);
 int da_linear_small_m_bf16(const void* x, const void* W, const void* bias, const void* res, void* out, int M, int N,

@@ -209,3 +209,32 @@ def test_head_dim_padding_is_exact():
     b = attn(pad_head_rows(wq, heads, d, dp), pad_head_rows(wk, heads, d, dp), pad_head_rows(wv, heads, d, dp),
              pad_head_cols(wo, heads, d, dp), dp)
     assert torch.allclose(a, b, atol=1e-5)
+
+
+def test_attention_backend_registers_with_reference_registry():
+    """Boundary B4: the backend function has the argument names the reference's dispatcher filters on and takes over a
+    registry slot.  Needs the reference sources (build container only); skipped where they are absent."""
+    import importlib
+    import inspect
+    import sys
+    ref_src = Path("/root/reference/src")
+    if not ref_src.exists():
+        pytest.skip("reference sources not present")
+    sys.path.insert(0, str(ref_src))
+    try:
+        ad = importlib.import_module("diffusers.models.attention_dispatch")
+    finally:
+        sys.path.remove(str(ref_src))
+    from diffusers_amd.attention_backend import mi355x_flash_attention, register_backend
+    ref_params = list(inspect.signature(ad._native_attention).parameters)
+    ours = list(inspect.signature(mi355x_flash_attention).parameters)
+    assert ours[:3] == ref_params[:3] == ["query", "key", "value"]
+    assert set(ref_params) <= set(ours), set(ref_params) - set(ours)
+    saved = {k: dict(getattr(ad._AttentionBackendRegistry, k)) for k in ("_backends", "_constraints", "_supported_arg_names")}
+    try:
+        name = register_backend()
+        assert ad._AttentionBackendRegistry._backends[name] is mi355x_flash_attention
+    finally:
+        for k, v in saved.items():
+            getattr(ad._AttentionBackendRegistry, k).clear()
+            getattr(ad._AttentionBackendRegistry, k).update(v)

@@ -646,3 +646,43 @@ def test_conv_downsample_asymmetric_pad():
     ref = F.conv2d(F.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1)), w.float(), b.float(), stride=2).permute(0, 2, 3, 1)
     assert y.shape == ref.shape == (B, H // 2, W // 2, 128)
     assert_close_bf16(y, ref, "conv3x3 stride 2, pad (0,1,0,1)", rtol=8e-3, atol_rms=4e-3)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Boundary B4 / B3: attention backend function ((B, S, H, D) layout) and attention processor for the reference module
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Sq,Skv,H,D", [(2, 200, 200, 4, 64), (1, 96, 77, 3, 128), (2, 64, 333, 2, 64)])
+def test_attention_backend_bshd(B, Sq, Skv, H, D):
+    from diffusers_amd.attention_backend import mi355x_flash_attention
+    q, k, v = rnd((B, Sq, H, D), 131), rnd((B, Skv, H, D), 132), rnd((B, Skv, H, D), 133)
+    o = mi355x_flash_attention(q, k, v)
+    ref = F.scaled_dot_product_attention(q.float().cpu().transpose(1, 2), k.float().cpu().transpose(1, 2),
+                                         v.float().cpu().transpose(1, 2)).transpose(1, 2)
+    assert o.shape == (B, Sq, H, D)
+    assert_close_bf16(o, ref, f"attention backend B{B} Sq{Sq} Skv{Skv} H{H} D{D}", rtol=1.6e-2, atol_rms=1.6e-2)
+    with pytest.raises(ValueError):
+        mi355x_flash_attention(q, k, v, is_causal=True)
+    t_ = rnd((70, 130), 134)
+    from diffusers_amd import ops
+    assert torch.equal(ops.transpose(t_), t_.t().contiguous())
+
+
+def test_attention_processor_on_reference_style_module():
+    """MI355XAttnProcessor against a duck-typed stand-in of the reference Attention module (to_q/k/v/out as nn.Linear)."""
+    import types
+    from diffusers_amd.attention_backend import MI355XAttnProcessor
+    torch.manual_seed(0)
+    C, heads, cross = 128, 2, 64
+    mk = lambda i, o, b: torch.nn.Linear(i, o, bias=b).to(DEV, bf16)  # noqa: E731
+    attn = types.SimpleNamespace(heads=heads, to_q=mk(C, C, False), to_k=mk(cross, C, False), to_v=mk(cross, C, False),
+                                 to_out=[mk(C, C, True)], scale=(C // heads) ** -0.5, residual_connection=False,
+                                 rescale_output_factor=1.0, group_norm=None, spatial_norm=None, norm_cross=None)
+    x, ctx = rnd((2, 96, C), 141), rnd((2, 77, cross), 142)
+    with torch.no_grad():
+        y = MI355XAttnProcessor()(attn, x, encoder_hidden_states=ctx)
+        f = lambda m, t_: F.linear(t_.float().cpu(), m.weight.float().cpu(), None if m.bias is None else m.bias.float().cpu())  # noqa: E731
+        q, k, v = f(attn.to_q, x), f(attn.to_k, ctx), f(attn.to_v, ctx)
+        sp = lambda t_: t_.view(2, -1, heads, C // heads).transpose(1, 2)  # noqa: E731
+        o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(2, 96, C)
+        ref = F.linear(o, attn.to_out[0].weight.float().cpu(), attn.to_out[0].bias.float().cpu())
+    assert_close_bf16(y, ref, "attention processor (cross-attention)", rtol=2e-2, atol_rms=2e-2)
