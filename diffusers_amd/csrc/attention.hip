@@ -51,8 +51,15 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // XCD-aware mapping (speed only): block id -> (XCD = id % 8, slot = id / 8).  All query tiles of one (batch, head)
+  // pair go to ONE XCD, so its K / V^T (1 MB at S = 4096, D = 64; a 17 MB stream for Wan) is pulled into a single L2
+  // and shared by the blocks that walk it side by side, instead of being fetched by all eight XCDs.
+  const int qtiles = (p.Sq + 127) >> 7;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot / qtiles) * 8 + xcd;            // (batch, head) pairs are dealt round-robin to the XCDs
+  if (pair >= p.B * p.H) return;                          // ragged last round: leaves before any barrier
+  const int b = pair / p.H, h = pair - b * p.H;
+  const int q0 = (slot % qtiles) * 128 + wave * 32;
 
   const uint16_t* __restrict__ Q = (const uint16_t*)p.q + (size_t)b * p.q_batch_stride + (size_t)h * D;
   const uint16_t* __restrict__ K = (const uint16_t*)p.k + (size_t)b * p.k_batch_stride + (size_t)h * D;
@@ -252,7 +259,8 @@ int launch_attn(const da_attention_params& p, hipStream_t s) {
       attr_set = true;
     }
   }
-  dim3 grid((p.Sq + 127) / 128, p.H, p.B);
+  const int qtiles = (p.Sq + 127) / 128, rounds = (p.B * p.H + 7) / 8;
+  dim3 grid(8 * rounds * qtiles);
   DA_LAUNCH(kern, grid, dim3(256), lds, s, p);
   DA_CHECK_LAUNCH();
   return DA_OK;

@@ -20,7 +20,7 @@ struct RowInfo {      // per staged activation row (implicit GEMM gather state)
 // (bytes in flight) / latency: the ring is made as deep as the 160 KiB of LDS allow and the wait before each
 // rendezvous is a COUNTED s_waitcnt vmcnt((PD-1)*LOADS), never 0, so PD-1 slices stay in flight across every barrier.
 template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, bool GLDS>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_params p) {
+__global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
   constexpr int NW = WM * WN, NTHR = 64 * NW, RP = NTHR / 8;  // RP = tile rows staged per pass (one 1 KiB piece per wave)
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr int XR = BM / RP, WR = BN / RP;  // staged rows per thread
@@ -38,16 +38,21 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   const int wm = wave / WN, wn = wave - wm * WN;
   const int l31 = lane & 31, hi = lane >> 5;
 
-  // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of tiles ----
+  // ---- XCD-aware tile mapping (speed only: nothing depends on where a block really runs) ----
+  // Block b is observed to run on XCD b % 8, each XCD has its own 4 MiB L2 and a CU's fill rate is set by the average
+  // latency of its ~64 outstanding L1 misses, i.e. by the L2 hit rate.  Each XCD therefore owns one RECTANGLE of the
+  // tile grid, (8 / xcd_gx) row groups x xcd_gx column groups, chosen on the host so that the operand panels one XCD
+  // touches, (rows + columns) * K bytes, are smallest: a weight matrix that does not fit L2 is then pulled from HBM by
+  // ONE XCD instead of all eight, and the blocks running side by side in an XCD share both operand panels.
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int gyn = 8 / xcd_gx;
+  const int tm_per = (tiles_m + gyn - 1) / gyn, tn_per = (tiles_n + xcd_gx - 1) / xcd_gx;
+  const int xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
+  const int gy = xcd / xcd_gx, gx = xcd - gy * xcd_gx;
+  const int lm = kblk / tn_per, ln = kblk - lm * tn_per;
+  const int tm = gy * tm_per + lm, tn = gx * tn_per + ln;
+  if (tm >= tiles_m || tn >= tiles_n) return;  // ragged rectangle: the whole block leaves before any barrier
   const int m0 = tm * BM, n0 = tn * BN;
 
   const uint16_t* __restrict__ A = (const uint16_t*)p.A;
@@ -387,10 +392,30 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
 }
 
 
+// Column groups (1, 2, 4 or 8) of the per-XCD rectangles: minimise (rows + columns) of operand panels per XCD, weighted
+// by the grid inflation a ragged split causes.
+inline int choose_xcd_gx(int tiles_m, int tiles_n, int BM, int BN) {
+  int best = 1;
+  double best_cost = 1e300;
+  for (int gx = 1; gx <= 8; gx *= 2) {
+    const int gy = 8 / gx;
+    const int tm_per = (tiles_m + gy - 1) / gy, tn_per = (tiles_n + gx - 1) / gx;
+    const double inflation = (double)(8 * tm_per * tn_per) / ((double)tiles_m * tiles_n);
+    const double cost = ((double)tm_per * BM + (double)tn_per * BN) * inflation * inflation;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = gx;
+    }
+  }
+  return best;
+}
+
 template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, bool GLDS>
 int launch(const da_gemm_params& p, hipStream_t s) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int gx = choose_xcd_gx(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
+  const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
   const size_t lds = (size_t)(BM + BN) * 128 * STAGES;
   auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, GLDS>;
   if (lds > 48 * 1024) {
@@ -401,11 +426,10 @@ int launch(const da_gemm_params& p, hipStream_t s) {
       attr_set = true;
     }
   }
-  DA_LAUNCH(kern, dim3(tiles), dim3(64 * WM * WN), lds, s, p);
+  DA_LAUNCH(kern, dim3(grid), dim3(64 * WM * WN), lds, s, p, gx);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
-
 
 // (tile, staging) -> kernel instantiation.  staging: 0 register staged (2 slots); 1..5 LDS-DMA with 2/3/4/6/8 ring slots.
 template <bool CONV>

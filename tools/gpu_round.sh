@@ -63,3 +63,16 @@ if [[ $WHAT == *pmc* ]]; then
   ls -la $O/pmc/*
   cd $R
 fi
+if [[ $WHAT == *lds2* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc2; mkdir -p $O/pmc2
+  run_pass() { name=$1; shift; timeout 200 rocprofv3 --kernel-trace --pmc "$@" -f csv -d $O/pmc2/$name -o focus -- python $R/tools/bench_focus.py > $O/pmc2/$name.log 2>&1; echo "pmc2 $name rc=$?"; python $R/tools/pmc_agg.py $O/pmc2/$name > $O/pmc2/$name.summary.csv 2>> $O/pmc2/agg.err; }
+  run_pass lds SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_BUSY_CYCLES
+  run_pass tcplat TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE
+  run_pass tcpstall TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum
+  run_pass ta TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum
+  find $O/pmc2 -name '*kernel_trace*' -delete
+  find $O/pmc2 -name '*counter_collection.csv' -delete
+  tail -2 $O/pmc2/*.log | cut -c1-200
+  cd $R
+fi
