@@ -10,10 +10,12 @@ which times them on the caller's stream; this module owns the resulting table:
     configs measured on an MI355X) and can be extended / saved with ``save()``.
 
 All variants produce bit-identical outputs (same K order, same MFMA), so the table affects speed only.
-Env: ``DIFFUSERS_AMD_TUNE=0`` disables live tuning, ``DIFFUSERS_AMD_TUNE_DB=<path>`` overrides the table location.
+Env: ``DIFFUSERS_AMD_TUNE=0`` disables live tuning, ``DIFFUSERS_AMD_TUNE_DB=<path>`` overrides the table location,
+``DIFFUSERS_AMD_TUNE_SAVE=<path>`` writes the (extended) table there at interpreter exit.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import json
 import os
@@ -96,3 +98,12 @@ def lookup(p: "L.GemmParams", stream: int) -> Tuple[int, int]:
         else:
             return L.TILE_AUTO, L.STAGE_LDS_DIRECT
     return ent[0], ent[1]
+
+
+def _save_at_exit() -> None:
+    path = os.environ.get("DIFFUSERS_AMD_TUNE_SAVE")
+    if path and _dirty:
+        save(path)
+
+
+atexit.register(_save_at_exit)

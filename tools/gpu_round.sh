@@ -6,6 +6,11 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 WHAT=${1:-test smoke kernels bench prof}
+if [[ $WHAT == *retune* ]]; then
+  # re-measure every GEMM variant choice with the current kernels: all workloads extend ONE table
+  export DIFFUSERS_AMD_TUNE_DB=$O/tuned_all.json DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_all.json
+  rm -f $O/tuned_all.json
+fi
 if [[ $WHAT == *test* ]]; then
   timeout 900 python -m pytest tests -m gpu -q -s --timeout 300 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
   grep -E "^\[tune\]|passed|failed|FAILED|Error|\[parity\]" $O/pytest_gpu.log | tail -40
