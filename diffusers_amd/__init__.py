@@ -24,6 +24,7 @@ _EXPORTS = {
     "DDIMScheduler": "schedulers",
     "DDPMScheduler": "schedulers",
     "FlowMatchEulerDiscreteScheduler": "schedulers",
+    "UniPCMultistepScheduler": "schedulers",
     "StableDiffusionPipeline": "pipelines",
     "StableDiffusionXLPipeline": "pipelines",
 }

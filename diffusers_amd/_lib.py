@@ -69,7 +69,9 @@ SIGNATURES = {
     "da_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
     "da_x0_linear_step": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
     "da_flowmatch_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
+    "da_unipc_flow_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _i, _vp]),
     "da_advance_step": (_i, [_vp, _vp]),
+    "da_cast_f32_bf16": (_i, [_vp, _vp, _i, _ll, _vp]),
     "da_mul_scalar": (_i, [_vp, _vp, _f, _i, _ll, _i, _vp]),
     "da_bcast_add_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "da_patchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -115,6 +115,61 @@ __global__ void flowmatch_step_kernel(const T* __restrict__ v, const T* __restri
   }
 }
 
+// UniPC (B(h), predict-x0, flow prediction) step, orders 1 / 2 -- schedulers/scheduling_unipc_multistep.py:760-1300.
+// One pass does convert_model_output, the corrector (multistep_uni_c_bh_update) and the predictor
+// (multistep_uni_p_bh_update) and rolls the history IN PLACE: x <- next sample, last <- corrected sample,
+// m2 <- m1, m1 <- this step's x0 prediction.  Every tensor op of the reference is reproduced with its rounding point
+// (TX = dtype of the sample / history, TV = dtype of the model output; 0-d fp32 scalars never promote a tensor).
+// coef row (16 floats): [sigma, use_corr, order_c, c1c, c2c, c3c, rk_c, rho0_c, rho_last_c, order_p, c1p, c2p, c3p, rk_p, -, -]
+//   c1 = sigma_t / sigma_s0, c2 = alpha_t * h_phi_1, c3 = alpha_t * B_h   (corrector: t = i, s0 = i-1; predictor: t = i+1, s0 = i)
+template <typename TX, typename TV, bool CFG>
+__global__ void unipc_flow_step_kernel(const TV* __restrict__ v, TX* __restrict__ x, TX* __restrict__ last,
+                                       TX* __restrict__ m1, TX* __restrict__ m2, const float* __restrict__ coef,
+                                       const int* __restrict__ step_idx, float g, size_t n) {
+  const float* r = coef + (size_t)(*step_idx) * 16;
+  const float sigma = r[0];
+  const bool use_corr = r[1] != 0.f;
+  const int order_c = (int)r[2], order_p = (int)r[9];
+  const float c1c = r[3], c2c = r[4], c3c = r[5], rk_c = r[6];
+  const float rho0 = IO<TX>::rnd(r[7]), rhol = IO<TX>::rnd(r[8]);   // rhos_c is a tensor of the sample dtype
+  const float c1p = r[10], c2p = r[11], c3p = r[12], rk_p = r[13];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float e = load_eps<TV, CFG>(v, i, n, g);
+    const float xs = IO<TX>::ld(x, i);
+    const float m1o = IO<TX>::ld(m1, i);
+    const float se = IO<TV>::rnd(__fmul_rn(sigma, e));
+    const float mn = IO<TX>::rnd(__fsub_rn(xs, se));                        // x0_pred = sample - sigma * model_output
+    float xc = xs;
+    if (use_corr) {
+      const float t1 = IO<TX>::rnd(__fmul_rn(c1c, IO<TX>::ld(last, i)));
+      const float t2 = IO<TX>::rnd(__fmul_rn(c2c, m1o));
+      const float xt = IO<TX>::rnd(__fsub_rn(t1, t2));
+      const float d1t = IO<TX>::rnd(__fsub_rn(mn, m1o));
+      float inner = IO<TX>::rnd(__fmul_rn(rhol, d1t));
+      if (order_c == 2) {
+        float d = IO<TX>::rnd(__fsub_rn(IO<TX>::ld(m2, i), m1o));
+        d = IO<TX>::rnd(__fdiv_rn(d, rk_c));
+        const float corr = IO<TX>::rnd(__fmul_rn(rho0, d));
+        inner = IO<TX>::rnd(__fadd_rn(corr, inner));
+      }
+      xc = IO<TX>::rnd(__fsub_rn(xt, IO<TX>::rnd(__fmul_rn(c3c, inner))));
+    }
+    const float p1 = IO<TX>::rnd(__fmul_rn(c1p, xc));
+    const float p2 = IO<TX>::rnd(__fmul_rn(c2p, mn));
+    float xn = IO<TX>::rnd(__fsub_rn(p1, p2));
+    if (order_p == 2) {
+      float d = IO<TX>::rnd(__fsub_rn(m1o, mn));
+      d = IO<TX>::rnd(__fdiv_rn(d, rk_p));
+      const float pred = IO<TX>::rnd(__fmul_rn(0.5f, d));
+      xn = IO<TX>::rnd(__fsub_rn(xn, IO<TX>::rnd(__fmul_rn(c3p, pred))));
+    }
+    IO<TX>::st(m2, i, m1o);
+    IO<TX>::st(m1, i, mn);
+    IO<TX>::st(last, i, xc);
+    IO<TX>::st(x, i, xn);
+  }
+}
+
 __global__ void advance_step_kernel(int* step_idx) { *step_idx += 1; }
 
 // out = x * s in the tensor dtype (latents * init_noise_sigma, pipeline_stable_diffusion.py:713)
@@ -123,6 +178,14 @@ __global__ void mul_scalar_kernel(const T* __restrict__ x, T* __restrict__ out, 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float v = __fmul_rn(IO<T>::ld(x, i), sc);
     for (int r = 0; r < rep; ++r) IO<T>::st(out, (size_t)r * n + i, v);  // rep > 1: torch.cat([x] * rep) fused
+  }
+}
+
+// latents.to(transformer_dtype) (pipeline_wan.py:600) fused with the CFG batch doubling: fp32 -> bf16, `rep` copies
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int rep, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint16_t v = f2bf(x[i]);
+    for (int r = 0; r < rep; ++r) out[(size_t)r * n + i] = v;
   }
 }
 
@@ -222,6 +285,32 @@ extern "C" int da_mul_scalar(const void* x, void* out, float sc, int rep, long l
     DA_LAUNCH((mul_scalar_kernel<float>), ew_grid(n), dim3(256), 0, s, (const float*)x, (float*)out, sc, rep, n);
   else
     return DA_ERR_UNSUPPORTED;
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_unipc_flow_step(const void* v, void* x, void* last, void* m1, void* m2, const float* coef,
+                                  const int* step_idx, int cfg, float guidance, long long n_, int x_dtype, int v_dtype,
+                                  void* stream) {
+  if (!v || !x || !last || !m1 || !m2 || !coef || !step_idx || n_ <= 0) return DA_ERR_INVALID;
+  const size_t n = (size_t)n_;
+  hipStream_t s = (hipStream_t)stream;
+#define DA_UP(TX, TV, C)                                                                                       \
+  DA_LAUNCH((unipc_flow_step_kernel<TX, TV, C>), ew_grid(n), dim3(256), 0, s, (const TV*)v, (TX*)x, (TX*)last, \
+            (TX*)m1, (TX*)m2, coef, step_idx, guidance, n)
+  if (x_dtype == DA_DTYPE_F32 && v_dtype == DA_DTYPE_F32) { if (cfg) DA_UP(float, float, true); else DA_UP(float, float, false); }
+  else if (x_dtype == DA_DTYPE_F32 && v_dtype == DA_DTYPE_BF16) { if (cfg) DA_UP(float, uint16_t, true); else DA_UP(float, uint16_t, false); }
+  else if (x_dtype == DA_DTYPE_BF16 && v_dtype == DA_DTYPE_BF16) { if (cfg) DA_UP(uint16_t, uint16_t, true); else DA_UP(uint16_t, uint16_t, false); }
+  else return DA_ERR_UNSUPPORTED;
+#undef DA_UP
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_cast_f32_bf16(const float* x, void* out, int rep, long long n_, void* stream) {
+  if (!x || !out || n_ <= 0 || rep <= 0) return DA_ERR_INVALID;
+  const size_t n = (size_t)n_;
+  DA_LAUNCH(cast_f32_bf16_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)out, rep, n);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

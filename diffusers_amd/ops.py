@@ -348,6 +348,31 @@ def flowmatch_step(v: torch.Tensor, x: torch.Tensor, table: torch.Tensor, step_i
     return out
 
 
+def unipc_flow_step_(v: torch.Tensor, x: torch.Tensor, last: torch.Tensor, m1: torch.Tensor, m2: torch.Tensor,
+                     coef: torch.Tensor, step_idx: torch.Tensor, *, cfg: bool = False, guidance: float = 0.0) -> torch.Tensor:
+    """IN PLACE UniPC step (see da_unipc_flow_step): x <- next sample; last / m1 / m2 roll."""
+    _req(x, "x", None), _req(v, "v", None)
+    for t_ in (last, m1, m2):
+        if t_.dtype != x.dtype or t_.numel() != x.numel() or not t_.is_contiguous():
+            raise ValueError("unipc_flow_step_: history tensors must match the sample (dtype, size, contiguous)")
+    if v.numel() != x.numel() * (2 if cfg else 1):
+        raise ValueError("unipc_flow_step_: model output must be [2 x sample] with cfg")
+    if (_dt(x), _dt(v)) not in ((L.DTYPE_F32, L.DTYPE_F32), (L.DTYPE_F32, L.DTYPE_BF16), (L.DTYPE_BF16, L.DTYPE_BF16)):
+        raise TypeError("unipc_flow_step_: (sample, model output) dtypes must be f32/f32, f32/bf16 or bf16/bf16")
+    L.check(L.load().da_unipc_flow_step(v.data_ptr(), x.data_ptr(), last.data_ptr(), m1.data_ptr(), m2.data_ptr(),
+                                        coef.data_ptr(), step_idx.data_ptr(), int(cfg), float(guidance), x.numel(),
+                                        _dt(x), _dt(v), _stream()), "da_unipc_flow_step")
+    return x
+
+
+def cast_f32_bf16(x: torch.Tensor, rep: int = 1) -> torch.Tensor:
+    """fp32 -> bf16, replicated ``rep`` times along the batch dim."""
+    _req(x, "x", torch.float32)
+    out = torch.empty((rep * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=bf16)
+    L.check(L.load().da_cast_f32_bf16(x.data_ptr(), out.data_ptr(), rep, x.numel(), _stream()), "da_cast_f32_bf16")
+    return out
+
+
 def mul_scalar(x: torch.Tensor, s: float, rep: int = 1) -> torch.Tensor:
     """x * s (in the tensor dtype), replicated ``rep`` times along the batch dim (fused torch.cat([x] * rep))."""
     _req(x, "x", None)

@@ -20,7 +20,8 @@ import torch
 
 from . import ops
 from .autoencoder_kl import AutoencoderKL
-from .schedulers import DDIMScheduler, DDPMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
+from .schedulers import (DDIMScheduler, DDPMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler,
+                         UniPCMultistepScheduler)
 from .transformer_flux import FluxTransformer2DModel
 from .transformer_wan import WanTransformer3DModel
 from .unet_2d import UNet2DModel
@@ -409,7 +410,11 @@ class WanPipeline:
 
     def _step(self, latents, cond, guidance_scale, do_cfg):
         sch = self.scheduler
-        x_in = ops.mul_scalar(latents, 1.0, rep=2) if do_cfg else latents       # cond / uncond share the latents
+        rep = 2 if do_cfg else 1                                              # cond / uncond share the latents
+        if latents.dtype == torch.float32:                                    # UniPC keeps fp32 latents (pipeline_wan.py:568)
+            x_in = ops.cast_f32_bf16(latents, rep=rep)
+        else:
+            x_in = ops.mul_scalar(latents, 1.0, rep=rep) if do_cfg else latents
         v = self.transformer(x_in, conditioning=cond, sampler_table=sch.device_table, step_idx=sch.device_step,
                              return_dict=False)[0]
         if do_cfg:
@@ -481,7 +486,10 @@ class WanPipeline:
         if latents is None:
             gdev = generator.device if generator is not None else torch.device("cpu")
             latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32)
-        latents = latents.to(device=dev, dtype=bf16).contiguous().clone()
+        # FlowMatchEuler returns the model dtype after its first step, so the loop runs on bf16 latents; UniPC (the
+        # scheduler Wan 2.1 ships) keeps the pipeline's fp32 latents and history (pipeline_wan.py:562-571)
+        lat_dtype = torch.float32 if isinstance(self.scheduler, UniPCMultistepScheduler) else bf16
+        latents = latents.to(device=dev, dtype=lat_dtype).contiguous().clone()
         self.scheduler.set_timesteps(num_inference_steps, device=dev)
         self.scheduler.set_begin_index(0)
         pe = prompt_embeds.to(device=dev, dtype=bf16)

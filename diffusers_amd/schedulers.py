@@ -596,3 +596,149 @@ class FlowMatchEulerDiscreteScheduler(_SchedulerBase):
                                   guidance=float(guidance_scale), out=out)
         self._advance()
         return prev
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class UniPCMultistepScheduler(_SchedulerBase):
+    """schedulers/scheduling_unipc_multistep.py in the configuration Wan 2.1 ships (pipeline_wan.py:52-59):
+    ``prediction_type="flow_prediction"``, ``use_flow_sigmas=True``, ``flow_shift``, ``solver_order`` <= 2, B(h) solver,
+    ``predict_x0``, ``lower_order_final``.  The order-2 predictor-corrector keeps two x0 predictions and the pre-predictor
+    sample; the host evaluates the per-step coefficients with the reference's fp32 scalar ops (set_timesteps :428-466,
+    _coeffs = :868-905 / :1030-1067) and ONE kernel per step (da_unipc_flow_step) applies them in the reference's
+    operation order and rolls the history in place, so the step is HIP-graph replayable."""
+
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                     trained_betas=None, solver_order=2, prediction_type="epsilon", thresholding=False,
+                     dynamic_thresholding_ratio=0.995, sample_max_value=1.0, predict_x0=True, solver_type="bh2",
+                     lower_order_final=True, disable_corrector=[], solver_p=None, use_karras_sigmas=False,
+                     use_exponential_sigmas=False, use_beta_sigmas=False, use_flow_sigmas=False, flow_shift=1.0,
+                     timestep_spacing="linspace", steps_offset=0, final_sigmas_type="zero",
+                     rescale_betas_zero_snr=False, use_dynamic_shifting=False, time_shift_type="exponential",
+                     sigma_min=None, sigma_max=None, shift_terminal=None)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        c = self.config
+        if c.prediction_type != "flow_prediction" or not c.use_flow_sigmas:
+            raise NotImplementedError("UniPCMultistepScheduler: only the flow-matching configuration "
+                                      "(prediction_type='flow_prediction', use_flow_sigmas=True) is on the hot path")
+        if (not c.predict_x0 or c.solver_order not in (1, 2) or c.solver_type not in ("bh1", "bh2") or c.thresholding
+                or c.disable_corrector or c.solver_p is not None or c.use_karras_sigmas or c.use_exponential_sigmas
+                or c.use_beta_sigmas or c.use_dynamic_shifting or c.shift_terminal or not c.lower_order_final
+                or c.final_sigmas_type != "zero"):
+            raise NotImplementedError("UniPCMultistepScheduler: unsupported option for the HIP step")
+        self.init_noise_sigma = 1.0
+        ts = np.linspace(0, c.num_train_timesteps - 1, c.num_train_timesteps, dtype=np.float32)[::-1].copy()
+        self.timesteps = torch.from_numpy(ts)
+        self._timesteps_host = ts
+        self._coef = None
+        self._hist = None
+        self.sigmas = None
+
+    def _coeffs(self, sigma_t, sigma_s0, hist_sigmas, order):
+        """The scalar part of multistep_uni_{p,c}_bh_update, fp32 torch ops in the reference's order."""
+        alpha_t, alpha_s0 = 1 - sigma_t, 1 - sigma_s0
+        lambda_t = torch.log(alpha_t) - torch.log(sigma_t)
+        lambda_s0 = torch.log(alpha_s0) - torch.log(sigma_s0)
+        h = lambda_t - lambda_s0
+        rks = [((torch.log(1 - s_) - torch.log(s_)) - lambda_s0) / h for s_ in hist_sigmas[: order - 1]]
+        rks.append(torch.ones(()))
+        rks = torch.stack(rks)
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = hh if self.config.solver_type == "bh1" else torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        return sigma_t / sigma_s0, alpha_t * h_phi_1, alpha_t * B_h, rks, torch.stack(R), torch.stack(b)
+
+    def set_timesteps(self, num_inference_steps: int = None, device=None, sigmas=None, mu=None):
+        c = self.config
+        if sigmas is not None:
+            raise NotImplementedError("custom sigmas are not supported by the HIP UniPC scheduler")
+        n = num_inference_steps
+        sig = np.linspace(1, 1 / c.num_train_timesteps, n + 1)[:-1]
+        sig = c.flow_shift * sig / (1 + (c.flow_shift - 1) * sig)
+        if np.fabs(sig[0] - 1) < 1e-6:
+            sig[0] -= 1e-6
+        ts = (sig * c.num_train_timesteps).copy()
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts).to(device=device, dtype=torch.int64)
+        self._timesteps_host = self.timesteps.cpu().numpy()
+        self.num_inference_steps = n
+        self._step_index = None
+        self._begin_index = None
+        S = self.sigmas
+        coef = np.zeros((n, 16), dtype=np.float32)
+        rows = np.zeros((n, 8), dtype=np.float32)
+        lower, prev_order = 0, None
+        for i in range(n):
+            coef[i, 0] = float(S[i])
+            if i > 0:      # corrector of step i runs with the predictor order of step i-1 (step(): :1262-1270)
+                oc = prev_order
+                c1, c2, c3, rks, R, b = self._coeffs(S[i], S[i - 1], [S[i - (k + 1)] for k in range(1, oc)], oc)
+                rhos = torch.ones(1) * 0.5 if oc == 1 else torch.linalg.solve(R, b)
+                coef[i, 1], coef[i, 2] = 1.0, float(oc)
+                coef[i, 3], coef[i, 4], coef[i, 5] = float(c1), float(c2), float(c3)
+                coef[i, 6] = float(rks[0]) if oc == 2 else 1.0
+                coef[i, 7] = float(rhos[0]) if oc == 2 else 0.0
+                coef[i, 8] = float(rhos[-1])
+            op = min(min(c.solver_order, n - i), lower + 1)
+            c1, c2, c3, rks, _, _ = self._coeffs(S[i + 1], S[i], [S[i - k] for k in range(1, op)], op)
+            coef[i, 9], coef[i, 10], coef[i, 11], coef[i, 12] = float(op), float(c1), float(c2), float(c3)
+            coef[i, 13] = float(rks[0]) if op == 2 else 1.0
+            rows[i, 0], rows[i, 1], rows[i, 7] = float(S[i]), float(S[i + 1]), float(self._timesteps_host[i])
+            prev_order = op
+            if lower < c.solver_order:
+                lower += 1
+        self._upload(rows, device)
+        host = torch.from_numpy(coef)
+        if self._coef is not None and tuple(self._coef.shape) == tuple(host.shape) and self._coef.device == self._table.device:
+            self._coef.copy_(host)          # in place: captured graphs keep their addresses
+        else:
+            self._coef = host.to(self._table.device)
+        # the history tensors are kept (a captured graph holds their addresses); their stale content is never used:
+        # step 0 runs without corrector at order 1, and every later read was written by an earlier step
+
+    def _history(self, sample):
+        if self._hist is None or self._hist[0].shape != sample.shape or self._hist[0].dtype != sample.dtype:
+            self._hist = tuple(torch.zeros_like(sample) for _ in range(3))     # last_sample, m1, m2
+        return self._hist
+
+    def step(self, model_output, timestep, sample, return_dict: bool = True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the "
+                             "scheduler")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        prev = sample.clone()
+        last, m1, m2 = self._history(sample)
+        ops.unipc_flow_step_(model_output, prev, last, m1, m2, self._coef, self._step_dev)
+        self._advance()
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev_sample=prev)
+
+    def step_cfg(self, model_output_2b, sample, guidance_scale: float, out=None):
+        """Engine extension: CFG combine + UniPC step, written over ``sample`` (graph replay)."""
+        if self._step_index is None:
+            self._init_step_index(self.timesteps[0])
+        if out is not None and out.data_ptr() != sample.data_ptr():
+            raise ValueError("UniPC step_cfg updates `sample` in place")
+        last, m1, m2 = self._history(sample)
+        ops.unipc_flow_step_(model_output_2b, sample, last, m1, m2, self._coef, self._step_dev, cfg=True,
+                             guidance=float(guidance_scale))
+        self._advance()
+        return sample
+
+    def step_inplace(self, model_output, sample):
+        if self._step_index is None:
+            self._init_step_index(self.timesteps[0])
+        last, m1, m2 = self._history(sample)
+        ops.unipc_flow_step_(model_output, sample, last, m1, m2, self._coef, self._step_dev)
+        self._advance()
+        return sample

@@ -195,7 +195,15 @@ int da_x0_linear_step(const void* eps, const void* x, const void* noise, long lo
                       void* stream);
 int da_flowmatch_step(const void* v, const void* x, void* out, const float* table, const int* step_idx, int cfg,
                       float guidance, long long n, int dtype, void* stream);
+/* da_unipc_flow_step: schedulers/scheduling_unipc_multistep.py:760-1300 (flow_prediction, predict_x0, B(h),
+ * solver_order <= 2): x0 conversion + corrector + predictor + history roll in ONE pass, in place on x / last / m1 / m2;
+ * coef = 16 floats per step [sigma, use_corr, order_c, c1c, c2c, c3c, rk_c, rho0_c, rho_last_c, order_p, c1p, c2p, c3p,
+ * rk_p, -, -]; x_dtype (sample + history) / v_dtype (model output): f32/f32, f32/bf16 (Wan pipeline) or bf16/bf16. */
+int da_unipc_flow_step(const void* v, void* x, void* last, void* m1, void* m2, const float* coef, const int* step_idx,
+                       int cfg, float guidance, long long n, int x_dtype, int v_dtype, void* stream);
 int da_advance_step(int* step_idx, void* stream);
+/* out[r][:] = bf16(x) for r < rep: latents.to(transformer_dtype) (pipeline_wan.py:600) + CFG batch doubling */
+int da_cast_f32_bf16(const float* x, void* out, int rep, long long n, void* stream);
 /* out[r][:] = x * s in the tensor dtype for r < rep: latents * scheduler.init_noise_sigma
  * (pipeline_stable_diffusion.py:713); rep = 2, s = 1 is the CFG batch doubling torch.cat([latents] * 2) (:1037) */
 int da_mul_scalar(const void* x, void* out, float s, int rep, long long n, int dtype, void* stream);

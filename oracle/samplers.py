@@ -221,3 +221,93 @@ class FlowMatchOracle:
         prev = sample + smul(dt, model_output, self.dev)
         self.step_index += 1
         return prev.to(model_output.dtype)
+
+
+class UniPCFlowOracle:
+    """UniPCMultistepScheduler in the configuration Wan 2.1 ships (pipeline_wan.py:52-59): prediction_type
+    "flow_prediction", use_flow_sigmas, flow_shift, solver_order 2, solver_type "bh2", predict_x0, lower_order_final.
+    Restates schedulers/scheduling_unipc_multistep.py: set_timesteps :428-466 (flow sigmas), convert_model_output
+    :760-831, multistep_uni_p_bh_update :833-975, multistep_uni_c_bh_update :977-1119, step :1153-1300."""
+
+    def __init__(self, num_train_timesteps=1000, solver_order=2, flow_shift=1.0, solver_type="bh2"):
+        self.n_train, self.order_max, self.shift, self.solver_type = num_train_timesteps, solver_order, flow_shift, solver_type
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n):
+        sig = np.linspace(1, 1 / self.n_train, n + 1)[:-1]
+        sig = self.shift * sig / (1 + (self.shift - 1) * sig)
+        if np.fabs(sig[0] - 1) < 1e-6:
+            sig[0] -= 1e-6
+        ts = (sig * self.n_train).copy()
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts).to(dtype=torch.int64)
+        self.model_outputs = [None] * self.order_max
+        self.lower_order_nums = 0
+        self.last_sample = None
+        self.step_index = 0
+        self.this_order = None
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        return 1 - sigma, sigma
+
+    def _coeffs(self, sigma_t, sigma_s0, hist_sigmas, order):
+        alpha_t, sigma_t = self._alpha_sigma(sigma_t)
+        alpha_s0, sigma_s0 = self._alpha_sigma(sigma_s0)
+        lambda_t = torch.log(alpha_t) - torch.log(sigma_t)
+        lambda_s0 = torch.log(alpha_s0) - torch.log(sigma_s0)
+        h = lambda_t - lambda_s0
+        rks = []
+        for s in hist_sigmas[: order - 1]:
+            a_si, s_si = self._alpha_sigma(s)
+            rks.append(((torch.log(a_si) - torch.log(s_si)) - lambda_s0) / h)
+        rks.append(torch.ones(()))
+        rks = torch.stack(rks)
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = hh if self.solver_type == "bh1" else torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        return alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, torch.stack(R), torch.stack(b)
+
+    def step(self, model_output, sample):
+        i = self.step_index
+        x0 = sample - self.sigmas[i] * model_output                       # convert_model_output, flow_prediction
+        if i > 0 and self.last_sample is not None:                       # corrector (multistep_uni_c_bh_update)
+            order = self.this_order
+            m0 = self.model_outputs[-1]
+            hist = [self.sigmas[i - (k + 1)] for k in range(1, order)]
+            alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coeffs(self.sigmas[i], self.sigmas[i - 1], hist, order)
+            D1s = [(self.model_outputs[-(k + 1)] - m0) / rks[k - 1] for k in range(1, order)]
+            rhos_c = torch.ones(1, dtype=sample.dtype) * 0.5 if order == 1 else torch.linalg.solve(R, b).to(sample.dtype)
+            x_t_ = sigma_t / sigma_s0 * self.last_sample - alpha_t * h_phi_1 * m0
+            corr = torch.einsum("k,bkc...->bc...", rhos_c[:-1], torch.stack(D1s, dim=1)) if D1s else 0
+            sample = (x_t_ - alpha_t * B_h * (corr + rhos_c[-1] * (x0 - m0))).to(sample.dtype)
+        for k in range(self.order_max - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+        self.model_outputs[-1] = x0
+        this_order = min(self.order_max, len(self.timesteps) - i)
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.last_sample = sample
+        order = self.this_order                                           # predictor (multistep_uni_p_bh_update)
+        m0 = self.model_outputs[-1]
+        hist = [self.sigmas[i - k] for k in range(1, order)]
+        alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coeffs(self.sigmas[i + 1], self.sigmas[i], hist, order)
+        D1s = [(self.model_outputs[-(k + 1)] - m0) / rks[k - 1] for k in range(1, order)]
+        x_t_ = sigma_t / sigma_s0 * sample - alpha_t * h_phi_1 * m0
+        if D1s:
+            rhos_p = torch.ones(1, dtype=sample.dtype) * 0.5 if order == 2 else \
+                torch.linalg.solve(R[:-1, :-1], b[:-1]).to(sample.dtype)
+            pred = torch.einsum("k,bkc...->bc...", rhos_p, torch.stack(D1s, dim=1))
+        else:
+            pred = 0
+        prev = (x_t_ - alpha_t * B_h * pred).to(sample.dtype)
+        if self.lower_order_nums < self.order_max:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return prev

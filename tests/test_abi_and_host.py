@@ -238,3 +238,39 @@ def test_attention_backend_registers_with_reference_registry():
         for k, v in saved.items():
             getattr(ad._AttentionBackendRegistry, k).clear()
             getattr(ad._AttentionBackendRegistry, k).update(v)
+
+
+def test_unipc_coefficient_table_reproduces_reference(golden, monkeypatch):
+    """Host half of the UniPC step: the per-step coefficient rows, applied in the kernel's operation order (emulated here
+    with fp32 torch ops), reproduce the reference's fp32 trajectory bit for bit."""
+    from diffusers_amd import schedulers as S
+    g = golden("unipc")
+
+    def fake_upload(self, rows, device):
+        self._table, self._step_dev = torch.from_numpy(rows), torch.zeros((), dtype=torch.int32)
+    monkeypatch.setattr(S._SchedulerBase, "_upload", fake_upload)
+    sch = S.UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=3.0)
+    n = len(g["timesteps"])
+    sch.set_timesteps(n, device="cpu")
+    assert np.array_equal(sch.timesteps.numpy(), g["timesteps"]) and np.array_equal(sch.sigmas.numpy(), g["sigmas"])
+    coef = sch._coef.numpy()
+    assert [int(r[9]) for r in coef] == [1] + [2] * (n - 2) + [1]          # warm-up and lower_order_final
+    f = lambda a: torch.tensor(a, dtype=torch.float32)  # noqa: E731
+    x = torch.from_numpy(g["x0"]).clone()
+    last, m1, m2 = (torch.zeros_like(x) for _ in range(3))
+    for i in range(n):
+        r, v = coef[i], torch.from_numpy(g["v"][i])
+        mn = x - f(r[0]) * v
+        xc = x
+        if r[1] != 0:
+            inner = f(r[8]) * (mn - m1)
+            if int(r[2]) == 2:
+                inner = f(r[7]) * ((m2 - m1) / f(r[6])) + inner
+            xc = (f(r[3]) * last - f(r[4]) * m1) - f(r[5]) * inner
+        xn = f(r[10]) * xc - f(r[11]) * mn
+        if int(r[9]) == 2:
+            xn = xn - f(r[12]) * (0.5 * ((m1 - mn) / f(r[13])))
+        m2, m1, last, x = m1, mn, xc, xn
+        assert torch.equal(x, torch.from_numpy(g["traj_f32"][i])), f"step {i}"
+    with pytest.raises(NotImplementedError):
+        S.UniPCMultistepScheduler()  # epsilon / VP-sigma configuration is not on the hot path

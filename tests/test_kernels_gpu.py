@@ -686,3 +686,47 @@ def test_attention_processor_on_reference_style_module():
         o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(2, 96, C)
         ref = F.linear(o, attn.to_out[0].weight.float().cpu(), attn.to_out[0].bias.float().cpu())
     assert_close_bf16(y, ref, "attention processor (cross-attention)", rtol=2e-2, atol_rms=2e-2)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# UniPC (flow mode) fused step vs the reference trajectories
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,xd,vd", [("f32", torch.float32, torch.float32), ("mixed", torch.float32, bf16),
+                                        ("bf16", bf16, bf16)])
+def test_unipc_step_vs_reference(golden, name, xd, vd):
+    from diffusers_amd import schedulers as S
+    g = golden("unipc")
+    n = len(g["timesteps"])
+    sch = S.UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=3.0)
+    sch.set_timesteps(n, device=DEV)
+    assert np.array_equal(sch.timesteps.cpu().numpy(), g["timesteps"])
+    x = torch.from_numpy(g["x0"]).to(xd).to(DEV)
+    nbad = 0
+    for i, t_ in enumerate(sch.timesteps):
+        x = sch.step(torch.from_numpy(g["v"][i]).to(vd).to(DEV), t_, x).prev_sample
+        want = torch.from_numpy(g[f"traj_{name}"][i])
+        nbad += int((x.float().cpu() != want).sum())
+        assert float((x.float().cpu() - want).abs().max()) <= 2e-2 * float(want.abs().max()), f"{name} step {i}"
+    print(f"[parity] unipc {name}: elements differing from the reference over {n} steps = {nbad}")
+    assert nbad == 0, f"UniPC {name}: {nbad} elements differ from the reference trajectory"
+
+
+def test_unipc_cfg_inplace_matches_separate_combine(golden):
+    """step_cfg (CFG combine fused, in place) == combine in bf16 then step."""
+    from diffusers_amd import schedulers as S
+    from oracle import samplers as OS
+    g = golden("unipc")
+    n = len(g["timesteps"])
+    a, b = (S.UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=3.0) for _ in range(2))
+    a.set_timesteps(n, device=DEV), b.set_timesteps(n, device=DEV)
+    xa = torch.from_numpy(g["x0"]).to(DEV)
+    xb = xa.clone()
+    for i, t_ in enumerate(a.timesteps):
+        u = torch.from_numpy(g["v"][i]).to(bf16)
+        c = torch.from_numpy(g["v"][(i + 1) % n]).to(bf16)
+        a.step_cfg(torch.cat([u, c]).to(DEV), xa, 5.0)
+        xb = b.step(OS.cfg_combine(u, c, 5.0).to(DEV), t_, xb).prev_sample
+        assert torch.equal(xa, xb), f"step {i}"
+    y = rnd((3, 5, 7), 151, dtype=torch.float32)
+    from diffusers_amd import ops
+    assert torch.equal(ops.cast_f32_bf16(y, rep=2), torch.cat([y, y]).to(bf16))

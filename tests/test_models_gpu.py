@@ -247,3 +247,33 @@ def test_tiny_ddpm_unet_and_pipeline_vs_reference(golden):
     ps = 10 * np.log10(1.0 / max(mse, 1e-12))
     print(f"[parity] tiny DDPM pipeline (5 steps): image PSNR vs reference fp32 = {ps:.1f} dB, max abs {np.abs(img - want).max():.3f}")
     assert ps >= 35.0
+
+
+def test_tiny_wan_pipeline_unipc_vs_oracle(golden):
+    """Wan's shipped sampler (UniPC, flow_shift 3, fp32 latents) in the engine loop vs the fp32 CPU oracle loop."""
+    from diffusers_amd import factory, init as dinit
+    from diffusers_amd.schedulers import UniPCMultistepScheduler
+    from oracle import reference_math as R
+    from oracle import samplers as OS
+    g = golden("tiny_wan_pipeline")
+    pipe = factory.build_wan_pipeline(device=DEV, tiny=True, seed=9)
+    pipe.scheduler = UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=3.0)
+    kw = dict(prompt_embeds=t(g, "prompt_embeds"), negative_prompt_embeds=t(g, "negative_prompt_embeds"),
+              num_inference_steps=4, guidance_scale=5.0, height=64, width=64, num_frames=9)
+    lat0 = torch.from_numpy(g["latents"])
+    eager = pipe(latents=lat0.clone(), use_graph=False, **kw).images.clone()
+    graph = pipe(latents=lat0.clone(), use_graph=True, **kw).images.clone()
+    assert eager.dtype == torch.float32 and torch.equal(eager, graph)
+    assert torch.equal(graph, pipe(latents=lat0.clone(), use_graph=True, **kw).images)
+    sd = {k: v.float() for k, v in dinit.random_state_dict(dinit.wan_param_shapes(dinit.TINY_WAN), seed=9).items()}
+    o = OS.UniPCFlowOracle(flow_shift=3.0)
+    o.set_timesteps(4)
+    x = lat0.clone()
+    pe, ne = torch.from_numpy(g["prompt_embeds"]), torch.from_numpy(g["negative_prompt_embeds"])
+    for tt in o.timesteps:
+        cond = R.wan_forward(sd, dinit.TINY_WAN, x, tt.expand(1), pe)
+        unc = R.wan_forward(sd, dinit.TINY_WAN, x, tt.expand(1), ne)
+        x = o.step(OS.cfg_combine(unc, cond, 5.0), x)
+    rr = rel_rms(eager, x)
+    print(f"[parity] tiny Wan + UniPC (4 steps, CFG 5): latents rel_rms vs fp32 oracle loop = {rr:.3e}")
+    assert rr < 4e-2
