@@ -229,9 +229,14 @@ class UniPCFlowOracle:
     Restates schedulers/scheduling_unipc_multistep.py: set_timesteps :428-466 (flow sigmas), convert_model_output
     :760-831, multistep_uni_p_bh_update :833-975, multistep_uni_c_bh_update :977-1119, step :1153-1300."""
 
-    def __init__(self, num_train_timesteps=1000, solver_order=2, flow_shift=1.0, solver_type="bh2"):
+    def __init__(self, num_train_timesteps=1000, solver_order=2, flow_shift=1.0, solver_type="bh2", device_scalars=False):
         self.n_train, self.order_max, self.shift, self.solver_type = num_train_timesteps, solver_order, flow_shift, solver_type
         self.init_noise_sigma = 1.0
+        # The reference keeps ``sigmas`` on the CPU (:466), so every coefficient below is a 0-d CPU fp32 tensor written
+        # FIRST in its product: torch's CPU kernels round it to the tensor's dtype, the device kernels keep fp32
+        # (module docstring).  ``(m - m0) / rk`` keeps the fp32 rk in both (CPU: original_scalar_value); the device
+        # kernel's a * (1 / rk) shortcut (<= 1 ulp of the quotient) is not modelled -- the HIP kernel divides.
+        self.dev = device_scalars
 
     def set_timesteps(self, n):
         sig = np.linspace(1, 1 / self.n_train, n + 1)[:-1]
@@ -277,7 +282,7 @@ class UniPCFlowOracle:
 
     def step(self, model_output, sample):
         i = self.step_index
-        x0 = sample - self.sigmas[i] * model_output                       # convert_model_output, flow_prediction
+        x0 = sample - smul(self.sigmas[i], model_output, self.dev)          # convert_model_output, flow_prediction
         if i > 0 and self.last_sample is not None:                       # corrector (multistep_uni_c_bh_update)
             order = self.this_order
             m0 = self.model_outputs[-1]
@@ -285,9 +290,9 @@ class UniPCFlowOracle:
             alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coeffs(self.sigmas[i], self.sigmas[i - 1], hist, order)
             D1s = [(self.model_outputs[-(k + 1)] - m0) / rks[k - 1] for k in range(1, order)]
             rhos_c = torch.ones(1, dtype=sample.dtype) * 0.5 if order == 1 else torch.linalg.solve(R, b).to(sample.dtype)
-            x_t_ = sigma_t / sigma_s0 * self.last_sample - alpha_t * h_phi_1 * m0
+            x_t_ = smul(sigma_t / sigma_s0, self.last_sample, self.dev) - smul(alpha_t * h_phi_1, m0, self.dev)
             corr = torch.einsum("k,bkc...->bc...", rhos_c[:-1], torch.stack(D1s, dim=1)) if D1s else 0
-            sample = (x_t_ - alpha_t * B_h * (corr + rhos_c[-1] * (x0 - m0))).to(sample.dtype)
+            sample = (x_t_ - smul(alpha_t * B_h, corr + rhos_c[-1] * (x0 - m0), self.dev)).to(sample.dtype)
         for k in range(self.order_max - 1):
             self.model_outputs[k] = self.model_outputs[k + 1]
         self.model_outputs[-1] = x0
@@ -299,14 +304,14 @@ class UniPCFlowOracle:
         hist = [self.sigmas[i - k] for k in range(1, order)]
         alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coeffs(self.sigmas[i + 1], self.sigmas[i], hist, order)
         D1s = [(self.model_outputs[-(k + 1)] - m0) / rks[k - 1] for k in range(1, order)]
-        x_t_ = sigma_t / sigma_s0 * sample - alpha_t * h_phi_1 * m0
+        x_t_ = smul(sigma_t / sigma_s0, sample, self.dev) - smul(alpha_t * h_phi_1, m0, self.dev)
         if D1s:
             rhos_p = torch.ones(1, dtype=sample.dtype) * 0.5 if order == 2 else \
                 torch.linalg.solve(R[:-1, :-1], b[:-1]).to(sample.dtype)
             pred = torch.einsum("k,bkc...->bc...", rhos_p, torch.stack(D1s, dim=1))
         else:
             pred = 0
-        prev = (x_t_ - alpha_t * B_h * pred).to(sample.dtype)
+        prev = (x_t_ - (smul(alpha_t * B_h, pred, self.dev) if D1s else 0)).to(sample.dtype)
         if self.lower_order_nums < self.order_max:
             self.lower_order_nums += 1
         self.step_index += 1
