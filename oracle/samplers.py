@@ -227,7 +227,7 @@ class UniPCFlowOracle:
     """UniPCMultistepScheduler in the configuration Wan 2.1 ships (pipeline_wan.py:52-59): prediction_type
     "flow_prediction", use_flow_sigmas, flow_shift, solver_order 2, solver_type "bh2", predict_x0, lower_order_final.
     Restates schedulers/scheduling_unipc_multistep.py: set_timesteps :428-466 (flow sigmas), convert_model_output
-    :760-831, multistep_uni_p_bh_update :833-975, multistep_uni_c_bh_update :977-1119, step :1153-1300."""
+    :760-831, multistep_uni_p_bh_update :833-960, multistep_uni_c_bh_update :962-1098, step :1153-1232."""
 
     def __init__(self, num_train_timesteps=1000, solver_order=2, flow_shift=1.0, solver_type="bh2", device_scalars=False):
         self.n_train, self.order_max, self.shift, self.solver_type = num_train_timesteps, solver_order, flow_shift, solver_type
