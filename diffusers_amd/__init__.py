@@ -14,6 +14,7 @@ __version__ = "0.1.0"
 _EXPORTS = {
     "UNet2DConditionModel": "unet_2d_condition",
     "AutoencoderKL": "autoencoder_kl",
+    "AutoencoderKLWan": "autoencoder_kl_wan",
     "FluxTransformer2DModel": "transformer_flux",
     "FluxPipeline": "pipelines",
     "WanTransformer3DModel": "transformer_wan",

@@ -250,6 +250,48 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   }
 }
 
+// dst[d0][d2][d1][:] = src[d0][d1][d2][:] in 16-byte chunks (D3 a multiple of 8 bf16).  WanResample 'upsample3d'
+// (autoencoder_kl_wan.py:297-299): time_conv produces 2C channels per position, [frame][pos][2][C] here, and the two
+// halves become consecutive frames, [frame][2][pos][C].  Pure copy: HBM-bound, chunk index = destination order.
+__global__ __launch_bounds__(256) void permute_0213_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                           long long D0, int D1, int D2, int ch) {
+  const long long total = D0 * D1 * D2 * ch;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % ch);
+    long long t = i / ch;
+    const int d1 = (int)(t % D1);
+    t /= D1;
+    const int d2 = (int)(t % D2);
+    const long long d0 = t / D2;
+    dst[i] = src[((d0 * D1 + d1) * D2 + d2) * ch + c];
+  }
+}
+
+// Channels-last frames [B*T][HW][Cs] (first C <= 4 channels used) -> video [B][C][T][HW], clamped to [lo, hi]
+// (AutoencoderKLWan._decode: torch.clamp(out, -1, 1), autoencoder_kl_wan.py:1210).  One thread per position.
+template <bool F32>
+__global__ __launch_bounds__(256) void frames_to_ncthw_kernel(const uint16_t* __restrict__ src, void* __restrict__ dst,
+                                                              int B, int T, long long HW, int Cs, int C, float lo,
+                                                              float hi) {
+  const long long total = (long long)B * T * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i % HW;
+    const long long bt = i / HW;
+    const int t = (int)(bt % T);
+    const long long b = bt / T;
+    const uint2 v = *(const uint2*)(src + (size_t)i * Cs);
+    const float f[4] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y)};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c >= C) break;
+      const float o = fminf(fmaxf(f[c], lo), hi);
+      const size_t at = (((size_t)b * C + c) * T + t) * (size_t)HW + (size_t)p;
+      if (F32) ((float*)dst)[at] = o;
+      else ((uint16_t*)dst)[at] = f2bf(o);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int da_transpose_bf16(const void* in, void* out, int R, int Cc, long long ldi, long long ldo, void* stream) {
@@ -379,6 +421,35 @@ extern "C" int da_conv_thin_out_bf16(const void* x, const void* w, const void* b
     default: return DA_ERR_UNSUPPORTED;
   }
 #undef DA_CO
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_permute_0213_bf16(const void* src, void* dst, long long D0, int D1, int D2, int D3, void* stream) {
+  if (!src || !dst || D0 <= 0 || D1 <= 0 || D2 <= 0 || D3 <= 0 || (D3 & 7)) return DA_ERR_INVALID;
+  const long long total = D0 * D1 * D2 * (D3 >> 3);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  DA_LAUNCH(permute_0213_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+            (uint4*)dst, D0, D1, D2, D3 >> 3);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_frames_to_ncthw_bf16(const void* src, void* dst, int B, int T, long long HW, int Cs, int C, float lo,
+                                       float hi, int out_f32, void* stream) {
+  if (!src || !dst || B <= 0 || T <= 0 || HW <= 0 || C <= 0 || C > 4 || Cs < 4 || (Cs & 3) || !(lo <= hi))
+    return DA_ERR_INVALID;
+  const long long total = (long long)B * T * HW;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (out_f32) {
+    DA_LAUNCH(frames_to_ncthw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+              (const uint16_t*)src, dst, B, T, HW, Cs, C, lo, hi);
+  } else {
+    DA_LAUNCH(frames_to_ncthw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+              (const uint16_t*)src, dst, B, T, HW, Cs, C, lo, hi);
+  }
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

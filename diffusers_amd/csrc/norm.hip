@@ -375,6 +375,77 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// WanRMS_norm over the channels of channels-last rows (+ SiLU): models/autoencoders/autoencoder_kl_wan.py:198-206 and
+// the nonlinearity that follows it at :352-353,:367-368,:899-900.  A group of LPR lanes owns one row (NCH 16-byte chunks
+// per lane), 64 / LPR rows per wave; the rounding points are the reference's (normalize in fp32 -> bf16, * sqrt(C) ->
+// bf16, * gamma -> bf16, SiLU -> bf16).  Zero-padded channels (gamma 0) stay exactly 0.
+// ------------------------------------------------------------------------------------------------------------------
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void rms_channels_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma,
+                                                           uint16_t* __restrict__ y, long long rows, int C, float scale,
+                                                           int act) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rsel = lane / LPR;
+  const int chunks = C >> 3;
+  float g[NCH][8];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int ch = sub + u * LPR;
+    if (ch < chunks) {
+      unpack8(*(const uint4*)(gamma + (size_t)ch * 8), g[u]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[u][e] = 0.f;
+    }
+  }
+  const long long stride = (long long)gridDim.x * 4 * RPW;
+  for (long long r = ((long long)blockIdx.x * 4 + wave) * RPW + rsel; r < rows + rsel; r += stride) {
+    // (rows + rsel bound keeps every lane of a row group in the loop for the shuffles; out-of-range rows do no I/O)
+    const bool live = r < rows;
+    float f[NCH][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = sub + u * LPR;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (live && ch < chunks) v = *(const uint4*)(x + (size_t)r * C + (size_t)ch * 8);
+      unpack8(v, f[u]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += f[u][e] * f[u][e];
+    }
+#pragma unroll
+    for (int m = LPR >> 1; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = sub + u * LPR;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = bf2f(f2bf(f[u][e] / nrm));
+        v = bf2f(f2bf(v * scale));
+        v = bf2f(f2bf(v * g[u][e]));
+        o[e] = (act == DA_ACT_SILU) ? silu_f(v) : v;
+      }
+      if (live && ch < chunks) *(uint4*)(y + (size_t)r * C + (size_t)ch * 8) = pack8(o);
+    }
+  }
+}
+
+template <int LPR, int NCH>
+int launch_rms_channels(const void* x, const void* gamma, void* y, long long rows, int C, float scale, int act,
+                        hipStream_t s) {
+  constexpr int RPW = 64 / LPR;
+  long long blocks = (rows + 4 * RPW - 1) / (4 * RPW);
+  if (blocks > 8192) blocks = 8192;
+  DA_LAUNCH((rms_channels_kernel<LPR, NCH>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x,
+            (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, act);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
 struct GnPlan {
   int threads, krows, nblk, pix_per_blk;
 };
@@ -493,4 +564,18 @@ extern "C" int da_softmax_rows_f32_bf16(const void* scores, void* probs, int M, 
                      (uint16_t*)probs, N, ld, ldo);
   DA_CHECK_LAUNCH();
   return DA_OK;
+}
+
+extern "C" int da_rmsnorm_channels_bf16(const void* x, const void* gamma, void* y, long long rows, int C, float scale,
+                                        int act, void* stream) {
+  if (!x || !gamma || !y || rows <= 0 || C <= 0 || (C & 7)) return DA_ERR_INVALID;
+  if (act != DA_ACT_NONE && act != DA_ACT_SILU) return DA_ERR_UNSUPPORTED;
+  if (C > 1024) return DA_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = C >> 3;
+  if (chunks <= 8) return launch_rms_channels<8, 1>(x, gamma, y, rows, C, scale, act, s);
+  if (chunks <= 16) return launch_rms_channels<16, 1>(x, gamma, y, rows, C, scale, act, s);
+  if (chunks <= 32) return launch_rms_channels<32, 1>(x, gamma, y, rows, C, scale, act, s);
+  if (chunks <= 64) return launch_rms_channels<64, 1>(x, gamma, y, rows, C, scale, act, s);
+  return launch_rms_channels<64, 2>(x, gamma, y, rows, C, scale, act, s);
 }

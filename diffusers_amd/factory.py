@@ -7,6 +7,7 @@ import torch
 
 from . import init as dinit
 from .autoencoder_kl import AutoencoderKL
+from .autoencoder_kl_wan import AutoencoderKLWan
 from .pipelines import DDPMPipeline, FluxPipeline, StableDiffusionPipeline, StableDiffusionXLPipeline, WanPipeline
 from .schedulers import DDPMScheduler
 from .unet_2d import UNet2DModel
@@ -34,6 +35,15 @@ def build_vae(cfg: dict, seed: int = 1, device="cuda", init_device: Optional[str
     vae = AutoencoderKL(**cfg)
     if state_dict is None:
         shapes = dinit.vae_decoder_param_shapes(vae.config)
+        state_dict = dinit.random_state_dict(shapes, seed=seed, device=init_device or "cpu")
+    vae.load_state_dict(state_dict, device=device)
+    return vae, state_dict
+
+
+def build_wan_vae(cfg: dict, seed: int = 21, device="cuda", init_device: Optional[str] = None, state_dict=None):
+    vae = AutoencoderKLWan(**cfg)
+    if state_dict is None:
+        shapes = dinit.wan_vae_decoder_param_shapes(vae.config)
         state_dict = dinit.random_state_dict(shapes, seed=seed, device=init_device or "cpu")
     vae.load_state_dict(state_dict, device=device)
     return vae, state_dict

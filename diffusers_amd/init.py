@@ -240,6 +240,56 @@ def wan_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
     return sh
 
 
+def wan_vae_decoder_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Decoder half (+ post_quant_conv) of AutoencoderKLWan's state_dict (autoencoder_kl_wan.py:803-877,:1056), the
+    Wan 2.1 layout (is_residual=False)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    dim = cfg.get("decoder_base_dim") or cfg["base_dim"]
+    z, mult, nres = cfg["z_dim"], list(cfg["dim_mult"]), cfg["num_res_blocks"]
+    t_up = list(cfg["temperal_downsample"])[::-1]
+    dims = [dim * u for u in [mult[-1]] + mult[::-1]]
+
+    def res(p, cin, cout):
+        sh[f"{p}.norm1.gamma"] = (cin, 1, 1, 1)
+        sh[f"{p}.conv1.weight"] = (cout, cin, 3, 3, 3)
+        sh[f"{p}.conv1.bias"] = (cout,)
+        sh[f"{p}.norm2.gamma"] = (cout, 1, 1, 1)
+        sh[f"{p}.conv2.weight"] = (cout, cout, 3, 3, 3)
+        sh[f"{p}.conv2.bias"] = (cout,)
+        if cin != cout:
+            sh[f"{p}.conv_shortcut.weight"] = (cout, cin, 1, 1, 1)
+            sh[f"{p}.conv_shortcut.bias"] = (cout,)
+
+    sh["post_quant_conv.weight"] = (z, z, 1, 1, 1)
+    sh["post_quant_conv.bias"] = (z,)
+    sh["decoder.conv_in.weight"] = (dims[0], z, 3, 3, 3)
+    sh["decoder.conv_in.bias"] = (dims[0],)
+    a = "decoder.mid_block.attentions.0"
+    sh[f"{a}.norm.gamma"] = (dims[0], 1, 1)
+    sh[f"{a}.to_qkv.weight"] = (3 * dims[0], dims[0], 1, 1)
+    sh[f"{a}.to_qkv.bias"] = (3 * dims[0],)
+    sh[f"{a}.proj.weight"] = (dims[0], dims[0], 1, 1)
+    sh[f"{a}.proj.bias"] = (dims[0],)
+    res("decoder.mid_block.resnets.0", dims[0], dims[0])
+    res("decoder.mid_block.resnets.1", dims[0], dims[0])
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        if i > 0:
+            cin //= 2
+        for j in range(nres + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != len(mult) - 1:
+            u = f"decoder.up_blocks.{i}.upsamplers.0"
+            sh[f"{u}.resample.1.weight"] = (cout // 2, cout, 3, 3)
+            sh[f"{u}.resample.1.bias"] = (cout // 2,)
+            if t_up[i]:
+                sh[f"{u}.time_conv.weight"] = (2 * cout, cout, 3, 1, 1)
+                sh[f"{u}.time_conv.bias"] = (2 * cout,)
+    sh["decoder.norm_out.gamma"] = (dims[-1], 1, 1, 1)
+    sh["decoder.conv_out.weight"] = (cfg["out_channels"], dims[-1], 3, 3, 3)
+    sh["decoder.conv_out.bias"] = (cfg["out_channels"],)
+    return sh
+
+
 def _attn_block(sh, p, c):
     sh[f"{p}.group_norm.weight"] = (c,)
     sh[f"{p}.group_norm.bias"] = (c,)
@@ -312,7 +362,7 @@ def random_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, device=
         g.manual_seed(_seed_for(name, seed))
         is_norm = (".norm" in name or "norm." in name or "group_norm" in name or name.startswith("conv_norm_out")
                    or "conv_norm_out" in name) and ".linear." not in name
-        if is_norm and name.endswith(".weight"):
+        if is_norm and (name.endswith(".weight") or name.endswith(".gamma")):
             t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=dev, dtype=torch.float32)
         elif name.endswith(".bias"):
             t = 0.05 * torch.randn(shape, generator=g, device=dev, dtype=torch.float32)
@@ -379,6 +429,17 @@ WAN_1_3B = dict(patch_size=(1, 2, 2), num_attention_heads=12, attention_head_dim
                 pos_embed_seq_len=None)
 TINY_WAN = dict(WAN_1_3B, num_attention_heads=2, attention_head_dim=64, text_dim=64, ffn_dim=256, num_layers=2,
                 rope_max_seq_len=32)
+WAN_VAE_LATENTS_MEAN = (-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517,
+                        -0.3632, -0.1922, -0.9497, 0.2503, -0.2921)
+WAN_VAE_LATENTS_STD = (2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652, 1.5579,
+                       1.6382, 1.1253, 2.8251, 1.9160)
+# AutoencoderKLWan defaults = the Wan 2.1 VAE (autoencoder_kl_wan.py:976-1030)
+WAN_VAE = dict(base_dim=96, decoder_base_dim=None, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, attn_scales=(),
+               temperal_downsample=(False, True, True), dropout=0.0, latents_mean=WAN_VAE_LATENTS_MEAN,
+               latents_std=WAN_VAE_LATENTS_STD, is_residual=False, in_channels=3, out_channels=3, patch_size=None,
+               scale_factor_temporal=4, scale_factor_spatial=8)
+# base_dim 24 -> channel counts 96 / 48 / 24: none a multiple of 64, so every zero-padding path is exercised
+TINY_WAN_VAE = dict(WAN_VAE, base_dim=24, num_res_blocks=1)
 # SD1.5's head geometry (attention_head_dim=8 means 8 HEADS: head dims 40 / 80 / 160) on a small spatial size
 SMALL_SD15_UNET = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280),
                        layers_per_block=1, cross_attention_dim=64, attention_head_dim=8,

@@ -21,10 +21,11 @@ DEFAULT_TILE = L.TILE_AUTO
 TUNING = True  # per-shape (tile, staging) from diffusers_amd.tuning when the caller does not pin them
 
 
-def _select_variant(p: "L.GemmParams", tile: Optional[int], staging: Optional[int], stream: int) -> None:
+def _select_variant(p: "L.GemmParams", tile: Optional[int], staging: Optional[int], stream: int,
+                    inplace: bool = False) -> None:
     if (TUNING and tile is None and staging is None and DEFAULT_TILE == L.TILE_AUTO
             and DEFAULT_STAGING == L.STAGE_LDS_DIRECT):
-        p.tile, p.staging = tuning.lookup(p, stream)
+        p.tile, p.staging = tuning.lookup(p, stream, inplace=inplace)
     else:
         p.tile = DEFAULT_TILE if tile is None else tile
         p.staging = DEFAULT_STAGING if staging is None else staging
@@ -87,12 +88,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         if gate.dtype not in (bf16, torch.float32):
             raise TypeError("linear: gate must be bf16 (Flux rounding) or float32 (Wan rounding)")
         p.gate_f32 = int(gate.dtype == torch.float32)
-    if out.data_ptr() == (residual.data_ptr() if residual is not None else -1):
-        raise ValueError("linear: `out` must not alias `residual` (variant tuning re-runs the launch)")
+    # out may BE the residual (accumulating launch: one lane reads and writes each element); variant tuning then
+    # times its repeated launches on a scratch output
+    inplace = residual is not None and out.data_ptr() == residual.data_ptr()
+    if inplace and p.ldr != p.ldc:
+        raise ValueError("linear: an aliased residual must have the output's row stride")
     p.rows_per_batch = rows_per_batch
     p.alpha, p.out_scale, p.act, p.out_f32, p.conv = alpha, out_scale, act, int(out_f32), 0
     st = _stream()
-    _select_variant(p, tile, staging, st)
+    _select_variant(p, tile, staging, st, inplace=inplace)
     L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(linear)")
     return out
 
@@ -101,10 +105,12 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                 x2: Optional[torch.Tensor] = None, stride: int = 1, up: bool = False, pad: Optional[int] = None,
                 rowvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 out_scale: float = 1.0, act: int = L.ACT_NONE, tile: Optional[int] = None,
-                staging: Optional[int] = None, pad_after: int = 0) -> torch.Tensor:
+                staging: Optional[int] = None, pad_after: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Implicit-GEMM Conv2d on channels-last tensors.  x: [B][H][W][C1] (x2: [B][H][W][C2] = fused channel concat),
     w: [Cout][k][k][C1+C2] flattened to [Cout][k*k*(C1+C2)].  up=True fuses a nearest 2x upsample of the input.
-    rowvec [B][Cout] is added per batch (time embedding); residual is [B][Hout][Wout][Cout]."""
+    rowvec [B][Cout] is added per batch (time embedding); residual is [B][Hout][Wout][Cout].  ``out`` (contiguous
+    [B][Hout][Wout][Cout]) may be the SAME tensor as ``residual``: every output element is read and written by one
+    lane, which is how the temporal taps of a causal Conv3d accumulate in place (autoencoder_kl_wan.py)."""
     _req(x, "x"), _req(w, "w")
     B, H, W_, C1 = x.shape
     C2 = 0
@@ -125,7 +131,13 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     # downsampling.py:139-141); out-of-range taps read zeros, so only the output extent changes
     Hout = (Hv + 2 * pad + pad_after - ksize) // stride + 1
     Wout = (Wv + 2 * pad + pad_after - ksize) // stride + 1
-    out = torch.empty((B, Hout, Wout, Cout), device=x.device, dtype=bf16)
+    if out is None:
+        out = torch.empty((B, Hout, Wout, Cout), device=x.device, dtype=bf16)
+    else:
+        _req(out, "out")
+        if tuple(out.shape) != (B, Hout, Wout, Cout) or not out.is_contiguous():
+            raise ValueError("conv2d_nhwc: out must be contiguous [B][Hout][Wout][Cout]")
+    inplace = residual is not None and residual.data_ptr() == out.data_ptr()
     p = L.GemmParams()
     p.A, p.A2, p.W, p.C = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
     p.bias, p.rowvec, p.residual = _ptr(bias), _ptr(rowvec), _ptr(residual)
@@ -144,7 +156,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     p.Hin, p.Win, p.C1, p.C2, p.Hout, p.Wout = H, W_, C1, C2, Hout, Wout
     p.stride, p.up, p.pad = stride, int(up), pad
     st = _stream()
-    _select_variant(p, tile, staging, st)
+    _select_variant(p, tile, staging, st, inplace=inplace)
     L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(conv)")
     return out
 
@@ -209,12 +221,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: 
     return out
 
 
-def softmax_rows(scores: torch.Tensor) -> torch.Tensor:
+def softmax_rows(scores: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row softmax of fp32 scores [M][N] -> bf16.  ``out`` may be wider than N (row stride free): columns >= N are left
+    untouched, so a zero-initialised [M][ceil64(N)] buffer is a valid K-padded GEMM operand."""
     _req(scores, "scores", torch.float32)
     M, N = scores.shape
-    out = torch.empty((M, N), device=scores.device, dtype=bf16)
-    L.check(L.load().da_softmax_rows_f32_bf16(scores.data_ptr(), out.data_ptr(), M, N, scores.stride(0), N, _stream()),
-            "da_softmax_rows_f32_bf16")
+    if out is None:
+        out = torch.empty((M, N), device=scores.device, dtype=bf16)
+    else:
+        _req(out, "out")
+        if out.shape[0] != M or out.shape[1] < N:
+            raise ValueError("softmax_rows: out must be [M][>= N]")
+    L.check(L.load().da_softmax_rows_f32_bf16(scores.data_ptr(), out.data_ptr(), M, N, _rows2d(scores, "scores"),
+                                              _rows2d(out, "out"), _stream()), "da_softmax_rows_f32_bf16")
     return out
 
 
@@ -241,6 +260,20 @@ def group_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gr
     L.check(lib.da_groupnorm_nhwc_bf16(x.data_ptr(), _ptr(x2), C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                        ws.data_ptr(), B, HW, Ctot, groups, eps, L.ACT_SILU if silu else L.ACT_NONE,
                                        _stream()), "da_groupnorm_nhwc_bf16")
+    return y
+
+
+def rmsnorm_channels(x: torch.Tensor, gamma: torch.Tensor, *, real_channels: int, silu: bool = False) -> torch.Tensor:
+    """WanRMS_norm over the last (channel) dim of a contiguous channels-last tensor; ``real_channels`` is the model's
+    channel count when the stored one is zero-padded (it sets the sqrt(C) scale)."""
+    _req(x, "x"), _req(gamma, "gamma")
+    Cc = x.shape[-1]
+    if not x.is_contiguous() or gamma.numel() != Cc:
+        raise ValueError("rmsnorm_channels: contiguous channels-last input and a [C] gamma required")
+    y = torch.empty_like(x)
+    L.check(L.load().da_rmsnorm_channels_bf16(x.data_ptr(), gamma.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc,
+                                              float(real_channels) ** 0.5, L.ACT_SILU if silu else L.ACT_NONE,
+                                              _stream()), "da_rmsnorm_channels_bf16")
     return y
 
 
@@ -411,6 +444,36 @@ def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
         out = torch.empty((Cc, R), device=x.device, dtype=bf16)
     L.check(L.load().da_transpose_bf16(x.data_ptr(), out.data_ptr(), R, Cc, _rows2d(x, "x"), _rows2d(out, "out"),
                                        _stream()), "da_transpose_bf16")
+    return out
+
+
+def permute_0213(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[D0][D1][D2][D3] -> [D0][D2][D1][D3] (D3 % 8 == 0); ``out``: any contiguous bf16 tensor of the same size."""
+    _req(x, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("permute_0213: contiguous 4-D tensor required")
+    D0, D1, D2, D3 = x.shape
+    if out is None:
+        out = torch.empty((D0, D2, D1, D3), device=x.device, dtype=bf16)
+    else:
+        _req(out, "out")
+        if out.numel() != x.numel() or not out.is_contiguous() or out.data_ptr() == x.data_ptr():
+            raise ValueError("permute_0213: out must be a distinct contiguous tensor of the same size")
+    L.check(L.load().da_permute_0213_bf16(x.data_ptr(), out.data_ptr(), D0, D1, D2, D3, _stream()), "da_permute_0213_bf16")
+    return out
+
+
+def frames_to_ncthw(x: torch.Tensor, *, batch: int, channels: int, lo: float = -1.0, hi: float = 1.0,
+                    out_f32: bool = False) -> torch.Tensor:
+    """Channels-last frames [B*T][H][W][Cs] -> video [B][channels][T][H][W], clamped to [lo, hi]."""
+    _req(x, "x")
+    if x.dim() != 4 or not x.is_contiguous() or x.shape[0] % batch:
+        raise ValueError("frames_to_ncthw: contiguous [B*T][H][W][Cs] required")
+    BT, H, W_, Cs = x.shape
+    T = BT // batch
+    out = torch.empty((batch, channels, T, H, W_), device=x.device, dtype=torch.float32 if out_f32 else bf16)
+    L.check(L.load().da_frames_to_ncthw_bf16(x.data_ptr(), out.data_ptr(), batch, T, H * W_, Cs, channels, lo, hi,
+                                             int(out_f32), _stream()), "da_frames_to_ncthw_bf16")
     return out
 
 

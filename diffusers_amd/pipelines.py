@@ -388,7 +388,8 @@ class WanPipeline:
     """pipelines/wan/pipeline_wan.py:380-700 (Wan 2.1 T2V) for pre-computed prompt embeddings: the denoising loop.
     The reference runs the transformer twice per step (cond / uncond, :613-632); here the two are one batch-2 call
     (identical arithmetic per sample, twice the GEMM M) and ``uncond + g (cond - uncond)`` is fused into the FlowMatch
-    update.  Decoding needs AutoencoderKLWan (a "next" row): ``output_type`` must be "latent"."""
+    update.  ``output_type="latent"`` returns the latents; "pt" / "raw" decode them with AutoencoderKLWan (the latent
+    de-normalisation of :653-661 is folded into its first conv) and return the clamped video [B][3][F][H][W]."""
 
     def __init__(self, tokenizer=None, text_encoder=None, vae=None, scheduler: FlowMatchEulerDiscreteScheduler = None,
                  transformer: WanTransformer3DModel = None, transformer_2=None, boundary_ratio=None,
@@ -469,8 +470,11 @@ class WanPipeline:
             raise ValueError("text encoders are outside the HIP hot path: pass `prompt_embeds`")
         if prompt_embeds is None:
             raise ValueError("Provide `prompt_embeds`.")
-        if output_type != "latent":
-            raise NotImplementedError("AutoencoderKLWan is a 'next' row (SURVEY.md 8f): use output_type='latent'")
+        if output_type not in ("latent", "pt", "raw"):
+            raise ValueError("output_type must be 'latent', 'pt' or 'raw' (video post-processing to PIL / numpy is "
+                             "outside the hot path)")
+        if output_type != "latent" and self.vae is None:
+            raise ValueError("decoding needs `vae` (diffusers_amd.AutoencoderKLWan)")
         do_cfg = guidance_scale > 1.0
         if do_cfg and negative_prompt_embeds is None:
             raise ValueError("classifier-free guidance needs `negative_prompt_embeds`")
@@ -497,6 +501,8 @@ class WanPipeline:
             pe = torch.cat([negative_prompt_embeds.to(device=dev, dtype=bf16), pe], dim=0)   # [uncond ; cond]
         cond = self.transformer.precompute_conditioning(pe.contiguous())
         latents = self._denoise(latents, cond, len(self.scheduler.timesteps), guidance_scale, do_cfg, use_graph)
+        if output_type != "latent":
+            latents = self.vae.decode(latents, return_dict=False, denormalize=True)[0]
         if not return_dict:
             return (latents,)
         return PipelineOutput(images=latents)

@@ -38,12 +38,21 @@ _dirty = False
 _scratch = {}
 
 
+def _m_key(m: int) -> int:
+    """Row counts above 2^20 keep their top three bits only: such a problem is thousands of tiles deep, so the best
+    variant does not move with the exact count (e.g. the 81 / 80 / 79-frame temporal taps of one video conv)."""
+    if m <= (1 << 20):
+        return m
+    sh = m.bit_length() - 3
+    return (m >> sh) << sh
+
+
 def key_of(p: "L.GemmParams") -> str:
     """Shape key: everything that changes the kernel's work or its memory pattern, nothing that is a pointer."""
     if p.conv:
-        return (f"conv{p.conv}:M{p.M}:N{p.N}:C{p.C1}+{p.C2}:H{p.Hin}x{p.Win}:s{p.stride}:u{p.up}:a{p.act}"
+        return (f"conv{p.conv}:M{_m_key(int(p.M))}:N{p.N}:C{p.C1}+{p.C2}:H{p.Hin}x{p.Win}:s{p.stride}:u{p.up}:a{p.act}"
                 f":r{int(bool(p.residual))}")
-    return f"lin:M{p.M}:N{p.N}:K{p.K}:a{p.act}:f{p.out_f32}:r{int(bool(p.residual))}"
+    return f"lin:M{_m_key(int(p.M))}:N{p.N}:K{p.K}:a{p.act}:f{p.out_f32}:r{int(bool(p.residual))}"
 
 
 def _load() -> None:
@@ -81,7 +90,9 @@ def tune(p: "L.GemmParams", stream: int) -> Tuple[int, int, float]:
     if FLUSH_BYTES and dev not in _scratch:
         _scratch[dev] = torch.empty(FLUSH_BYTES, dtype=torch.uint8, device=f"cuda:{dev}")
     sp = _scratch[dev].data_ptr() if FLUSH_BYTES else None
-    L.check(L.load().da_gemm_tune(C.byref(p), stream, ITERS, sp, FLUSH_BYTES if sp else 0, C.byref(bt), C.byref(bs),
+    # a launch of more than ~2 TFLOP runs for milliseconds: one timed launch per variant is already stable
+    iters = 1 if 2.0 * p.M * p.N * p.K > 2e12 else ITERS
+    L.check(L.load().da_gemm_tune(C.byref(p), stream, iters, sp, FLUSH_BYTES if sp else 0, C.byref(bt), C.byref(bs),
                                   C.byref(us)), "da_gemm_tune")
     ent = (bt.value, bs.value, us.value)
     table()[key_of(p)] = ent
@@ -89,12 +100,23 @@ def tune(p: "L.GemmParams", stream: int) -> Tuple[int, int, float]:
     return ent
 
 
-def lookup(p: "L.GemmParams", stream: int) -> Tuple[int, int]:
-    """(tile, staging) to launch this problem with."""
+def lookup(p: "L.GemmParams", stream: int, inplace: bool = False) -> Tuple[int, int]:
+    """(tile, staging) to launch this problem with.  ``inplace``: the output aliases the residual (accumulating launch),
+    so the repeated timing launches write to a scratch output instead of accumulating into the caller's tensor."""
     ent = table().get(key_of(p))
     if ent is None:
         if LIVE and not torch.cuda.is_current_stream_capturing():
-            ent = tune(p, stream)
+            if inplace:
+                keep = p.C
+                tmp = torch.empty(int(p.M) * int(p.ldc), dtype=torch.float32 if p.out_f32 else torch.bfloat16,
+                                  device=f"cuda:{torch.cuda.current_device()}")
+                p.C = tmp.data_ptr()
+                try:
+                    ent = tune(p, stream)
+                finally:
+                    p.C = keep
+            else:
+                ent = tune(p, stream)
         else:
             return L.TILE_AUTO, L.STAGE_LDS_DIRECT
     return ent[0], ent[1]

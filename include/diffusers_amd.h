@@ -168,6 +168,11 @@ int da_rmsnorm_rope_bf16(void* x, int ld, int rows, int rows_per_batch, int head
                          const void* const* weight, float eps, const float* cos, const float* sin, int rope_row0,
                          int do_norm, void* stream);
 int da_softmax_rows_f32_bf16(const void* scores, void* probs, int M, int N, long long ld, long long ldo, void* stream);
+/* WanRMS_norm over the channels of channels-last rows x[rows][C] (autoencoder_kl_wan.py:198-206, bias-free):
+ * y = bf16(bf16(bf16(x / max(||x||_2, 1e-12)) * scale) * gamma) [+ SiLU, :352,:367,:899]; scale = sqrt(real channel
+ * count) (zero-padded channels with gamma 0 stay 0).  C a multiple of 8, <= 1024. */
+int da_rmsnorm_channels_bf16(const void* x, const void* gamma, void* y, long long rows, int C, float scale, int act,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Sampler (sampler.hip): fused classifier-free-guidance combine + scheduler.step.
@@ -233,6 +238,13 @@ int da_unpatchify3d_bf16(const void* tokens, void* x, int B, int C, int F, int H
 /* out[c][r] = in[r][c]: turns a token-major value tensor into the V^T operand of da_attention_bf16 (attention backends
  * that receive (B, S, H, D) tensors, attention_dispatch.py:494-515) */
 int da_transpose_bf16(const void* in, void* out, int R, int C, long long ldi, long long ldo, void* stream);
+/* dst[D0][D2][D1][D3] = src[D0][D1][D2][D3] (bf16, D3 % 8 == 0): the channel-halves -> frame pairs interleave of
+ * WanResample 'upsample3d' (autoencoder_kl_wan.py:297-299) on channels-last frames. */
+int da_permute_0213_bf16(const void* src, void* dst, long long D0, int D1, int D2, int D3, void* stream);
+/* Channels-last frames src[B*T][HW][Cs] (channels [0, C), C <= 4 <= Cs) -> video dst[B][C][T][HW] (bf16, or fp32 when
+ * out_f32), clamped to [lo, hi]: the output layout + torch.clamp of AutoencoderKLWan._decode (autoencoder_kl_wan.py:1210). */
+int da_frames_to_ncthw_bf16(const void* src, void* dst, int B, int T, long long HW, int Cs, int C, float lo, float hi,
+                            int out_f32, void* stream);
 int da_timestep_embedding(const float* t, const float* table, const int* step_idx, void* out, int B, int dim,
                           int flip_sin_to_cos, float shift, float scale, float max_period, int out_f32, void* stream);
 int da_linear_small_m_bf16(const void* x, const void* W, const void* bias, const void* res, void* out, int M, int N,

@@ -527,3 +527,84 @@ def unet2d_forward(sd: Dict[str, torch.Tensor], cfg: dict, sample, timestep):
             x = F.conv2d(x, sd[f"{p}.weight"], sd[f"{p}.bias"], padding=1)
     x = F.group_norm(x, groups, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps)
     return F.conv2d(F.silu(x), sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# AutoencoderKLWan.decode (models/autoencoders/autoencoder_kl_wan.py) -- SURVEY.md 8f rank 2
+# --------------------------------------------------------------------------------------------------------------------
+def wan_causal_conv3d(x, w, b):
+    """WanCausalConv3d (:131-173): zero padding (kt - 1) frames in FRONT only, symmetric in space."""
+    kt, kh, kw = w.shape[2:]
+    x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, kt - 1, 0))
+    return F.conv3d(x, w, b)
+
+
+def wan_rms_norm(x, gamma):
+    """WanRMS_norm (:176-206), channel-first, no bias: F.normalize over channels * sqrt(C) * gamma."""
+    return F.normalize(x, dim=1) * (x.shape[1] ** 0.5) * gamma
+
+
+def wan_vae_resblock(sd, p, x):
+    """WanResidualBlock (:315-386) over the WHOLE frame sequence.  The reference decodes one latent frame per call and
+    hands each causal conv its previous two input frames through ``feat_cache``; with zero frames in front of frame 0
+    that is exactly the causal convolution of the full sequence."""
+    h = wan_causal_conv3d(x, sd[f"{p}.conv_shortcut.weight"], sd[f"{p}.conv_shortcut.bias"]) \
+        if f"{p}.conv_shortcut.weight" in sd else x
+    x = F.silu(wan_rms_norm(x, sd[f"{p}.norm1.gamma"]))
+    x = wan_causal_conv3d(x, sd[f"{p}.conv1.weight"], sd[f"{p}.conv1.bias"])
+    x = F.silu(wan_rms_norm(x, sd[f"{p}.norm2.gamma"]))
+    x = wan_causal_conv3d(x, sd[f"{p}.conv2.weight"], sd[f"{p}.conv2.bias"])
+    return x + h
+
+
+def wan_vae_attention(sd, p, x):
+    """WanAttentionBlock (:389-431): per-frame single-head self-attention over the h*w positions."""
+    B, C, T, H, W = x.shape
+    y = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    y = wan_rms_norm(y, sd[f"{p}.norm.gamma"])
+    qkv = F.conv2d(y, sd[f"{p}.to_qkv.weight"], sd[f"{p}.to_qkv.bias"]).reshape(B * T, 3 * C, H * W).transpose(1, 2)
+    q, k, v = qkv.chunk(3, dim=-1)
+    o = torch.softmax(q @ k.transpose(1, 2) * (C ** -0.5), dim=-1) @ v
+    o = o.transpose(1, 2).reshape(B * T, C, H, W)
+    o = F.conv2d(o, sd[f"{p}.proj.weight"], sd[f"{p}.proj.bias"])
+    return o.view(B, T, C, H, W).permute(0, 2, 1, 3, 4) + x
+
+
+def wan_vae_upsample(sd, p, x, temporal: bool):
+    """WanResample 'upsample2d' / 'upsample3d' (:224-312) over the whole sequence.  Chunked decoding marks the FIRST
+    latent frame "Rep": it skips time_conv and stays one frame; every later frame t goes through the causal (3,1,1)
+    time_conv whose history starts at frame 1 (the cache after the "Rep" chunk is zeros, :286-287), and its 2C output
+    channels become the two frames 2t-1, 2t (:297-299)."""
+    B, C, T, H, W = x.shape
+    if temporal and T > 1:
+        y = wan_causal_conv3d(x[:, :, 1:], sd[f"{p}.time_conv.weight"], sd[f"{p}.time_conv.bias"])   # [B][2C][T-1]
+        y = y.reshape(B, 2, C, T - 1, H, W)
+        y = torch.stack((y[:, 0], y[:, 1]), 3).reshape(B, C, 2 * (T - 1), H, W)
+        x = torch.cat([x[:, :, :1], y], 2)
+    T2 = x.shape[2]
+    y = x.permute(0, 2, 1, 3, 4).reshape(B * T2, C, H, W)
+    y = F.interpolate(y, scale_factor=(2.0, 2.0), mode="nearest-exact")
+    y = F.conv2d(y, sd[f"{p}.resample.1.weight"], sd[f"{p}.resample.1.bias"], padding=1)
+    return y.view(B, T2, y.shape[1], 2 * H, 2 * W).permute(0, 2, 1, 3, 4)
+
+
+def wan_vae_decode(sd: Dict[str, torch.Tensor], cfg: dict, z):
+    """AutoencoderKLWan._decode (:1187-1217) + WanDecoder3d.forward (:879-914), Wan 2.1 layout (is_residual False,
+    patch_size None).  z: [B][z_dim][T][H][W] -> [B][3][1 + 4 (T-1)][8H][8W], clamped to [-1, 1]."""
+    if cfg.get("is_residual") or cfg.get("patch_size") is not None:
+        raise NotImplementedError("Wan 2.2 residual / patchified VAE")
+    mult = list(cfg["dim_mult"])
+    t_up = list(cfg["temperal_downsample"])[::-1]
+    x = wan_causal_conv3d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+    x = wan_causal_conv3d(x, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"])
+    x = wan_vae_resblock(sd, "decoder.mid_block.resnets.0", x)
+    x = wan_vae_attention(sd, "decoder.mid_block.attentions.0", x)
+    x = wan_vae_resblock(sd, "decoder.mid_block.resnets.1", x)
+    for i in range(len(mult)):
+        for j in range(cfg["num_res_blocks"] + 1):
+            x = wan_vae_resblock(sd, f"decoder.up_blocks.{i}.resnets.{j}", x)
+        if i != len(mult) - 1:
+            x = wan_vae_upsample(sd, f"decoder.up_blocks.{i}.upsamplers.0", x, t_up[i])
+    x = F.silu(wan_rms_norm(x, sd["decoder.norm_out.gamma"]))
+    x = wan_causal_conv3d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"])
+    return torch.clamp(x, min=-1.0, max=1.0)

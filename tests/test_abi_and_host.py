@@ -274,3 +274,28 @@ def test_unipc_coefficient_table_reproduces_reference(golden, monkeypatch):
         assert torch.equal(x, torch.from_numpy(g["traj_f32"][i])), f"step {i}"
     with pytest.raises(NotImplementedError):
         S.UniPCMultistepScheduler()  # epsilon / VP-sigma configuration is not on the hot path
+
+
+def test_wan_vae_host_logic_vs_reference(golden, monkeypatch):
+    """AutoencoderKLWan's host half (zero padding to 64 channels, one launch per temporal tap accumulating in place over
+    frame-shifted views, the "Rep" first frame of the temporal upsamplers, folded V bias / latent de-normalisation) on
+    torch-CPU stand-ins of the kernels (tests/ops_emulation.py): bf16 activations vs the reference's fp32 decode."""
+    from diffusers_amd import init as dinit, ops
+    from diffusers_amd.autoencoder_kl_wan import AutoencoderKLWan
+    import ops_emulation
+    ops_emulation.install(monkeypatch, ops)
+    g = golden("tiny_wan_vae")
+    cfg = dinit.TINY_WAN_VAE
+    sd = dinit.random_state_dict(dinit.wan_vae_decoder_param_shapes(cfg), seed=21)
+    vae = AutoencoderKLWan(**cfg).load_state_dict(sd, device="cpu", strict=True)
+    want = torch.from_numpy(g["video"])
+    for z, dn in ((g["z"], False), (g["latents"], True)):
+        video = vae._decode_one(torch.from_numpy(z)[0].to(torch.bfloat16), dn, True)
+        assert tuple(video.shape) == tuple(want.shape)
+        rel = float((video - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+        print(f"[host] tiny Wan VAE (denormalize={dn}): rel rms vs reference fp32 = {rel:.3e}")
+        assert rel < 2.5e-2
+    with pytest.raises(ValueError):
+        vae.decode(torch.zeros((1, 16, 2, 4, 4)))            # CPU tensor: there is no fallback
+    with pytest.raises(NotImplementedError):
+        AutoencoderKLWan(is_residual=True)

@@ -743,3 +743,74 @@ def test_unipc_cfg_inplace_matches_separate_combine(golden):
     y = rnd((3, 5, 7), 151, dtype=torch.float32)
     from diffusers_amd import ops
     assert torch.equal(ops.cast_f32_bf16(y, rep=2), torch.cat([y, y]).to(bf16))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# AutoencoderKLWan kernels: channel RMS-norm (+SiLU), frame-pair permute, NCTHW clamp, and the
+# in-place accumulating GEMM / conv launches the temporal taps of a causal Conv3d are made of
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,real,rows,silu", [(64, 24, 1000, True), (64, 48, 257, False), (128, 96, 4097, True),
+                                              (192, 192, 333, True), (384, 384, 1024, False), (1024, 1000, 67, True)])
+def test_rmsnorm_channels_vs_reference_ops(C, real, rows, silu):
+    """WanRMS_norm with the reference's own rounding points (fp32 normalise -> bf16, * sqrt(C) -> bf16, * gamma -> bf16,
+    SiLU -> bf16): at most one bf16 ulp from the same chain evaluated by torch."""
+    ops, L = _ops()
+    x = rnd((rows, C), 31 + C, scale=3.0)
+    gm = (1.0 + 0.1 * rnd((C,), 32).float()).to(bf16)
+    x[:, real:] = 0
+    gm[real:] = 0
+    y = ops.rmsnorm_channels(x, gm, real_channels=real, silu=silu)
+    n = F.normalize(x.float()[:, :real], dim=1).to(bf16)
+    ref = n * (real ** 0.5) * gm[:real]
+    if silu:
+        ref = F.silu(ref)
+    assert y.shape == x.shape and y.dtype == bf16
+    assert torch.equal(y[:, real:], torch.zeros_like(y[:, real:])), "zero-padded channels must stay zero"
+    d = (y[:, :real].float() - ref.float()).abs()
+    ulp = ref.float().abs() * 2.0 ** -7 + 1e-6
+    nbad = int((d > ulp).sum())
+    print(f"[parity] rmsnorm_channels C={C} real={real} silu={silu}: exact {float((d == 0).float().mean()):.4f}, >1ulp {nbad}")
+    assert nbad == 0
+
+
+def test_permute_0213_and_frames_to_ncthw():
+    ops, L = _ops()
+    x = rnd((5, 77, 2, 64), 41)
+    assert torch.equal(ops.permute_0213(x), x.permute(0, 2, 1, 3).contiguous())
+    buf = torch.zeros((1 + 10, 7, 11, 64), device=DEV, dtype=bf16)
+    ops.permute_0213(x, out=buf[1:])
+    assert torch.equal(buf[1:].reshape(5, 2, 77, 64), x.permute(0, 2, 1, 3)) and float(buf[0].abs().max()) == 0.0
+    f = rnd((2 * 5, 6, 10, 4), 42, scale=0.8)
+    for f32 in (False, True):
+        v = ops.frames_to_ncthw(f, batch=2, channels=3, out_f32=f32)
+        ref = f.float()[..., :3].clamp(-1, 1).view(2, 5, 6, 10, 3).permute(0, 4, 1, 2, 3)
+        assert v.shape == (2, 3, 5, 6, 10) and v.dtype == (torch.float32 if f32 else bf16)
+        assert torch.equal(v.float(), ref.contiguous())
+
+
+def test_gemm_and_conv_accumulate_in_place():
+    """out == residual: each launch adds its product to the buffer exactly once (also on the launch that tunes the
+    shape), bit-identical to the out-of-place launch with the same residual."""
+    ops, L = _ops()
+    x = rnd((3, 12, 20, 64), 51)
+    w = ops.pack_conv_weight(rnd((128, 64, 3, 3), 52, scale=(9 * 64) ** -0.5))
+    base = rnd((3, 12, 20, 128), 53)
+    want = ops.conv2d_nhwc(x, w, None, ksize=3, residual=base)
+    acc = base.clone()
+    got = ops.conv2d_nhwc(x, w, None, ksize=3, residual=acc, out=acc)
+    assert got.data_ptr() == acc.data_ptr() and torch.equal(acc, want)
+    # frame-shifted views of one buffer: the temporal-tap pattern
+    acc2 = base.clone()
+    ops.conv2d_nhwc(x[:2], w, None, ksize=3, residual=acc2[1:], out=acc2[1:])
+    assert torch.equal(acc2[0], base[0]) and torch.equal(acc2[1:], ops.conv2d_nhwc(x[:2], w, None, ksize=3, residual=base[1:].contiguous()))
+    xl, wl, bl = rnd((777, 128), 54), rnd((192, 128), 55, scale=128 ** -0.5), rnd((777, 192), 56)
+    wantl = ops.linear(xl, wl, residual=bl)
+    accl = bl.clone()
+    ops.linear(xl, wl, residual=accl, out=accl)
+    assert torch.equal(accl, wantl)
+    # narrow output (conv_out: 3 channels padded to 4)
+    w4 = ops.pack_conv_weight(rnd((4, 64, 3, 3), 57, scale=(9 * 64) ** -0.5))
+    y4 = ops.conv2d_nhwc(x, w4, rnd((4,), 58), ksize=3)
+    ref4 = F.conv2d(x.float().permute(0, 3, 1, 2), w4.float().view(4, 3, 3, 64).permute(0, 3, 1, 2), rnd((4,), 58).float(),
+                    padding=1).permute(0, 2, 3, 1)
+    assert_close_bf16(y4, ref4, "conv3x3 N=4", rtol=8e-3, atol_rms=4e-3)

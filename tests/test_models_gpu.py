@@ -277,3 +277,31 @@ def test_tiny_wan_pipeline_unipc_vs_oracle(golden):
     rr = rel_rms(eager, x)
     print(f"[parity] tiny Wan + UniPC (4 steps, CFG 5): latents rel_rms vs fp32 oracle loop = {rr:.3e}")
     assert rr < 4e-2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# AutoencoderKLWan.decode vs the live-reference golden (frame-by-frame cached decode, fp32)
+# ----------------------------------------------------------------------------------------------------------------------
+def test_tiny_wan_vae_decode_vs_reference(golden):
+    """Whole-clip decode (all frames resident, one launch per temporal tap) vs the reference's chunked decode: 5 latent
+    frames -> 17 video frames.  The reference itself run in bf16 sits at 1.83e-2 rel. RMS of its fp32 run."""
+    from diffusers_amd import factory, init as dinit
+    g = golden("tiny_wan_vae")
+    vae, _ = factory.build_wan_vae(dinit.TINY_WAN_VAE, seed=21, device=DEV)
+    want = torch.from_numpy(g["video"])
+    v = vae.decode(t(g, "z")).sample
+    assert v.shape == want.shape and v.dtype == bf16 and torch.isfinite(v.float()).all()
+    rr = rel_rms(v, want)
+    print(f"[parity] tiny Wan VAE decode: rel_rms vs reference fp32 = {rr:.3e}, PSNR {_psnr(v, want):.1f} dB")
+    assert rr < 3e-2
+    assert float(v.float().abs().max()) <= 1.0
+    # pipeline latents (fp32, normalised): the de-normalisation folded into post_quant_conv
+    v2 = vae.decode(torch.from_numpy(g["latents"]).to(DEV), denormalize=True, out_f32=True, return_dict=False)[0]
+    rr2 = rel_rms(v2, want)
+    print(f"[parity] tiny Wan VAE decode (normalised fp32 latents): rel_rms = {rr2:.3e}")
+    assert v2.dtype == torch.float32 and rr2 < 3e-2
+    assert torch.equal(v, vae.decode(t(g, "z")).sample), "decode must be deterministic"
+    with pytest.raises(ValueError):
+        vae.decode(torch.from_numpy(g["z"]))                     # CPU tensor
+    with pytest.raises(NotImplementedError):
+        vae.encode(t(g, "z"))

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""AutoencoderKLWan.decode at the size BASELINE config 5 produces: latents (16, 21, 60, 104) ->
+video (3, 81, 480, 832), whole clip resident in HBM, seeded random weights.  Reports wall time per decode, the model's
+algorithmic FLOPs (real channel counts) and the FLOPs actually executed (channels zero-padded to multiples of 64)."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from diffusers_amd import factory, init as dinit  # noqa: E402
+
+bf16 = torch.bfloat16
+
+
+def decode_flops(cfg, T, H, W_, pad=lambda c: c):
+    """2 * MACs of every conv / GEMM of the decoder on T latent frames of H x W (causal taps that fall in front of the
+    clip included: the reference's chunked decode multiplies those zeros too)."""
+    dim = cfg["base_dim"]
+    mult = list(cfg["dim_mult"])
+    t_up = list(cfg["temperal_downsample"])[::-1]
+    dims = [dim * u for u in [mult[-1]] + mult[::-1]]
+    fl = 0
+
+    def conv3(cin, cout, px, k=27):
+        return 2 * px * pad(cin) * pad(cout) * k
+
+    px = T * H * W_
+    fl += 2 * px * cfg["z_dim"] * cfg["z_dim"] + conv3(cfg["z_dim"], dims[0], px)
+    res = lambda cin, cout, px: conv3(cin, cout, px) + conv3(cout, cout, px) + (conv3(cin, cout, px, 1) if cin != cout else 0)  # noqa: E731
+    fl += 2 * res(dims[0], dims[0], px)
+    c = dims[0]
+    fl += 2 * px * pad(c) * pad(c) * 4 + T * 2 * 2 * (H * W_) ** 2 * pad(c)          # qkv + proj, QK^T + PV per frame
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        if i > 0:
+            cin //= 2
+        for j in range(cfg["num_res_blocks"] + 1):
+            fl += res(cin if j == 0 else cout, cout, px)
+        if i != len(mult) - 1:
+            if t_up[i]:
+                fl += conv3(cout, 2 * cout, (T - 1) * H * W_, 3)
+                T = 2 * T - 1
+            H, W_ = 2 * H, 2 * W_
+            px = T * H * W_
+            fl += conv3(cout, cout // 2, px, 9)
+    fl += conv3(dims[-1], cfg["out_channels"], px)
+    return fl
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    cfg = dinit.WAN_VAE
+    vae, _ = factory.build_wan_vae(cfg, seed=21, device=dev, init_device=str(dev))
+    g = torch.Generator("cpu").manual_seed(4321)
+    lat = torch.randn((1, 16, 21, 60, 104), generator=g).to(dev)                     # fp32, as the UniPC loop leaves them
+    res, out = [], None
+    for i in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = vae.decode(lat, denormalize=True, return_dict=False)[0]
+        torch.cuda.synchronize()
+        res.append(time.perf_counter() - t0)
+        print(f"[bench_wan_vae] decode {i}: {res[-1]:.3f} s", file=sys.stderr, flush=True)
+    best = min(res[1:])
+    alg = decode_flops(cfg, 21, 60, 104) / 1e12
+    exe = decode_flops(cfg, 21, 60, 104, pad=lambda c: (c + 63) // 64 * 64 if c > 4 else 4) / 1e12
+    rec = {"op": "wan_vae_decode_81x480x832", "s_per_decode": round(best, 3), "algorithmic_tflop": round(alg, 1),
+           "executed_tflop": round(exe, 1), "algorithmic_tflops": round(alg / best, 1), "executed_tflops": round(exe / best, 1),
+           "first_call_s": round(res[0], 2), "finite": bool(torch.isfinite(out.float()).all()), "shape": list(out.shape),
+           "mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+    print(json.dumps(rec), flush=True)
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    (ROOT / "gpurun_out" / "wan_vae.jsonl").write_text(json.dumps(rec) + "\n")
+
+
+if __name__ == "__main__":
+    main()

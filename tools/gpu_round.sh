@@ -31,6 +31,12 @@ if [[ $WHAT == *wan* ]]; then
   timeout 900 python tools/bench_wan.py > $O/wan.log 2>&1; echo "wan rc=$?"
   tail -3 $O/wan.log | cut -c1-400
 fi
+if [[ $WHAT == *wanvae* ]]; then
+  timeout 300 python -m pytest tests -m gpu -q -s --timeout 200 -k "rmsnorm_channels or permute_0213 or accumulate_in_place or wan_vae" > $O/pytest_wanvae.log 2>&1; echo "pytest wanvae rc=$?"
+  grep -E "passed|failed|FAILED|Error|\[parity\]" $O/pytest_wanvae.log | tail -20
+  DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_wanvae.json timeout 400 python tools/bench_wan_vae.py > $O/wan_vae.log 2>&1; echo "wan_vae rc=$?"
+  tail -5 $O/wan_vae.log | cut -c1-400
+fi
 if [[ $WHAT == *ddpm* ]]; then
   timeout 600 python tools/bench_ddpm.py > $O/ddpm.log 2>&1; echo "ddpm rc=$?"
   tail -3 $O/ddpm.log | cut -c1-400
