@@ -98,13 +98,17 @@ def build_wan_transformer(cfg: dict, seed: int = 9, device="cuda", init_device: 
 
 
 def build_wan_pipeline(device="cuda", tiny: bool = False, seed: int = 9, init_device: Optional[str] = None,
-                       flow_shift: float = 3.0):
-    """Wan2.1-T2V-1.3B (BASELINE config 5) or its tiny sibling with the FlowMatch-Euler scheduler of SURVEY.md 8d."""
+                       flow_shift: float = 3.0, with_vae: bool = False):
+    """Wan2.1-T2V-1.3B (BASELINE config 5) or its tiny sibling with the FlowMatch-Euler scheduler of SURVEY.md 8d;
+    ``with_vae`` adds AutoencoderKLWan (seed + 12) so that ``output_type="pt"`` decodes the video."""
     cfg = dinit.TINY_WAN if tiny else dinit.WAN_1_3B
     idev = init_device or ("cpu" if tiny else str(device))
     tr, _ = build_wan_transformer(cfg, seed=seed, device=device, init_device=idev)
     sch = FlowMatchEulerDiscreteScheduler(shift=flow_shift, use_dynamic_shifting=False)
-    return WanPipeline(scheduler=sch, transformer=tr)
+    vae = None
+    if with_vae:
+        vae, _ = build_wan_vae(dinit.TINY_WAN_VAE if tiny else dinit.WAN_VAE, seed=seed + 12, device=device, init_device=idev)
+    return WanPipeline(scheduler=sch, transformer=tr, vae=vae)
 
 
 def build_unet2d(cfg: dict, seed: int = 0, device="cuda", init_device: Optional[str] = None, state_dict=None):

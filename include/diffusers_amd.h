@@ -79,7 +79,8 @@ typedef struct da_gemm_params {
   void* C;
   const void* bias;     /* [N] or NULL */
   const void* rowvec;   /* [M / rows_per_batch][ld_rowvec] or NULL */
-  const void* residual; /* [M][ldr] or NULL */
+  const void* residual; /* [M][ldr] or NULL; may be C itself (ldr == ldc): every element is read and written by one lane,
+                           so the launch accumulates in place (temporal taps of WanCausalConv3d, autoencoder_kl_wan.py:131-173) */
   const void* bias_rows; /* [M] or NULL */
   const void* gate;      /* [M / rows_per_batch][ld_gate] or NULL (bf16, or fp32 when gate_f32) */
   int M, N, K;

@@ -305,3 +305,31 @@ def test_tiny_wan_vae_decode_vs_reference(golden):
         vae.decode(torch.from_numpy(g["z"]))                     # CPU tensor
     with pytest.raises(NotImplementedError):
         vae.encode(t(g, "z"))
+
+
+def test_tiny_wan_pipeline_decodes_video(golden):
+    """Denoising loop (UniPC, fp32 latents) -> AutoencoderKLWan.decode in one pipeline call: the video equals decoding the
+    pipeline's own latents, and matches the fp32 oracle decode of those latents."""
+    from diffusers_amd import factory, init as dinit
+    from diffusers_amd.schedulers import UniPCMultistepScheduler
+    from oracle import reference_math as R
+    g = golden("tiny_wan_pipeline")
+    pipe = factory.build_wan_pipeline(device=DEV, tiny=True, seed=9, with_vae=True)
+    pipe.scheduler = UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=3.0)
+    kw = dict(prompt_embeds=t(g, "prompt_embeds"), negative_prompt_embeds=t(g, "negative_prompt_embeds"),
+              num_inference_steps=3, guidance_scale=5.0, height=64, width=64, num_frames=9)
+    lat = pipe(latents=torch.from_numpy(g["latents"]), output_type="latent", **kw).images.clone()
+    video = pipe(latents=torch.from_numpy(g["latents"]), output_type="pt", **kw).images
+    assert video.shape == (1, 3, 9, 64, 64) and video.dtype == bf16
+    assert torch.equal(video, pipe.vae.decode(lat, denormalize=True).sample)
+    cfg = dinit.TINY_WAN_VAE
+    sd = {k: v.float() for k, v in dinit.random_state_dict(dinit.wan_vae_decoder_param_shapes(cfg), seed=21).items()}
+    mean = torch.tensor(cfg["latents_mean"]).view(1, 16, 1, 1, 1)
+    std = torch.tensor(cfg["latents_std"]).view(1, 16, 1, 1, 1)
+    with torch.no_grad():
+        ref = R.wan_vae_decode(sd, cfg, lat.float().cpu() * std + mean)
+    rr = rel_rms(video, ref)
+    print(f"[parity] tiny Wan pipeline video (3 UniPC steps + decode): rel_rms vs fp32 oracle decode of the same latents = {rr:.3e}")
+    assert rr < 3e-2
+    with pytest.raises(ValueError):
+        factory.build_wan_pipeline(device=DEV, tiny=True, seed=9)(latents=torch.from_numpy(g["latents"]), output_type="pt", **kw)
