@@ -8,6 +8,18 @@ namespace da_gemm {
 
 static __device__ uint4 g_zero_line[8];  // 128 B of zeros: source for out-of-bounds rows in the direct-to-LDS path
 
+// Buffer descriptors must be PROVABLY wave-uniform or the compiler wraps every buffer op in a readfirstlane waterfall
+// loop: pass the base pointer (as two halves) and the byte count through readfirstlane once.
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, size_t bytes) {
+  const uint64_t v = (uint64_t)base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+#endif
+
 struct RowInfo {      // per staged activation row (implicit GEMM gather state)
   int base;           // linear: row index (or -1 if out of range); conv: b*Hin
   int oy, ox;         // conv: oy*stride - pad, ox*stride - pad
@@ -19,8 +31,20 @@ struct RowInfo {      // per staged activation row (implicit GEMM gather state)
 // were written by the previous kernel), i.e. at ~2 k cycles of latency, so the sustained fill rate of a CU is
 // (bytes in flight) / latency: the ring is made as deep as the 160 KiB of LDS allow and the wait before each
 // rendezvous is a COUNTED s_waitcnt vmcnt((PD-1)*LOADS), never 0, so PD-1 slices stay in flight across every barrier.
-template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, bool GLDS>
+//
+// SM = staging mode: 0 register staged (global_load -> ds_write), 1 LDS-DMA with per-lane 64-bit source pointers
+// (global_load_lds; the only mode that can redirect a lane to the zero line, which conv padding needs), 2 LDS-DMA through
+// a buffer descriptor (buffer_load ... lds): descriptor base = the block's first operand row, per-lane byte offset fixed
+// for the whole K loop, K-slice advance in ONE scalar offset -- no vector address arithmetic inside the loop.  Mode 2
+// For nn.Linear rows past M / N are clamped to the last valid row (their products land in output rows / columns the
+// epilogue never stores).  For conv the per-lane offset is recomputed once per TAP (not per slice) and a padded tap sets
+// bit 31 of it: beyond num_records, so the hardware range check writes zeros to LDS (the convention of
+// ck::amd_direct_load_global_to_lds); descriptor bases sit at the tile's first input row, which keeps offsets 31-bit on
+// tensors of any size.
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and cannot parse the buffer builtins)
+  constexpr bool GLDS = (SM != 0), BLDS = (SM == 2);
   constexpr int NW = WM * WN, NTHR = 64 * NW, RP = NTHR / 8;  // RP = tile rows staged per pass (one 1 KiB piece per wave)
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr int XR = BM / RP, WR = BN / RP;  // staged rows per thread
@@ -34,7 +58,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  // the wave index is wave-uniform but only readfirstlane proves it: LDS-DMA destinations (M0) and the fragment bases
+  // below then stay in scalar registers
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   const int l31 = lane & 31, hi = lane >> 5;
 
@@ -100,6 +126,53 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   const int nk = p.K >> 6;
   const int Ctot = CONV ? (p.C1 + p.C2) : 0;
 
+  // buffer-addressed staging: descriptors over the block's operand panels, per-lane byte offsets in vo_*
+  // (descriptors are built unconditionally -- the type has no default initialiser -- and are dead unless BLDS)
+  size_t xbase = 0, xbytes = 0x7fffffff, x2bytes = 0x7fffffff;
+  int pb = 0;  // conv: first input pixel the tile can touch (descriptor origin)
+  if constexpr (BLDS) {
+    if constexpr (CONV) {
+      const int hw = p.Hout * p.Wout;
+      const int b0 = m0 / hw;
+      const int oy0 = (m0 - b0 * hw) / p.Wout;
+      pb = __builtin_amdgcn_readfirstlane((b0 * p.Hin + (max(0, oy0 * p.stride - p.pad) >> p.up)) * p.Win);
+      const size_t pix_left = (size_t)(p.M / hw) * p.Hin * p.Win - (size_t)pb;
+      xbytes = min(pix_left * p.C1 * 2, (size_t)0x7fffffff);
+      x2bytes = min(pix_left * p.C2 * 2, (size_t)0x7fffffff);
+    } else {
+      xbase = (size_t)m0 * p.lda;
+    }
+  }
+  __amdgpu_buffer_rsrc_t rs_x = uniform_rsrc(A + (CONV ? (size_t)pb * p.C1 : xbase), xbytes);
+  __amdgpu_buffer_rsrc_t rs_x2 = uniform_rsrc((CONV && A2) ? A2 + (size_t)pb * p.C2 : A, x2bytes);
+  __amdgpu_buffer_rsrc_t rs_w = uniform_rsrc(Wt + (BLDS ? (size_t)n0 * p.ldw : 0), 0x7fffffff);
+  int vo_x[XR], vo_x2[XR], vo_w[WR];
+  int bk_off = 0;  // byte offset of the cursor K slice inside a weight / activation row (scalar)
+  // conv: offsets of the activation rows for tap (kh, kw) -- called once per tap, not per K slice
+  auto tap_offsets = [&](int kh, int kw) {
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int iy = xr[i].oy + kh, ix = xr[i].ox + kw;
+      const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+      const int rel = (xr[i].base + (iy >> p.up)) * p.Win + (ix >> p.up) - pb;
+      vo_x[i] = ok ? (rel * p.C1 + sc * 8) * 2 : (int)0x80000000;
+      vo_x2[i] = ok ? (rel * p.C2 + sc * 8) * 2 : (int)0x80000000;
+    }
+  };
+  if constexpr (BLDS) {
+    if constexpr (CONV) {
+      tap_offsets(0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        vo_x[i] = (min(srow + RP * i, p.M - 1 - m0) * p.lda + sc * 8) * 2;
+        vo_x2[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) vo_w[i] = (min(srow + RP * i, p.N - 1 - n0) * p.ldw + sc * 8) * 2;
+  }
+
   f32x16_t acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -140,7 +213,33 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   // Staging is written as macros (not lambdas) so the staged registers stay in VGPRs.
 #define DA_STAGE_ISSUE(BUF)                                                                                            \
   do {                                                                                                                 \
-    if (GLDS) {                                                                                                        \
+    if constexpr (BLDS) {                                                                                              \
+      unsigned char* xb_ = smem + (BUF) * STAGE;                                                                       \
+      unsigned char* wb_ = xb_ + XBYTES;                                                                               \
+      if (CONV && is_c0 >= p.C1) { /* second concat source (wave-uniform choice) */                                    \
+        _Pragma("unroll") for (int i = 0; i < XR; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(                       \
+            rs_x2, (__attribute__((address_space(3))) void*)(xb_ + (i * NW + wave) * 1024), 16, vo_x2[i],              \
+            (is_c0 - p.C1) * 2, 0, 0);                                                                                 \
+      } else {                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < XR; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(                       \
+            rs_x, (__attribute__((address_space(3))) void*)(xb_ + (i * NW + wave) * 1024), 16, vo_x[i],                \
+            CONV ? is_c0 * 2 : bk_off, 0, 0);                                                                          \
+      }                                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < WR; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(                         \
+          rs_w, (__attribute__((address_space(3))) void*)(wb_ + (i * NW + wave) * 1024), 16, vo_w[i], bk_off, 0, 0);   \
+      bk_off += 128;                                                                                                   \
+      if constexpr (CONV) {                                                                                            \
+        is_c0 += 64;                                                                                                   \
+        if (is_c0 >= Ctot) {                                                                                           \
+          is_c0 = 0;                                                                                                   \
+          if (++is_kw >= p.conv) {                                                                                     \
+            is_kw = 0;                                                                                                 \
+            ++is_kh;                                                                                                   \
+          }                                                                                                            \
+          tap_offsets(is_kh, is_kw);                                                                                   \
+        }                                                                                                              \
+      }                                                                                                                \
+    } else if (GLDS) {                                                                                                 \
       unsigned char* xb_ = smem + (BUF) * STAGE;                                                                       \
       unsigned char* wb_ = xb_ + XBYTES;                                                                               \
       _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                                                 \
@@ -169,15 +268,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         wg3 = *(const uint4*)w_src(3);                                                                                 \
       }                                                                                                                \
     }                                                                                                                  \
-    /* advance the cursor to the next K slice */                                                                       \
-    is_k += 64;                                                                                                        \
-    if (CONV) {                                                                                                        \
-      is_c0 += 64;                                                                                                     \
-      if (is_c0 >= Ctot) {                                                                                             \
-        is_c0 = 0;                                                                                                     \
-        if (++is_kw >= p.conv) {                                                                                       \
-          is_kw = 0;                                                                                                   \
-          ++is_kh;                                                                                                     \
+    /* advance the cursor to the next K slice (the buffer mode advanced its own above) */                              \
+    if constexpr (!BLDS) {                                                                                             \
+      is_k += 64;                                                                                                      \
+      if (CONV) {                                                                                                      \
+        is_c0 += 64;                                                                                                   \
+        if (is_c0 >= Ctot) {                                                                                           \
+          is_c0 = 0;                                                                                                   \
+          if (++is_kw >= p.conv) {                                                                                     \
+            is_kw = 0;                                                                                                 \
+            ++is_kh;                                                                                                   \
+          }                                                                                                            \
         }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
@@ -229,20 +330,48 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   auto compute = [&](int buf) {
     const unsigned char* xb = smem + buf * STAGE + (wm * MT * 32) * 128 + frow;
     const unsigned char* wb = smem + buf * STAGE + XBYTES + (wn * NT * 32) * 128 + frow;
+    // two fragment register sets: the ds_reads of k-step ks+1 are issued before the MFMAs of k-step ks, so the LDS
+    // latency of one step hides under the matrix work of the previous one instead of in front of it
+    bf16x8_t wf[2][NT], xf[2][MT];
+    auto frag = [&](int set, int ks) {
+      const int off = ((2 * ks + hi) ^ fsw) << 4;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[set][j] = *(const bf16x8_t*)(wb + j * 32 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[set][i] = *(const bf16x8_t*)(xb + i * 32 * 128 + off);
+    };
+    frag(0, 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int off = ((2 * ks + hi) ^ fsw) << 4;
-      bf16x8_t wf[NT], xf[MT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8_t*)(wb + j * 32 * 128 + off);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) xf[i] = *(const bf16x8_t*)(xb + i * 32 * 128 + off);
+      if (ks < 3) frag((ks + 1) & 1, ks + 1);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
     }
+    // The order above is only a wish: without these directives the scheduler folds both fragment sets back into one
+    // (read, wait, multiply).  Pin it: first set, then each step's MFMAs interleaved with the NEXT step's ds_reads.
+#define DA_SG_DS(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define DA_SG_MF(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+    DA_SG_DS(MT + NT);
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      if constexpr (MT * NT == 4) {         // 4 reads under 4 MFMAs
+        DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1);
+      } else if constexpr (MT * NT == 2) {  // 3 reads, 2 MFMAs
+        DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1);
+      } else if constexpr (MT * NT == 1) {  // 2 reads, 1 MFMA
+        DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1);
+      } else {                              // 4 x 2: 6 reads under 8 MFMAs
+        static_assert(MT * NT == 8, "add an interleave pattern for this wave tile");
+        DA_SG_DS(1); DA_SG_MF(2); DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1);
+        DA_SG_DS(1); DA_SG_MF(2); DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1);
+      }
+    }
+    DA_SG_MF(MT * NT);
+#undef DA_SG_DS
+#undef DA_SG_MF
   };
 
   // ---- main loop: LDS ring of STAGES slices, one rendezvous per K slice ----
@@ -389,6 +518,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
       }
     }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 
@@ -410,14 +540,14 @@ inline int choose_xcd_gx(int tiles_m, int tiles_n, int BM, int BN) {
   return best;
 }
 
-template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, bool GLDS>
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM>
 int launch(const da_gemm_params& p, hipStream_t s) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int gx = choose_xcd_gx(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
   const size_t lds = (size_t)(BM + BN) * 128 * STAGES;
-  auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, GLDS>;
+  auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, SM>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -431,10 +561,40 @@ int launch(const da_gemm_params& p, hipStream_t s) {
   return DA_OK;
 }
 
+// A/B switch for measurements: DA_GEMM_FLAT_STAGING=1 in the environment keeps nn.Linear on per-lane pointers (mode 1).
+inline bool flat_staging_forced() {
+  static const bool forced = [] {
+    const char* e = getenv("DA_GEMM_FLAT_STAGING");
+    return e && e[0] == '1';
+  }();
+  return forced;
+}
+
+// 31-bit offset budget of the buffer-addressed mode.  Linear: 256 rows of a panel + the K offset.  Conv: the input
+// pixels one 256-row tile can reach -- its own rows scaled by stride^2 (or / 4 when upsampling), one image row above and
+// three below, an image seam -- times the channel count.
+inline bool buffer_staging_fits(const da_gemm_params& p) {
+  const size_t lim = 0x3fffffffull;
+  if ((size_t)p.ldw * 512 >= lim || (size_t)p.K * 2 >= lim) return false;
+  if (!p.conv) return (size_t)p.lda * 512 < lim;
+  const size_t cmax = (size_t)(p.C1 > p.C2 ? p.C1 : p.C2);
+  const size_t span = (size_t)256 * p.stride * p.stride + (size_t)(6 + 2 * p.stride) * p.Win + 64;
+  return span * cmax * 2 < lim && (size_t)p.M / ((size_t)p.Hout * p.Wout) * p.Hin * p.Win < 0x7fffffffull;
+}
+
 // (tile, staging) -> kernel instantiation.  staging: 0 register staged (2 slots); 1..5 LDS-DMA with 2/3/4/6/8 ring slots.
 template <bool CONV>
 int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
-#define DA_V(WM_, WN_, MT_, NT_, ST_, G_) return launch<WM_, WN_, MT_, NT_, ST_, CONV, G_>(p, s)
+  // LDS-DMA variants use the buffer-addressed mode whenever a tile's operand panels fit 31-bit byte offsets (always,
+  // for the shapes of this engine); per-lane pointers (mode 1) are the fallback
+  const bool buf = !flat_staging_forced() && buffer_staging_fits(p);
+#define DA_V(WM_, WN_, MT_, NT_, ST_, G_)                                                         \
+  do {                                                                                            \
+    if constexpr (G_) {                                                                           \
+      if (buf) return launch<WM_, WN_, MT_, NT_, ST_, CONV, 2>(p, s);                             \
+    }                                                                                             \
+    return launch<WM_, WN_, MT_, NT_, ST_, CONV, (G_) ? 1 : 0>(p, s);                             \
+  } while (0)
   switch (staging) {
     case DA_STAGE_REGISTER:
       switch (tile) {

@@ -31,6 +31,12 @@ if [[ $WHAT == *wan* ]]; then
   timeout 900 python tools/bench_wan.py > $O/wan.log 2>&1; echo "wan rc=$?"
   tail -3 $O/wan.log | cut -c1-400
 fi
+if [[ $WHAT == *abstage* ]]; then
+  # A/B of the GEMM staging modes on the whole SDXL image: buffer-addressed LDS-DMA (default) vs per-lane pointers
+  timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/ab_buffer.json 2> $O/ab_buffer.err; echo "ab buffer rc=$?"
+  DA_GEMM_FLAT_STAGING=1 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/ab_flat.json 2> $O/ab_flat.err; echo "ab flat rc=$?"
+  cut -c1-160 $O/ab_buffer.json; cut -c1-160 $O/ab_flat.json
+fi
 if [[ $WHAT == *wanvae* ]]; then
   timeout 300 python -m pytest tests -m gpu -q -s --timeout 200 -k "rmsnorm_channels or permute_0213 or accumulate_in_place or wan_vae" > $O/pytest_wanvae.log 2>&1; echo "pytest wanvae rc=$?"
   grep -E "passed|failed|FAILED|Error|\[parity\]" $O/pytest_wanvae.log | tail -20
