@@ -31,6 +31,30 @@ if [[ $WHAT == *wan* ]]; then
   timeout 900 python tools/bench_wan.py > $O/wan.log 2>&1; echo "wan rc=$?"
   tail -3 $O/wan.log | cut -c1-400
 fi
+if [[ $WHAT == *final* ]]; then
+  # re-measure the variant choice of every SDXL shape with the current kernels, merge over the shipped table, then the
+  # bench line and the rocprofv3 kernel statistics of that build
+  timeout 120 python -m pytest tests -m gpu -q --timeout 100 -k "gate_and_row_bias or accumulate_in_place" > $O/pytest_final.log 2>&1; echo "pytest final rc=$?"; tail -2 $O/pytest_final.log
+  rm -f $O/tuned_sdxl.json
+  DIFFUSERS_AMD_TUNE_DB=$O/none.json DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_sdxl.json timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/retune.json 2> $O/retune.err; echo "retune rc=$?"
+  python - <<PYEOF
+import json
+a = json.load(open("$R/diffusers_amd/tuned/gfx950.json"))
+b = json.load(open("$O/tuned_sdxl.json"))
+ch = sum(1 for k, v in b["entries"].items() if k in a["entries"] and a["entries"][k][:2] != v[:2])
+a["entries"].update(b["entries"])
+json.dump(a, open("$O/tuned_merged.json", "w"), indent=0)
+print("retuned", len(b["entries"]), "shapes;", ch, "changed variant; table now", len(a["entries"]))
+PYEOF
+  DIFFUSERS_AMD_TUNE_DB=$O/tuned_merged.json timeout 400 python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+  cat $O/bench.json
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/prof
+  DIFFUSERS_AMD_TUNE_DB=$O/tuned_merged.json timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o sdxl -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof.log 2>&1; echo "prof rc=$?"
+  grep '"metric"' $O/prof.log | cut -c1-200
+  find $O/prof -name '*kernel_trace*' -size +30M -delete
+  cd $R
+fi
 if [[ $WHAT == *abstage* ]]; then
   # A/B of the GEMM staging modes on the whole SDXL image: buffer-addressed LDS-DMA (default) vs per-lane pointers
   timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/ab_buffer.json 2> $O/ab_buffer.err; echo "ab buffer rc=$?"
