@@ -162,28 +162,25 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
     }
 
     // ---- online softmax; lane owns query l31, kv index of s[st][r] = 32*st + (r&3) + 8*(r>>2) + 4*hi ----
+    // The softmax scale is folded into the exponent: p = exp2(s * sl2 - m) is one fma + one exp per score, and the
+    // running maximum is tracked on the scaled values (sl2 > 0).
     const int kv0 = j * 64;
     float mx = -1e30f;
-    if (kv0 + 64 > p.Skv) {
+    if (kv0 + 64 > p.Skv) {  // ragged last tile only (wave-uniform)
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kv = kv0 + 32 * st + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          s[st][r] = (kv < p.Skv) ? s[st][r] * sl2 : -1e30f;
+          if (kv >= p.Skv) s[st][r] = -1e30f;
         }
-    } else {
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[st][r] *= sl2;
     }
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx * sl2);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
@@ -191,7 +188,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[st][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sl2, -m_new));
         s[st][r] = e;
         psum += e;
       }
@@ -201,14 +198,14 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 
-    // ---- P^T fragments: MFMA u (K=16) takes registers 8*(u&1)..+7 of tile u>>1 ----
+    // ---- P^T fragments: MFMA u (K=16) takes registers 8*(u&1)..+7 of tile u>>1; packed two per v_cvt_pk_bf16_f32 ----
     bf16x8_t pf[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      bf16x8_t f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = (__bf16)s[u >> 1][8 * (u & 1) + e];
-      pf[u] = f;
+      const int b = 8 * (u & 1);
+      const uint4 pk = make_uint4(pack_bf2(s[u >> 1][b + 0], s[u >> 1][b + 1]), pack_bf2(s[u >> 1][b + 2], s[u >> 1][b + 3]),
+                                  pack_bf2(s[u >> 1][b + 4], s[u >> 1][b + 5]), pack_bf2(s[u >> 1][b + 6], s[u >> 1][b + 7]));
+      pf[u] = __builtin_bit_cast(bf16x8_t, pk);
     }
 
     // ---- O^T += V^T . P^T ; V^T fragment of lane (d = 32*dt + l31, hi): kv 16u+4hi+{0..3} and 16u+8+4hi+{0..3} ----

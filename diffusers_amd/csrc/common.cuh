@@ -36,8 +36,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(uint16_t, b);
 }
+// two fp32 -> one packed bf16 pair, round-to-nearest-even: ONE v_cvt_pk_bf16_f32 (converting the halves separately and
+// OR-ing them costs four instructions)
+typedef __bf16 da_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float da_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const da_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, da_bf16x2_t));
 }
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
