@@ -29,6 +29,10 @@ from .unet_2d_condition import UNet2DConditionModel
 
 bf16 = torch.bfloat16
 
+# Capture mode of the denoising-step graphs.  "thread_local": only THIS thread's calls are checked against the capture,
+# so the RCCL watchdog thread of a multi-GPU job (which polls events while we capture) cannot invalidate it.
+GRAPH_CAPTURE_MODE = "thread_local"
+
 
 @dataclass
 class PipelineOutput:
@@ -86,7 +90,7 @@ class _LatentDiffusionBase:
             latents.copy_(saved)
             sch.reset(0)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE):
                 self._step(latents, cond, guidance_scale, do_cfg)
             self._graph, self._graph_key = g, key
             self._static = {"latents": latents, "cond": cond}
@@ -302,7 +306,7 @@ class FluxPipeline:
             latents.copy_(saved)
             sch.reset(0)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE):
                 self._step(latents, pe, cond)
             self._graph, self._graph_key = g, key
             self._static = {"latents": latents, "pe": pe, "cond": cond}
@@ -442,7 +446,7 @@ class WanPipeline:
             latents.copy_(saved)
             sch.reset(0)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE):
                 self._step(latents, cond, guidance_scale, do_cfg)
             self._graph, self._graph_key = g, key
             self._static = {"latents": latents, "cond": cond}
@@ -562,7 +566,7 @@ class DDPMPipeline:
                 image.copy_(saved)
                 sch.reset(0)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE):
                     self._step(image, noise_table)
                 self._graph, self._graph_key = g, key
                 self._static = {"image": image, "noise": noise_table}
