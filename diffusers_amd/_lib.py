@@ -77,6 +77,7 @@ SIGNATURES = {
     "da_patchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_unpatchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_transpose_bf16": (_i, [_vp, _vp, _i, _i, _ll, _ll, _vp]),
+    "da_image_postprocess": (_i, [_vp, _vp, _i, _i, _ll, _i, _i, _vp]),
     "da_permute_0213_bf16": (_i, [_vp, _vp, _ll, _i, _i, _i, _vp]),
     "da_frames_to_ncthw_bf16": (_i, [_vp, _vp, _i, _i, _ll, _i, _i, _f, _f, _i, _vp]),
     "da_rmsnorm_channels_bf16": (_i, [_vp, _vp, _vp, _ll, _i, _f, _i, _vp]),

@@ -292,6 +292,28 @@ __global__ __launch_bounds__(256) void frames_to_ncthw_kernel(const uint16_t* __
   }
 }
 
+// VaeImageProcessor.postprocess (image_processor.py:738-786): denormalize (x * 0.5 + 0.5).clamp(0, 1) (:191-205), then
+// "pt" keeps NCHW, "np" moves channels last (pt_to_numpy, :148-155), "pil" additionally (x * 255).round() -> uint8
+// (numpy_to_pil, :118-135; numpy rounds half to even, so does v_rndne).  One thread per position, C <= 4 planes.
+template <bool IN_F32, int MODE>  // MODE 0: NCHW fp32, 1: NHWC fp32, 2: NHWC uint8
+__global__ __launch_bounds__(256) void image_postprocess_kernel(const void* __restrict__ img, void* __restrict__ out,
+                                                                int B, int C, long long HW) {
+  const long long total = (long long)B * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long b = i / HW, p = i - b * HW;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c >= C) break;
+      const size_t src = ((size_t)b * C + c) * (size_t)HW + (size_t)p;
+      const float x = IN_F32 ? ((const float*)img)[src] : bf2f(((const uint16_t*)img)[src]);
+      const float v = fminf(fmaxf(x * 0.5f + 0.5f, 0.f), 1.f);
+      if (MODE == 0) ((float*)out)[src] = v;
+      else if (MODE == 1) ((float*)out)[(size_t)i * C + c] = v;
+      else ((uint8_t*)out)[(size_t)i * C + c] = (uint8_t)rintf(v * 255.f);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int da_transpose_bf16(const void* in, void* out, int R, int Cc, long long ldi, long long ldo, void* stream) {
@@ -450,6 +472,25 @@ extern "C" int da_frames_to_ncthw_bf16(const void* src, void* dst, int B, int T,
     DA_LAUNCH(frames_to_ncthw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
               (const uint16_t*)src, dst, B, T, HW, Cs, C, lo, hi);
   }
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_image_postprocess(const void* img, void* out, int B, int C, long long HW, int in_f32, int mode,
+                                    void* stream) {
+  if (!img || !out || B <= 0 || C <= 0 || C > 4 || HW <= 0 || mode < 0 || mode > 2) return DA_ERR_INVALID;
+  const long long total = (long long)B * HW;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t s = (hipStream_t)stream;
+#define DA_PP(F_, M_)                                                                                              \
+  DA_LAUNCH((image_postprocess_kernel<F_, M_>), dim3((unsigned)blocks), dim3(256), 0, s, img, out, B, C, HW)
+  if (in_f32) {
+    if (mode == 0) DA_PP(true, 0); else if (mode == 1) DA_PP(true, 1); else DA_PP(true, 2);
+  } else {
+    if (mode == 0) DA_PP(false, 0); else if (mode == 1) DA_PP(false, 1); else DA_PP(false, 2);
+  }
+#undef DA_PP
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

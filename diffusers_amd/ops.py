@@ -477,6 +477,29 @@ def frames_to_ncthw(x: torch.Tensor, *, batch: int, channels: int, lo: float = -
     return out
 
 
+def image_postprocess(img: torch.Tensor, output_type: str) -> torch.Tensor:
+    """VaeImageProcessor.postprocess on a decoded image [B][C][H][W] or video [B][C][T][H][W] (bf16 / fp32):
+    "pt" -> same layout, fp32 in [0, 1]; "np" -> channels last fp32; "uint8" -> channels last bytes (what numpy_to_pil
+    hands to PIL)."""
+    if not img.is_cuda or img.dtype not in (bf16, torch.float32):
+        raise TypeError("image_postprocess: bf16 / fp32 HIP tensor required")
+    if not img.is_contiguous() or img.dim() not in (4, 5) or img.shape[1] > 4:
+        raise ValueError("image_postprocess: contiguous [B][C<=4][...] tensor required")
+    mode = {"pt": 0, "np": 1, "uint8": 2}.get(output_type)
+    if mode is None:
+        raise ValueError(f"image_postprocess: output_type {output_type!r} (use 'pt', 'np' or 'uint8')")
+    B, Cc = img.shape[:2]
+    sp = tuple(img.shape[2:])
+    HW = 1
+    for d in sp:
+        HW *= d
+    shape = tuple(img.shape) if mode == 0 else (B,) + sp + (Cc,)
+    out = torch.empty(shape, device=img.device, dtype=torch.uint8 if mode == 2 else torch.float32)
+    L.check(L.load().da_image_postprocess(img.data_ptr(), out.data_ptr(), B, Cc, HW, int(img.dtype == torch.float32), mode,
+                                          _stream()), "da_image_postprocess")
+    return out
+
+
 def bcast_add_f32(a: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
     """out[b] = a (fp32 [n]) + m[b] (bf16 [B][n]) in fp32."""
     _req(a, "a", torch.float32), _req(m, "m")

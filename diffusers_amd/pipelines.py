@@ -34,6 +34,25 @@ bf16 = torch.bfloat16
 GRAPH_CAPTURE_MODE = "thread_local"
 
 
+def postprocess_images(img: torch.Tensor, output_type: str):
+    """VaeImageProcessor.postprocess / VideoProcessor.postprocess_video (image_processor.py:738-786) fused into one kernel
+    pass over the decoded tensor: "raw" = the decoder output in [-1, 1]; "pt" = [0, 1] fp32, same layout; "np" = channels
+    last numpy fp32; "pil" = list of PIL images (stills only) built from the kernel's uint8 bytes."""
+    if output_type == "raw":
+        return img
+    if output_type == "pt":
+        return ops.image_postprocess(img, "pt")
+    if output_type == "np":
+        return ops.image_postprocess(img, "np").cpu().numpy()
+    if output_type == "pil":
+        if img.dim() != 4:
+            raise ValueError("output_type='pil' is for stills; use 'np' for video")
+        from PIL import Image
+        arr = ops.image_postprocess(img, "uint8").cpu().numpy()
+        return [Image.fromarray(a.squeeze(-1), mode="L") if a.shape[-1] == 1 else Image.fromarray(a) for a in arr]
+    raise ValueError(f"output_type={output_type!r}: use 'pil', 'np', 'pt', 'raw' or 'latent'")
+
+
 @dataclass
 class PipelineOutput:
     images: torch.Tensor
@@ -116,12 +135,7 @@ class _LatentDiffusionBase:
         if output_type == "latent":
             return latents
         img = self.vae.decode(latents, return_dict=False, latents_div=float(self.vae.config.scaling_factor))[0]
-        if output_type == "raw":
-            return img
-        if output_type == "pt":
-            # VaeImageProcessor.postprocess (image_processor.py:738; out of hot-path scope): denormalise to [0,1]
-            return (img.float() * 0.5 + 0.5).clamp(0, 1)
-        raise ValueError(f"output_type={output_type!r}: use 'pt', 'raw' or 'latent'")
+        return postprocess_images(img, output_type)
 
 
 class StableDiffusionXLPipeline(_LatentDiffusionBase):
@@ -377,12 +391,7 @@ class FluxPipeline:
             vc = self.vae.config
             img = self.vae.decode(unp, return_dict=False, latents_div=float(vc.scaling_factor),
                                   latents_add=float(vc.shift_factor or 0.0))[0]
-            if output_type == "raw":
-                images = img
-            elif output_type == "pt":
-                images = (img.float() * 0.5 + 0.5).clamp(0, 1)
-            else:
-                raise ValueError(f"output_type={output_type!r}: use 'pt', 'raw' or 'latent'")
+            images = postprocess_images(img, output_type)
         if not return_dict:
             return (images,)
         return PipelineOutput(images=images)
@@ -392,8 +401,9 @@ class WanPipeline:
     """pipelines/wan/pipeline_wan.py:380-700 (Wan 2.1 T2V) for pre-computed prompt embeddings: the denoising loop.
     The reference runs the transformer twice per step (cond / uncond, :613-632); here the two are one batch-2 call
     (identical arithmetic per sample, twice the GEMM M) and ``uncond + g (cond - uncond)`` is fused into the FlowMatch
-    update.  ``output_type="latent"`` returns the latents; "pt" / "raw" decode them with AutoencoderKLWan (the latent
-    de-normalisation of :653-661 is folded into its first conv) and return the clamped video [B][3][F][H][W]."""
+    update.  ``output_type="latent"`` returns the latents; "raw" / "pt" / "np" decode them with AutoencoderKLWan (the
+    latent de-normalisation of :653-661 is folded into its first conv): "raw" = the clamped decoder output
+    [B][3][F][H][W] in [-1, 1], "pt" / "np" = VideoProcessor.postprocess_video of it."""
 
     def __init__(self, tokenizer=None, text_encoder=None, vae=None, scheduler: FlowMatchEulerDiscreteScheduler = None,
                  transformer: WanTransformer3DModel = None, transformer_2=None, boundary_ratio=None,
@@ -474,9 +484,8 @@ class WanPipeline:
             raise ValueError("text encoders are outside the HIP hot path: pass `prompt_embeds`")
         if prompt_embeds is None:
             raise ValueError("Provide `prompt_embeds`.")
-        if output_type not in ("latent", "pt", "raw"):
-            raise ValueError("output_type must be 'latent', 'pt' or 'raw' (video post-processing to PIL / numpy is "
-                             "outside the hot path)")
+        if output_type not in ("latent", "pt", "raw", "np"):
+            raise ValueError("output_type must be 'latent', 'raw', 'pt' or 'np'")
         if output_type != "latent" and self.vae is None:
             raise ValueError("decoding needs `vae` (diffusers_amd.AutoencoderKLWan)")
         do_cfg = guidance_scale > 1.0
@@ -506,7 +515,11 @@ class WanPipeline:
         cond = self.transformer.precompute_conditioning(pe.contiguous())
         latents = self._denoise(latents, cond, len(self.scheduler.timesteps), guidance_scale, do_cfg, use_graph)
         if output_type != "latent":
-            latents = self.vae.decode(latents, return_dict=False, denormalize=True)[0]
+            video = self.vae.decode(latents, return_dict=False, denormalize=True)[0]            # [B][3][F][H][W]
+            # VideoProcessor.postprocess_video (video_processor.py): "np" [B][F][H][W][C], "pt" [B][F][C][H][W], in [0, 1]
+            latents = postprocess_images(video, output_type)
+            if output_type == "pt":
+                latents = latents.permute(0, 2, 1, 3, 4)
         if not return_dict:
             return (latents,)
         return PipelineOutput(images=latents)
@@ -579,13 +592,7 @@ class DDPMPipeline:
             for _ in ts:
                 self._graph.replay()
             sch._step_index = len(ts)
-        image = (image.float() / 2 + 0.5).clamp(0, 1)
-        if output_type == "pt":
-            out = image
-        elif output_type == "np":
-            out = image.cpu().permute(0, 2, 3, 1).numpy()
-        else:
-            raise ValueError(f"output_type={output_type!r}: use 'np' or 'pt' (PIL conversion is outside the hot path)")
+        out = postprocess_images(image.contiguous(), output_type)    # pipeline_ddpm.py:118-121
         if not return_dict:
             return (out,)
         return PipelineOutput(images=out)

@@ -812,3 +812,22 @@ def test_gemm_and_conv_accumulate_in_place():
     ref4 = F.conv2d(x.float().permute(0, 3, 1, 2), w4.float().view(4, 3, 3, 64).permute(0, 3, 1, 2), rnd((4,), 58).float(),
                     padding=1).permute(0, 2, 3, 1)
     assert_close_bf16(y4, ref4, "conv3x3 N=4", rtol=8e-3, atol_rms=4e-3)
+
+
+@pytest.mark.parametrize("dtype", [bf16, torch.float32])
+def test_image_postprocess_matches_reference_chain(dtype):
+    """VaeImageProcessor.postprocess: denormalize -> (channels last) -> (x * 255).round() uint8, bit for bit against the
+    same chain in torch / numpy (fp32 arithmetic on the decoded values; numpy rounds half to even)."""
+    ops, L = _ops()
+    x = rnd((2, 3, 37, 53), 71, scale=0.8, dtype=dtype)
+    x[0, 0, 0, :8] = torch.tensor([-1.0, 1.0, 0.0, 1.5, -1.5, 1 / 255 - 1, 2 / 255 - 1, 0.00390625], dtype=dtype)
+    want = (x.float() * 0.5 + 0.5).clamp(0, 1)
+    assert torch.equal(ops.image_postprocess(x, "pt"), want)
+    nhwc = want.permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(ops.image_postprocess(x, "np"), nhwc)
+    u8 = ops.image_postprocess(x, "uint8")
+    assert u8.dtype == torch.uint8 and np.array_equal(u8.cpu().numpy(), (nhwc.cpu().numpy() * 255).round().astype("uint8"))
+    v = rnd((1, 3, 4, 6, 10), 72, dtype=dtype)                       # video: [B][C][T][H][W] -> [B][T][H][W][C]
+    assert torch.equal(ops.image_postprocess(v, "np"), (v.float() * 0.5 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1).contiguous())
+    with pytest.raises(ValueError):
+        ops.image_postprocess(x, "jpeg")

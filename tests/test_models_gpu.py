@@ -319,9 +319,15 @@ def test_tiny_wan_pipeline_decodes_video(golden):
     kw = dict(prompt_embeds=t(g, "prompt_embeds"), negative_prompt_embeds=t(g, "negative_prompt_embeds"),
               num_inference_steps=3, guidance_scale=5.0, height=64, width=64, num_frames=9)
     lat = pipe(latents=torch.from_numpy(g["latents"]), output_type="latent", **kw).images.clone()
-    video = pipe(latents=torch.from_numpy(g["latents"]), output_type="pt", **kw).images
+    video = pipe(latents=torch.from_numpy(g["latents"]), output_type="raw", **kw).images
     assert video.shape == (1, 3, 9, 64, 64) and video.dtype == bf16
     assert torch.equal(video, pipe.vae.decode(lat, denormalize=True).sample)
+    # VideoProcessor.postprocess_video: "pt" [B][F][C][H][W], "np" [B][F][H][W][C], both (x / 2 + 0.5).clamp(0, 1)
+    want01 = (video.float() / 2 + 0.5).clamp(0, 1)
+    vpt = pipe(latents=torch.from_numpy(g["latents"]), output_type="pt", **kw).images
+    vnp = pipe(latents=torch.from_numpy(g["latents"]), output_type="np", **kw).images
+    assert vpt.shape == (1, 9, 3, 64, 64) and torch.equal(vpt, want01.permute(0, 2, 1, 3, 4))
+    assert vnp.shape == (1, 9, 64, 64, 3) and np.array_equal(vnp, want01.permute(0, 2, 3, 4, 1).cpu().numpy())
     cfg = dinit.TINY_WAN_VAE
     sd = {k: v.float() for k, v in dinit.random_state_dict(dinit.wan_vae_decoder_param_shapes(cfg), seed=21).items()}
     mean = torch.tensor(cfg["latents_mean"]).view(1, 16, 1, 1, 1)
@@ -332,4 +338,4 @@ def test_tiny_wan_pipeline_decodes_video(golden):
     print(f"[parity] tiny Wan pipeline video (3 UniPC steps + decode): rel_rms vs fp32 oracle decode of the same latents = {rr:.3e}")
     assert rr < 3e-2
     with pytest.raises(ValueError):
-        factory.build_wan_pipeline(device=DEV, tiny=True, seed=9)(latents=torch.from_numpy(g["latents"]), output_type="pt", **kw)
+        factory.build_wan_pipeline(device=DEV, tiny=True, seed=9)(latents=torch.from_numpy(g["latents"]), output_type="pt", **kw)  # no vae
