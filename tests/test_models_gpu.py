@@ -339,3 +339,18 @@ def test_tiny_wan_pipeline_decodes_video(golden):
     assert rr < 3e-2
     with pytest.raises(ValueError):
         factory.build_wan_pipeline(device=DEV, tiny=True, seed=9)(latents=torch.from_numpy(g["latents"]), output_type="pt", **kw)  # no vae
+
+
+def test_packed_cache_model_is_bit_identical(golden, tmp_path):
+    """A model rebuilt from its packed-weight cache (no checkpoint, no re-packing) computes exactly what the original does."""
+    from diffusers_amd import factory, init as dinit, packed_cache as PC
+    from diffusers_amd.unet_2d_condition import UNet2DConditionModel
+    g = golden("tiny_unet_sdxl")
+    unet, sd = factory.build_unet(dinit.TINY_SDXL_UNET, seed=0, device=DEV)
+    path = PC.save_packed(unet, tmp_path / "unet.safetensors", source_fingerprint=PC.fingerprint(sd))
+    again = PC.load_packed(UNet2DConditionModel, path, device=DEV, expect_fingerprint=PC.fingerprint(sd))
+    kw = {"added_cond_kwargs": {"text_embeds": t(g, "text_embeds"), "time_ids": t(g, "time_ids", torch.float32)}}
+    a = unet(t(g, "sample"), torch.tensor(float(g["t"])), t(g, "ehs"), **kw).sample
+    b = again(t(g, "sample"), torch.tensor(float(g["t"])), t(g, "ehs"), **kw).sample
+    assert all(v.is_cuda for v in PC.packed_tensors(again).values())
+    assert torch.equal(a, b)
