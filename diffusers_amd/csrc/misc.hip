@@ -292,9 +292,9 @@ __global__ __launch_bounds__(256) void frames_to_ncthw_kernel(const uint16_t* __
   }
 }
 
-// VaeImageProcessor.postprocess (image_processor.py:738-786): denormalize (x * 0.5 + 0.5).clamp(0, 1) (:191-205), then
-// "pt" keeps NCHW, "np" moves channels last (pt_to_numpy, :148-155), "pil" additionally (x * 255).round() -> uint8
-// (numpy_to_pil, :118-135; numpy rounds half to even, so does v_rndne).  One thread per position, C <= 4 planes.
+// VaeImageProcessor.postprocess (image_processor.py:738-786): denormalize (x * 0.5 + 0.5).clamp(0, 1) (:222-234), then
+// "pt" keeps NCHW, "np" moves channels last (pt_to_numpy, :191-204), "pil" additionally (x * 255).round() -> uint8
+// (numpy_to_pil, :128-149; numpy rounds half to even, so does v_rndne).  One thread per position, C <= 4 planes.
 template <bool IN_F32, int MODE>  // MODE 0: NCHW fp32, 1: NHWC fp32, 2: NHWC uint8
 __global__ __launch_bounds__(256) void image_postprocess_kernel(const void* __restrict__ img, void* __restrict__ out,
                                                                 int B, int C, long long HW) {

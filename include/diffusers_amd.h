@@ -245,9 +245,9 @@ int da_permute_0213_bf16(const void* src, void* dst, long long D0, int D1, int D
 /* Channels-last frames src[B*T][HW][Cs] (channels [0, C), C <= 4 <= Cs) -> video dst[B][C][T][HW] (bf16, or fp32 when
  * out_f32), clamped to [lo, hi]: the output layout + torch.clamp of AutoencoderKLWan._decode (autoencoder_kl_wan.py:1210). */
 /* VaeImageProcessor.postprocess (image_processor.py:738-786) on the decoded image / video img[B][C][HW] (bf16, or fp32
- * when in_f32): v = clamp(x * 0.5 + 0.5, 0, 1) (denormalize, :191-205); mode 0 "pt": out[B][C][HW] fp32; mode 1 "np":
- * out[B][HW][C] fp32 (pt_to_numpy, :148-155); mode 2 "pil" bytes: out[B][HW][C] uint8 = round-half-even(255 v)
- * (numpy_to_pil, :118-135).  C <= 4. */
+ * when in_f32): v = clamp(x * 0.5 + 0.5, 0, 1) (denormalize, :222-234); mode 0 "pt": out[B][C][HW] fp32; mode 1 "np":
+ * out[B][HW][C] fp32 (pt_to_numpy, :191-204); mode 2 "pil" bytes: out[B][HW][C] uint8 = round-half-even(255 v)
+ * (numpy_to_pil, :128-149).  C <= 4. */
 int da_image_postprocess(const void* img, void* out, int B, int C, long long HW, int in_f32, int mode, void* stream);
 int da_frames_to_ncthw_bf16(const void* src, void* dst, int B, int T, long long HW, int Cs, int C, float lo, float hi,
                             int out_f32, void* stream);

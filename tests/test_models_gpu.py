@@ -123,6 +123,14 @@ def test_sdxl_architecture_small_latents_vs_oracle():
     print(f"[parity] SDXL U-Net (full architecture, 32x32 latents): rel_rms vs fp32 oracle = {rr:.3e}")
     assert torch.isfinite(y.float()).all()
     assert rr < 4e-2
+    # BASELINE size (128x128 latents = the bench workload), size-independent property: a batch made of the SAME sample
+    # twice gives bit-identical halves (no cross-sample leakage through tile mapping, GroupNorm partials or attention)
+    s1 = torch.randn((1, 4, 128, 128), generator=gcpu).to(bf16).to(DEV)
+    yf = unet(torch.cat([s1, s1]), torch.tensor(961.0), torch.cat([ehs[:1], ehs[:1]]).to(DEV),
+              added_cond_kwargs={"text_embeds": torch.cat([te[:1], te[:1]]).to(DEV), "time_ids": ids.to(DEV)}).sample
+    assert yf.shape == (2, 4, 128, 128) and torch.isfinite(yf.float()).all()
+    assert torch.equal(yf[0], yf[1]), "full-size batch halves differ"
+    print(f"[parity] SDXL U-Net at 128x128 latents: identical samples -> identical outputs, rms {float(yf.float().pow(2).mean().sqrt()):.3f}")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
