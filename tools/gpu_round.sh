@@ -31,6 +31,15 @@ if [[ $WHAT == *wan* ]]; then
   timeout 900 python tools/bench_wan.py > $O/wan.log 2>&1; echo "wan rc=$?"
   tail -3 $O/wan.log | cut -c1-400
 fi
+if [[ $WHAT == *lastcall* ]]; then
+  # end-of-round confirmation on the final build: whole GPU suite, smoke, then the secondary configs with the new kernels
+  timeout 150 python -m pytest tests -m gpu -q -s --timeout 120 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
+  grep -E "passed|failed|FAILED|Error" $O/pytest_gpu.log | tail -5
+  timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/smoke.log
+  timeout 60 python tools/bench_wan_vae.py > $O/wan_vae.log 2>&1; echo "wan_vae rc=$?"; tail -1 $O/wan_vae.log | cut -c1-300
+  timeout 60 python tools/bench_flux.py > $O/flux.log 2>&1; echo "flux rc=$?"; tail -2 $O/flux.log | cut -c1-300
+  timeout 60 python tools/bench_sd15.py > $O/sd15.log 2>&1; echo "sd15 rc=$?"; tail -1 $O/sd15.log | cut -c1-300
+fi
 if [[ $WHAT == *final* ]]; then
   # re-measure the variant choice of every SDXL shape with the current kernels, merge over the shipped table, then the
   # bench line and the rocprofv3 kernel statistics of that build
