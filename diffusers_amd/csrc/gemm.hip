@@ -15,8 +15,9 @@
 // per-lane fused epilogues (bias, per-batch channel vector, residual, GEGLU / GELU / SiLU).
 // K is consumed in 64-wide slices (one 128-byte line per tile row) through a double-buffered LDS image whose
 // 16-byte slots are XOR-swizzled with ((row>>1)&7) so every ds_read_b128 lane group is bank-conflict free.
-// Staging is either register-staged (global_load_dwordx4 -> ds_write_b128) or direct-to-LDS
-// (global_load_lds_dwordx4, swizzle applied on the per-lane SOURCE address, LDS image lane-linear).
+// Staging is either register-staged (global_load_dwordx4 -> ds_write_b128) or direct-to-LDS (LDS-DMA: buffer_load ... lds
+// through a per-tile descriptor, or global_load_lds_dwordx4 with per-lane pointers; swizzle applied on the per-lane SOURCE
+// offset, LDS image lane-linear) -- see the staging-mode notes in gemm_kernel.cuh.
 #include "gemm_kernel.cuh"
 
 namespace da_gemm {

@@ -44,7 +44,11 @@ extern "C" {
 #define DA_TILE_256x256 7 /* 8 waves (2x4), 128x64 per wave; LDS-direct, 2-stage only */
 
 #define DA_STAGE_REGISTER 0   /* global_load_dwordx4 -> ds_write_b128 */
-#define DA_STAGE_LDS_DIRECT 1 /* global_load_lds_dwordx4 (LDS-DMA), 2-slot ring: prefetch distance 1 */
+/* LDS-DMA variants: buffer-addressed (buffer_load_dwordx4 ... offen lds: descriptor base at the tile's first operand row,
+ * loop-invariant per-lane offsets, scalar K advance, range-check zero fill for conv padding) whenever the tile's operand
+ * panels fit 31-bit offsets -- always, for this engine's shapes; per-lane 64-bit pointers (global_load_lds_dwordx4)
+ * otherwise, or when DA_GEMM_FLAT_STAGING=1 is set in the environment (A/B measurements).  Both give identical results. */
+#define DA_STAGE_LDS_DIRECT 1 /* LDS-DMA, 2-slot ring: prefetch distance 1 */
 #define DA_STAGE_LDS_DIRECT3 2 /* LDS-DMA, 3-slot ring: prefetch distance 2, counted vmcnt across the barrier */
 #define DA_STAGE_LDS_DIRECT4 3 /* LDS-DMA, 4-slot ring (tiles up to 128x128) */
 #define DA_STAGE_LDS_DIRECT6 4 /* LDS-DMA, 6-slot ring (64x128, 128x64, 64x64) */
