@@ -143,6 +143,24 @@ class StableDiffusionXLPipeline(_LatentDiffusionBase):
                  force_zeros_for_empty_prompt: bool = True):
         super().__init__(vae, unet, scheduler)
         self.default_sample_size = unet.config.sample_size
+        # optional caller-side components (transformers modules): with them `prompt=` works as in the reference
+        self.text_encoder, self.text_encoder_2 = text_encoder, text_encoder_2
+        self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2
+        self.force_zeros_for_empty_prompt = force_zeros_for_empty_prompt
+
+    def encode_prompt(self, prompt, prompt_2=None, device=None, num_images_per_prompt: int = 1,
+                      do_classifier_free_guidance: bool = True, negative_prompt=None, negative_prompt_2=None,
+                      clip_skip=None):
+        """pipeline_stable_diffusion_xl.py:283-518 through the caller's CLIP encoders (text_encoding.encode_prompt_sdxl)."""
+        from .text_encoding import encode_prompt_sdxl
+        if self.tokenizer_2 is None or self.text_encoder_2 is None:
+            raise ValueError("`prompt=` needs tokenizer_2 / text_encoder_2 (and optionally tokenizer / text_encoder); "
+                             "without them pass `prompt_embeds` and `pooled_prompt_embeds`")
+        toks = [self.tokenizer, self.tokenizer_2] if self.tokenizer is not None else [self.tokenizer_2]
+        encs = [self.text_encoder, self.text_encoder_2] if self.text_encoder is not None else [self.text_encoder_2]
+        return encode_prompt_sdxl(toks, encs, prompt, prompt_2, device or self.device, num_images_per_prompt,
+                                  do_classifier_free_guidance, negative_prompt, negative_prompt_2,
+                                  self.force_zeros_for_empty_prompt, clip_skip)
 
     def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, text_encoder_projection_dim):
         add_time_ids = list(original_size + crops_coords_top_left + target_size)
@@ -161,12 +179,20 @@ class StableDiffusionXLPipeline(_LatentDiffusionBase):
                  prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None,
                  negative_pooled_prompt_embeds=None, output_type: str = "pt", return_dict: bool = True,
                  original_size: Optional[Tuple[int, int]] = None, crops_coords_top_left: Tuple[int, int] = (0, 0),
-                 target_size: Optional[Tuple[int, int]] = None, generator=None, use_graph: bool = True):
-        if prompt is not None:
-            raise ValueError("text encoders are outside the HIP hot path: pass `prompt_embeds`/`pooled_prompt_embeds`")
-        if prompt_embeds is None or pooled_prompt_embeds is None:
-            raise ValueError("Provide `prompt_embeds` and `pooled_prompt_embeds`.")
+                 target_size: Optional[Tuple[int, int]] = None, generator=None, use_graph: bool = True,
+                 prompt_2=None, negative_prompt=None, negative_prompt_2=None, num_images_per_prompt: int = 1,
+                 clip_skip=None):
         do_cfg = guidance_scale > 1.0
+        if prompt is not None:
+            if prompt_embeds is not None:
+                raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one "
+                                 "of the two.")
+            prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = \
+                self.encode_prompt(prompt, prompt_2, self.device, num_images_per_prompt, do_cfg, negative_prompt,
+                                   negative_prompt_2, clip_skip)
+        if prompt_embeds is None or pooled_prompt_embeds is None:
+            raise ValueError("Provide either `prompt` (with the text encoders given to the pipeline) or `prompt_embeds` "
+                             "and `pooled_prompt_embeds`.")
         if do_cfg and (negative_prompt_embeds is None or negative_pooled_prompt_embeds is None):
             raise ValueError("classifier-free guidance needs `negative_prompt_embeds` and "
                              "`negative_pooled_prompt_embeds`")
@@ -206,19 +232,36 @@ class StableDiffusionPipeline(_LatentDiffusionBase):
     def __init__(self, vae, unet, scheduler, text_encoder=None, tokenizer=None, safety_checker=None,
                  feature_extractor=None, requires_safety_checker: bool = False):
         super().__init__(vae, unet, scheduler)
+        if safety_checker is not None:
+            raise NotImplementedError("the safety checker is outside this engine: post-filter the returned images")
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer   # optional caller-side transformers modules
+
+    def encode_prompt(self, prompt, device=None, num_images_per_prompt: int = 1, do_classifier_free_guidance: bool = True,
+                      negative_prompt=None, clip_skip=None):
+        """pipeline_stable_diffusion.py:332-513 through the caller's CLIP encoder (text_encoding.encode_prompt_sd)."""
+        from .text_encoding import encode_prompt_sd
+        if self.tokenizer is None or self.text_encoder is None:
+            raise ValueError("`prompt=` needs the pipeline's tokenizer / text_encoder; without them pass `prompt_embeds`")
+        return encode_prompt_sd(self.tokenizer, self.text_encoder, prompt, device or self.device, num_images_per_prompt,
+                                do_classifier_free_guidance, negative_prompt, clip_skip)
 
     @torch.no_grad()
     def __call__(self, prompt=None, height: Optional[int] = None, width: Optional[int] = None,
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, eta: float = 0.0,
                  latents: Optional[torch.Tensor] = None, prompt_embeds=None, negative_prompt_embeds=None,
-                 output_type: str = "pt", return_dict: bool = True, generator=None, use_graph: bool = True):
-        if prompt is not None:
-            raise ValueError("text encoders are outside the HIP hot path: pass `prompt_embeds`")
-        if prompt_embeds is None:
-            raise ValueError("Provide `prompt_embeds`.")
+                 output_type: str = "pt", return_dict: bool = True, generator=None, use_graph: bool = True,
+                 negative_prompt=None, num_images_per_prompt: int = 1, clip_skip=None):
         if eta != 0.0:
             raise NotImplementedError("eta > 0 in the fused pipeline loop")
         do_cfg = guidance_scale > 1.0
+        if prompt is not None:
+            if prompt_embeds is not None:
+                raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one "
+                                 "of the two.")
+            prompt_embeds, negative_prompt_embeds = self.encode_prompt(prompt, self.device, num_images_per_prompt, do_cfg,
+                                                                        negative_prompt, clip_skip)
+        if prompt_embeds is None:
+            raise ValueError("Provide either `prompt` (with the text encoder given to the pipeline) or `prompt_embeds`.")
         if do_cfg and negative_prompt_embeds is None:
             raise ValueError("classifier-free guidance needs `negative_prompt_embeds`")
         dev = self.device

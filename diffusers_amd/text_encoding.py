@@ -1,0 +1,135 @@
+"""Text-encoder front end of the CLIP-conditioned pipelines (the step in front of the hot path).
+
+The encoders themselves are the caller's ``transformers`` modules (CLIPTextModel / CLIPTextModelWithProjection) running
+on PyTorch-ROCm -- they are not re-implemented here; this module is the host logic around them that the reference keeps
+inside its pipelines: tokenise with max-length padding, pick the hidden state the model family conditions on, build the
+classifier-free-guidance negatives, duplicate per image, and hand bf16 tensors to the denoiser.  Mirrors
+
+  * ``StableDiffusionPipeline.encode_prompt``     pipelines/stable_diffusion/pipeline_stable_diffusion.py:332-513
+  * ``StableDiffusionXLPipeline.encode_prompt``   pipelines/stable_diffusion_xl/pipeline_stable_diffusion_xl.py:283-518
+
+(same arguments, same errors; LoRA scaling and textual inversion are loader features outside this engine).  In a
+multi-GPU job rank 0 encodes and the embeddings are broadcast (``distributed.broadcast_tensors``), so the text encoders
+are loaded once per node, not once per GPU.
+"""
+from __future__ import annotations
+
+import logging
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+
+logger = logging.getLogger(__name__)
+Prompt = Union[str, List[str]]
+
+
+def _as_list(p: Prompt) -> List[str]:
+    return [p] if isinstance(p, str) else list(p)
+
+
+def _tokenize(tokenizer, prompt: Sequence[str], max_length: Optional[int] = None):
+    ids = tokenizer(list(prompt), padding="max_length", max_length=max_length or tokenizer.model_max_length,
+                    truncation=True, return_tensors="pt")
+    if max_length is None:
+        untruncated = tokenizer(list(prompt), padding="longest", return_tensors="pt").input_ids
+        if untruncated.shape[-1] >= ids.input_ids.shape[-1] and not torch.equal(ids.input_ids, untruncated):
+            removed = tokenizer.batch_decode(untruncated[:, tokenizer.model_max_length - 1: -1])
+            logger.warning("The following part of your input was truncated because CLIP can only handle sequences up to"
+                           f" {tokenizer.model_max_length} tokens: {removed}")
+    return ids
+
+
+def _check_negative(prompt: Optional[Prompt], negative_prompt: Prompt, batch_size: int) -> None:
+    if prompt is not None and type(prompt) is not type(negative_prompt):
+        raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} !="
+                        f" {type(prompt)}.")
+    if not isinstance(negative_prompt, str) and batch_size != len(negative_prompt):
+        raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`:"
+                         f" {prompt} has batch size {batch_size}. Please make sure that passed `negative_prompt` matches"
+                         " the batch size of `prompt`.")
+
+
+def _repeat(t: torch.Tensor, n: int) -> torch.Tensor:
+    """[B][...] -> [B * n][...], each prompt's copies adjacent (the reference's repeat + view)."""
+    if n == 1:
+        return t
+    return t.repeat_interleave(n, dim=0)
+
+
+@torch.no_grad()
+def encode_prompt_sd(tokenizer, text_encoder, prompt: Prompt, device, num_images_per_prompt: int = 1,
+                     do_classifier_free_guidance: bool = True, negative_prompt: Optional[Prompt] = None,
+                     clip_skip: Optional[int] = None, dtype: torch.dtype = torch.bfloat16
+                     ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """SD 1.x / 2.x: one CLIP text encoder, last hidden state (or, with ``clip_skip``, an earlier one passed through the
+    final layer norm).  Returns (prompt_embeds, negative_prompt_embeds) in ``dtype`` on ``device``."""
+    batch_size = 1 if isinstance(prompt, str) else len(prompt)
+    use_mask = bool(getattr(text_encoder.config, "use_attention_mask", False))
+
+    def run(texts, max_length=None, skip=None):
+        tok = _tokenize(tokenizer, texts, max_length)
+        mask = tok.attention_mask.to(device) if use_mask else None
+        if skip is None:
+            return text_encoder(tok.input_ids.to(device), attention_mask=mask)[0]
+        out = text_encoder(tok.input_ids.to(device), attention_mask=mask, output_hidden_states=True)
+        # (transformers >= 5 flattened CLIPTextModel: the norm sits on the model itself, not on `.text_model`)
+        return getattr(text_encoder, "text_model", text_encoder).final_layer_norm(out[-1][-(skip + 1)])
+
+    pe = run(_as_list(prompt), skip=clip_skip)
+    ne = None
+    if do_classifier_free_guidance:
+        if negative_prompt is None:
+            uncond = [""] * batch_size
+        else:
+            _check_negative(prompt, negative_prompt, batch_size)
+            uncond = _as_list(negative_prompt)
+        ne = run(uncond, max_length=pe.shape[1])
+        ne = _repeat(ne.to(device=device, dtype=dtype), num_images_per_prompt)
+    return _repeat(pe.to(device=device, dtype=dtype), num_images_per_prompt), ne
+
+
+@torch.no_grad()
+def encode_prompt_sdxl(tokenizers: Sequence, text_encoders: Sequence, prompt: Prompt, prompt_2: Optional[Prompt] = None,
+                       device=None, num_images_per_prompt: int = 1, do_classifier_free_guidance: bool = True,
+                       negative_prompt: Optional[Prompt] = None, negative_prompt_2: Optional[Prompt] = None,
+                       force_zeros_for_empty_prompt: bool = True, clip_skip: Optional[int] = None,
+                       dtype: torch.dtype = torch.bfloat16):
+    """SDXL: the penultimate hidden states of both encoders concatenated on the feature axis, and the pooled output of
+    the LAST encoder (the one with the projection head).  ``tokenizers`` / ``text_encoders`` are [first, second], or
+    [second] alone (the refiner layout).  Returns (prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds,
+    negative_pooled_prompt_embeds)."""
+    if len(tokenizers) != len(text_encoders) or not 1 <= len(tokenizers) <= 2:
+        raise ValueError("encode_prompt_sdxl: pass one or two (tokenizer, text_encoder) pairs")
+    prompt_l = _as_list(prompt)
+    batch_size = len(prompt_l)
+    # the reference zips [prompt, prompt_2] with the encoder list: a lone (second) encoder therefore reads `prompt`
+    prompts = [prompt_l, _as_list(prompt_2) if prompt_2 else prompt_l][:len(tokenizers)]
+
+    def run(texts_per_encoder, max_length=None, skip=None):
+        hidden, pooled = [], None
+        for texts, tok, enc in zip(texts_per_encoder, tokenizers, text_encoders):
+            ids = _tokenize(tok, texts, max_length).input_ids.to(device)
+            out = enc(ids, output_hidden_states=True)
+            if pooled is None and out[0].ndim == 2:       # only the projection model returns a pooled [B][D] first
+                pooled = out[0]
+            hidden.append(out.hidden_states[-2] if skip is None else out.hidden_states[-(skip + 2)])
+        return torch.concat(hidden, dim=-1), pooled
+
+    pe, pooled = run(prompts, skip=clip_skip)
+    ne = npooled = None
+    if do_classifier_free_guidance:
+        if negative_prompt is None and force_zeros_for_empty_prompt:
+            ne, npooled = torch.zeros_like(pe), torch.zeros_like(pooled)
+        else:
+            neg = negative_prompt or ""
+            neg2 = negative_prompt_2 or neg
+            _check_negative(prompt, neg, batch_size)
+            neg_l = batch_size * [neg] if isinstance(neg, str) else list(neg)
+            neg2_l = batch_size * [neg2] if isinstance(neg2, str) else list(neg2)
+            uncond = [neg_l, neg2_l][:len(tokenizers)]
+            ne, npooled = run(uncond, max_length=pe.shape[1])
+        ne = _repeat(ne.to(device=device, dtype=dtype), num_images_per_prompt)
+        npooled = _repeat(npooled.to(device=device, dtype=dtype), num_images_per_prompt)
+    pe = _repeat(pe.to(device=device, dtype=dtype), num_images_per_prompt)
+    pooled = _repeat(pooled.to(device=device, dtype=dtype), num_images_per_prompt)
+    return pe, ne, pooled, npooled

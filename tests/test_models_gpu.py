@@ -362,3 +362,28 @@ def test_packed_cache_model_is_bit_identical(golden, tmp_path):
     b = again(t(g, "sample"), torch.tensor(float(g["t"])), t(g, "ehs"), **kw).sample
     assert all(v.is_cuda for v in PC.packed_tensors(again).values())
     assert torch.equal(a, b)
+
+
+def test_sdxl_pipeline_accepts_prompts_with_caller_text_encoders(golden):
+    """`prompt=` with the caller's (transformers) CLIP encoders: the pipeline's front end (text_encoding.py, checked
+    against the reference's encode_prompt on CPU) feeds the same tensors as passing the embeddings by hand."""
+    from test_text_encoding import _clip, _tokenizer
+    from diffusers_amd import factory
+    g = golden("tiny_sdxl_pipeline")
+    tok, nv = _tokenizer()
+    tok2, _ = _tokenizer()
+    e1 = _clip(nv, 32, seed=1).to(DEV, bf16)
+    e2 = _clip(nv, 32, proj=64, seed=2).to(DEV, bf16)
+    pipe = factory.build_sdxl_pipeline(device=DEV, tiny=True)
+    pipe.tokenizer, pipe.tokenizer_2, pipe.text_encoder, pipe.text_encoder_2 = tok, tok2, e1, e2
+    kw = dict(num_inference_steps=3, guidance_scale=5.0, height=32, width=32, output_type="raw")
+    a = pipe(prompt="hello a cat", negative_prompt="cat", latents=t(g, "latents").clone(), **kw).images
+    pe, ne, pp, npp = pipe.encode_prompt("hello a cat", negative_prompt="cat")
+    assert pe.shape == (1, 16, 64) and pp.shape == (1, 64) and pe.dtype == bf16 and pe.is_cuda
+    b = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=npp,
+             latents=t(g, "latents").clone(), **kw).images
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    with pytest.raises(ValueError):
+        pipe(prompt="a cat", prompt_embeds=pe, **kw)
+    with pytest.raises(ValueError):
+        factory.build_sdxl_pipeline(device=DEV, tiny=True)(prompt="a cat", **kw)      # no encoders given

@@ -1,0 +1,108 @@
+"""Text-encoder front end against the reference pipelines' own ``encode_prompt`` on tiny random
+CLIP encoders and an in-memory byte-level tokenizer.  Needs the reference sources (build container); the encoders are
+the caller's ``transformers`` modules, so only the host logic around them is under test."""
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+REF = Path("/root/reference/src")
+pytestmark = pytest.mark.skipif(not REF.exists(), reason="reference sources not present")
+
+
+def _tokenizer(max_len=16):
+    from tokenizers import pre_tokenizers
+    from transformers import CLIPTokenizer
+    alpha = sorted(pre_tokenizers.ByteLevel.alphabet())
+    vocab = {}
+    for c in alpha:
+        vocab[c] = len(vocab)
+    for c in alpha:
+        vocab[c + "</w>"] = len(vocab)
+    merges = [("h", "e"), ("l", "l"), ("he", "ll"), ("hell", "o</w>"), ("c", "a"), ("ca", "t</w>")]
+    for a, b in merges:
+        vocab[a + b] = len(vocab)
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    return CLIPTokenizer(vocab=vocab, merges=merges, model_max_length=max_len), len(vocab)
+
+
+def _clip(vocab, hidden, proj=None, seed=0):
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    torch.manual_seed(seed)
+    cfg = CLIPTextConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=3,
+                         num_attention_heads=2, max_position_embeddings=16, projection_dim=proj or hidden,
+                         bos_token_id=vocab - 2, eos_token_id=vocab - 1, pad_token_id=vocab - 1)
+    return (CLIPTextModelWithProjection(cfg) if proj else CLIPTextModel(cfg)).eval()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.path.insert(0, str(REF))
+    try:
+        import diffusers
+        yield diffusers
+    finally:
+        sys.path.remove(str(REF))
+
+
+def _ref_unet_vae(ref, cross, sdxl):
+    kw = dict(addition_embed_type="text_time", addition_time_embed_dim=8, projection_class_embeddings_input_dim=80) if sdxl else {}
+    unet = ref.UNet2DConditionModel(block_out_channels=(32, 64), layers_per_block=1, sample_size=8, in_channels=4, out_channels=4,
+                                    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"),
+                                    up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"), cross_attention_dim=cross,
+                                    attention_head_dim=(2, 4) if sdxl else 8, norm_num_groups=32, **kw)
+    vae = ref.AutoencoderKL(block_out_channels=(32, 64), in_channels=3, out_channels=3, latent_channels=4,
+                            down_block_types=("DownEncoderBlock2D",) * 2, up_block_types=("UpDecoderBlock2D",) * 2)
+    return unet, vae
+
+
+@pytest.mark.parametrize("kw", [dict(prompt="hello a cat"), dict(prompt=["hello", "a cat cat"], negative_prompt=["cat", ""]),
+                                dict(prompt="a cat", negative_prompt="hello", num_images_per_prompt=2),
+                                dict(prompt="hello " * 30, do_classifier_free_guidance=False)])
+def test_sd_encode_prompt_matches_reference(ref, kw):
+    from diffusers_amd.text_encoding import encode_prompt_sd
+    tok, nv = _tokenizer()
+    enc = _clip(nv, 32)
+    unet, vae = _ref_unet_vae(ref, 32, sdxl=False)
+    pipe = ref.StableDiffusionPipeline(vae=vae, text_encoder=enc, tokenizer=tok, unet=unet, scheduler=ref.DDIMScheduler(),
+                                       safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    args = dict(num_images_per_prompt=1, do_classifier_free_guidance=True)
+    args.update(kw)
+    want_p, want_n = pipe.encode_prompt(device="cpu", **args)
+    got_p, got_n = encode_prompt_sd(tok, enc, device="cpu", dtype=torch.float32, **args)
+    assert torch.equal(got_p, want_p)
+    assert (got_n is None and want_n is None) or torch.equal(got_n, want_n)
+
+
+@pytest.mark.parametrize("kw", [dict(prompt="hello a cat"), dict(prompt="hello", prompt_2="a cat", negative_prompt="cat"),
+                                dict(prompt=["hello", "a cat"], negative_prompt=["", "cat"], negative_prompt_2=["hello", ""],
+                                     num_images_per_prompt=2),
+                                dict(prompt="a cat", clip_skip=1), dict(prompt="a cat", do_classifier_free_guidance=False)])
+@pytest.mark.parametrize("force_zeros", [True, False])
+def test_sdxl_encode_prompt_matches_reference(ref, kw, force_zeros):
+    from diffusers_amd.text_encoding import encode_prompt_sdxl
+    tok, nv = _tokenizer()
+    tok2, _ = _tokenizer()
+    e1, e2 = _clip(nv, 32, seed=1), _clip(nv, 32, proj=32, seed=2)
+    unet, vae = _ref_unet_vae(ref, 64, sdxl=True)
+    pipe = ref.StableDiffusionXLPipeline(vae=vae, text_encoder=e1, text_encoder_2=e2, tokenizer=tok, tokenizer_2=tok2, unet=unet,
+                                         scheduler=ref.EulerDiscreteScheduler(), force_zeros_for_empty_prompt=force_zeros)
+    args = dict(num_images_per_prompt=1, do_classifier_free_guidance=True)
+    args.update(kw)
+    want = pipe.encode_prompt(device="cpu", **args)
+    got = encode_prompt_sdxl([tok, tok2], [e1, e2], device="cpu", force_zeros_for_empty_prompt=force_zeros,
+                             dtype=torch.float32, **args)
+    for g, w in zip(got, want):
+        assert (g is None and w is None) or (g.shape == w.shape and torch.equal(g, w))
+
+
+def test_negative_prompt_errors_match_reference():
+    from diffusers_amd.text_encoding import encode_prompt_sd
+    tok, nv = _tokenizer()
+    enc = _clip(nv, 32)
+    with pytest.raises(TypeError):
+        encode_prompt_sd(tok, enc, "a cat", "cpu", negative_prompt=["cat"])
+    with pytest.raises(ValueError):
+        encode_prompt_sd(tok, enc, ["a cat", "hello"], "cpu", negative_prompt=["cat"])
