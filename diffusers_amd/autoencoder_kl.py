@@ -180,8 +180,7 @@ class AutoencoderKL:
         the first conv's input read."""
         if not self._built:
             raise RuntimeError("AutoencoderKL: call load_state_dict() first")
-        if z.dtype != bf16 or not z.is_cuda:
-            raise ValueError("z must be a bf16 HIP tensor (there is no CPU / fp32 fallback)")
+        ops.require_hip(z, "z")
         z = z.contiguous()
         if self.post_quant_conv:
             x = ops.conv_thin_in(z, self.pqc_w, self.pqc_b, ksize=1, in_nchw=True, in_div=latents_div, in_add=latents_add)

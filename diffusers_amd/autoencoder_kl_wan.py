@@ -281,8 +281,7 @@ class AutoencoderKLWan:
         ``denormalize=True``: z are the pipeline's normalised latents (see load_state_dict)."""
         if not self._built:
             raise RuntimeError("AutoencoderKLWan: call load_state_dict() first")
-        if not z.is_cuda or z.dtype not in (bf16, torch.float32):
-            raise ValueError("z must be a bf16 / fp32 HIP tensor (there is no CPU fallback)")
+        ops.require_hip(z, "z", (bf16, torch.float32))
         if z.dim() != 5 or z.shape[1] != self.config.z_dim:
             raise ValueError(f"z must be [B][{self.config.z_dim}][T][H][W]")
         z = z.contiguous()

@@ -46,6 +46,13 @@ def _req(t: torch.Tensor, name: str, dtype=bf16) -> None:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
+def require_hip(t: torch.Tensor, name: str, dtypes=(bf16,)) -> None:
+    """Entry check of every model forward: the engine computes on HIP device tensors only."""
+    if t.dtype not in dtypes or not t.is_cuda:
+        kinds = " / ".join(str(d).replace("torch.", "").replace("bfloat16", "bf16").replace("float32", "fp32") for d in dtypes)
+        raise ValueError(f"{name} must be a {kinds} HIP tensor (there is no CPU / fp32 fallback)")
+
+
 def _rows2d(t: torch.Tensor, name: str) -> int:
     """Leading dimension (elements) of a 2-D row-major view whose last dim is contiguous."""
     if t.dim() != 2 or t.stride(1) != 1:

@@ -150,8 +150,7 @@ class FluxTransformer2DModel:
     # ------------------------------------------------------------------------------------------------------------
     def precompute_conditioning(self, pooled_projections: torch.Tensor, img_ids: torch.Tensor,
                                 txt_ids: torch.Tensor) -> Dict[str, Any]:
-        if pooled_projections.dtype != bf16 or not pooled_projections.is_cuda:
-            raise ValueError("pooled_projections must be a bf16 HIP tensor")
+        ops.require_hip(pooled_projections, "pooled_projections")
         if txt_ids.ndim == 3:
             txt_ids = txt_ids[0]
         if img_ids.ndim == 3:
@@ -186,8 +185,7 @@ class FluxTransformer2DModel:
                 raise ValueError(f"diffusers_amd FluxTransformer2DModel.forward: `{name}` is not supported on the HIP path")
         if joint_attention_kwargs:
             raise ValueError("diffusers_amd FluxTransformer2DModel.forward: `joint_attention_kwargs` is not supported")
-        if hidden_states.dtype != bf16 or not hidden_states.is_cuda:
-            raise ValueError("hidden_states must be a bf16 HIP tensor (there is no CPU / fp32 fallback)")
+        ops.require_hip(hidden_states, "hidden_states")
         c = self.config
         C, Hh, D = self.inner_dim, c.num_attention_heads, c.attention_head_dim
         B, Si, Cin = hidden_states.shape

@@ -129,8 +129,7 @@ class WanTransformer3DModel:
     # ------------------------------------------------------------------------------------------------------------
     def precompute_conditioning(self, encoder_hidden_states: torch.Tensor) -> Dict[str, Any]:
         """Step-invariant work: the text embedder MLP and every block's cross-attention K (RMS-normed) / V^T."""
-        if encoder_hidden_states.dtype != bf16 or not encoder_hidden_states.is_cuda:
-            raise ValueError("encoder_hidden_states must be a bf16 HIP tensor")
+        ops.require_hip(encoder_hidden_states, "encoder_hidden_states")
         c = self.config
         B, St, Td = encoder_hidden_states.shape
         if St % 8:
@@ -171,8 +170,7 @@ class WanTransformer3DModel:
             raise ValueError("diffusers_amd WanTransformer3DModel.forward: `encoder_hidden_states_image` is not supported")
         if attention_kwargs:
             raise ValueError("diffusers_amd WanTransformer3DModel.forward: `attention_kwargs` is not supported")
-        if hidden_states.dtype != bf16 or not hidden_states.is_cuda:
-            raise ValueError("hidden_states must be a bf16 HIP tensor (there is no CPU / fp32 fallback)")
+        ops.require_hip(hidden_states, "hidden_states")
         if timestep is not None and torch.is_tensor(timestep) and timestep.ndim == 2:
             raise ValueError("per-token timesteps (Wan 2.2 TI2V) are not supported")
         c = self.config

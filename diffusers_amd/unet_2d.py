@@ -139,8 +139,7 @@ class UNet2DModel:
             raise RuntimeError("UNet2DModel: call load_state_dict() first")
         if class_labels is not None:
             raise ValueError("class_labels should not be provided: the model has no class embedding")
-        if sample.dtype != bf16 or not sample.is_cuda:
-            raise ValueError("sample must be a bf16 HIP tensor (there is no CPU / fp32 fallback)")
+        ops.require_hip(sample, "sample")
         c = self.config
         B = sample.shape[0]
         if sampler_table is not None:

@@ -182,8 +182,7 @@ class UNet2DConditionModel:
     def precompute_conditioning(self, encoder_hidden_states: torch.Tensor,
                                 added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, Any]:
         """Everything in forward() that does not depend on the timestep or the latents."""
-        if encoder_hidden_states.dtype != bf16 or not encoder_hidden_states.is_cuda:
-            raise ValueError("encoder_hidden_states must be a bf16 HIP tensor")
+        ops.require_hip(encoder_hidden_states, "encoder_hidden_states")
         B = encoder_hidden_states.shape[0]
         ehs_pad, skv, skv_alloc = pad_encoder_states(encoder_hidden_states.contiguous())
         kvs = [tr.precompute_kv(ehs_pad, B, skv, skv_alloc) for tr in self._transformers()]
@@ -234,8 +233,7 @@ class UNet2DConditionModel:
                         ("encoder_attention_mask", encoder_attention_mask)):
             if v is not None:
                 raise ValueError(f"diffusers_amd UNet2DConditionModel.forward: `{name}` is not supported on the HIP path")
-        if sample.dtype != bf16 or not sample.is_cuda:
-            raise ValueError("sample must be a bf16 HIP tensor (there is no CPU / fp32 fallback)")
+        ops.require_hip(sample, "sample")
         c = self.config
         B, Cin, H, W_ = sample.shape
         n_up = len(c.block_out_channels) - 1

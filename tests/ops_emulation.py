@@ -18,18 +18,40 @@ def _store(val, out, dtype=bf16):
     return out
 
 
+ACT_NONE, ACT_GEGLU, ACT_GELU_TANH, ACT_SILU, ACT_GELU_ERF = 0, 1, 2, 3, 4
+
+
+def _act(y, act):
+    if act == ACT_NONE:
+        return y
+    y = y.to(bf16).float()                       # the kernels activate the bf16-rounded projection
+    if act == ACT_SILU:
+        return F.silu(y)
+    if act == ACT_GELU_TANH:
+        return F.gelu(y, approximate="tanh")
+    if act == ACT_GELU_ERF:
+        return F.gelu(y)
+    raise AssertionError(f"activation {act}")
+
+
 def conv2d_nhwc(x, w, bias=None, *, ksize=3, x2=None, stride=1, up=False, pad=None, rowvec=None, residual=None,
                 out_scale=1.0, act=0, tile=None, staging=None, pad_after=0, out=None):
-    assert x2 is None and rowvec is None and act == 0 and pad_after == 0 and x.is_contiguous()
-    assert x.shape[-1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: conv channels % 64, N % 4"
+    assert x.is_contiguous() and x.shape[-1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: conv channels % 64, N % 4"
+    if x2 is not None:
+        assert x2.is_contiguous() and x2.shape[-1] % 64 == 0 and x2.shape[:3] == x.shape[:3]
+        x = torch.cat([x, x2], -1)
     B, H, W_, C = x.shape
     co = w.shape[0]
     wt = w.float().view(co, ksize, ksize, C).permute(0, 3, 1, 2)
     xi = x.float().permute(0, 3, 1, 2)
     if up:
         xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
-    y = F.conv2d(xi, wt, None if bias is None else bias.float(), stride=stride, padding=(ksize - 1) // 2 if pad is None else pad)
-    y = y.permute(0, 2, 3, 1)
+    pd = (ksize - 1) // 2 if pad is None else pad
+    xi = F.pad(xi, (pd, pd + pad_after, pd, pd + pad_after))
+    y = F.conv2d(xi, wt, None if bias is None else bias.float(), stride=stride).permute(0, 2, 3, 1)
+    if rowvec is not None:
+        y = y + rowvec.float()[:, None, None, :]
+    y = _act(y, act)
     if residual is not None:
         assert tuple(residual.shape) == tuple(y.shape) and residual.is_contiguous()
         y = y + residual.float()
@@ -40,14 +62,172 @@ def conv2d_nhwc(x, w, bias=None, *, ksize=3, x2=None, stride=1, up=False, pad=No
 
 def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch=0, alpha=1.0, out_scale=1.0, out=None,
            out_f32=False, bias_rows=None, gate=None, tile=None, staging=None):
-    assert act == 0 and rowvec is None and bias_rows is None and gate is None
     assert x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: K % 64, N % 4"
+    assert x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0, "C ABI: row strides % 8"
     y = alpha * (x.float() @ w.float().t())
     if bias is not None:
         y = y + bias.float()
+    if bias_rows is not None:
+        y = y + bias_rows.float()[:, None]
+    M = y.shape[0]
+    bidx = None
+    if rowvec is not None or gate is not None:
+        assert rows_per_batch > 0
+        bidx = torch.arange(M) // rows_per_batch
+    if rowvec is not None:
+        y = y + rowvec.float()[bidx]
+    if act == ACT_GEGLU:                          # packed rows: per 64 = [32 value | 32 gate] (ops.pack_geglu)
+        assert w.shape[0] % 128 == 0 and residual is None and gate is None and rowvec is None and not out_f32
+        g = y.to(bf16).float().view(M, -1, 2, 32)
+        y = (g[:, :, 0] * F.gelu(g[:, :, 1]).to(bf16).float()).reshape(M, -1)
+    else:
+        y = _act(y, act)
+    if gate is not None:
+        gv = gate.float()[bidx]
+        y = y.to(bf16).float() * gv
+        if gate.dtype == bf16:
+            y = y.to(bf16).float()
     if residual is not None:
         y = y + residual.float()
     return _store(y * out_scale, out, torch.float32 if out_f32 else bf16)
+
+
+def linear_small_m(x, w, bias=None, *, act_in=0, act_out=0, residual=None, out=None):
+    assert x.shape[0] <= 8 and w.is_contiguous()
+    xi = x.float()
+    if act_in == ACT_SILU:
+        xi = F.silu(xi).to(bf16).float()
+    else:
+        assert act_in == ACT_NONE
+    y = xi @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    y = _act(y, act_out)
+    if residual is not None:
+        y = y + residual.float()
+    return _store(y, out)
+
+
+def attention(q, k, vt, *, B, H, D, Sq, Skv, Skv_alloc, q_row_stride, k_row_stride, q_batch_stride, k_batch_stride,
+              vt_ld, vt_batch_stride, scale=None, out=None):
+    assert D in (64, 96, 128, 160) and Skv_alloc % 8 == 0 and Skv_alloc >= Skv
+    for s_ in (q_row_stride, k_row_stride, q_batch_stride, k_batch_stride, vt_ld, vt_batch_stride):
+        assert s_ % 8 == 0, "C ABI: attention strides % 8"
+    qq = q.as_strided((B, H, Sq, D), (q_batch_stride, D, q_row_stride, 1)).float()
+    kk = k.as_strided((B, H, Skv, D), (k_batch_stride, D, k_row_stride, 1)).float()
+    vv = vt.as_strided((B, H, D, Skv), (vt_batch_stride, D * vt_ld, vt_ld, 1)).float()
+    p = torch.softmax(qq @ kk.transpose(2, 3) * (D ** -0.5 if scale is None else scale), dim=-1)
+    o = (p @ vv.transpose(2, 3)).permute(0, 2, 1, 3).reshape(B * Sq, H * D)
+    return _store(o, out)
+
+
+def group_norm_nhwc(x, gamma, beta, groups, eps, silu=False, x2=None):
+    if x2 is not None:
+        x = torch.cat([x, x2], -1)
+    shp = x.shape
+    B, C = shp[0], shp[-1]
+    y = F.group_norm(x.float().reshape(B, -1, C).transpose(1, 2), groups, gamma.float(), beta.float(), eps).transpose(1, 2)
+    y = y.to(bf16)
+    if silu:
+        y = F.silu(y.float()).to(bf16)
+    return y.reshape(shp).contiguous()
+
+
+def layer_norm(x, gamma, beta, eps, *, mod_scale=None, mod_shift=None, rows_per_batch=0):
+    M, C = x.shape
+    y = F.layer_norm(x.float(), (C,), None if gamma is None else gamma.float(), None if beta is None else beta.float(), eps)
+    if mod_scale is not None:
+        bidx = torch.arange(M) // rows_per_batch
+        if mod_scale.dtype == bf16:
+            y = y.to(bf16).float()
+        y = y * (1 + mod_scale.float()[bidx]) + mod_shift.float()[bidx]
+    return y.to(bf16)
+
+
+def rmsnorm_rope_(x, *, heads, head_dim, col_offsets, weights=None, eps=1e-6, cos=None, sin=None, rope_row0=0,
+                  rows_per_batch=0, norm="per_head"):
+    rows = x.shape[0]
+    rpb = rows_per_batch or rows
+    C = heads * head_dim
+    for j, off in enumerate(col_offsets):
+        blk = x[:, off:off + C].float().view(rows, heads, head_dim)
+        w = weights[j] if weights is not None else None
+        if norm == "per_head":
+            blk = blk * torch.rsqrt(blk.pow(2).mean(-1, keepdim=True) + eps)
+            if w is not None:
+                blk = blk * w.float().view(1, 1, head_dim)
+            blk = blk.to(bf16).float()
+        elif norm == "across_heads":
+            blk = blk * torch.rsqrt(blk.pow(2).mean((-2, -1), keepdim=True) + eps)
+            if w is not None:
+                blk = blk * w.float().view(1, heads, head_dim)
+            blk = blk.to(bf16).float()
+        else:
+            assert norm == "none"
+        if cos is not None:
+            r = rope_row0 + (torch.arange(rows) % rpb)
+            c, s_ = cos[r][:, None, :], sin[r][:, None, :]
+            ev, od = blk[..., 0::2], blk[..., 1::2]
+            o = torch.empty_like(blk)
+            o[..., 0::2] = ev * c[..., 0::2] - od * s_[..., 0::2]
+            o[..., 1::2] = od * c[..., 1::2] + ev * s_[..., 1::2]
+            blk = o
+        x[:, off:off + C] = blk.reshape(rows, C).to(bf16)
+    return x
+
+
+def timestep_embedding(t, dim, *, batch, flip_sin_to_cos, shift, scale=1.0, max_period=10000.0, table=None, step_idx=None,
+                       out_f32=False):
+    import math
+    if t is None:
+        t = table.view(-1, 8)[int(step_idx), 7].reshape(1)
+    t = t.float().reshape(-1).expand(batch) if t.numel() == 1 else t.float().reshape(-1)
+    half = dim // 2
+    e = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - shift))
+    a = scale * t[:, None] * e[None, :]
+    emb = torch.cat([torch.sin(a), torch.cos(a)], -1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], -1)
+    return emb if out_f32 else emb.to(bf16)
+
+
+def conv_thin_out(x, w, bias, *, out_f32=False):
+    B, H, W_, C = x.shape
+    co = w.shape[0]
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, C).permute(0, 3, 1, 2),
+                 None if bias is None else bias.float(), padding=1)
+    return y.contiguous() if out_f32 else y.to(bf16).contiguous()
+
+
+def bcast_add_f32(a, m):
+    return a.float()[None, :] + m.float()
+
+
+def patchify3d(x, patch):
+    B, C, Fr, H, W_ = x.shape
+    pt, ph, pw = patch
+    y = x.view(B, C, Fr // pt, pt, H // ph, ph, W_ // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    return y.reshape(-1, C * pt * ph * pw).contiguous()
+
+
+def unpatchify3d(tok, shape, patch):
+    B, C, Fr, H, W_ = shape
+    pt, ph, pw = patch
+    y = tok.view(B, Fr // pt, H // ph, W_ // pw, pt, ph, pw, C).permute(0, 7, 1, 4, 2, 5, 3, 6)
+    return y.reshape(B, C, Fr, H, W_).contiguous()
+
+
+def transpose(x, out=None):
+    return _store(x.t().float(), out)
+
+
+def mul_scalar(x, s, rep=1):
+    return torch.cat([(x.float() * s).to(x.dtype)] * rep, 0)
+
+
+def require_hip(t, name, dtypes=(bf16,)):
+    if t.dtype not in dtypes:
+        raise ValueError(f"{name}: dtype {t.dtype}")
 
 
 def softmax_rows(scores, out=None):
@@ -86,11 +266,17 @@ def frames_to_ncthw(x, *, batch, channels, lo=-1.0, hi=1.0, out_f32=False):
 
 
 def conv_thin_in(x, w, bias, *, ksize, in_nchw, in_div=1.0, in_add=0.0):
-    assert ksize == 1 and in_nchw and in_div == 1.0 and in_add == 0.0 and x.shape[1] <= 16 and w.shape[0] % 8 == 0
-    y = torch.einsum("bchw,oc->bhwo", x.float(), w.float())
-    if bias is not None:
-        y = y + bias.float()
-    return y.to(bf16).contiguous()
+    assert w.shape[0] % 8 == 0
+    xi = x.float() if in_nchw else x.float().permute(0, 3, 1, 2)
+    assert xi.shape[1] <= 16
+    if in_div != 1.0:
+        xi = (x.to(bf16) / in_div).float() if in_nchw else (x.to(bf16) / in_div).float().permute(0, 3, 1, 2)
+    if in_add != 0.0:
+        xi = (xi.to(bf16) + in_add).float()
+    co, cin = w.shape[0], xi.shape[1]
+    wt = w.float().view(co, ksize, ksize, cin).permute(0, 3, 1, 2) if ksize == 3 else w.float().view(co, cin, 1, 1)
+    y = F.conv2d(xi, wt, None if bias is None else bias.float(), padding=(ksize - 1) // 2)
+    return y.permute(0, 2, 3, 1).to(bf16).contiguous()
 
 
 def cast_f32_bf16(x, rep=1):
@@ -99,6 +285,8 @@ def cast_f32_bf16(x, rep=1):
 
 def install(monkeypatch, ops_module):
     """Replace the kernels behind ``ops_module`` with the stand-ins above (pack_* helpers are pure torch and stay)."""
-    for name in ("conv2d_nhwc", "linear", "softmax_rows", "rmsnorm_channels", "permute_0213", "frames_to_ncthw",
-                 "conv_thin_in", "cast_f32_bf16"):
+    for name in ("conv2d_nhwc", "linear", "linear_small_m", "attention", "softmax_rows", "group_norm_nhwc", "layer_norm",
+                 "rmsnorm_rope_", "rmsnorm_channels", "timestep_embedding", "permute_0213", "frames_to_ncthw",
+                 "conv_thin_in", "conv_thin_out", "bcast_add_f32", "patchify3d", "unpatchify3d", "transpose",
+                 "mul_scalar", "cast_f32_bf16", "require_hip"):
         monkeypatch.setattr(ops_module, name, globals()[name])

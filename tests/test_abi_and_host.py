@@ -283,11 +283,13 @@ def test_wan_vae_host_logic_vs_reference(golden, monkeypatch):
     from diffusers_amd import init as dinit, ops
     from diffusers_amd.autoencoder_kl_wan import AutoencoderKLWan
     import ops_emulation
-    ops_emulation.install(monkeypatch, ops)
     g = golden("tiny_wan_vae")
     cfg = dinit.TINY_WAN_VAE
     sd = dinit.random_state_dict(dinit.wan_vae_decoder_param_shapes(cfg), seed=21)
     vae = AutoencoderKLWan(**cfg).load_state_dict(sd, device="cpu", strict=True)
+    with pytest.raises(ValueError):
+        vae.decode(torch.zeros((1, 16, 2, 4, 4)))            # CPU tensor: there is no fallback
+    ops_emulation.install(monkeypatch, ops)
     want = torch.from_numpy(g["video"])
     for z, dn in ((g["z"], False), (g["latents"], True)):
         video = vae._decode_one(torch.from_numpy(z)[0].to(torch.bfloat16), dn, True)
@@ -295,7 +297,5 @@ def test_wan_vae_host_logic_vs_reference(golden, monkeypatch):
         rel = float((video - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
         print(f"[host] tiny Wan VAE (denormalize={dn}): rel rms vs reference fp32 = {rel:.3e}")
         assert rel < 2.5e-2
-    with pytest.raises(ValueError):
-        vae.decode(torch.zeros((1, 16, 2, 4, 4)))            # CPU tensor: there is no fallback
     with pytest.raises(NotImplementedError):
         AutoencoderKLWan(is_residual=True)
