@@ -1,0 +1,117 @@
+// The drop-in boundary without Python or torch: plain HIP memory + the C ABI of include/diffusers_amd.h.
+//
+//   hipcc --offload-arch=gfx950 -Iinclude examples/abi_demo.cpp -Ldiffusers_amd/_C -ldiffusers_amd \
+//         -Wl,-rpath,$PWD/diffusers_amd/_C -o abi_demo && ./abi_demo
+//
+// 1. y = x W^T + b through da_gemm_bf16 (the F.linear call sites of the reference), checked
+//    against a host loop;  2. one fused classifier-free-guidance + EulerDiscrete step through da_euler_step
+//    (scheduling_euler_discrete.py:685-800 + pipeline_stable_diffusion_xl.py:1223-1225), checked the same way.
+// Exit code 0 = both match.  tests/test_abi_and_host.py compiles and links this file on every CPU run (no GPU needed for
+// that); running it needs an MI355X.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "diffusers_amd.h"
+
+static uint16_t f2bf(float f) {  // round to nearest even
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+#define HIP_OK(x)                                                              \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));             \
+      return 2;                                                                \
+    }                                                                          \
+  } while (0)
+
+int main() {
+  std::printf("libdiffusers_amd ABI version %d\n", da_version());
+  const int M = 200, N = 128, K = 256;
+  std::vector<uint16_t> x(M * K), w(N * K), b(N), y(M * N);
+  uint32_t s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+  for (auto& v : x) v = f2bf(rnd());
+  for (auto& v : w) v = f2bf(rnd() / 16.0f);
+  for (auto& v : b) v = f2bf(rnd());
+  void *dx, *dw, *db, *dy;
+  HIP_OK(hipMalloc(&dx, x.size() * 2));
+  HIP_OK(hipMalloc(&dw, w.size() * 2));
+  HIP_OK(hipMalloc(&db, b.size() * 2));
+  HIP_OK(hipMalloc(&dy, y.size() * 2));
+  HIP_OK(hipMemcpy(dx, x.data(), x.size() * 2, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(db, b.data(), b.size() * 2, hipMemcpyHostToDevice));
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+
+  da_gemm_params p;
+  std::memset(&p, 0, sizeof p);
+  p.A = dx, p.W = dw, p.C = dy, p.bias = db;
+  p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N;
+  p.alpha = 1.0f, p.out_scale = 1.0f, p.act = DA_ACT_NONE;
+  p.tile = DA_TILE_AUTO, p.staging = DA_STAGE_LDS_DIRECT;
+  int rc = da_gemm_bf16(&p, stream);
+  if (rc != DA_OK) {
+    std::fprintf(stderr, "da_gemm_bf16: %d (%s)\n", rc, da_last_error());
+    return 1;
+  }
+  HIP_OK(hipStreamSynchronize(stream));
+  HIP_OK(hipMemcpy(y.data(), dy, y.size() * 2, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      float acc = bf2f(b[n]);
+      for (int k = 0; k < K; ++k) acc += bf2f(x[m * K + k]) * bf2f(w[n * K + k]);
+      worst = std::fmax(worst, std::fabs(bf2f(y[m * N + n]) - acc) / (1.0 + std::fabs(acc)));
+    }
+  std::printf("linear %dx%dx%d: worst relative error %.3e\n", M, N, K, worst);
+  if (!(worst < 1e-2)) return 1;
+
+  // fused CFG + Euler step on fp32 latents: table row = {sigma, sigma_next, dt, sqrt(sigma^2 + 1), -, -, -, timestep}
+  const int n = 4 * 64 * 64;
+  std::vector<float> lat(n), eps2(2 * n), out(n), table(8, 0.f);
+  for (auto& v : lat) v = rnd();
+  for (auto& v : eps2) v = rnd();
+  table[0] = 14.6f, table[1] = 12.9f, table[2] = table[1] - table[0];
+  void *dl, *de, *dt;
+  int* dstep;
+  HIP_OK(hipMalloc(&dl, n * 4));
+  HIP_OK(hipMalloc(&de, 2 * n * 4));
+  HIP_OK(hipMalloc(&dt, 8 * 4));
+  HIP_OK(hipMalloc((void**)&dstep, 4));
+  HIP_OK(hipMemcpy(dl, lat.data(), n * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(de, eps2.data(), 2 * n * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dt, table.data(), 8 * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemset(dstep, 0, 4));
+  const float g = 5.0f;
+  rc = da_euler_step(de, dl, dl, (const float*)dt, dstep, /*cfg=*/1, g, n, DA_DTYPE_F32, stream);
+  if (rc != DA_OK) {
+    std::fprintf(stderr, "da_euler_step: %d\n", rc);
+    return 1;
+  }
+  HIP_OK(hipStreamSynchronize(stream));
+  HIP_OK(hipMemcpy(out.data(), dl, n * 4, hipMemcpyDeviceToHost));
+  worst = 0;
+  for (int i = 0; i < n; ++i) {
+    const float e = eps2[i] + g * (eps2[n + i] - eps2[i]);              // uncond + g (cond - uncond)
+    const float want = lat[i] + e * table[2];                            // x + derivative * dt, derivative = eps
+    worst = std::fmax(worst, std::fabs(out[i] - want));
+  }
+  std::printf("euler CFG step on %d elements: worst absolute error %.3e\n", n, worst);
+  return worst < 1e-3 ? 0 : 1;
+}

@@ -299,3 +299,22 @@ def test_wan_vae_host_logic_vs_reference(golden, monkeypatch):
         assert rel < 2.5e-2
     with pytest.raises(NotImplementedError):
         AutoencoderKLWan(is_residual=True)
+
+
+def test_cpp_abi_example_compiles_and_links(tmp_path):
+    """examples/abi_demo.cpp drives the C ABI from plain C++ (hipMalloc'd memory, no Python, no torch types): it must
+    compile against include/diffusers_amd.h and link against the built library.  Running it needs an MI355X."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    from diffusers_amd import build as B
+    lib = B.build_extension()
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "abi_demo"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", f"-I{root / 'include'}", str(root / "examples" / "abi_demo.cpp"),
+                        f"-L{lib.parent}", "-ldiffusers_amd", f"-Wl,-rpath,{lib.parent}", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert exe.exists()
