@@ -303,6 +303,8 @@ class FluxPipeline:
                  text_encoder_2=None, tokenizer_2=None, transformer: FluxTransformer2DModel = None, image_encoder=None,
                  feature_extractor=None):
         self.scheduler, self.vae, self.transformer = scheduler, vae, transformer
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer          # optional caller-side transformers modules
+        self.text_encoder_2, self.tokenizer_2 = text_encoder_2, tokenizer_2
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
         self.default_sample_size = 128
         self._graph = None
@@ -390,10 +392,20 @@ class FluxPipeline:
                  latents: Optional[torch.Tensor] = None, prompt_embeds=None, pooled_prompt_embeds=None,
                  negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, output_type: str = "pt",
                  return_dict: bool = True, max_sequence_length: int = 512, use_graph: bool = True):
-        if prompt is not None or prompt_2 is not None:
-            raise ValueError("text encoders are outside the HIP hot path: pass `prompt_embeds`/`pooled_prompt_embeds`")
+        if prompt is not None:
+            if prompt_embeds is not None:
+                raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one "
+                                 "of the two.")
+            if None in (self.tokenizer, self.text_encoder, self.tokenizer_2, self.text_encoder_2):
+                raise ValueError("`prompt=` needs the pipeline's CLIP and T5 tokenizers / encoders; without them pass "
+                                 "`prompt_embeds` and `pooled_prompt_embeds`")
+            from .text_encoding import encode_prompt_flux
+            prompt_embeds, pooled_prompt_embeds, _ = encode_prompt_flux(
+                self.tokenizer, self.text_encoder, self.tokenizer_2, self.text_encoder_2, prompt, prompt_2, self.device,
+                num_images_per_prompt, max_sequence_length)
         if prompt_embeds is None or pooled_prompt_embeds is None:
-            raise ValueError("Provide `prompt_embeds` and `pooled_prompt_embeds`.")
+            raise ValueError("Provide either `prompt` (with the text encoders given to the pipeline) or `prompt_embeds` "
+                             "and `pooled_prompt_embeds`.")
         if negative_prompt_embeds is not None or negative_pooled_prompt_embeds is not None or negative_prompt is not None:
             raise NotImplementedError("true-CFG (negative prompts) is not on the FLUX.1-schnell hot path")
         dev = self.device
@@ -454,6 +466,7 @@ class WanPipeline:
         if transformer_2 is not None or boundary_ratio is not None or expand_timesteps:
             raise NotImplementedError("Wan 2.2 two-stage / TI2V options are not on the BASELINE hot path")
         self.scheduler, self.transformer, self.vae = scheduler, transformer, vae
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer          # optional caller-side transformers modules
         self.vae_scale_factor_temporal, self.vae_scale_factor_spatial = 4, 8
         self._graph = None
         self._graph_key = None
@@ -522,11 +535,20 @@ class WanPipeline:
                  num_inference_steps: int = 50, guidance_scale: float = 5.0, num_videos_per_prompt: int = 1,
                  generator=None, latents: Optional[torch.Tensor] = None, prompt_embeds=None,
                  negative_prompt_embeds=None, output_type: str = "latent", return_dict: bool = True,
-                 use_graph: bool = True):
-        if prompt is not None or negative_prompt is not None:
-            raise ValueError("text encoders are outside the HIP hot path: pass `prompt_embeds`")
+                 use_graph: bool = True, max_sequence_length: int = 512):
+        if prompt is not None:
+            if prompt_embeds is not None:
+                raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one "
+                                 "of the two.")
+            if self.tokenizer is None or self.text_encoder is None:
+                raise ValueError("`prompt=` needs the pipeline's tokenizer / text_encoder (UMT5); without them pass "
+                                 "`prompt_embeds`")
+            from .text_encoding import encode_prompt_wan
+            prompt_embeds, negative_prompt_embeds = encode_prompt_wan(
+                self.tokenizer, self.text_encoder, prompt, negative_prompt, guidance_scale > 1.0, num_videos_per_prompt,
+                max_sequence_length, self.device)
         if prompt_embeds is None:
-            raise ValueError("Provide `prompt_embeds`.")
+            raise ValueError("Provide either `prompt` (with the text encoder given to the pipeline) or `prompt_embeds`.")
         if output_type not in ("latent", "pt", "raw", "np"):
             raise ValueError("output_type must be 'latent', 'raw', 'pt' or 'np'")
         if output_type != "latent" and self.vae is None:

@@ -133,3 +133,76 @@ def encode_prompt_sdxl(tokenizers: Sequence, text_encoders: Sequence, prompt: Pr
     pe = _repeat(pe.to(device=device, dtype=dtype), num_images_per_prompt)
     pooled = _repeat(pooled.to(device=device, dtype=dtype), num_images_per_prompt)
     return pe, ne, pooled, npooled
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# T5-conditioned families
+# ----------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def encode_prompt_flux(tokenizer, text_encoder, tokenizer_2, text_encoder_2, prompt: Prompt, prompt_2: Optional[Prompt] = None,
+                       device=None, num_images_per_prompt: int = 1, max_sequence_length: int = 512,
+                       dtype: torch.dtype = torch.bfloat16):
+    """``FluxPipeline.encode_prompt`` (pipelines/flux/pipeline_flux.py:219-399): the CLIP encoder's pooled output on
+    ``prompt`` and the T5 encoder's last hidden state on ``prompt_2`` (max_length padding, no attention mask), plus the
+    all-zero text position ids.  Returns (prompt_embeds, pooled_prompt_embeds, text_ids)."""
+    p1 = _as_list(prompt)
+    p2 = _as_list(prompt_2) if prompt_2 else p1
+    ids = tokenizer(p1, padding="max_length", max_length=tokenizer.model_max_length, truncation=True,
+                    return_overflowing_tokens=False, return_length=False, return_tensors="pt").input_ids
+    pooled = text_encoder(ids.to(device), output_hidden_states=False).pooler_output
+    pooled = _repeat(pooled.to(device=device, dtype=dtype), num_images_per_prompt)
+    ids2 = tokenizer_2(p2, padding="max_length", max_length=max_sequence_length, truncation=True, return_length=False,
+                       return_overflowing_tokens=False, return_tensors="pt").input_ids
+    untruncated = tokenizer_2(p2, padding="longest", return_tensors="pt").input_ids
+    if untruncated.shape[-1] >= ids2.shape[-1] and not torch.equal(ids2, untruncated):
+        logger.warning(f"part of the prompt was truncated because `max_sequence_length` is {max_sequence_length} tokens")
+    pe = text_encoder_2(ids2.to(device), output_hidden_states=False)[0]
+    pe = _repeat(pe.to(device=device, dtype=dtype), num_images_per_prompt)
+    text_ids = torch.zeros(pe.shape[1], 3, device=device, dtype=dtype)
+    return pe, pooled, text_ids
+
+
+def prompt_clean(text: str) -> str:
+    """pipelines/wan/pipeline_wan.py:78-93: ftfy (when installed), double html-unescape, whitespace collapse."""
+    import html
+    import re
+    try:
+        import ftfy
+        text = ftfy.fix_text(text)
+    except ImportError:
+        pass
+    text = html.unescape(html.unescape(text)).strip()
+    return re.sub(r"\s+", " ", text).strip()
+
+
+@torch.no_grad()
+def encode_prompt_wan(tokenizer, text_encoder, prompt: Prompt, negative_prompt: Optional[Prompt] = None,
+                      do_classifier_free_guidance: bool = True, num_videos_per_prompt: int = 1,
+                      max_sequence_length: int = 226, device=None, dtype: torch.dtype = torch.bfloat16):
+    """``WanPipeline.encode_prompt`` (pipelines/wan/pipeline_wan.py:158-279): UMT5 last hidden state WITH the attention
+    mask, positions past each prompt's length zeroed (trim + re-pad, :187-190).  Returns (prompt_embeds,
+    negative_prompt_embeds)."""
+    def t5(texts):
+        texts = [prompt_clean(u) for u in texts]
+        tok = tokenizer(texts, padding="max_length", max_length=max_sequence_length, truncation=True, add_special_tokens=True,
+                        return_attention_mask=True, return_tensors="pt")
+        mask = tok.attention_mask
+        h = text_encoder(tok.input_ids.to(device), mask.to(device)).last_hidden_state.to(device=device, dtype=dtype)
+        keep = (torch.arange(h.shape[1])[None, :] < mask.gt(0).sum(dim=1)[:, None]).to(h.device)
+        return _repeat(h * keep[..., None].to(h.dtype), num_videos_per_prompt)
+
+    prompt_l = _as_list(prompt)
+    pe = t5(prompt_l)
+    ne = None
+    if do_classifier_free_guidance:
+        neg = negative_prompt or ""
+        neg_l = len(prompt_l) * [neg] if isinstance(neg, str) else list(neg)
+        # (the reference compares against the LIST form of `prompt`, so a str negative with a list prompt is accepted)
+        if not isinstance(neg_l, list):
+            raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(neg_l)} != {list}.")
+        if len(neg_l) != len(prompt_l):
+            raise ValueError(f"`negative_prompt`: {neg_l} has batch size {len(neg_l)}, but `prompt`: {prompt_l} has batch "
+                             f"size {len(prompt_l)}. Please make sure that passed `negative_prompt` matches the batch size "
+                             "of `prompt`.")
+        ne = t5(neg_l)
+    return pe, ne

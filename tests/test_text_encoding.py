@@ -106,3 +106,70 @@ def test_negative_prompt_errors_match_reference():
         encode_prompt_sd(tok, enc, "a cat", "cpu", negative_prompt=["cat"])
     with pytest.raises(ValueError):
         encode_prompt_sd(tok, enc, ["a cat", "hello"], "cpu", negative_prompt=["cat"])
+
+
+def _t5_tokenizer(max_len=24):
+    """In-memory word-level tokenizer with T5's special tokens (<pad> = 0, </s> appended)."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    words = ["<pad>", "</s>", "<unk>", "hello", "a", "cat", "on", "the", "mat", "&", "red"]
+    tk = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.post_processor = processors.TemplateProcessing(single="$A </s>", special_tokens=[("</s>", 1)])
+    return PreTrainedTokenizerFast(tokenizer_object=tk, pad_token="<pad>", eos_token="</s>", unk_token="<unk>",
+                                   model_max_length=max_len), len(words)
+
+
+def _t5(vocab, d=32, seed=0, umt5=False):
+    from transformers import T5Config, T5EncoderModel, UMT5Config, UMT5EncoderModel
+    torch.manual_seed(seed)
+    kw = dict(vocab_size=vocab, d_model=d, d_kv=8, d_ff=64, num_layers=2, num_heads=4, relative_attention_num_buckets=8,
+              relative_attention_max_distance=16, dropout_rate=0.0, pad_token_id=0, eos_token_id=1)
+    return (UMT5EncoderModel(UMT5Config(**kw)) if umt5 else T5EncoderModel(T5Config(**kw))).eval()
+
+
+@pytest.mark.parametrize("kw", [dict(prompt="hello a cat"), dict(prompt=["hello", "a cat on the mat"], prompt_2=["red cat", "hello"],
+                                                                 num_images_per_prompt=2),
+                                dict(prompt="a cat", max_sequence_length=8)])
+def test_flux_encode_prompt_matches_reference(ref, kw):
+    from diffusers_amd.text_encoding import encode_prompt_flux
+    tok, nv = _tokenizer()
+    tok2, nv2 = _t5_tokenizer()
+    clip, t5 = _clip(nv, 32, seed=3), _t5(nv2, seed=4)
+    tr = ref.FluxTransformer2DModel(patch_size=1, in_channels=4, num_layers=1, num_single_layers=1, attention_head_dim=16,
+                                    num_attention_heads=2, joint_attention_dim=32, pooled_projection_dim=32, axes_dims_rope=[4, 4, 8])
+    vae = ref.AutoencoderKL(block_out_channels=(32,), in_channels=3, out_channels=3, latent_channels=1,
+                            down_block_types=("DownEncoderBlock2D",), up_block_types=("UpDecoderBlock2D",))
+    pipe = ref.FluxPipeline(scheduler=ref.FlowMatchEulerDiscreteScheduler(), vae=vae, text_encoder=clip, tokenizer=tok,
+                            text_encoder_2=t5, tokenizer_2=tok2, transformer=tr)
+    args = dict(num_images_per_prompt=1, max_sequence_length=16)
+    args.update(kw)
+    with torch.no_grad():                                   # the reference's __call__ runs under no_grad as well
+        want = pipe.encode_prompt(device="cpu", **args)
+    got = encode_prompt_flux(tok, clip, tok2, t5, device="cpu", dtype=torch.float32, **args)
+    for g_, w_ in zip(got, want):
+        assert g_.shape == w_.shape and torch.equal(g_, w_)
+
+
+@pytest.mark.parametrize("kw", [dict(prompt="hello a cat"), dict(prompt=["hello   a &amp; cat", "a cat on the mat"],
+                                                                 negative_prompt=["red", "hello"], num_videos_per_prompt=2),
+                                dict(prompt=["a cat", "hello"], negative_prompt="red cat"),
+                                dict(prompt="a cat on the mat", do_classifier_free_guidance=False, max_sequence_length=6)])
+def test_wan_encode_prompt_matches_reference(ref, kw):
+    from diffusers_amd.text_encoding import encode_prompt_wan
+    tok, nv = _t5_tokenizer()
+    enc = _t5(nv, seed=5, umt5=True)
+    tr = ref.WanTransformer3DModel(patch_size=(1, 2, 2), num_attention_heads=2, attention_head_dim=12, in_channels=16,
+                                   out_channels=16, text_dim=32, freq_dim=32, ffn_dim=32, num_layers=1, rope_max_seq_len=32)
+    vae = ref.AutoencoderKLWan(base_dim=8, z_dim=16, dim_mult=[1, 1, 1, 1], num_res_blocks=1, temperal_downsample=[False, True, True])
+    pipe = ref.WanPipeline(tokenizer=tok, text_encoder=enc, vae=vae, scheduler=ref.FlowMatchEulerDiscreteScheduler(shift=3.0),
+                           transformer=tr)
+    args = dict(do_classifier_free_guidance=True, num_videos_per_prompt=1, max_sequence_length=12)
+    args.update(kw)
+    with torch.no_grad():
+        want_p, want_n = pipe.encode_prompt(device="cpu", dtype=torch.float32, **args)
+    got_p, got_n = encode_prompt_wan(tok, enc, device="cpu", dtype=torch.float32, **args)
+    assert got_p.shape == want_p.shape and torch.equal(got_p, want_p)
+    assert (got_n is None and want_n is None) or torch.equal(got_n, want_n)
+    with pytest.raises(ValueError):
+        encode_prompt_wan(tok, enc, ["a cat", "hello"], negative_prompt=["red"], device="cpu")
