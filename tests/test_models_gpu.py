@@ -387,3 +387,33 @@ def test_sdxl_pipeline_accepts_prompts_with_caller_text_encoders(golden):
         pipe(prompt="a cat", prompt_embeds=pe, **kw)
     with pytest.raises(ValueError):
         factory.build_sdxl_pipeline(device=DEV, tiny=True)(prompt="a cat", **kw)      # no encoders given
+
+
+def test_flux_and_wan_pipelines_accept_prompts_with_caller_text_encoders(golden):
+    """`prompt=` through the caller's CLIP / T5 / UMT5 modules equals passing the embeddings the front end computes."""
+    from test_text_encoding import _clip, _t5, _t5_tokenizer, _tokenizer
+    from diffusers_amd import factory
+    from diffusers_amd.text_encoding import encode_prompt_flux, encode_prompt_wan
+    tok, nv = _tokenizer()
+    tok2, nv2 = _t5_tokenizer()
+    # Flux (tiny: joint_attention_dim 64, pooled_projection_dim 64)
+    g = golden("tiny_flux_pipeline")
+    pipe = factory.build_flux_pipeline(device=DEV, tiny=True)
+    pipe.tokenizer, pipe.text_encoder = tok, _clip(nv, 64, seed=3).to(DEV, bf16)
+    pipe.tokenizer_2, pipe.text_encoder_2 = tok2, _t5(nv2, d=64, seed=4).to(DEV, bf16)
+    kw = dict(num_inference_steps=2, guidance_scale=0.0, height=int(g["height"]), width=int(g["height"]), output_type="raw",
+              max_sequence_length=16)
+    a = pipe(prompt="hello a cat", latents=t(g, "latents").clone(), **kw).images
+    pe, pp, _ = encode_prompt_flux(tok, pipe.text_encoder, tok2, pipe.text_encoder_2, "hello a cat", device=DEV,
+                                   max_sequence_length=16)
+    b = pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, latents=t(g, "latents").clone(), **kw).images
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    # Wan (tiny: text_dim 64)
+    gw = golden("tiny_wan_pipeline")
+    wpipe = factory.build_wan_pipeline(device=DEV, tiny=True, seed=9)
+    wpipe.tokenizer, wpipe.text_encoder = tok2, _t5(nv2, d=64, seed=5, umt5=True).to(DEV, bf16)
+    wkw = dict(num_inference_steps=2, guidance_scale=5.0, height=64, width=64, num_frames=9, max_sequence_length=16)
+    wa = wpipe(prompt="a cat on the mat", negative_prompt="red", latents=t(gw, "latents"), **wkw).images.clone()
+    wpe, wne = encode_prompt_wan(tok2, wpipe.text_encoder, "a cat on the mat", "red", device=DEV, max_sequence_length=16)
+    wb = wpipe(prompt_embeds=wpe, negative_prompt_embeds=wne, latents=t(gw, "latents"), **wkw).images
+    assert wpe.shape == (1, 16, 64) and torch.isfinite(wa.float()).all() and torch.equal(wa, wb)
