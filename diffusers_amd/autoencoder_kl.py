@@ -7,13 +7,12 @@ path is on the BASELINE hot path; ``encode`` raises.  Input latents NCHW bf16, o
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 
-from . import _lib as L
 from . import ops
-from .layers import Conv3x3, GroupNorm, Linear, ResnetBlock2D, Upsample2D, Weights
+from .layers import GroupNorm, ResnetBlock2D, Upsample2D, Weights
 from .unet_2d_condition import FrozenConfig
 
 bf16 = torch.bfloat16

@@ -7,7 +7,6 @@ images [B][H][W][C], tokens [B*S][C].
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, Optional
 
 import torch

@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from .autoencoder_kl import AutoencoderKL
-from .schedulers import (DDIMScheduler, DDPMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler,
+from .schedulers import (DDPMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler,
                          UniPCMultistepScheduler)
 from .transformer_flux import FluxTransformer2DModel
 from .transformer_wan import WanTransformer3DModel

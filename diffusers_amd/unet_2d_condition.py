@@ -8,13 +8,12 @@ a hand-written HIP kernel (see layers.py / csrc/).
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional, Tuple, Union
+from typing import Any, Dict, List, Optional
 
 import torch
 
-from . import _lib as L
 from . import ops
-from .layers import (Conv3x3, Downsample2D, GroupNorm, Linear, ResnetBlock2D, TimestepEmbedding, Transformer2DModel,
+from .layers import (Downsample2D, GroupNorm, ResnetBlock2D, TimestepEmbedding, Transformer2DModel,
                      Upsample2D, Weights, pad_encoder_states)
 
 bf16 = torch.bfloat16

@@ -1,6 +1,5 @@
 """CPU: the C-ABI library builds/loads and exports every symbol include/diffusers_amd.h declares; host-side logic of the
 product (schedule tables, parameter inventories, weight packing, argument validation) -- no kernel is launched."""
-import ctypes
 import re
 from pathlib import Path
 

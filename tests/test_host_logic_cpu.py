@@ -2,7 +2,6 @@
 (fused Q/K, V^T products, GEGLU interleave, head / channel zero padding, folded biases), call sequencing and strides are
 checked against the reference's golden outputs without a GPU.  bf16 activations vs the fp32 reference: the same 2.5e-2
 relative-RMS bound the GPU parity tests use.  The kernels themselves are only ever tested on the GPU."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,13 +1,11 @@
 """GPU parity tests of every HIP kernel, called through the C ABI (diffusers_amd.ops -> ctypes -> libdiffusers_amd.so)
 and checked against plain PyTorch fp32 references of the same op / the oracle restatement / the golden vectors."""
-import math
-
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_close_bf16, rel_rms
+from conftest import assert_close_bf16
 
 pytestmark = pytest.mark.gpu
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close_bf16, rel_rms
+from conftest import rel_rms
 
 pytestmark = pytest.mark.gpu
 bf16 = torch.bfloat16
