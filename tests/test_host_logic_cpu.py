@@ -2,6 +2,7 @@
 (fused Q/K, V^T products, GEGLU interleave, head / channel zero padding, folded biases), call sequencing and strides are
 checked against the reference's golden outputs without a GPU.  bf16 activations vs the fp32 reference: the same 2.5e-2
 relative-RMS bound the GPU parity tests use.  The kernels themselves are only ever tested on the GPU."""
+import numpy as np
 import pytest
 import torch
 
@@ -103,3 +104,75 @@ def test_unet2d_ddpm(golden):
     rr = _rel(y, torch.from_numpy(g["out"]))
     print(f"[host] tiny UNet2DModel: rel rms = {rr:.3e}")
     assert rr < TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# whole pipelines (eager launch path): latent scaling, CFG batching order, conditioning precompute, scheduler tables,
+# decode + post-processing -- against the reference pipelines' golden outputs
+# ----------------------------------------------------------------------------------------------------------------------
+def _psnr01(a, b):
+    return 10 * np.log10(1.0 / max(float((a - b).pow(2).mean()), 1e-12))
+
+
+def test_sdxl_pipeline(golden):
+    from diffusers_amd import factory
+    g = golden("tiny_sdxl_pipeline")
+    pipe = factory.build_sdxl_pipeline(device="cpu", tiny=True, seed=0)
+    kw = dict(prompt_embeds=_t(g, "prompt_embeds"), negative_prompt_embeds=_t(g, "negative_prompt_embeds"),
+              pooled_prompt_embeds=_t(g, "pooled"), negative_pooled_prompt_embeds=_t(g, "negative_pooled"),
+              num_inference_steps=4, guidance_scale=5.0, height=128, width=128, use_graph=False)
+    lat = pipe(latents=_t(g, "latents").clone(), output_type="latent", **kw).images
+    img = pipe(latents=_t(g, "latents").clone(), output_type="pt", **kw).images
+    rr = _rel(lat, torch.from_numpy(g["final_latents"]))
+    ps = _psnr01(img, (torch.from_numpy(g["image"]) * 0.5 + 0.5).clamp(0, 1))
+    print(f"[host] tiny SDXL pipeline: latents rel rms {rr:.3e}, image PSNR {ps:.1f} dB")
+    assert rr < 4e-2 and ps >= 35.0
+    pil = pipe(latents=_t(g, "latents").clone(), output_type="pil", **kw).images
+    assert len(pil) == 1 and pil[0].size == (32, 32)
+
+
+def test_flux_pipeline(golden):
+    from diffusers_amd import factory
+    g = golden("tiny_flux_pipeline")
+    pipe = factory.build_flux_pipeline(device="cpu", tiny=True, seed=5)
+    size = int(g["height"])
+    kw = dict(prompt_embeds=_t(g, "prompt_embeds"), pooled_prompt_embeds=_t(g, "pooled"), num_inference_steps=4,
+              guidance_scale=0.0, height=size, width=size, max_sequence_length=16, use_graph=False)
+    lat = pipe(latents=_t(g, "latents"), output_type="latent", **kw).images
+    assert np.allclose(pipe.scheduler.timesteps.numpy(), g["timesteps"]) and np.allclose(pipe.scheduler.sigmas.numpy(), g["sigmas"])
+    img = pipe(latents=_t(g, "latents"), output_type="raw", **kw).images
+    rr = _rel(lat, torch.from_numpy(g["final_latents"]))
+    ps = _psnr01((img.float() * 0.5 + 0.5).clamp(0, 1), (torch.from_numpy(g["image"]) * 0.5 + 0.5).clamp(0, 1))
+    print(f"[host] tiny Flux pipeline: latents rel rms {rr:.3e}, image PSNR {ps:.1f} dB")
+    assert rr < 4e-2 and ps >= 35.0
+
+
+def test_wan_pipeline_flowmatch_and_unipc_with_decode(golden):
+    from diffusers_amd import factory
+    from diffusers_amd.schedulers import UniPCMultistepScheduler
+    g = golden("tiny_wan_pipeline")
+    pipe = factory.build_wan_pipeline(device="cpu", tiny=True, seed=9, with_vae=True)
+    kw = dict(prompt_embeds=_t(g, "prompt_embeds"), negative_prompt_embeds=_t(g, "negative_prompt_embeds"),
+              num_inference_steps=3, guidance_scale=float(g["guidance_scale"]), height=64, width=64, num_frames=9,
+              use_graph=False)
+    lat = pipe(latents=_t(g, "latents"), **kw).images
+    assert np.allclose(pipe.scheduler.timesteps.numpy(), g["timesteps"], rtol=1e-6)
+    rr = _rel(lat, torch.from_numpy(g["final_latents"]))
+    print(f"[host] tiny Wan CFG loop: latents rel rms {rr:.3e}")
+    assert lat.shape == (1, 16, 3, 8, 8) and rr < 4e-2
+    pipe.scheduler = UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=3.0)
+    video = pipe(latents=torch.from_numpy(g["latents"]), output_type="np", **kw).images
+    assert video.shape == (1, 9, 64, 64, 3) and video.dtype == np.float32
+    assert np.isfinite(video).all() and 0.0 <= video.min() and video.max() <= 1.0
+
+
+def test_ddpm_pipeline(golden):
+    from diffusers_amd import factory
+    g = golden("tiny_ddpm")
+    pipe = factory.build_ddpm_pipeline(device="cpu", tiny=True, seed=11)
+    img = pipe(batch_size=1, generator=torch.Generator().manual_seed(0), num_inference_steps=5, output_type="np",
+               use_graph=False).images
+    want = g["pipeline_image"]
+    ps = 10 * np.log10(1.0 / max(float(((img - want) ** 2).mean()), 1e-12))
+    print(f"[host] tiny DDPM pipeline: image PSNR {ps:.1f} dB")
+    assert img.shape == want.shape and ps >= 35.0
