@@ -176,3 +176,39 @@ def test_ddpm_pipeline(golden):
     ps = 10 * np.log10(1.0 / max(float(((img - want) ** 2).mean()), 1e-12))
     print(f"[host] tiny DDPM pipeline: image PSNR {ps:.1f} dB")
     assert img.shape == want.shape and ps >= 35.0
+
+
+def test_sd15_pipeline_vs_oracle_loop():
+    """StableDiffusionPipeline (DDIM, CFG 7.5) on the stand-ins vs the fp32 oracle loop written the reference's way
+    (pipeline_stable_diffusion.py:1038-1060: latents doubled, [uncond ; cond] embeddings, uncond + g (cond - uncond),
+    scheduler.step, then vae.decode(latents / scaling_factor))."""
+    from diffusers_amd import factory
+    from diffusers_amd.autoencoder_kl import _DEFAULTS as VD
+    from diffusers_amd.unet_2d_condition import _DEFAULTS as UD
+    from oracle import reference_math as R
+    from oracle import samplers as OS
+    pipe = factory.build_sd15_pipeline(device="cpu", tiny=True, seed=0)
+    gen = torch.Generator().manual_seed(5)
+    lat0 = torch.randn((1, 4, 16, 16), generator=gen).to(bf16)
+    pe = torch.randn((1, 7, 64), generator=gen).to(bf16)
+    ne = torch.randn((1, 7, 64), generator=gen).to(bf16)
+    img = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat0.clone(), num_inference_steps=4, guidance_scale=7.5,
+               height=32, width=32, output_type="raw", use_graph=False).images
+    ucfg, vcfg = dict(UD), dict(VD)
+    ucfg.update(dinit.TINY_SD15_UNET)
+    vcfg.update(dinit.TINY_VAE)
+    usd = {k: v.float() for k, v in dinit.random_state_dict(dinit.unet_param_shapes(pipe.unet.config), seed=0).items()}
+    vsd = {k: v.float() for k, v in dinit.random_state_dict(dinit.vae_decoder_param_shapes(pipe.vae.config), seed=1).items()}
+    sch = OS.DDIMOracle(**factory.SD15_SCHEDULER)
+    sch.set_timesteps(4)
+    assert np.array_equal(sch.timesteps.numpy(), pipe.scheduler.timesteps.numpy())
+    x = lat0.float() * sch.init_noise_sigma
+    ehs = torch.cat([ne, pe]).float()
+    with torch.no_grad():
+        for t_ in sch.timesteps:
+            eps = R.unet_forward(usd, ucfg, torch.cat([x, x]), float(t_), ehs, None)
+            x = sch.step(OS.cfg_combine(eps[:1], eps[1:], 7.5), t_, x)
+        want = R.vae_decode(vsd, vcfg, x / vcfg["scaling_factor"])
+    ps = _psnr01((img.float() * 0.5 + 0.5).clamp(0, 1), (want * 0.5 + 0.5).clamp(0, 1))
+    print(f"[host] tiny SD1.5 pipeline (4 DDIM steps, CFG 7.5): image PSNR vs fp32 oracle loop = {ps:.1f} dB")
+    assert img.shape == want.shape and ps >= 35.0
