@@ -130,6 +130,18 @@ class _SchedulerBase:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def _sigma_to_t(sigma, log_sigmas):
+    """Fractional training timestep whose log sigma equals ``log(sigma)`` (piecewise-linear inverse,
+    scheduling_euler_discrete.py:483-517)."""
+    log_sigma = np.log(np.maximum(sigma, 1e-10))
+    dists = log_sigma - log_sigmas[:, np.newaxis]
+    low_idx = np.cumsum((dists >= 0), axis=0).argmax(axis=0).clip(max=log_sigmas.shape[0] - 2)
+    high_idx = low_idx + 1
+    low, high = log_sigmas[low_idx], log_sigmas[high_idx]
+    w = np.clip((low - log_sigma) / (low - high), 0, 1)
+    return ((1 - w) * low_idx + w * high_idx).reshape(np.shape(sigma))
+
+
 class EulerDiscreteScheduler(_SchedulerBase):
     _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                      trained_betas=None, prediction_type="epsilon", interpolation_type="linear",
@@ -140,8 +152,11 @@ class EulerDiscreteScheduler(_SchedulerBase):
     def __init__(self, **kwargs):
         super().__init__(**kwargs)
         c = self.config
-        if c.use_karras_sigmas or c.use_exponential_sigmas or c.use_beta_sigmas or c.rescale_betas_zero_snr:
-            raise NotImplementedError("EulerDiscreteScheduler: karras/exponential/beta sigmas are not on the hot path")
+        if c.use_beta_sigmas or c.rescale_betas_zero_snr:
+            raise NotImplementedError("EulerDiscreteScheduler: beta sigmas / zero-SNR rescaling are not on the hot path")
+        if sum([bool(c.use_karras_sigmas), bool(c.use_exponential_sigmas)]) > 1:
+            raise ValueError("Only one of `config.use_beta_sigmas`, `config.use_exponential_sigmas`, "
+                             "`config.use_karras_sigmas` can be used.")
         if c.prediction_type != "epsilon" or c.timestep_type != "discrete" or c.interpolation_type != "linear":
             raise NotImplementedError("EulerDiscreteScheduler: only epsilon / discrete / linear interpolation")
         self.betas = _betas(c.beta_schedule, c.beta_start, c.beta_end, c.num_train_timesteps, c.trained_betas)
@@ -184,6 +199,19 @@ class EulerDiscreteScheduler(_SchedulerBase):
                              "'leading' or 'trailing'.")
         base = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sig = np.interp(ts, np.arange(0, len(base)), base)
+        if c.use_karras_sigmas or c.use_exponential_sigmas:
+            # a re-spaced sigma ladder between the interpolated extremes (scheduling_euler_discrete.py:446-452, :520-585);
+            # the model then sees fractional timesteps found by inverting log sigma(t) (:483-517).  Host tables only:
+            # the step kernel reads sigma / dt / timestep from the same table as before.
+            smin = c.sigma_min if c.sigma_min is not None else sig[-1].item()
+            smax = c.sigma_max if c.sigma_max is not None else sig[0].item()
+            if c.use_karras_sigmas:
+                rho = 7.0
+                ramp = np.linspace(0, 1, num_inference_steps)
+                sig = (smax ** (1 / rho) + ramp * (smin ** (1 / rho) - smax ** (1 / rho))) ** rho
+            else:
+                sig = np.exp(np.linspace(math.log(smax), math.log(smin), num_inference_steps))
+            ts = np.array([_sigma_to_t(s_, np.log(base)) for s_ in sig])
         if c.final_sigmas_type == "sigma_min":
             last = float(((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5)
         elif c.final_sigmas_type == "zero":

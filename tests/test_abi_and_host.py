@@ -100,7 +100,7 @@ def test_scheduler_error_behaviour():
     with pytest.raises(TypeError):
         S.EulerDiscreteScheduler(bogus=1)
     with pytest.raises(NotImplementedError):
-        S.EulerDiscreteScheduler(use_karras_sigmas=True)
+        S.EulerDiscreteScheduler(use_beta_sigmas=True)
 
 
 def test_param_inventory_counts():
@@ -317,3 +317,35 @@ def test_cpp_abi_example_compiles_and_links(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert exe.exists()
+
+
+def test_euler_karras_and_exponential_sigma_tables(golden, monkeypatch):
+    """`use_karras_sigmas` / `use_exponential_sigmas` only change the host tables (sigma ladder + fractional timesteps)
+    the step kernels read: bit-equal to the reference's (tests/golden/euler_karras.npz, oracle/make_golden_euler_karras.py)."""
+    from diffusers_amd import schedulers as S
+    sys_path_cases = {
+        "karras": dict(use_karras_sigmas=True),
+        "exponential": dict(use_exponential_sigmas=True),
+        "karras_minmax_trailing": dict(use_karras_sigmas=True, sigma_min=0.05, sigma_max=10.0, timestep_spacing="trailing"),
+        "karras_sigma_min_last": dict(use_karras_sigmas=True, final_sigmas_type="sigma_min"),
+    }
+
+    def fake_upload(self, rows, device):
+        self._table, self._step_dev = torch.from_numpy(rows), torch.zeros((), dtype=torch.int32)
+    monkeypatch.setattr(S._SchedulerBase, "_upload", fake_upload)
+    g = golden("euler_karras")
+    base = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1, timestep_spacing="leading")
+    for name, extra in sys_path_cases.items():
+        for n in (4, 25, 50):
+            sch = S.EulerDiscreteScheduler(**dict(base, **extra))
+            sch.set_timesteps(n, device="cpu")
+            assert np.array_equal(sch.sigmas.numpy(), g[f"{name}_{n}_sigmas"]), (name, n)
+            assert np.array_equal(sch.timesteps.numpy(), g[f"{name}_{n}_timesteps"]), (name, n)
+            assert np.float32(float(sch.init_noise_sigma)) == g[f"{name}_{n}_init_noise_sigma"]
+            t = sch._table.view(-1, 8)
+            assert torch.equal(t[:, 0], sch.sigmas[:-1]) and torch.equal(t[:, 1], sch.sigmas[1:])
+            assert torch.equal(t[:, 7], sch.timesteps.float())
+    with pytest.raises(ValueError):
+        S.EulerDiscreteScheduler(use_karras_sigmas=True, use_exponential_sigmas=True)
+    with pytest.raises(NotImplementedError):
+        S.EulerDiscreteScheduler(use_beta_sigmas=True)
