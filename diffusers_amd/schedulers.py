@@ -57,6 +57,17 @@ class _SchedulerBase:
         self._device = None
         self.num_inference_steps = None
 
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        """``SchedulerMixin.from_config`` (configuration_utils.py:179-260): build from another scheduler's ``config``
+        (a mapping; the reference's FrozenDict or this package's FrozenConfig).  Private entries (``_class_name``,
+        ``_diffusers_version`` ...) and options this class does not have are dropped, as the reference does when a config
+        is handed to a compatible scheduler class; ``kwargs`` override."""
+        src = dict(config)
+        src.update(kwargs)
+        known = {k: (tuple(v) if isinstance(v, list) else v) for k, v in src.items() if k in cls._defaults}
+        return cls(**known)
+
     # -- reference-compatible index bookkeeping (scheduling_euler_discrete.py:293-324, :640-683) --
     @property
     def step_index(self):

@@ -349,3 +349,20 @@ def test_euler_karras_and_exponential_sigma_tables(golden, monkeypatch):
         S.EulerDiscreteScheduler(use_karras_sigmas=True, use_exponential_sigmas=True)
     with pytest.raises(NotImplementedError):
         S.EulerDiscreteScheduler(use_beta_sigmas=True)
+
+
+def test_scheduler_from_config_round_trip_and_reference_config():
+    """`Scheduler.from_config(other.config)` -- the idiom for swapping schedulers -- incl. a reference-style config that
+    carries private keys and options of another scheduler class."""
+    from diffusers_amd import schedulers as S
+    a = S.EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                                 timestep_spacing="leading")
+    b = S.EulerDiscreteScheduler.from_config(a.config)
+    assert dict(b.config) == dict(a.config)
+    ref_like = dict(a.config, _class_name="EulerDiscreteScheduler", _diffusers_version="0.36.0", clip_sample=False,
+                    set_alpha_to_one=False, skip_prk_steps=True)
+    d = S.DDIMScheduler.from_config(ref_like)
+    assert d.config.beta_schedule == "scaled_linear" and d.config.clip_sample is False and d.config.steps_offset == 1
+    assert S.EulerDiscreteScheduler.from_config(ref_like, use_karras_sigmas=True).config.use_karras_sigmas is True
+    with pytest.raises(NotImplementedError):
+        S.EulerDiscreteScheduler.from_config(dict(ref_like, prediction_type="v_prediction"))
