@@ -28,6 +28,7 @@ _EXPORTS = {
     "UniPCMultistepScheduler": "schedulers",
     "StableDiffusionPipeline": "pipelines",
     "StableDiffusionXLPipeline": "pipelines",
+    "from_reference_config": "config_utils",
 }
 
 __all__ = sorted(_EXPORTS)

@@ -173,3 +173,38 @@ def test_wan_encode_prompt_matches_reference(ref, kw):
     assert (got_n is None and want_n is None) or torch.equal(got_n, want_n)
     with pytest.raises(ValueError):
         encode_prompt_wan(tok, enc, ["a cat", "hello"], negative_prompt=["red"], device="cpu")
+
+
+def test_engine_classes_build_from_reference_configs(ref):
+    """`from_reference_config(EngineClass, reference_object.config)` for every model class and scheduler, and the packed
+    layout the engine builds from the reference module's own state_dict has the inventory the engine expects."""
+    import diffusers_amd as da
+    from diffusers_amd import init as dinit
+    pairs = [
+        (da.UNet2DConditionModel, ref.UNet2DConditionModel, dinit.TINY_SDXL_UNET, dinit.unet_param_shapes),
+        (da.AutoencoderKL, ref.AutoencoderKL, dinit.TINY_VAE, None),
+        (da.FluxTransformer2DModel, ref.FluxTransformer2DModel, dinit.TINY_FLUX, dinit.flux_param_shapes),
+        (da.WanTransformer3DModel, ref.WanTransformer3DModel, dinit.TINY_WAN, dinit.wan_param_shapes),
+        (da.UNet2DModel, ref.UNet2DModel, dinit.TINY_DDPM, dinit.unet2d_param_shapes),
+        (da.AutoencoderKLWan, ref.AutoencoderKLWan, dinit.TINY_WAN_VAE, None),
+    ]
+    for ours, theirs, cfg, shapes in pairs:
+        rm = theirs(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()})
+        m = da.from_reference_config(ours, rm.config)
+        for k, v in cfg.items():
+            got = m.config[k]
+            assert (tuple(got) if isinstance(got, (list, tuple)) else got) == (tuple(v) if isinstance(v, (list, tuple)) else v), (ours.__name__, k)
+        m.load_state_dict(rm.state_dict(), device="cpu")           # the reference module's own keys / shapes
+        if shapes is not None:
+            assert {k: tuple(v.shape) for k, v in rm.state_dict().items()} == dict(shapes(dict(m.config)))
+    for ours, theirs in [(da.EulerDiscreteScheduler, ref.EulerDiscreteScheduler), (da.DDIMScheduler, ref.DDIMScheduler),
+                         (da.DDPMScheduler, ref.DDPMScheduler),
+                         (da.FlowMatchEulerDiscreteScheduler, ref.FlowMatchEulerDiscreteScheduler)]:
+        rs = theirs()
+        s = da.from_reference_config(ours, rs.config)
+        for k in s.config:
+            assert k in rs.config and (s.config[k] == rs.config[k] or list(s.config[k]) == list(rs.config[k])), (ours.__name__, k)
+    # swapping scheduler classes through a foreign config (Euler config -> DDIM), the reference idiom
+    assert da.from_reference_config(da.DDIMScheduler, ref.EulerDiscreteScheduler(beta_schedule="scaled_linear").config).config.beta_schedule == "scaled_linear"
+    with pytest.raises(TypeError):
+        da.from_reference_config(da.AutoencoderKL, dict(ref.AutoencoderKL().config, not_an_option=1))
