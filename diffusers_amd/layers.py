@@ -58,6 +58,14 @@ class Linear:
     def __call__(self, x, **kw):
         return ops.linear(x, self.weight, self.bias, **kw)
 
+    @property
+    def in_features(self) -> int:          # what reference pipelines read off nn.Linear (e.g. add_embedding.linear_1)
+        return self.weight.shape[1]
+
+    @property
+    def out_features(self) -> int:
+        return self.weight.shape[0]
+
 
 class Conv3x3:
     """nn.Conv2d(k=3, pad=1) as implicit GEMM (resnet.py:340,:365; downsampling.py:145; upsampling.py:186)."""
@@ -326,6 +334,14 @@ class TimestepEmbedding:
     def __call__(self, x, residual=None):
         h = ops.linear_small_m(x, self.l1.weight, self.l1.bias, act_out=L.ACT_SILU)
         return ops.linear_small_m(h, self.l2.weight, self.l2.bias, residual=residual)
+
+    @property
+    def linear_1(self) -> Linear:          # the reference's attribute names (pipeline_stable_diffusion_xl.py:737)
+        return self.l1
+
+    @property
+    def linear_2(self) -> Linear:
+        return self.l2
 
 
 def pad_encoder_states(ehs: torch.Tensor):

@@ -208,3 +208,42 @@ def test_engine_classes_build_from_reference_configs(ref):
     assert da.from_reference_config(da.DDIMScheduler, ref.EulerDiscreteScheduler(beta_schedule="scaled_linear").config).config.beta_schedule == "scaled_linear"
     with pytest.raises(TypeError):
         da.from_reference_config(da.AutoencoderKL, dict(ref.AutoencoderKL().config, not_an_option=1))
+
+
+def test_engine_components_under_the_unchanged_reference_pipeline(ref, monkeypatch):
+    """Boundary B1 / B2 / B5: engine UNet + VAE + scheduler registered into the REAL reference
+    StableDiffusionXLPipeline, whose own __call__ then drives them (encode_prompt, prepare_latents, scale_model_input,
+    unet(...), CFG, scheduler.step, vae.decode, postprocess).  Kernels are the torch stand-ins of tests/ops_emulation.py, so
+    this checks the duck-typed surface -- signatures, config attributes, return conventions -- not the kernels."""
+    import numpy as np
+    import diffusers_amd as da
+    import ops_emulation
+    from diffusers_amd import init as dinit, ops
+    ops_emulation.install(monkeypatch, ops)
+    monkeypatch.setattr(ops, "TUNING", False)
+    tok, nv = _tokenizer()
+    tok2, _ = _tokenizer()
+    e1, e2 = _clip(nv, 32, seed=1), _clip(nv, 32, proj=64, seed=2)
+    as_lists = lambda c: {k: (list(v) if isinstance(v, tuple) else v) for k, v in c.items()}     # noqa: E731
+    torch.manual_seed(0)
+    runet = ref.UNet2DConditionModel(**as_lists(dinit.TINY_SDXL_UNET)).eval()
+    rvae = ref.AutoencoderKL(**as_lists(dinit.TINY_VAE)).eval()
+    rs = ref.EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                                    timestep_spacing="leading")
+    pipe = ref.StableDiffusionXLPipeline(vae=rvae, text_encoder=e1, text_encoder_2=e2, tokenizer=tok, tokenizer_2=tok2,
+                                         unet=runet, scheduler=rs)
+    pipe.set_progress_bar_config(disable=True)
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(3))
+    kw = dict(prompt="hello a cat", negative_prompt="cat", num_inference_steps=3, guidance_scale=5.0, height=32, width=32,
+              output_type="pt")
+    want = pipe(latents=lat.clone(), **kw).images                               # the reference, fp32
+    pipe.to(torch.bfloat16)                                                     # deployment dtype (text encoders included)
+    unet = da.from_reference_config(da.UNet2DConditionModel, runet.config)
+    unet.load_state_dict(runet.state_dict(), device="cpu")
+    vae = da.from_reference_config(da.AutoencoderKL, rvae.config)
+    vae.load_state_dict(rvae.state_dict(), device="cpu")
+    pipe.register_modules(unet=unet, vae=vae, scheduler=da.EulerDiscreteScheduler.from_config(rs.config))
+    got = pipe(latents=lat.clone().to(torch.bfloat16), **kw).images
+    psnr = 10 * np.log10(1.0 / float((got.float() - want).pow(2).mean()))
+    print(f"[drop-in] engine under the reference SDXL pipeline: PSNR vs the all-reference fp32 run = {psnr:.1f} dB")
+    assert got.shape == want.shape and psnr >= 40.0
