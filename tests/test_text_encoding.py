@@ -1,6 +1,12 @@
-"""Text-encoder front end against the reference pipelines' own ``encode_prompt`` on tiny random
-CLIP encoders and an in-memory byte-level tokenizer.  Needs the reference sources (build container); the encoders are
-the caller's ``transformers`` modules, so only the host logic around them is under test."""
+"""Tests that run the LIVE reference (needs /root/reference/src: build container only, skipped elsewhere).
+
+1. Text-encoder front end against the reference pipelines' own ``encode_prompt`` on tiny random
+   CLIP / T5 / UMT5 encoders and in-memory tokenizers -- the encoders are the caller's ``transformers`` modules, so only
+   the host logic around them is under test.
+2. ``from_reference_config`` on real reference objects and their ``state_dict``s.
+3. The drop-in boundary: engine models + schedulers registered into the UNCHANGED reference
+   SDXL / SD / Flux / Wan pipelines, whose own ``__call__`` drives them (kernels = the torch stand-ins of
+   tests/ops_emulation.py; the kernels themselves are tested on the GPU)."""
 import sys
 from pathlib import Path
 
@@ -247,3 +253,105 @@ def test_engine_components_under_the_unchanged_reference_pipeline(ref, monkeypat
     psnr = 10 * np.log10(1.0 / float((got.float() - want).pow(2).mean()))
     print(f"[drop-in] engine under the reference SDXL pipeline: PSNR vs the all-reference fp32 run = {psnr:.1f} dB")
     assert got.shape == want.shape and psnr >= 40.0
+
+
+def _as_lists(c):
+    return {k: (list(v) if isinstance(v, tuple) else v) for k, v in c.items()}
+
+
+def _psnr(a, b):
+    import numpy as np
+    return 10 * np.log10(1.0 / float((a.float() - b.float()).pow(2).mean()))
+
+
+@pytest.fixture()
+def emulated_kernels(monkeypatch):
+    import ops_emulation
+    from diffusers_amd import ops
+    ops_emulation.install(monkeypatch, ops)
+    monkeypatch.setattr(ops, "TUNING", False)
+
+
+def test_engine_under_the_reference_flux_pipeline(ref, emulated_kernels):
+    """FluxTransformer2DModel + AutoencoderKL + FlowMatchEuler under the unchanged reference FluxPipeline.__call__
+    (its latent packing, image ids, timestep / 1000, shift handling, retrieve_timesteps(sigmas=...))."""
+    import diffusers_amd as da
+    from diffusers_amd import init as dinit
+    tok, nv = _tokenizer()
+    tok2, nv2 = _t5_tokenizer()
+    torch.manual_seed(0)
+    rtr = ref.FluxTransformer2DModel(**_as_lists(dinit.TINY_FLUX)).eval()
+    rvae = ref.AutoencoderKL(**_as_lists(dinit.TINY_FLUX_VAE)).eval()
+    rs = ref.FlowMatchEulerDiscreteScheduler(shift=1.0, use_dynamic_shifting=False)
+    pipe = ref.FluxPipeline(scheduler=rs, vae=rvae, text_encoder=_clip(nv, 64, seed=3), tokenizer=tok,
+                            text_encoder_2=_t5(nv2, d=64, seed=4), tokenizer_2=tok2, transformer=rtr)
+    pipe.set_progress_bar_config(disable=True)
+    lat = torch.randn(1, 64, 64, generator=torch.Generator().manual_seed(1))
+    kw = dict(prompt="hello a cat", num_inference_steps=3, guidance_scale=0.0, height=32, width=32, output_type="pt",
+              max_sequence_length=16)
+    want = pipe(latents=lat.clone(), **kw).images
+    pipe.to(torch.bfloat16)
+    tr = da.from_reference_config(da.FluxTransformer2DModel, rtr.config)
+    tr.load_state_dict(rtr.state_dict(), device="cpu")
+    vae = da.from_reference_config(da.AutoencoderKL, rvae.config)
+    vae.load_state_dict(rvae.state_dict(), device="cpu")
+    pipe.register_modules(transformer=tr, vae=vae, scheduler=da.FlowMatchEulerDiscreteScheduler.from_config(rs.config))
+    got = pipe(latents=lat.clone().to(torch.bfloat16), **kw).images
+    ps = _psnr(got, want)
+    print(f"[drop-in] engine under the reference Flux pipeline: PSNR {ps:.1f} dB")
+    assert got.shape == want.shape and ps >= 40.0
+
+
+def test_engine_under_the_reference_wan_pipeline(ref, emulated_kernels):
+    """WanTransformer3DModel + AutoencoderKLWan + UniPC under the unchanged reference WanPipeline.__call__ (two
+    transformer calls per step with cache contexts, fp32 latents, latent de-normalisation, video post-processing)."""
+    import diffusers_amd as da
+    from diffusers_amd import init as dinit
+    tok, nv = _t5_tokenizer()
+    torch.manual_seed(0)
+    rtr = ref.WanTransformer3DModel(**_as_lists(dinit.TINY_WAN)).eval()
+    rvae = ref.AutoencoderKLWan(**_as_lists(dinit.TINY_WAN_VAE)).eval()
+    rs = ref.UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=3.0)
+    pipe = ref.WanPipeline(tokenizer=tok, text_encoder=_t5(nv, d=64, seed=5, umt5=True), vae=rvae, scheduler=rs, transformer=rtr)
+    pipe.set_progress_bar_config(disable=True)
+    lat = torch.randn(1, 16, 3, 8, 8, generator=torch.Generator().manual_seed(1))
+    kw = dict(prompt="a cat on the mat", negative_prompt="red", num_inference_steps=3, guidance_scale=5.0, height=64, width=64,
+              num_frames=9, output_type="pt", max_sequence_length=16)
+    want = pipe(latents=lat.clone(), **kw).frames
+    pipe.to(torch.bfloat16)
+    tr = da.from_reference_config(da.WanTransformer3DModel, rtr.config)
+    tr.load_state_dict(rtr.state_dict(), device="cpu")
+    vae = da.from_reference_config(da.AutoencoderKLWan, rvae.config)
+    vae.load_state_dict(rvae.state_dict(), device="cpu")
+    pipe.register_modules(transformer=tr, vae=vae, scheduler=da.UniPCMultistepScheduler.from_config(rs.config))
+    got = pipe(latents=lat.clone(), **kw).frames
+    ps = _psnr(got, want)
+    print(f"[drop-in] engine under the reference Wan pipeline (UniPC + AutoencoderKLWan): PSNR {ps:.1f} dB")
+    assert got.shape == want.shape == (1, 9, 3, 64, 64) and ps >= 40.0
+
+
+def test_engine_under_the_reference_sd_pipeline(ref, emulated_kernels):
+    import diffusers_amd as da
+    from diffusers_amd import factory, init as dinit
+    tok, nv = _tokenizer()
+    torch.manual_seed(0)
+    runet = ref.UNet2DConditionModel(**_as_lists(dinit.TINY_SD15_UNET)).eval()
+    rvae = ref.AutoencoderKL(**_as_lists(dinit.TINY_VAE)).eval()
+    rs = ref.DDIMScheduler(**factory.SD15_SCHEDULER)
+    pipe = ref.StableDiffusionPipeline(vae=rvae, text_encoder=_clip(nv, 64, seed=3), tokenizer=tok, unet=runet, scheduler=rs,
+                                       safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    pipe.set_progress_bar_config(disable=True)
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(2))
+    kw = dict(prompt="hello a cat", negative_prompt="cat", num_inference_steps=3, guidance_scale=7.5, height=32, width=32,
+              output_type="pt")
+    want = pipe(latents=lat.clone(), **kw).images
+    pipe.to(torch.bfloat16)
+    unet = da.from_reference_config(da.UNet2DConditionModel, runet.config)
+    unet.load_state_dict(runet.state_dict(), device="cpu")
+    vae = da.from_reference_config(da.AutoencoderKL, rvae.config)
+    vae.load_state_dict(rvae.state_dict(), device="cpu")
+    pipe.register_modules(unet=unet, vae=vae, scheduler=da.DDIMScheduler.from_config(rs.config))
+    got = pipe(latents=lat.clone().to(torch.bfloat16), **kw).images
+    ps = _psnr(got, want)
+    print(f"[drop-in] engine under the reference SD pipeline (DDIM): PSNR {ps:.1f} dB")
+    assert got.shape == want.shape and ps >= 40.0
