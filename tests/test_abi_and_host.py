@@ -366,3 +366,22 @@ def test_scheduler_from_config_round_trip_and_reference_config():
     assert S.EulerDiscreteScheduler.from_config(ref_like, use_karras_sigmas=True).config.use_karras_sigmas is True
     with pytest.raises(NotImplementedError):
         S.EulerDiscreteScheduler.from_config(dict(ref_like, prediction_type="v_prediction"))
+
+
+def test_tuning_keys_bucket_giant_row_counts_only():
+    """Variant-table keys: exact shapes up to 2^20 rows (every entry of the shipped table), top-three-bit buckets above --
+    the 81 / 80 / 79-frame temporal taps of one video conv share an entry, SDXL's 1024^2-pixel convs keep theirs."""
+    import json
+    from diffusers_amd import _lib as L, tuning
+    assert tuning._m_key(1 << 20) == 1 << 20 and tuning._m_key(2048) == 2048
+    taps = {tuning._m_key(t * 480 * 832) for t in (81, 80, 79)}
+    assert len(taps) == 1 and next(iter(taps)) <= 79 * 480 * 832
+    p = L.GemmParams()
+    p.M, p.N, p.K, p.conv, p.act, p.out_f32 = 81 * 480 * 832, 128, 1152, 0, 0, 0
+    k81 = tuning.key_of(p)
+    p.M = 79 * 480 * 832
+    assert tuning.key_of(p) == k81
+    table = json.loads((Path(tuning.__file__).parent / "tuned" / "gfx950.json").read_text())
+    assert table["arch"] == "gfx950" and len(table["entries"]) >= 250
+    for key, (tile, staging, us) in table["entries"].items():
+        assert 1 <= tile <= 7 and 0 <= staging <= 5 and us > 0, key
