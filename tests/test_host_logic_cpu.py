@@ -212,3 +212,20 @@ def test_sd15_pipeline_vs_oracle_loop():
     ps = _psnr01((img.float() * 0.5 + 0.5).clamp(0, 1), (want * 0.5 + 0.5).clamp(0, 1))
     print(f"[host] tiny SD1.5 pipeline (4 DDIM steps, CFG 7.5): image PSNR vs fp32 oracle loop = {ps:.1f} dB")
     assert img.shape == want.shape and ps >= 35.0
+
+
+def test_sd15_pipeline_vs_reference_golden(golden):
+    """BASELINE config 2's loop (DDIM, CFG 7.5) against the REAL reference StableDiffusionPipeline's output
+    (tests/golden/tiny_sd15_pipeline.npz, oracle/make_golden_sd15_pipeline.py)."""
+    from diffusers_amd import factory
+    g = golden("tiny_sd15_pipeline")
+    pipe = factory.build_sd15_pipeline(device="cpu", tiny=True, seed=0)
+    kw = dict(prompt_embeds=_t(g, "prompt_embeds"), negative_prompt_embeds=_t(g, "negative_prompt_embeds"), num_inference_steps=4,
+              guidance_scale=7.5, height=32, width=32, use_graph=False)
+    lat = pipe(latents=_t(g, "latents").clone(), output_type="latent", **kw).images
+    assert np.array_equal(pipe.scheduler.timesteps.numpy(), g["timesteps"])
+    img = pipe(latents=_t(g, "latents").clone(), output_type="pt", **kw).images
+    rr = _rel(lat, torch.from_numpy(g["final_latents"]))
+    ps = _psnr01(img, torch.from_numpy(g["image01"]))
+    print(f"[host] tiny SD1.5 pipeline vs the reference pipeline: latents rel rms {rr:.3e}, image PSNR {ps:.1f} dB")
+    assert rr < 4e-2 and ps >= 35.0
