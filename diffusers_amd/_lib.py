@@ -19,6 +19,8 @@ TILE_NAMES = ("auto", "128x128", "64x128", "128x64", "64x64", "256x128", "128x25
 STAGE_REGISTER, STAGE_LDS_DIRECT, STAGE_LDS_DIRECT3, STAGE_LDS_DIRECT4, STAGE_LDS_DIRECT6, STAGE_LDS_DIRECT8 = range(6)
 RING_SLOTS = (2, 2, 3, 4, 6, 8)  # LDS ring depth per staging code
 DTYPE_BF16, DTYPE_F32 = 0, 1
+PRED_EPSILON, PRED_V, PRED_SAMPLE = 0, 1, 2
+PRED_TYPES = {"epsilon": PRED_EPSILON, "v_prediction": PRED_V, "sample": PRED_SAMPLE}
 
 
 class GemmParams(C.Structure):
@@ -66,9 +68,9 @@ SIGNATURES = {
                                   _i, _i, _vp]),
     "da_softmax_rows_f32_bf16": (_i, [_vp, _vp, _i, _i, _ll, _ll, _vp]),
     "da_euler_scale_model_input": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
-    "da_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
-    "da_x0_linear_step": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
-    "da_flowmatch_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _vp]),
+    "da_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _i, _vp]),
+    "da_x0_linear_step": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp, _i, _f, _ll, _i, _i, _vp]),
+    "da_flowmatch_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _i, _vp]),
     "da_unipc_flow_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _i, _vp]),
     "da_advance_step": (_i, [_vp, _vp]),
     "da_cast_f32_bf16": (_i, [_vp, _vp, _i, _ll, _vp]),

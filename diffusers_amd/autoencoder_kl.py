@@ -12,6 +12,7 @@ from typing import Dict
 import torch
 
 from . import ops
+from .config_utils import check_to
 from .layers import GroupNorm, ResnetBlock2D, Upsample2D, Weights
 from .unet_2d_condition import FrozenConfig
 
@@ -163,8 +164,8 @@ class AutoencoderKL:
         self._built = True
         return self
 
-    def to(self, *a, **k):
-        return self
+    def to(self, *args, **kwargs):
+        return check_to(self, args, kwargs)
 
     def eval(self):
         return self

@@ -27,6 +27,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
+from .config_utils import check_to
 from .autoencoder_kl import DecoderOutput
 from .layers import Weights
 from .unet_2d_condition import FrozenConfig
@@ -250,8 +251,8 @@ class AutoencoderKLWan:
         self._built = True
         return self
 
-    def to(self, *a, **k):
-        return self
+    def to(self, *args, **kwargs):
+        return check_to(self, args, kwargs)
 
     def eval(self):
         return self

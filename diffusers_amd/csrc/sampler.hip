@@ -47,18 +47,27 @@ __device__ __forceinline__ float load_eps(const T* eps, size_t i, size_t n, floa
   return IO<T>::ld(eps, i);
 }
 
-// Euler (epsilon prediction, gamma = 0): table row = [sigma, sigma_next, dt, sqrt(sigma^2+1), -, -, -, timestep]
-template <typename T, bool CFG>
+// Euler (gamma = 0): table row = [sigma, sigma_next, dt, sqrt(sigma^2+1), c_out, sigma^2+1, -, timestep]
+// PRED: 0 epsilon, 1 v_prediction, 2 sample (scheduling_euler_discrete.py:760-775)
+template <typename T, bool CFG, int PRED>
 __global__ void euler_step_kernel(const T* __restrict__ eps, const T* __restrict__ x, T* __restrict__ out,
                                   const float* __restrict__ table, const int* __restrict__ step_idx, float g,
                                   size_t n) {
   const float* row = table + (size_t)(*step_idx) * 8;
-  const float sigma = row[0], dt = row[2];
+  const float sigma = row[0], dt = row[2], c_out = row[4], s2p1 = row[5];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float e = load_eps<T, CFG>(eps, i, n, g);
     const float s = IO<T>::ld(x, i);                       // sample.to(float32)
-    const float se = IO<T>::rnd(__fmul_rn(sigma, e));      // sigma_hat * model_output  (model dtype)
-    const float x0 = __fsub_rn(s, se);                     // pred_original_sample (fp32)
+    float x0;                                              // pred_original_sample (fp32)
+    if (PRED == 0) {
+      const float se = IO<T>::rnd(__fmul_rn(sigma, e));    // sigma_hat * model_output  (model dtype)
+      x0 = __fsub_rn(s, se);
+    } else if (PRED == 1) {
+      // model_output * (-sigma / sqrt(sigma^2+1)) (model dtype) + sample / (sigma^2+1) (fp32)
+      x0 = __fadd_rn(IO<T>::rnd(__fmul_rn(e, c_out)), __fdiv_rn(s, s2p1));
+    } else {
+      x0 = e;
+    }
     const float der = __fdiv_rn(__fsub_rn(s, x0), sigma);  // derivative
     const float prev = __fadd_rn(s, __fmul_rn(der, dt));
     IO<T>::st(out, i, prev);
@@ -76,10 +85,14 @@ __global__ void euler_scale_input_kernel(const T* __restrict__ x, T* __restrict_
   }
 }
 
-// DDIM / DDPM (epsilon prediction): row = [sqrt(beta_t), sqrt(alpha_t), k0, ke, kx, kn, clip_range(0=off), timestep]
-//   x0   = (x - sqrt(beta_t) * eps) / sqrt(alpha_t)   [clamped]
-//   prev = k0*x0 (+ ke*eps) (+ kx*x) (+ kn*noise)     each product / sum rounded in the tensor dtype
-template <typename T, bool CFG>
+// DDIM / DDPM: row = [sqrt(beta_t), sqrt(alpha_t), k0, ke, kx, kn, clip_range(0=off), timestep]
+//   PRED 0 (epsilon)       x0 = (x - sqrt(beta_t) * out) / sqrt(alpha_t)                 pred_eps = out
+//   PRED 1 (v_prediction)  x0 = sqrt(alpha_t) * x - sqrt(beta_t) * out                   pred_eps = sqrt(alpha_t) * out + sqrt(beta_t) * x
+//   PRED 2 (sample)        x0 = out                                                      pred_eps = (x - sqrt(alpha_t) * x0) / sqrt(beta_t)
+//   (scheduling_ddim.py:455-468, scheduling_ddpm.py:505-517; pred_eps is formed from the UNCLIPPED x0, as the reference
+//   does unless use_clipped_model_output)
+//   prev = k0*x0 [clamped] (+ ke*pred_eps) (+ kx*x) (+ kn*noise)     each product / sum rounded in the tensor dtype
+template <typename T, bool CFG, int PRED>
 __global__ void x0_linear_step_kernel(const T* __restrict__ eps, const T* __restrict__ x, const T* __restrict__ noise,
                                       T* __restrict__ out, const float* __restrict__ table,
                                       const int* __restrict__ step_idx, float g, size_t n, size_t noise_step_stride) {
@@ -89,29 +102,42 @@ __global__ void x0_linear_step_kernel(const T* __restrict__ eps, const T* __rest
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float e = load_eps<T, CFG>(eps, i, n, g);
     const float s = IO<T>::ld(x, i);
-    float x0 = IO<T>::rnd(__fmul_rn(cb, e));
-    x0 = IO<T>::rnd(__fsub_rn(s, x0));
-    x0 = IO<T>::rnd(__fdiv_rn(x0, ca));
+    float x0, pe;
+    if (PRED == 0) {
+      x0 = IO<T>::rnd(__fmul_rn(cb, e));
+      x0 = IO<T>::rnd(__fsub_rn(s, x0));
+      x0 = IO<T>::rnd(__fdiv_rn(x0, ca));
+      pe = e;
+    } else if (PRED == 1) {
+      x0 = IO<T>::rnd(__fsub_rn(IO<T>::rnd(__fmul_rn(ca, s)), IO<T>::rnd(__fmul_rn(cb, e))));
+      pe = IO<T>::rnd(__fadd_rn(IO<T>::rnd(__fmul_rn(ca, e)), IO<T>::rnd(__fmul_rn(cb, s))));
+    } else {
+      x0 = e;
+      pe = IO<T>::rnd(__fdiv_rn(IO<T>::rnd(__fsub_rn(s, IO<T>::rnd(__fmul_rn(ca, x0)))), cb));
+    }
     if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
     float acc = IO<T>::rnd(__fmul_rn(k0, x0));
-    if (ke != 0.f) acc = IO<T>::rnd(__fadd_rn(acc, IO<T>::rnd(__fmul_rn(ke, e))));
+    if (ke != 0.f) acc = IO<T>::rnd(__fadd_rn(acc, IO<T>::rnd(__fmul_rn(ke, pe))));
     if (kx != 0.f) acc = IO<T>::rnd(__fadd_rn(acc, IO<T>::rnd(__fmul_rn(kx, s))));
     if (kn != 0.f && noise) acc = IO<T>::rnd(__fadd_rn(acc, IO<T>::rnd(__fmul_rn(kn, IO<T>::ld(noise, i)))));
     IO<T>::st(out, i, acc);
   }
 }
 
-// FlowMatch Euler: row = [sigma, sigma_next, dt, -, -, -, -, timestep]; prev = float(x) + (dt * v in model dtype)
-template <typename T, bool CFG>
-__global__ void flowmatch_step_kernel(const T* __restrict__ v, const T* __restrict__ x, T* __restrict__ out,
+// FlowMatch Euler: row = [sigma, sigma_next, dt, -, -, -, -, timestep]; prev = float(x) + (dt * v in model dtype), stored in
+// the MODEL OUTPUT's dtype (scheduling_flow_match_euler_discrete.py:484,:517: sample.to(float32) ... .to(model_output.dtype)).
+// TX = dtype of the sample, TV = dtype of the model output and of `out` (TX = float, TV = bf16 is what the reference's
+// Wan loop hands over on its first step).
+template <typename TX, typename TV, bool CFG>
+__global__ void flowmatch_step_kernel(const TV* __restrict__ v, const TX* __restrict__ x, TV* __restrict__ out,
                                       const float* __restrict__ table, const int* __restrict__ step_idx, float g,
                                       size_t n) {
   const float dt = table[(size_t)(*step_idx) * 8 + 2];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float e = load_eps<T, CFG>(v, i, n, g);
-    const float s = IO<T>::ld(x, i);
-    const float de = IO<T>::rnd(__fmul_rn(dt, e));
-    IO<T>::st(out, i, __fadd_rn(s, de));
+    const float e = load_eps<TV, CFG>(v, i, n, g);
+    const float s = IO<TX>::ld(x, i);
+    const float de = IO<TV>::rnd(__fmul_rn(dt, e));
+    IO<TV>::st(out, i, __fadd_rn(s, de));
   }
 }
 
@@ -199,19 +225,24 @@ inline dim3 ew_grid(size_t n) {
 }  // namespace
 
 extern "C" int da_euler_step(const void* eps, const void* x, void* out, const float* table, const int* step_idx,
-                             int cfg, float guidance, long long n_, int dtype, void* stream) {
+                             int cfg, float guidance, long long n_, int dtype, int pred_type, void* stream) {
   if (!eps || !x || !out || !table || !step_idx || n_ <= 0) return DA_ERR_INVALID;
+  if (pred_type < 0 || pred_type > 2) return DA_ERR_INVALID;
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
+#define DA_EU(T, C, P) \
+  DA_LAUNCH((euler_step_kernel<T, C, P>), ew_grid(n), dim3(256), 0, s, (const T*)eps, (const T*)x, (T*)out, table, step_idx, guidance, n)
+#define DA_EU_P(T, C) \
+  do { if (pred_type == 0) DA_EU(T, C, 0); else if (pred_type == 1) DA_EU(T, C, 1); else DA_EU(T, C, 2); } while (0)
   if (dtype == DA_DTYPE_BF16) {
-    if (cfg) DA_LAUNCH((euler_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
-    else DA_LAUNCH((euler_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
+    if (cfg) DA_EU_P(uint16_t, true); else DA_EU_P(uint16_t, false);
   } else if (dtype == DA_DTYPE_F32) {
-    if (cfg) DA_LAUNCH((euler_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (float*)out, table, step_idx, guidance, n);
-    else DA_LAUNCH((euler_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (float*)out, table, step_idx, guidance, n);
+    if (cfg) DA_EU_P(float, true); else DA_EU_P(float, false);
   } else {
     return DA_ERR_UNSUPPORTED;
   }
+#undef DA_EU_P
+#undef DA_EU
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -233,37 +264,41 @@ extern "C" int da_euler_scale_model_input(const void* x, void* out, const float*
 
 extern "C" int da_x0_linear_step(const void* eps, const void* x, const void* noise, long long noise_step_stride,
                                  void* out, const float* table, const int* step_idx, int cfg, float guidance,
-                                 long long n_, int dtype, void* stream) {
+                                 long long n_, int dtype, int pred_type, void* stream) {
   if (!eps || !x || !out || !table || !step_idx || n_ <= 0 || noise_step_stride < 0) return DA_ERR_INVALID;
+  if (pred_type < 0 || pred_type > 2) return DA_ERR_INVALID;
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
+#define DA_XL(T, C, P)                                                                                              \
+  DA_LAUNCH((x0_linear_step_kernel<T, C, P>), ew_grid(n), dim3(256), 0, s, (const T*)eps, (const T*)x, (const T*)noise, \
+            (T*)out, table, step_idx, guidance, n, (size_t)noise_step_stride)
+#define DA_XL_P(T, C) \
+  do { if (pred_type == 0) DA_XL(T, C, 0); else if (pred_type == 1) DA_XL(T, C, 1); else DA_XL(T, C, 2); } while (0)
   if (dtype == DA_DTYPE_BF16) {
-    if (cfg) DA_LAUNCH((x0_linear_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n, (size_t)noise_step_stride);
-    else DA_LAUNCH((x0_linear_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (const uint16_t*)x, (const uint16_t*)noise, (uint16_t*)out, table, step_idx, guidance, n, (size_t)noise_step_stride);
+    if (cfg) DA_XL_P(uint16_t, true); else DA_XL_P(uint16_t, false);
   } else if (dtype == DA_DTYPE_F32) {
-    if (cfg) DA_LAUNCH((x0_linear_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n, (size_t)noise_step_stride);
-    else DA_LAUNCH((x0_linear_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (const float*)x, (const float*)noise, (float*)out, table, step_idx, guidance, n, (size_t)noise_step_stride);
+    if (cfg) DA_XL_P(float, true); else DA_XL_P(float, false);
   } else {
     return DA_ERR_UNSUPPORTED;
   }
+#undef DA_XL_P
+#undef DA_XL
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
 extern "C" int da_flowmatch_step(const void* v, const void* x, void* out, const float* table, const int* step_idx,
-                                 int cfg, float guidance, long long n_, int dtype, void* stream) {
+                                 int cfg, float guidance, long long n_, int dtype, int x_dtype, void* stream) {
   if (!v || !x || !out || !table || !step_idx || n_ <= 0) return DA_ERR_INVALID;
   const size_t n = (size_t)n_;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == DA_DTYPE_BF16) {
-    if (cfg) DA_LAUNCH((flowmatch_step_kernel<uint16_t, true>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)v, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
-    else DA_LAUNCH((flowmatch_step_kernel<uint16_t, false>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)v, (const uint16_t*)x, (uint16_t*)out, table, step_idx, guidance, n);
-  } else if (dtype == DA_DTYPE_F32) {
-    if (cfg) DA_LAUNCH((flowmatch_step_kernel<float, true>), ew_grid(n), dim3(256), 0, s, (const float*)v, (const float*)x, (float*)out, table, step_idx, guidance, n);
-    else DA_LAUNCH((flowmatch_step_kernel<float, false>), ew_grid(n), dim3(256), 0, s, (const float*)v, (const float*)x, (float*)out, table, step_idx, guidance, n);
-  } else {
-    return DA_ERR_UNSUPPORTED;
-  }
+#define DA_FM(TX, TV, C) \
+  DA_LAUNCH((flowmatch_step_kernel<TX, TV, C>), ew_grid(n), dim3(256), 0, s, (const TV*)v, (const TX*)x, (TV*)out, table, step_idx, guidance, n)
+  if (dtype == DA_DTYPE_BF16 && x_dtype == DA_DTYPE_BF16) { if (cfg) DA_FM(uint16_t, uint16_t, true); else DA_FM(uint16_t, uint16_t, false); }
+  else if (dtype == DA_DTYPE_F32 && x_dtype == DA_DTYPE_F32) { if (cfg) DA_FM(float, float, true); else DA_FM(float, float, false); }
+  else if (dtype == DA_DTYPE_BF16 && x_dtype == DA_DTYPE_F32) { if (cfg) DA_FM(float, uint16_t, true); else DA_FM(float, uint16_t, false); }
+  else return DA_ERR_UNSUPPORTED;
+#undef DA_FM
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -340,8 +340,27 @@ def _dt(t: torch.Tensor) -> int:
     raise TypeError(f"sampler kernels support bf16 / fp32 latents, got {t.dtype}")
 
 
+def _check_sampler(what: str, x: torch.Tensor, model_out: torch.Tensor, out: Optional[torch.Tensor], cfg: bool,
+                   same_dtype: bool = True) -> None:
+    """The sampler kernels index their operands flat: every tensor must be a contiguous HIP tensor of the right size."""
+    _req(x, "sample", None), _req(model_out, "model_output", None)
+    if model_out.numel() != x.numel() * (2 if cfg else 1):
+        raise ValueError(f"{what}: model_output must hold {'[2 x sample] (uncond, cond)' if cfg else 'as many'} "
+                         f"elements{'' if cfg else ' as the sample'} (got {model_out.numel()} vs {x.numel()})")
+    if same_dtype and model_out.dtype != x.dtype:
+        raise TypeError(f"{what}: model_output ({model_out.dtype}) and sample ({x.dtype}) must have the same dtype")
+    if not x.is_contiguous() or not model_out.is_contiguous():
+        raise ValueError(f"{what}: sample and model_output must be contiguous")
+    if out is not None:
+        _req(out, "out", None)
+        if out.numel() != x.numel() or not out.is_contiguous():
+            raise ValueError(f"{what}: out must be a contiguous tensor of the sample's size")
+
+
 def euler_scale_model_input(x: torch.Tensor, table: torch.Tensor, step_idx: torch.Tensor, rep: int = 1) -> torch.Tensor:
     _req(x, "x", None)
+    if not x.is_contiguous():
+        raise ValueError("euler_scale_model_input: contiguous sample required")
     out = torch.empty((rep * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
     L.check(L.load().da_euler_scale_model_input(x.data_ptr(), out.data_ptr(), table.data_ptr(), step_idx.data_ptr(),
                                                 rep, x.numel(), _dt(x), _stream()), "da_euler_scale_model_input")
@@ -349,41 +368,54 @@ def euler_scale_model_input(x: torch.Tensor, table: torch.Tensor, step_idx: torc
 
 
 def euler_step(eps: torch.Tensor, x: torch.Tensor, table: torch.Tensor, step_idx: torch.Tensor, *, cfg: bool,
-               guidance: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(x, "x", None)
+               guidance: float, out: Optional[torch.Tensor] = None, pred_type: int = L.PRED_EPSILON) -> torch.Tensor:
+    _check_sampler("euler_step", x, eps, out, cfg)
     if out is None:
         out = torch.empty_like(x)
-    if eps.numel() != x.numel() * (2 if cfg else 1) or eps.dtype != x.dtype:
-        raise ValueError("euler_step: eps must be [2 x latents] with cfg, same dtype")
+    elif out.dtype != x.dtype:
+        raise TypeError("euler_step: out must have the sample's dtype")
     L.check(L.load().da_euler_step(eps.data_ptr(), x.data_ptr(), out.data_ptr(), table.data_ptr(), step_idx.data_ptr(),
-                                   int(cfg), guidance, x.numel(), _dt(x), _stream()), "da_euler_step")
+                                   int(cfg), guidance, x.numel(), _dt(x), int(pred_type), _stream()), "da_euler_step")
     return out
 
 
 def x0_linear_step(eps: torch.Tensor, x: torch.Tensor, noise: Optional[torch.Tensor], table: torch.Tensor,
                    step_idx: torch.Tensor, *, cfg: bool, guidance: float,
-                   out: Optional[torch.Tensor] = None, noise_step_stride: int = 0) -> torch.Tensor:
-    _req(x, "x", None)
+                   out: Optional[torch.Tensor] = None, noise_step_stride: int = 0,
+                   pred_type: int = L.PRED_EPSILON) -> torch.Tensor:
+    _check_sampler("x0_linear_step", x, eps, out, cfg)
     if out is None:
         out = torch.empty_like(x)
-    if eps.numel() != x.numel() * (2 if cfg else 1) or eps.dtype != x.dtype:
-        raise ValueError("x0_linear_step: eps must be [2 x latents] with cfg, same dtype")
-    if noise is not None and noise.dtype != x.dtype:
-        raise ValueError("x0_linear_step: noise must have the dtype of the sample")
+    elif out.dtype != x.dtype:
+        raise TypeError("x0_linear_step: out must have the sample's dtype")
+    if noise is not None:
+        _req(noise, "noise", None)
+        if noise.dtype != x.dtype or not noise.is_contiguous():
+            raise ValueError("x0_linear_step: noise must be contiguous and have the dtype of the sample")
+        if noise.numel() < x.numel() or (noise_step_stride and noise.numel() % x.numel()):
+            raise ValueError("x0_linear_step: noise must hold one sample-sized block (per step, with a step stride)")
     L.check(L.load().da_x0_linear_step(eps.data_ptr(), x.data_ptr(), _ptr(noise), noise_step_stride, out.data_ptr(),
                                        table.data_ptr(),
-                                       step_idx.data_ptr(), int(cfg), guidance, x.numel(), _dt(x), _stream()),
+                                       step_idx.data_ptr(), int(cfg), guidance, x.numel(), _dt(x), int(pred_type),
+                                       _stream()),
             "da_x0_linear_step")
     return out
 
 
 def flowmatch_step(v: torch.Tensor, x: torch.Tensor, table: torch.Tensor, step_idx: torch.Tensor, *, cfg: bool = False,
                    guidance: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(x, "x", None)
+    """FlowMatch-Euler update.  The result has the MODEL OUTPUT's dtype, as in the reference (the sample is upcast to
+    fp32 for the update and the result cast ``.to(model_output.dtype)``): (sample, model output) = bf16/bf16, f32/f32 or
+    f32/bf16 -- the last is what the reference's Wan loop passes on its first step."""
+    _check_sampler("flowmatch_step", x, v, out, cfg, same_dtype=False)
+    if (_dt(x), _dt(v)) not in ((L.DTYPE_BF16, L.DTYPE_BF16), (L.DTYPE_F32, L.DTYPE_F32), (L.DTYPE_F32, L.DTYPE_BF16)):
+        raise TypeError("flowmatch_step: (sample, model output) dtypes must be bf16/bf16, f32/f32 or f32/bf16")
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty(x.shape, device=x.device, dtype=v.dtype)
+    elif out.dtype != v.dtype:
+        raise TypeError("flowmatch_step: out must have the model output's dtype (the reference casts the result to it)")
     L.check(L.load().da_flowmatch_step(v.data_ptr(), x.data_ptr(), out.data_ptr(), table.data_ptr(),
-                                       step_idx.data_ptr(), int(cfg), guidance, x.numel(), _dt(x), _stream()),
+                                       step_idx.data_ptr(), int(cfg), guidance, x.numel(), _dt(v), _dt(x), _stream()),
             "da_flowmatch_step")
     return out
 

@@ -65,6 +65,8 @@ class _LatentDiffusionBase:
         self._graph = None
         self._graph_key = None
         self._static = {}
+        self._eta = 0.0            # DDIM only: eta > 0 adds pre-drawn variance noise (one row per step) in the fused step
+        self._noise_table = None
 
     @property
     def device(self):
@@ -83,10 +85,10 @@ class _LatentDiffusionBase:
             x_in = ops.mul_scalar(latents, 1.0, rep=rep) if rep > 1 else latents  # DDIM: scale_model_input = identity
         eps = self.unet(x_in, None, None, conditioning=cond, sampler_table=sch.device_table,
                         step_idx=sch.device_step, return_dict=False)[0]
-        if do_cfg:
-            sch.step_cfg(eps, latents, guidance_scale, out=latents)  # in place: same buffer every replay
-        else:
-            raise NotImplementedError("guidance_scale <= 1 (no CFG) path")
+        # in place (same buffer every replay); without CFG (guidance_scale <= 1, pipeline_stable_diffusion_xl.py:1202,
+        # :1223) the U-Net ran on the un-doubled batch and the same kernel skips the combine
+        kw = {"eta": self._eta, "noise_table": self._noise_table} if self._eta > 0 else {}
+        sch.step_cfg(eps, latents, guidance_scale, out=latents, cfg=do_cfg, **kw)
         return latents
 
     def _denoise(self, latents, cond, num_steps, guidance_scale, do_cfg, use_graph):
@@ -96,8 +98,9 @@ class _LatentDiffusionBase:
             for _ in range(num_steps):
                 self._step(latents, cond, guidance_scale, do_cfg)
             return latents
-        key = (tuple(latents.shape), float(guidance_scale), cond["kvs"][0][0].skv if cond["kvs"] else 0,
-               sch.device_table.data_ptr(), sch.device_step.data_ptr())
+        key = (tuple(latents.shape), float(guidance_scale), bool(do_cfg), cond["kvs"][0][0].skv if cond["kvs"] else 0,
+               sch.device_table.data_ptr(), sch.device_step.data_ptr(),
+               self._noise_table.data_ptr() if self._noise_table is not None else 0)
         if self._graph is None or self._graph_key != key:
             # warm-up on a side stream (lazy one-time driver calls must not happen during capture), then capture
             saved = latents.clone()
@@ -112,7 +115,7 @@ class _LatentDiffusionBase:
             with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE):
                 self._step(latents, cond, guidance_scale, do_cfg)
             self._graph, self._graph_key = g, key
-            self._static = {"latents": latents, "cond": cond}
+            self._static = {"latents": latents, "cond": cond, "noise_table": self._noise_table}
             latents.copy_(saved)
             sch.reset(0)
         else:
@@ -134,7 +137,13 @@ class _LatentDiffusionBase:
     def _decode(self, latents, output_type):
         if output_type == "latent":
             return latents
-        img = self.vae.decode(latents, return_dict=False, latents_div=float(self.vae.config.scaling_factor))[0]
+        vc = self.vae.config
+        if vc.get("latents_mean") is not None or vc.get("latents_std") is not None:
+            # pipeline_stable_diffusion_xl.py:1267-1277 de-normalises per channel with these before decoding; the fused
+            # decode entry takes one scalar divisor, so a VAE that ships them is refused rather than decoded wrongly
+            raise NotImplementedError("AutoencoderKL configs with latents_mean / latents_std are not supported by the "
+                                      "engine pipelines (decode the returned output_type='latent' tensor yourself)")
+        img = self.vae.decode(latents, return_dict=False, latents_div=float(vc.scaling_factor))[0]
         return postprocess_images(img, output_type)
 
 
@@ -251,8 +260,8 @@ class StableDiffusionPipeline(_LatentDiffusionBase):
                  latents: Optional[torch.Tensor] = None, prompt_embeds=None, negative_prompt_embeds=None,
                  output_type: str = "pt", return_dict: bool = True, generator=None, use_graph: bool = True,
                  negative_prompt=None, num_images_per_prompt: int = 1, clip_skip=None):
-        if eta != 0.0:
-            raise NotImplementedError("eta > 0 in the fused pipeline loop")
+        if eta < 0.0 or eta > 1.0:
+            raise ValueError("eta (DDIM) must be in [0, 1]")
         do_cfg = guidance_scale > 1.0
         if prompt is not None:
             if prompt_embeds is not None:
@@ -279,6 +288,22 @@ class StableDiffusionPipeline(_LatentDiffusionBase):
         if do_cfg:
             pe = torch.cat([negative_prompt_embeds.to(device=dev, dtype=bf16), pe], dim=0)
         cond = self.unet.precompute_conditioning(pe.contiguous(), None)
+        self._eta, self._noise_table = float(eta), None
+        if eta > 0:
+            if not hasattr(self.scheduler, "_get_variance"):
+                raise ValueError("eta > 0 is a DDIMScheduler option (pipeline_stable_diffusion.py:608-625 passes it only "
+                                 "to schedulers whose step() accepts it)")
+            # the reference draws one randn per step inside scheduler.step (scheduling_ddim.py:500-507), from `generator`
+            # in the latents dtype: same draws, in the same order, made up front so the step stays graph-replayable
+            gdev = generator.device if generator is not None else dev
+            draws = [torch.randn(latents.shape, generator=generator, device=gdev, dtype=bf16)
+                     for _ in range(num_inference_steps)]
+            table = torch.stack(draws).to(dev).contiguous()
+            if self._static.get("noise_table") is not None and self._static["noise_table"].shape == table.shape:
+                self._static["noise_table"].copy_(table)       # keep the address the captured graph reads
+                table = self._static["noise_table"]
+            self._static["noise_table"] = table
+            self._noise_table = table
         latents = self._denoise(latents, cond, num_inference_steps, guidance_scale, do_cfg, use_graph)
         images = self._decode(latents, output_type)
         if not return_dict:
@@ -376,7 +401,7 @@ class FluxPipeline:
             st["latents"].copy_(latents)
             st["pe"].copy_(pe)
             st["cond"]["pooled_emb"].copy_(cond["pooled_emb"])
-            if st["cond"]["cos"].data_ptr() != cond["cos"].data_ptr():
+            if st["cond"]["cos"] is not cond["cos"]:     # a different id grid of the same size (e.g. HxW after WxH)
                 st["cond"]["cos"].copy_(cond["cos"])
                 st["cond"]["sin"].copy_(cond["sin"])
             latents = st["latents"]

@@ -19,6 +19,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import ops
 from .unet_2d_condition import FrozenConfig
 
@@ -168,8 +169,14 @@ class EulerDiscreteScheduler(_SchedulerBase):
         if sum([bool(c.use_karras_sigmas), bool(c.use_exponential_sigmas)]) > 1:
             raise ValueError("Only one of `config.use_beta_sigmas`, `config.use_exponential_sigmas`, "
                              "`config.use_karras_sigmas` can be used.")
-        if c.prediction_type != "epsilon" or c.timestep_type != "discrete" or c.interpolation_type != "linear":
-            raise NotImplementedError("EulerDiscreteScheduler: only epsilon / discrete / linear interpolation")
+        if c.timestep_type != "discrete" or c.interpolation_type != "linear":
+            raise NotImplementedError("EulerDiscreteScheduler: only discrete timesteps / linear interpolation")
+        if c.prediction_type == "original_sample":       # backwards-compatible alias (scheduling_euler_discrete.py:762)
+            self._pred = L.PRED_SAMPLE
+        elif c.prediction_type in L.PRED_TYPES:
+            self._pred = L.PRED_TYPES[c.prediction_type]
+        else:
+            raise ValueError(f"prediction_type given as {c.prediction_type} must be one of `epsilon`, or `v_prediction`")
         self.betas = _betas(c.beta_schedule, c.beta_start, c.beta_end, c.num_train_timesteps, c.trained_betas)
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
@@ -242,6 +249,8 @@ class EulerDiscreteScheduler(_SchedulerBase):
             rows[i, 1] = float(s_next)
             rows[i, 2] = float(s_next - s)                 # dt, fp32 torch scalar arithmetic as the reference
             rows[i, 3] = float((s ** 2 + 1) ** 0.5)        # scale_model_input denominator
+            rows[i, 4] = float(-s / (s ** 2 + 1) ** 0.5)   # v_prediction: c_out (scheduling_euler_discrete.py:767)
+            rows[i, 5] = float(s ** 2 + 1)                 # v_prediction: sample / (sigma^2 + 1)
             rows[i, 7] = float(ts[i])
         self._upload(rows, device)
 
@@ -261,18 +270,20 @@ class EulerDiscreteScheduler(_SchedulerBase):
             raise NotImplementedError("s_churn > 0 (stochastic Euler) is not on the hot path")
         if self._step_index is None:
             self._init_step_index(timestep)
-        prev = ops.euler_step(model_output, sample, self._table, self._step_dev, cfg=False, guidance=0.0)
+        prev = ops.euler_step(model_output.contiguous(), sample.contiguous(), self._table, self._step_dev, cfg=False,
+                              guidance=0.0, pred_type=self._pred)
         self._advance()
         if not return_dict:
             return (prev, None)
         return SchedulerOutput(prev_sample=prev)
 
-    def step_cfg(self, model_output_2b, sample, guidance_scale: float, out=None):
-        """Engine extension: CFG combine + Euler step in one kernel; model_output_2b = [uncond ; cond]."""
+    def step_cfg(self, model_output_2b, sample, guidance_scale: float, out=None, cfg: bool = True):
+        """Engine extension: CFG combine + Euler step in one kernel; model_output_2b = [uncond ; cond] (``cfg=False``:
+        a plain model output -- the ``guidance_scale <= 1`` loop of the pipelines -- with the same in-place ``out``)."""
         if self._step_index is None:
             self._init_step_index(self.timesteps[0])
-        prev = ops.euler_step(model_output_2b, sample, self._table, self._step_dev, cfg=True,
-                              guidance=float(guidance_scale), out=out)
+        prev = ops.euler_step(model_output_2b, sample, self._table, self._step_dev, cfg=cfg,
+                              guidance=float(guidance_scale), out=out, pred_type=self._pred)
         self._advance()
         return prev
 
@@ -288,8 +299,12 @@ class DDIMScheduler(_SchedulerBase):
     def __init__(self, **kwargs):
         super().__init__(**kwargs)
         c = self.config
-        if c.prediction_type != "epsilon" or c.thresholding or c.rescale_betas_zero_snr:
-            raise NotImplementedError("DDIMScheduler: only epsilon prediction without thresholding")
+        if c.thresholding or c.rescale_betas_zero_snr:
+            raise NotImplementedError("DDIMScheduler: dynamic thresholding / zero-SNR rescaling are not on the hot path")
+        if c.prediction_type not in L.PRED_TYPES:
+            raise ValueError(f"prediction_type given as {c.prediction_type} must be one of `epsilon`, `sample`, or "
+                             "`v_prediction`")
+        self._pred = L.PRED_TYPES[c.prediction_type]
         self.betas = _betas(c.beta_schedule, c.beta_start, c.beta_end, c.num_train_timesteps, c.trained_betas)
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
@@ -390,18 +405,24 @@ class DDIMScheduler(_SchedulerBase):
                 variance_noise = torch.randn(model_output.shape, generator=generator, device=gdev,
                                              dtype=model_output.dtype).to(model_output.device)
             noise = variance_noise
-        prev = ops.x0_linear_step(model_output, sample, noise, self._table, self._step_dev, cfg=False, guidance=0.0)
+        prev = ops.x0_linear_step(model_output.contiguous(), sample.contiguous(), noise, self._table, self._step_dev,
+                                  cfg=False, guidance=0.0, pred_type=self._pred)
         self._advance()
         if not return_dict:
             return (prev, None)
         return SchedulerOutput(prev_sample=prev)
 
-    def step_cfg(self, model_output_2b, sample, guidance_scale: float, eta: float = 0.0, out=None):
+    def step_cfg(self, model_output_2b, sample, guidance_scale: float, eta: float = 0.0, out=None, cfg: bool = True,
+                 noise_table=None):
+        """Engine extension: CFG combine (``cfg=False``: plain model output) + DDIM update in one kernel, in place when
+        ``out`` is the sample.  ``eta > 0`` needs ``noise_table`` [steps][numel]: every step's variance noise drawn up
+        front (the kernel picks the row of the device step counter, so the step stays HIP-graph replayable)."""
         self._ensure(eta, self.timesteps[0])
-        if eta > 0:
-            raise NotImplementedError("step_cfg with eta > 0")
-        prev = ops.x0_linear_step(model_output_2b, sample, None, self._table, self._step_dev, cfg=True,
-                                  guidance=float(guidance_scale), out=out)
+        if eta > 0 and noise_table is None:
+            raise ValueError("DDIMScheduler.step_cfg: eta > 0 needs the pre-drawn `noise_table` [steps][numel]")
+        prev = ops.x0_linear_step(model_output_2b, sample, noise_table if eta > 0 else None, self._table, self._step_dev,
+                                  cfg=cfg, guidance=float(guidance_scale), out=out, pred_type=self._pred,
+                                  noise_step_stride=sample.numel() if eta > 0 else 0)
         self._advance()
         return prev
 
@@ -428,8 +449,12 @@ class DDPMScheduler(_SchedulerBase):
     def __init__(self, **kwargs):
         super().__init__(**kwargs)
         c = self.config
-        if c.prediction_type != "epsilon" or c.thresholding or c.rescale_betas_zero_snr:
-            raise NotImplementedError("DDPMScheduler: only epsilon prediction without thresholding")
+        if c.thresholding or c.rescale_betas_zero_snr:
+            raise NotImplementedError("DDPMScheduler: dynamic thresholding / zero-SNR rescaling are not on the hot path")
+        if c.prediction_type not in L.PRED_TYPES:
+            raise ValueError(f"prediction_type given as {c.prediction_type} must be one of `epsilon`, `sample` or "
+                             "`v_prediction`  for the DDPMScheduler.")
+        self._pred = L.PRED_TYPES[c.prediction_type]
         if c.variance_type not in ("fixed_small", "fixed_large"):
             raise NotImplementedError("DDPMScheduler: only fixed_small / fixed_large variance")
         self.betas = _betas(c.beta_schedule, c.beta_start, c.beta_end, c.num_train_timesteps, c.trained_betas)
@@ -469,7 +494,9 @@ class DDPMScheduler(_SchedulerBase):
         rows = np.zeros((len(ts), 8), dtype=np.float32)
         for i, t in enumerate(ts):
             t = int(t)
-            prev_t = t - n_train // num_inference_steps
+            # previous_timestep() (scheduling_ddpm.py:648-668): the NEXT entry of the schedule, -1 after the last one --
+            # not t - n_train // n_steps, which differs for 'linspace' / 'trailing' spacings
+            prev_t = int(ts[i + 1]) if i + 1 < len(ts) else -1
             a_t = self.alphas_cumprod[t]
             a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
             b_t = 1 - a_t
@@ -504,8 +531,8 @@ class DDPMScheduler(_SchedulerBase):
             gdev = generator.device if generator is not None else model_output.device
             noise = torch.randn(model_output.shape, generator=generator, device=gdev,
                                 dtype=model_output.dtype).to(model_output.device)
-        prev = ops.x0_linear_step(model_output, sample, noise if t > 0 else None, self._table, self._step_dev, cfg=False,
-                                  guidance=0.0)
+        prev = ops.x0_linear_step(model_output.contiguous(), sample.contiguous(), noise if t > 0 else None, self._table,
+                                  self._step_dev, cfg=False, guidance=0.0, pred_type=self._pred)
         self._advance()
         if not return_dict:
             return (prev, None)
@@ -518,7 +545,7 @@ class DDPMScheduler(_SchedulerBase):
             self._step_index = 0
             self._sync_device_step()
         ops.x0_linear_step(model_output, sample, noise_table, self._table, self._step_dev, cfg=False, guidance=0.0,
-                           out=sample, noise_step_stride=sample.numel())
+                           out=sample, noise_step_stride=sample.numel(), pred_type=self._pred)
         self._advance()
         return sample
 

@@ -123,9 +123,12 @@ def encode_prompt_sdxl(tokenizers: Sequence, text_encoders: Sequence, prompt: Pr
         else:
             neg = negative_prompt or ""
             neg2 = negative_prompt_2 or neg
-            _check_negative(prompt, neg, batch_size)
-            neg_l = batch_size * [neg] if isinstance(neg, str) else list(neg)
-            neg2_l = batch_size * [neg2] if isinstance(neg2, str) else list(neg2)
+            # the SDXL reference normalises BOTH sides to lists before its type check
+            # (pipeline_stable_diffusion_xl.py:360, :431-446): a str negative prompt broadcasts over a list of prompts
+            neg_l = batch_size * [neg] if isinstance(neg, str) else neg
+            neg2_l = batch_size * [neg2] if isinstance(neg2, str) else neg2
+            _check_negative(prompt_l, neg_l, batch_size)
+            neg_l, neg2_l = list(neg_l), list(neg2_l)
             uncond = [neg_l, neg2_l][:len(tokenizers)]
             ne, npooled = run(uncond, max_length=pe.shape[1])
         ne = _repeat(ne.to(device=device, dtype=dtype), num_images_per_prompt)

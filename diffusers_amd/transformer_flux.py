@@ -19,12 +19,14 @@ copies (one (1, 4608, 3072) tensor per block) never happen.  Per block:
 """
 from __future__ import annotations
 
+import hashlib
 from dataclasses import dataclass
 from typing import Any, Dict, Optional
 
 import torch
 
 from . import _lib as L
+from .config_utils import check_to
 from . import ops
 from .layers import Linear, TimestepEmbedding, Weights
 from .unet_2d_condition import FrozenConfig
@@ -134,8 +136,8 @@ class FluxTransformer2DModel:
         self._built = True
         return self
 
-    def to(self, *a, **k):
-        return self
+    def to(self, *args, **kwargs):
+        return check_to(self, args, kwargs)
 
     def eval(self):
         return self
@@ -154,9 +156,13 @@ class FluxTransformer2DModel:
             txt_ids = txt_ids[0]
         if img_ids.ndim == 3:
             img_ids = img_ids[0]
-        key = (tuple(img_ids.shape), tuple(txt_ids.shape), float(img_ids.float().sum()), float(txt_ids.float().sum()))
+        # the key must IDENTIFY the id tensors: (shape, sum) does not -- a 48x84 and an 84x48 grid have the same count
+        # and the same coordinate sum -- so it is a digest of the exact id values (a few tens of KB, once per call)
+        ids_host = torch.cat((txt_ids.detach().to("cpu", torch.float32), img_ids.detach().to("cpu", torch.float32)), dim=0)
+        key = (tuple(img_ids.shape), tuple(txt_ids.shape),
+               hashlib.sha1(ids_host.contiguous().numpy().tobytes()).hexdigest())
         if key not in self._rope_cache:
-            cos, sin = rope_tables(torch.cat((txt_ids.cpu(), img_ids.cpu()), dim=0), self.config.axes_dims_rope)
+            cos, sin = rope_tables(ids_host, self.config.axes_dims_rope)
             self._rope_cache = {key: (cos.to(self.device), sin.to(self.device))}
         cos, sin = self._rope_cache[key]
         pooled_emb = self.text_embedder(pooled_projections.contiguous())  # (B, inner)

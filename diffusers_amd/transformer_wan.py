@@ -19,6 +19,7 @@ from typing import Any, Dict, Optional
 import torch
 
 from . import _lib as L
+from .config_utils import check_to
 from . import ops
 from .layers import LayerNorm, Linear, TimestepEmbedding, Weights
 from .transformer_flux import Transformer2DModelOutput
@@ -116,8 +117,8 @@ class WanTransformer3DModel:
         self._built = True
         return self
 
-    def to(self, *a, **k):
-        return self
+    def to(self, *args, **kwargs):
+        return check_to(self, args, kwargs)
 
     def eval(self):
         return self

@@ -15,6 +15,7 @@ from typing import Dict
 import torch
 
 from . import ops
+from .config_utils import check_to
 from .autoencoder_kl import VaeAttention
 from .layers import Downsample2D, GroupNorm, ResnetBlock2D, TimestepEmbedding, Upsample2D, Weights
 from .unet_2d_condition import FrozenConfig
@@ -123,8 +124,8 @@ class UNet2DModel:
         self._built = True
         return self
 
-    def to(self, *a, **k):
-        return self
+    def to(self, *args, **kwargs):
+        return check_to(self, args, kwargs)
 
     def eval(self):
         return self

@@ -13,6 +13,7 @@ from typing import Any, Dict, List, Optional
 import torch
 
 from . import ops
+from .config_utils import check_to
 from .layers import (Downsample2D, GroupNorm, ResnetBlock2D, TimestepEmbedding, Transformer2DModel,
                      Upsample2D, Weights, pad_encoder_states)
 
@@ -55,10 +56,6 @@ def _tup(v, n):
     return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
 
 
-class _CrossAttnStage:
-    """resnet -> transformer pairs (CrossAttnDownBlock2D / CrossAttnUpBlock2D / mid), unet_2d_blocks.py:1239-1291."""
-
-
 class UNet2DConditionModel:
     """Drop-in for the reference ``UNet2DConditionModel`` (inference, bf16, HIP device only)."""
 
@@ -81,6 +78,15 @@ class UNet2DConditionModel:
             raise ValueError("unsupported attention variant")
         if c.conv_in_kernel != 3 or c.conv_out_kernel != 3 or c.time_cond_proj_dim is not None:
             raise ValueError("unsupported conv_in/out kernel or time_cond_proj_dim")
+        # options the engine has no code for must sit at their reference defaults: a non-default value would change the
+        # reference's arithmetic, so it is refused rather than ignored
+        for k in ("center_input_sample", "dropout", "resnet_skip_time_act", "resnet_out_scale_factor",
+                  "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "encoder_hid_dim",
+                  "class_embeddings_concat", "mid_block_only_cross_attention", "cross_attention_norm",
+                  "projection_class_embeddings_input_dim" if c.addition_embed_type is None else "dropout"):
+            if c[k] != _DEFAULTS[k]:
+                raise ValueError(f"diffusers_amd UNet2DConditionModel: config option {k}={c[k]!r} is not implemented on "
+                                 f"the HIP path (only the default {_DEFAULTS[k]!r})")
         if len(c.down_block_types) != len(c.up_block_types) or len(c.block_out_channels) != len(c.down_block_types):
             raise ValueError("Must provide the same number of `down_block_types`, `up_block_types`, `block_out_channels`.")
         for t in c.down_block_types:
@@ -160,8 +166,8 @@ class UNet2DConditionModel:
         self._built = True
         return self
 
-    def to(self, *a, **k):
-        return self
+    def to(self, *args, **kwargs):
+        return check_to(self, args, kwargs)
 
     def eval(self):
         return self

@@ -99,7 +99,7 @@ int main() {
   HIP_OK(hipMemcpy(dt, table.data(), 8 * 4, hipMemcpyHostToDevice));
   HIP_OK(hipMemset(dstep, 0, 4));
   const float g = 5.0f;
-  rc = da_euler_step(de, dl, dl, (const float*)dt, dstep, /*cfg=*/1, g, n, DA_DTYPE_F32, stream);
+  rc = da_euler_step(de, dl, dl, (const float*)dt, dstep, /*cfg=*/1, g, n, DA_DTYPE_F32, DA_PRED_EPSILON, stream);
   if (rc != DA_OK) {
     std::fprintf(stderr, "da_euler_step: %d\n", rc);
     return 1;

@@ -185,9 +185,11 @@ int da_rmsnorm_channels_bf16(const void* x, const void* gamma, void* y, long lon
  *   model output holds [uncond | cond] halves of n elements each and noise_pred = u + guidance * (c - u)
  *   (pipeline_stable_diffusion.py:1054-1055).  dtype selects bf16 or fp32 tensors.
  *   da_euler_scale_model_input  scheduling_euler_discrete.py:326-348, output replicated `rep` times (torch.cat([x]*2))
- *                               row = [sigma, sigma_next, dt, sqrt(sigma^2+1), -, -, -, timestep]
- *   da_euler_step               scheduling_euler_discrete.py:685-800 (epsilon prediction, gamma = 0)
- *   da_x0_linear_step           scheduling_ddim.py:384-514 and scheduling_ddpm.py:461-567 (epsilon prediction)
+ *                               row = [sigma, sigma_next, dt, sqrt(sigma^2+1), c_out, sigma^2+1, -, timestep]
+ *   da_euler_step               scheduling_euler_discrete.py:685-800 (gamma = 0); pred_type = DA_PRED_* selects the
+ *                               pred_original_sample form of :760-775 (c_out = -sigma / sqrt(sigma^2+1) for v_prediction)
+ *   da_x0_linear_step           scheduling_ddim.py:384-514 and scheduling_ddpm.py:461-567; pred_type = DA_PRED_* selects
+ *                               the x0 / pred_epsilon forms of scheduling_ddim.py:455-468
  *                               row = [sqrt(beta_t), sqrt(alpha_t), k0, ke, kx, kn, clip_range, timestep]
  *                               noise (may be NULL) + step * noise_step_stride elements = this step's variance noise
  *                               (stride 0: one buffer refilled by the host per step; > 0: all steps pre-drawn)
@@ -196,15 +198,20 @@ int da_rmsnorm_channels_bf16(const void* x, const void* gamma, void* y, long lon
  * ------------------------------------------------------------------------------------------------------------------ */
 #define DA_DTYPE_BF16 0
 #define DA_DTYPE_F32 1
+#define DA_PRED_EPSILON 0
+#define DA_PRED_V 1
+#define DA_PRED_SAMPLE 2
 int da_euler_scale_model_input(const void* x, void* out, const float* table, const int* step_idx, int rep, long long n,
                                int dtype, void* stream);
 int da_euler_step(const void* eps, const void* x, void* out, const float* table, const int* step_idx, int cfg,
-                  float guidance, long long n, int dtype, void* stream);
+                  float guidance, long long n, int dtype, int pred_type, void* stream);
 int da_x0_linear_step(const void* eps, const void* x, const void* noise, long long noise_step_stride, void* out,
                       const float* table, const int* step_idx, int cfg, float guidance, long long n, int dtype,
-                      void* stream);
+                      int pred_type, void* stream);
+/* dtype = dtype of the model output v AND of out; x_dtype = dtype of the sample (fp32 sample + bf16 model output is the
+ * reference's Wan hand-over: the update is formed in fp32 and stored in the model output's dtype, :484,:517) */
 int da_flowmatch_step(const void* v, const void* x, void* out, const float* table, const int* step_idx, int cfg,
-                      float guidance, long long n, int dtype, void* stream);
+                      float guidance, long long n, int dtype, int x_dtype, void* stream);
 /* da_unipc_flow_step: schedulers/scheduling_unipc_multistep.py:760-1300 (flow_prediction, predict_x0, B(h),
  * solver_order <= 2): x0 conversion + corrector + predictor + history roll in ONE pass, in place on x / last / m1 / m2;
  * coef = 16 floats per step [sigma, use_corr, order_c, c1c, c2c, c3c, rk_c, rho0_c, rho_last_c, order_p, c1p, c2p, c3p,

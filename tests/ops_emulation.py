@@ -244,23 +244,33 @@ def euler_scale_model_input(x, table, step_idx, rep=1):
     return torch.cat([y] * rep, 0)
 
 
-def euler_step(eps, x, table, step_idx, *, cfg, guidance, out=None):
+def euler_step(eps, x, table, step_idx, *, cfg, guidance, out=None, pred_type=0):
     r = _row(table, step_idx)
     e = _cfg(eps, cfg, guidance, x.numel()).view(x.shape)
     xf = x.float()
-    pred = xf - (r[0] * e).to(eps.dtype).float()
+    if pred_type == 0:
+        pred = xf - (r[0] * e).to(eps.dtype).float()
+    elif pred_type == 1:
+        pred = (e * r[4]).to(eps.dtype).float() + xf / r[5]
+    else:
+        pred = e
     prev = xf + ((xf - pred) / r[0]) * r[2]
     return _store(prev, out, x.dtype)
 
 
-def x0_linear_step(eps, x, noise, table, step_idx, *, cfg, guidance, out=None, noise_step_stride=0):
+def x0_linear_step(eps, x, noise, table, step_idx, *, cfg, guidance, out=None, noise_step_stride=0, pred_type=0):
     r = _row(table, step_idx)
     e = _cfg(eps, cfg, guidance, x.numel()).view(x.shape)
     xf = x.float()
-    x0 = (xf - r[0] * e) / r[1]
+    if pred_type == 0:
+        x0, pe = (xf - r[0] * e) / r[1], e
+    elif pred_type == 1:
+        x0, pe = r[1] * xf - r[0] * e, r[1] * e + r[0] * xf
+    else:
+        x0, pe = e, (xf - r[1] * e) / r[0]
     if r[6] > 0:
         x0 = x0.clamp(-r[6], r[6])
-    prev = r[2] * x0 + r[3] * e + r[4] * xf
+    prev = r[2] * x0 + r[3] * pe + r[4] * xf
     if noise is not None and float(r[5]) != 0.0:
         off = int(step_idx) * noise_step_stride
         nz = noise.reshape(-1)[off:off + x.numel()].view(x.shape).float()
@@ -271,7 +281,7 @@ def x0_linear_step(eps, x, noise, table, step_idx, *, cfg, guidance, out=None, n
 def flowmatch_step(v, x, table, step_idx, *, cfg=False, guidance=0.0, out=None):
     r = _row(table, step_idx)
     vv = _cfg(v, cfg, guidance, x.numel()).view(x.shape)
-    return _store(x.float() + r[2] * vv, out, x.dtype)
+    return _store(x.float() + (r[2] * vv).to(v.dtype).float(), out, v.dtype)   # result in the model output's dtype
 
 
 def unipc_flow_step_(v, x, last, m1, m2, coef, step_idx, *, cfg=False, guidance=0.0):

@@ -364,8 +364,11 @@ def test_scheduler_from_config_round_trip_and_reference_config():
     d = S.DDIMScheduler.from_config(ref_like)
     assert d.config.beta_schedule == "scaled_linear" and d.config.clip_sample is False and d.config.steps_offset == 1
     assert S.EulerDiscreteScheduler.from_config(ref_like, use_karras_sigmas=True).config.use_karras_sigmas is True
+    assert S.EulerDiscreteScheduler.from_config(dict(ref_like, prediction_type="v_prediction"))._pred == 1
+    with pytest.raises(ValueError):
+        S.EulerDiscreteScheduler.from_config(dict(ref_like, prediction_type="flow_prediction"))
     with pytest.raises(NotImplementedError):
-        S.EulerDiscreteScheduler.from_config(dict(ref_like, prediction_type="v_prediction"))
+        S.EulerDiscreteScheduler.from_config(dict(ref_like, rescale_betas_zero_snr=True))
 
 
 def test_tuning_keys_bucket_giant_row_counts_only():
