@@ -65,9 +65,10 @@ def cfg_combine(uncond: torch.Tensor, cond: torch.Tensor, g: float) -> torch.Ten
 
 class EulerOracle:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
-                 timestep_spacing="linspace", steps_offset=0, device_scalars=False):
+                 timestep_spacing="linspace", steps_offset=0, prediction_type="epsilon", device_scalars=False):
         self.n_train = num_train_timesteps
         self.dev = device_scalars
+        self.pred = prediction_type
         self.spacing, self.offset = timestep_spacing, steps_offset
         betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
@@ -97,7 +98,14 @@ class EulerOracle:
         sample = sample.to(torch.float32)
         sigma = self.sigmas[self.step_index]
         sigma_hat = sigma * (0.0 + 1)
-        pred_original = sample - smul(sigma_hat, model_output, self.dev)
+        if self.pred in ("sample", "original_sample"):                     # scheduling_euler_discrete.py:760-775
+            pred_original = model_output
+        elif self.pred == "epsilon":
+            pred_original = sample - smul(sigma_hat, model_output, self.dev)
+        elif self.pred == "v_prediction":
+            pred_original = model_output * (-sigma / (sigma ** 2 + 1) ** 0.5) + (sample / (sigma ** 2 + 1))
+        else:
+            raise ValueError(self.pred)
         derivative = (sample - pred_original) / sigma_hat
         dt = self.sigmas[self.step_index + 1] - sigma_hat
         prev = sample + derivative * dt
@@ -108,9 +116,10 @@ class EulerOracle:
 class DDIMOracle:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  clip_sample=True, set_alpha_to_one=True, steps_offset=0, timestep_spacing="leading",
-                 clip_sample_range=1.0, device_scalars=False):
+                 clip_sample_range=1.0, prediction_type="epsilon", device_scalars=False):
         self.n_train = num_train_timesteps
         self.dev = device_scalars
+        self.pred = prediction_type
         betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
@@ -128,12 +137,22 @@ class DDIMOracle:
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         b_t = 1 - a_t
-        x0 = (sample - smul(b_t ** 0.5, model_output, self.dev)) / a_t ** 0.5
+        if self.pred == "epsilon":                                          # scheduling_ddim.py:455-468
+            x0 = (sample - smul(b_t ** 0.5, model_output, self.dev)) / a_t ** 0.5
+            pred_eps = model_output
+        elif self.pred == "sample":
+            x0 = model_output
+            pred_eps = (sample - smul(a_t ** 0.5, x0, self.dev)) / b_t ** 0.5
+        elif self.pred == "v_prediction":
+            x0 = smul(a_t ** 0.5, sample, self.dev) - smul(b_t ** 0.5, model_output, self.dev)
+            pred_eps = smul(a_t ** 0.5, model_output, self.dev) + smul(b_t ** 0.5, sample, self.dev)
+        else:
+            raise ValueError(self.pred)
         if self.clip:
             x0 = x0.clamp(-self.clip_range, self.clip_range)
         variance = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
         std = eta * variance ** 0.5
-        direction = smul((1 - a_prev - std ** 2) ** 0.5, model_output, self.dev)
+        direction = smul((1 - a_prev - std ** 2) ** 0.5, pred_eps, self.dev)
         prev = smul(a_prev ** 0.5, x0, self.dev) + direction
         if eta > 0:
             prev = prev + smul(std, variance_noise, self.dev)
@@ -143,9 +162,10 @@ class DDIMOracle:
 class DDPMOracle:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  variance_type="fixed_small", clip_sample=True, clip_sample_range=1.0, timestep_spacing="leading",
-                 steps_offset=0, device_scalars=False):
+                 steps_offset=0, prediction_type="epsilon", device_scalars=False):
         self.n_train = num_train_timesteps
         self.dev = device_scalars
+        self.pred = prediction_type
         betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.one = torch.tensor(1.0)
@@ -161,7 +181,13 @@ class DDPMOracle:
         self.timesteps = torch.from_numpy(spaced_timesteps(self.spacing, self.n_train, n, self.offset, as_float=False))
 
     def _prev(self, t):
-        return t - self.n_train // self.n_inf if self.n_inf else t - 1
+        """previous_timestep (scheduling_ddpm.py:648-668): the next entry of the schedule once set_timesteps has run
+        (-1 after the last), t - 1 otherwise."""
+        if not self.n_inf:
+            return t - 1
+        ts = [int(v) for v in self.timesteps]
+        i = ts.index(int(t))
+        return ts[i + 1] if i + 1 < len(ts) else -1
 
     def step(self, model_output, timestep, sample, generator=None, noise=None):
         t = int(timestep)
@@ -171,7 +197,14 @@ class DDPMOracle:
         b_t, b_prev = 1 - a_t, 1 - a_prev
         cur_a = a_t / a_prev
         cur_b = 1 - cur_a
-        x0 = (sample - smul(b_t ** 0.5, model_output, self.dev)) / a_t ** 0.5
+        if self.pred == "epsilon":                                          # scheduling_ddpm.py:505-517
+            x0 = (sample - smul(b_t ** 0.5, model_output, self.dev)) / a_t ** 0.5
+        elif self.pred == "sample":
+            x0 = model_output
+        elif self.pred == "v_prediction":
+            x0 = smul(a_t ** 0.5, sample, self.dev) - smul(b_t ** 0.5, model_output, self.dev)
+        else:
+            raise ValueError(self.pred)
         if self.clip:
             x0 = x0.clamp(-self.clip_range, self.clip_range)
         k0 = (a_prev ** 0.5 * cur_b) / b_t

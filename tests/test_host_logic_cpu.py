@@ -229,3 +229,82 @@ def test_sd15_pipeline_vs_reference_golden(golden):
     ps = _psnr01(img, torch.from_numpy(g["image01"]))
     print(f"[host] tiny SD1.5 pipeline vs the reference pipeline: latents rel rms {rr:.3e}, image PSNR {ps:.1f} dB")
     assert rr < 4e-2 and ps >= 35.0
+
+
+@pytest.mark.parametrize("guidance,eta,pred", [(1.0, 0.0, "epsilon"), (7.5, 0.4, "epsilon"), (1.0, 0.0, "v_prediction")])
+def test_sd15_pipeline_no_cfg_eta_and_v_prediction_vs_oracle_loop(guidance, eta, pred):
+    """The loop variants VERDICT r1 listed as refused: guidance_scale <= 1 (no batch doubling, no combine --
+    pipeline_stable_diffusion.py:1037-1055 with do_classifier_free_guidance False), DDIM eta > 0 (one randn per step from
+    the generator, scheduling_ddim.py:500-507), v_prediction (scheduling_ddim.py:462-464) -- on the kernel stand-ins vs
+    the fp32 oracle loop on the same draws."""
+    from diffusers_amd import factory
+    from diffusers_amd.autoencoder_kl import _DEFAULTS as VD
+    from diffusers_amd.pipelines import StableDiffusionPipeline
+    from diffusers_amd.schedulers import DDIMScheduler
+    from diffusers_amd.unet_2d_condition import _DEFAULTS as UD
+    from oracle import reference_math as R
+    from oracle import samplers as OS
+    base = factory.build_sd15_pipeline(device="cpu", tiny=True, seed=0)
+    skw = dict(factory.SD15_SCHEDULER, prediction_type=pred)
+    pipe = StableDiffusionPipeline(vae=base.vae, unet=base.unet, scheduler=DDIMScheduler(**skw))
+    gen = torch.Generator().manual_seed(6)
+    lat0 = torch.randn((1, 4, 16, 16), generator=gen).to(bf16)
+    pe = torch.randn((1, 7, 64), generator=gen).to(bf16)
+    ne = torch.randn((1, 7, 64), generator=gen).to(bf16)
+    n = 4
+    g1, g2 = torch.Generator().manual_seed(99), torch.Generator().manual_seed(99)
+    img = pipe(prompt_embeds=pe, negative_prompt_embeds=ne if guidance > 1 else None, latents=lat0.clone(),
+               num_inference_steps=n, guidance_scale=guidance, eta=eta, generator=g1, height=32, width=32,
+               output_type="raw", use_graph=False).images
+    ucfg, vcfg = dict(UD), dict(VD)
+    ucfg.update(dinit.TINY_SD15_UNET)
+    vcfg.update(dinit.TINY_VAE)
+    usd = {k: v.float() for k, v in dinit.random_state_dict(dinit.unet_param_shapes(pipe.unet.config), seed=0).items()}
+    vsd = {k: v.float() for k, v in dinit.random_state_dict(dinit.vae_decoder_param_shapes(pipe.vae.config), seed=1).items()}
+    sch = OS.DDIMOracle(**skw)
+    sch.set_timesteps(n)
+    x = lat0.float()
+    draws = [torch.randn(lat0.shape, generator=g2, dtype=bf16).float() for _ in range(n)] if eta > 0 else [None] * n
+    with torch.no_grad():
+        for i, t_ in enumerate(sch.timesteps):
+            if guidance > 1:
+                e2 = R.unet_forward(usd, ucfg, torch.cat([x, x]), float(t_), torch.cat([ne, pe]).float(), None)
+                eps = OS.cfg_combine(e2[:1], e2[1:], guidance)
+            else:
+                eps = R.unet_forward(usd, ucfg, x, float(t_), pe.float(), None)
+            x = sch.step(eps, t_, x, eta=eta, variance_noise=draws[i])
+        want = R.vae_decode(vsd, vcfg, x / vcfg["scaling_factor"])
+    ps = _psnr01((img.float() * 0.5 + 0.5).clamp(0, 1), (want * 0.5 + 0.5).clamp(0, 1))
+    print(f"[host] tiny SD1.5 pipeline guidance={guidance} eta={eta} {pred}: PSNR vs fp32 oracle loop = {ps:.1f} dB")
+    assert img.shape == want.shape and ps >= 35.0
+
+
+def test_sdxl_pipeline_without_cfg():
+    """SDXL with guidance_scale = 1: no negative embeddings needed, batch of one through the U-Net, the fused Euler step
+    without the combine (pipeline_stable_diffusion_xl.py:1202, :1223)."""
+    from diffusers_amd import factory
+    from diffusers_amd.unet_2d_condition import _DEFAULTS as UD
+    from oracle import reference_math as R
+    from oracle import samplers as OS
+    pipe = factory.build_sdxl_pipeline(device="cpu", tiny=True, seed=0)
+    gen = torch.Generator().manual_seed(8)
+    lat0 = torch.randn((1, 4, 16, 16), generator=gen).to(bf16)
+    pe = torch.randn((1, 7, 64), generator=gen).to(bf16)
+    pp = torch.randn((1, 64), generator=gen).to(bf16)
+    lat = pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, latents=lat0.clone(), num_inference_steps=3, guidance_scale=1.0,
+               height=128, width=128, output_type="latent", use_graph=False).images
+    ucfg = dict(UD)
+    ucfg.update(dinit.TINY_SDXL_UNET)
+    usd = {k: v.float() for k, v in dinit.random_state_dict(dinit.unet_param_shapes(pipe.unet.config), seed=0).items()}
+    sch = OS.EulerOracle(**factory.SDXL_SCHEDULER)
+    sch.set_timesteps(3)
+    x = (lat0.float() * sch.init_noise_sigma)
+    ids = torch.tensor([[128., 128., 0., 0., 128., 128.]])
+    with torch.no_grad():
+        for t_ in sch.timesteps:
+            eps = R.unet_forward(usd, ucfg, sch.scale_model_input(x), float(t_), pe.float(),
+                                 {"text_embeds": pp.float(), "time_ids": ids})
+            x = sch.step(eps, x)
+    rr = _rel(lat, x)
+    print(f"[host] tiny SDXL pipeline without CFG: latents rel rms vs fp32 oracle loop = {rr:.3e}")
+    assert rr < 4e-2

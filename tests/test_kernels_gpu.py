@@ -415,6 +415,115 @@ def test_sampler_vs_oracle_and_golden(golden, dt_name):
 
 
 @pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+def test_sampler_round2_cases_vs_oracle_and_golden(golden, dt_name):
+    """Prediction types (v_prediction / sample) of the Euler, DDIM and DDPM kernels, DDIM eta > 0, DDPM on spacings whose
+    previous timestep is not t - 1000 // n, FlowMatch with an fp32 sample and a bf16 model output: per step on the
+    golden's inputs, BIT-EXACT against the oracle with device scalar semantics and within the sampler tolerance of the
+    frozen reference run (tests/golden/schedulers_r2.npz; see test_sampler_vs_oracle_and_golden for the bound)."""
+    from diffusers_amd import schedulers as S
+    from oracle import samplers as OS
+    gz = golden("schedulers_r2")
+    dt = torch.float32 if dt_name == "f32" else bf16
+    tol = 2e-6 if dt_name == "f32" else 2.0 ** -5
+    N = 6
+    load = lambda k: torch.from_numpy(gz[k]).to(dt)  # noqa: E731
+    x0, eps, noise, draws = load(f"x0_{dt_name}"), load(f"eps_{dt_name}"), load(f"noise_{dt_name}"), load(f"ddpm_draws_{dt_name}")
+    sd = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+
+    def cmp(got, want, ref_gold, name):
+        got = got.cpu()
+        nbad = int((got.float() != want.float()).sum())
+        err = _golden_err(got, ref_gold)
+        print(f"[parity] {name}: vs same-host oracle mismatches = {nbad}/{got.numel()}; vs golden max err {err:.2e} rms")
+        assert nbad == 0, f"{name}: {nbad} elements differ from the oracle"
+        assert err <= tol, f"{name}: {err:.3e} (rms units) from the golden reference step"
+
+    for pred in ("v_prediction", "sample"):
+        dk = dict(clip_sample=False, set_alpha_to_one=False, steps_offset=1, prediction_type=pred, **sd)
+        d, od = S.DDIMScheduler(**dk), OS.DDIMOracle(device_scalars=True, **dk)
+        d.set_timesteps(N, device=DEV), od.set_timesteps(N)
+        gt, x_in = load(f"ddim_{pred}_{dt_name}"), x0
+        for i, t in enumerate(d.timesteps):
+            d.reset(i)
+            cmp(d.step(eps[i].to(DEV), t, x_in.to(DEV)).prev_sample, od.step(eps[i], od.timesteps[i], x_in), gt[i],
+                f"ddim {pred}[{i}] {dt_name}")
+            x_in = gt[i]
+        ek = dict(steps_offset=1, timestep_spacing="leading", prediction_type=pred, **sd)
+        e, oe = S.EulerDiscreteScheduler(**ek), OS.EulerOracle(device_scalars=True, **ek)
+        e.set_timesteps(N, device=DEV), oe.set_timesteps(N)
+        gt, x_in = load(f"euler_{pred}_{dt_name}"), load(f"euler_{pred}_start_{dt_name}")
+        for i, t in enumerate(e.timesteps):
+            e.reset(i)
+            oe.step_index = i
+            cmp(e.step(eps[i].to(DEV), t, x_in.to(DEV)).prev_sample, oe.step(eps[i], x_in), gt[i],
+                f"euler {pred}[{i}] {dt_name}")
+            x_in = gt[i]
+        pk = dict(prediction_type=pred, clip_sample=True)
+        p, op_ = S.DDPMScheduler(**pk), OS.DDPMOracle(device_scalars=True, **pk)
+        p.set_timesteps(N, device=DEV), op_.set_timesteps(N)
+        gt, x_in = load(f"ddpm_{pred}_{dt_name}"), x0
+        for i, t in enumerate(p.timesteps):
+            p.reset(i)
+            cmp(p.step(eps[i].to(DEV), t, x_in.to(DEV), noise=draws[i].to(DEV)).prev_sample,
+                op_.step(eps[i], op_.timesteps[i], x_in, noise=draws[i]), gt[i], f"ddpm {pred}[{i}] {dt_name}")
+            x_in = gt[i]
+
+    for pred in ("epsilon", "v_prediction"):        # DDIM eta = 0.6, caller-supplied variance noise
+        dk = dict(clip_sample=False, set_alpha_to_one=False, steps_offset=1, prediction_type=pred, **sd)
+        d, od = S.DDIMScheduler(**dk), OS.DDIMOracle(device_scalars=True, **dk)
+        d.set_timesteps(N, device=DEV), od.set_timesteps(N)
+        gt, x_in = load(f"ddim_eta_{pred}_{dt_name}"), x0
+        for i, t in enumerate(d.timesteps):
+            d.reset(i)
+            cmp(d.step(eps[i].to(DEV), t, x_in.to(DEV), eta=0.6, variance_noise=noise[i].to(DEV)).prev_sample,
+                od.step(eps[i], od.timesteps[i], x_in, eta=0.6, variance_noise=noise[i]), gt[i],
+                f"ddim eta {pred}[{i}] {dt_name}")
+            x_in = gt[i]
+
+    for spacing in ("linspace", "trailing", "leading"):
+        p, op_ = S.DDPMScheduler(timestep_spacing=spacing, clip_sample=True), OS.DDPMOracle(timestep_spacing=spacing, clip_sample=True, device_scalars=True)
+        p.set_timesteps(7, device=DEV), op_.set_timesteps(7)
+        assert np.array_equal(p.timesteps.cpu().numpy(), gz[f"ddpm_{spacing}7_timesteps"])
+        gt, x_in = load(f"ddpm_{spacing}7_{dt_name}"), x0
+        for i, t in enumerate(p.timesteps[:N]):
+            p.reset(i)
+            cmp(p.step(eps[i].to(DEV), t, x_in.to(DEV), noise=draws[i].to(DEV)).prev_sample,
+                op_.step(eps[i], op_.timesteps[i], x_in, noise=draws[i]), gt[i], f"ddpm {spacing}7[{i}] {dt_name}")
+            x_in = gt[i]
+
+
+def test_flowmatch_fp32_sample_bf16_output_and_operand_checks(golden):
+    """The reference's Wan hand-over: FlowMatchEulerDiscreteScheduler.step(model_output=bf16, sample=fp32) forms the
+    update in fp32 and returns the MODEL OUTPUT's dtype (scheduling_flow_match_euler_discrete.py:484,:517) -- bit-exact
+    against the frozen reference run; and the operand checks ADVICE r1 asked for (dtype / size / contiguity raise instead
+    of reading out of bounds)."""
+    from diffusers_amd import schedulers as S
+    ops, L = _ops()
+    gz = golden("schedulers_r2")
+    f = S.FlowMatchEulerDiscreteScheduler(shift=3.0)
+    f.set_timesteps(6, device=DEV)
+    assert np.array_equal(f.sigmas.cpu().numpy(), gz["flow_mixed_sigmas"])
+    x = torch.from_numpy(gz["x0_f32"]).to(DEV)
+    v = torch.from_numpy(gz["eps_bf16"]).to(bf16).to(DEV)
+    for i, t in enumerate(f.timesteps):
+        y = f.step(v[i], t, x).prev_sample
+        assert y.dtype == bf16 and torch.equal(y.float().cpu(), torch.from_numpy(gz["flow_mixed"][i])), f"step {i}"
+        x = y.float()
+    f.reset(0)
+    xb = x.to(bf16)
+    with pytest.raises(TypeError):          # bf16 sample with an fp32 model output is not a reference combination
+        ops.flowmatch_step(v[0].float(), xb, f.device_table, f.device_step)
+    with pytest.raises(ValueError):         # wrong-sized model output with cfg
+        ops.flowmatch_step(v[0], xb, f.device_table, f.device_step, cfg=True)
+    with pytest.raises(ValueError):         # non-contiguous sample
+        ops.flowmatch_step(v[0], xb.transpose(-1, -2), f.device_table, f.device_step)
+    with pytest.raises(TypeError):          # `out` must have the model output's dtype
+        ops.flowmatch_step(v[0], x, f.device_table, f.device_step, out=torch.empty_like(x))
+    with pytest.raises(TypeError):
+        ops.euler_step(v[0], x, f.device_table, f.device_step, cfg=False, guidance=0.0)
+
+
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
 def test_fused_cfg_step_equals_unfused(golden, dt_name):
     """step_cfg([u;c]) == step(u + g*(c-u)) bit for bit, and both equal the oracle's CFG combine + Euler step."""
     from diffusers_amd import schedulers as S
