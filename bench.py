@@ -7,13 +7,25 @@
 A "step" is one complete image per GPU: 50 x (scale_model_input + CFG-batched U-Net + fused CFG/Euler step) + the VAE
 decode, on synthetic prompt embeddings / latents that are resident in HBM before the timed region (weights are seeded
 random, there are no checkpoints offline).  With N > 1 every rank owns one prompt (weak scaling, no collective in the
-data path; rank 0 broadcasts the text embeddings once before the timed region).  Rank 0 prints ONE JSON line.
+data path; rank 0 broadcasts the text embeddings once before the timed region).  ``python bench.py --gpus N`` without a
+launcher re-executes itself under ``torch.distributed.run`` with N ranks (the reference's own recipe spawns its ranks the
+same way, docs/source/en/training/distributed_inference.md:62-108).  Rank 0 prints ONE JSON line.
+
+Besides the contract keys the line carries, all measured OUTSIDE the timed region on rank 0 at N = 1:
+  roofline            dominant kernel (igemm_bf16_kernel), HIP events around every launch of one eager denoising step
+  parity              PSNR of the engine's 50-step image against the reference graph run by PyTorch-ROCm in fp32 on this
+                      GPU on the same weights / latents / embeddings, with the bf16 run of the same graph as noise floor
+  torch_rocm_baseline the same reference graph, eager bf16 on PyTorch-ROCm (hipBLASLt / MIOpen / SDPA): the denominator
+                      of BASELINE.json's ">= 1.5x stock diffusers on PyTorch-ROCm"
+  cpu_baseline        the oracle U-Net forward on the host cores (bounded sample, extrapolated by FLOPs)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -26,9 +38,11 @@ sys.path.insert(0, str(ROOT))
 TFLOP_PER_IMAGE = 50 * 13.5225 + 10.4704   # 686.6 TFLOP per SDXL 1024^2 50-step image
 UNET_TFLOP = 13.5225                        # one CFG-batched (B=2) U-Net forward at 128x128 latents
 MFMA_PEAK_TFLOPS = 2500.0                   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+GUIDANCE = 5.0
+TRAFFIC_FILE = ROOT / "profiles" / "sdxl_traffic.json"   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed images per GPU")
@@ -38,8 +52,40 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-reference", action="store_true", help="skip the parity / torch_rocm_baseline legs")
     ap.add_argument("--save-tuning", default=None, help="write the GEMM variant table measured during warm-up here")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ---- device plumbing (one place, so the world-size-2 CPU test can run main() on the kernel stand-ins) ----------------
+def _device(local: int) -> torch.device:
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    return torch.device("cuda", local)
+
+
+def _sync() -> None:
+    torch.cuda.synchronize()
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: one process per GPU under torch.distributed.run, rendezvous
+    on 127.0.0.1 (the container hostname may not resolve).  The children print the JSON line; this process only waits."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    log(f"--gpus {args.gpus} without a launcher: re-executing as {' '.join(cmd[1:8])} ...")
+    return subprocess.call(cmd, env=env)
 
 
 def synth_inputs(n_prompts, tiny, device):
@@ -93,20 +139,49 @@ def instrumented_gemm_pass(pipe, run_one_step):
     return len(recs), sum(r[0] for r in recs), sum(r[1] for r in recs)
 
 
+def roofline_leg(pipe, mine, world, images_per_s):
+    """Dominant kernel = igemm_bf16_kernel (all Linear + Conv2d 3x3/1x1): MFMA-bound.  The conditioning is built here
+    (not taken from the graph's static inputs), so the leg also works after --no-graph / the eager fallback."""
+    sch = pipe.scheduler
+    dev = mine["latents"].device
+    pe = torch.cat([mine["negative_prompt_embeds"], mine["prompt_embeds"]], dim=0).contiguous()
+    te = torch.cat([mine["negative_pooled"], mine["pooled"]], dim=0)
+    ids = torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]], device=dev).repeat(pe.shape[0], 1)
+    cond = pipe.unet.precompute_conditioning(pe, {"text_embeds": te, "time_ids": ids})
+    sch.set_timesteps(50, device=dev)
+    lat = mine["latents"].clone()
+
+    def one_step():
+        sch.reset(0)
+        pipe._step(lat, cond, GUIDANCE, True)
+    one_step()  # untimed warm pass
+    n, ms, fl = instrumented_gemm_pass(pipe, one_step)
+    ach = fl / (ms * 1e-3) / 1e12
+    traffic, note = None, "no committed PMC measurement (profiles/sdxl_traffic.json)"
+    if TRAFFIC_FILE.exists():
+        try:
+            tr = json.loads(TRAFFIC_FILE.read_text())
+            traffic, note = tr["igemm_bytes_per_launch"], tr.get("source", str(TRAFFIC_FILE.name))
+        except (ValueError, KeyError) as e:
+            note = f"unreadable {TRAFFIC_FILE.name}: {e}"
+    return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": note,
+            "kernel": "igemm_bf16_kernel (Linear + Conv2d implicit GEMM)",
+            "launches_per_denoise_step": n, "avg_launch_us": 1000.0 * ms / max(n, 1),
+            "algorithmic_tflop_per_denoise_step": fl / 1e12,
+            "end_to_end_frac": images_per_s * TFLOP_PER_IMAGE / world / MFMA_PEAK_TFLOPS}
+
+
 # CFG-batched (B=2) SDXL U-Net forward at 32x32 latents, from the 128x128 op census of SURVEY.md 8a: conv 3.246/16,
 # linear (8.709 - 0.105)/16 + 0.105 (the cross-attention K/V projections see 154 text rows at any resolution),
 # attention 1.503/256 (self, quadratic in tokens) + 0.0646/16 (cross)
 CPU_SAMPLE_TFLOP = 3.246 / 16 + (8.709 - 0.105) / 16 + 0.105 + 1.503 / 256 + 0.0646 / 16
 
 
-def log(msg):
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
-
-
 def cpu_baseline(unet_sd, cfg_full, budget_s=25.0):
     """CPU leg (rank 0, N=1): the oracle restatement of the U-Net forward (oracle/reference_math.py, kind "port") on the
     host cores this process may run on, on a bounded sample: CFG-batched forward of the FULL SDXL architecture at 32x32
-    latents, fp32.  images/s is scaled by algorithmic FLOPs (CPU_SAMPLE_TFLOP per sample, 686.6 TFLOP per image)."""
+    latents, fp32.  images/s is EXTRAPOLATED by algorithmic FLOPs (CPU_SAMPLE_TFLOP per sample, 686.6 TFLOP per image)."""
     from oracle import reference_math as R
     try:
         cores = len(os.sched_getaffinity(0))
@@ -133,30 +208,118 @@ def cpu_baseline(unet_sd, cfg_full, budget_s=25.0):
                 break
     tflops = CPU_SAMPLE_TFLOP * reps / tot
     return {"value": tflops / TFLOP_PER_IMAGE, "unit": "images/s", "cores": threads, "kind": "port",
+            "extrapolated": True,
             "sample": f"{reps}x oracle fp32 CFG-batched SDXL U-Net forward at 32x32 latents ({CPU_SAMPLE_TFLOP:.3f} "
-                      f"TFLOP each, {tot:.1f} s); scaled by FLOPs to 686.6 TFLOP/image",
+                      f"TFLOP each, {tot:.1f} s); EXTRAPOLATED by FLOPs to 686.6 TFLOP/image",
             "cpu_tflops": tflops}
 
 
-def main():
-    args = parse()
+def _psnr01(a, b):
+    """PSNR on [0, 1] images (output_type="pt" convention, 40 dB = MSE 1e-4)."""
+    a = (a.float() * 0.5 + 0.5).clamp(0, 1)
+    b = (b.float() * 0.5 + 0.5).clamp(0, 1)
+    mse = float((a - b).pow(2).mean())
+    return 10.0 * torch.log10(torch.tensor(1.0 / max(mse, 1e-12))).item()
+
+
+def reference_pipeline_on_device(unet_sd, vae_sd, ucfg, vcfg, inp, steps, dtype, timed=False, budget_s=240.0):
+    """CHECKER / BASELINE, never the product: StableDiffusionXLPipeline's denoising loop
+    (pipeline_stable_diffusion_xl.py:1193-1257: cat([latents] * 2), scale_model_input, U-Net, uncond + g (text - uncond),
+    scheduler.step) and vae.decode(latents / scaling_factor) (:1262-1290), written over the oracle restatement of the
+    reference modules (plain torch ops = what the reference executes), on THIS GPU through PyTorch-ROCm in ``dtype``.
+    Returns (final latents, image in [-1, 1], seconds for the timed loop + decode or None)."""
+    from diffusers_amd import factory
+    from oracle import reference_math as R
+    from oracle import samplers as OS
+    dev = inp["latents"].device
+    usd = {k: v.to(dev, dtype) for k, v in unet_sd.items()}
+    vsd = {k: v.to(dev, dtype) for k, v in vae_sd.items()}
+    ehs = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]], dim=0).to(dtype)
+    added = {"text_embeds": torch.cat([inp["negative_pooled"], inp["pooled"]], dim=0).to(dtype),
+             "time_ids": torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]], device=dev).repeat(2, 1)}
+    sch = OS.EulerOracle(**factory.SDXL_SCHEDULER)
+
+    def loop(n_run):
+        sch.set_timesteps(steps)
+        x = (inp["latents"].to(dtype) * sch.init_noise_sigma).to(dtype)
+        for t_ in sch.timesteps[:n_run]:
+            xin = sch.scale_model_input(torch.cat([x] * 2))
+            eps = R.unet_forward(usd, ucfg, xin, float(t_), ehs, added)
+            u, c = eps.chunk(2)
+            x = sch.step(u + GUIDANCE * (c - u), x)
+        return x
+
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        x = loop(2)                                              # warm-up: library handles, MIOpen / hipBLASLt solutions
+        R.vae_decode(vsd, vcfg, x / vcfg["scaling_factor"])
+        torch.cuda.synchronize()
+        warm_s = time.perf_counter() - t_start
+        if warm_s * steps / 2 > budget_s:
+            raise TimeoutError(f"2 warm steps + decode took {warm_s:.1f} s: the {steps}-step run would exceed {budget_s:.0f} s")
+        t0 = time.perf_counter()
+        x = loop(steps)
+        img = R.vae_decode(vsd, vcfg, x / vcfg["scaling_factor"])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return x, img, (dt if timed else None)
+
+
+def reference_legs(engine_img, engine_lat, unet_sd, vae_sd, ucfg, vcfg, inp, steps, engine_images_per_s):
+    """parity + torch_rocm_baseline objects (rank 0, N = 1, outside the timed region)."""
+    parity = {"psnr_db": None, "ref": "reference graph (oracle restatement) on PyTorch-ROCm fp32, this GPU",
+              "steps": steps, "noise_floor_db": None}
+    base = {"images_per_s": None, "kind": "port of the reference module graph, PyTorch-ROCm eager bf16 "
+                                          "(F.conv2d / F.linear / F.scaled_dot_product_attention / F.group_norm)",
+            "unit": "images/s"}
+    try:
+        log("torch_rocm_baseline leg: reference graph, eager bf16, 50 steps + decode")
+        lat_b, img_b, secs = reference_pipeline_on_device(unet_sd, vae_sd, ucfg, vcfg, inp, steps, torch.bfloat16, timed=True)
+        base.update({"images_per_s": 1.0 / secs, "seconds_per_image": secs})
+        log(f"torch_rocm_baseline: {secs:.2f} s / image")
+    except Exception as e:  # a failing baseline must not cost the measurement
+        base["error"] = f"{type(e).__name__}: {e}"
+        lat_b = img_b = None
+        log(f"torch_rocm_baseline failed: {base['error']}")
+    try:
+        log("parity leg: reference graph, fp32, 50 steps + decode")
+        lat_f, img_f, _ = reference_pipeline_on_device(unet_sd, vae_sd, ucfg, vcfg, inp, steps, torch.float32)
+        parity["psnr_db"] = _psnr01(engine_img, img_f)
+        d = engine_lat.float() - lat_f
+        parity["latents_rel_rms"] = float(d.pow(2).mean().sqrt() / lat_f.pow(2).mean().sqrt())
+        if img_b is not None:
+            parity["noise_floor_db"] = _psnr01(img_b, img_f)            # reference bf16 vs reference fp32
+            parity["vs_torch_bf16_db"] = _psnr01(engine_img, img_b)
+            db = lat_b.float() - lat_f
+            parity["noise_floor_latents_rel_rms"] = float(db.pow(2).mean().sqrt() / lat_f.pow(2).mean().sqrt())
+        parity["finite"] = bool(torch.isfinite(img_f).all())
+        log(f"parity: engine vs fp32 {parity['psnr_db']:.1f} dB, torch-bf16 vs fp32 {parity['noise_floor_db']} dB")
+    except Exception as e:
+        parity["error"] = f"{type(e).__name__}: {e}"
+        log(f"parity leg failed: {parity['error']}")
+    vs = engine_images_per_s / base["images_per_s"] if base.get("images_per_s") else None
+    return parity, base, vs
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
     from diffusers_amd import distributed as D
     rank, world, local = D.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = _device(local)
 
     from diffusers_amd import factory, init as dinit
+    from diffusers_amd.autoencoder_kl import _DEFAULTS as VD
     from diffusers_amd.unet_2d_condition import _DEFAULTS as UD
     ucfg = dinit.TINY_SDXL_UNET if args.tiny else dinit.SDXL_UNET
     vcfg = dinit.TINY_VAE if args.tiny else dinit.SDXL_VAE
     log(f"rank {rank}/{world}: building models on {dev}")
     unet, unet_sd = factory.build_unet(ucfg, seed=0, device=dev, init_device=str(dev))
-    vae, _ = factory.build_vae(vcfg, seed=1, device=dev, init_device=str(dev))
+    vae, vae_sd = factory.build_vae(vcfg, seed=1, device=dev, init_device=str(dev))
     from diffusers_amd.pipelines import StableDiffusionXLPipeline
     from diffusers_amd.schedulers import EulerDiscreteScheduler
     pipe = StableDiffusionXLPipeline(vae=vae, unet=unet, scheduler=EulerDiscreteScheduler(**factory.SDXL_SCHEDULER))
@@ -172,13 +335,14 @@ def main():
 
     state = {"graph": not args.no_graph}
 
-    def one_image():
+    def one_image(output_type="raw"):
         return pipe(prompt_embeds=mine["prompt_embeds"], negative_prompt_embeds=mine["negative_prompt_embeds"],
                     pooled_prompt_embeds=mine["pooled"], negative_pooled_prompt_embeds=mine["negative_pooled"],
-                    latents=mine["latents"].clone(), num_inference_steps=args.denoise_steps, guidance_scale=5.0,
-                    height=hw, width=hw, output_type="raw", use_graph=state["graph"]).images
+                    latents=mine["latents"].clone(), num_inference_steps=args.denoise_steps, guidance_scale=GUIDANCE,
+                    height=hw, width=hw, output_type=output_type, use_graph=state["graph"]).images
 
     log("warm-up (tunes GEMM variants for unseen shapes, captures the denoising-step HIP graph)")
+    img = None
     for _ in range(args.warmup):
         try:
             img = one_image()
@@ -188,61 +352,69 @@ def main():
             if not state["graph"]:
                 raise
             log(f"HIP-graph capture failed ({e}); continuing with eager launches")
-            torch.cuda.synchronize()
+            _sync()
             state["graph"] = False
             pipe._graph = None
             img = one_image()
-    torch.cuda.synchronize()
+    _sync()
     log("timed region")
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img = one_image()
-    torch.cuda.synchronize()
+    _sync()
+    mine_s = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    _sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    per_rank = [args.steps / mine_s]
+    if world > 1:
+        tt = torch.tensor([args.steps / mine_s], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        torch.distributed.all_gather(gathered, tt)
+        per_rank = [float(g.item()) for g in gathered]
     finite = bool(torch.isfinite(img.float()).all())
     log(f"timed region done: {elapsed:.3f} s for {args.steps} image(s) per GPU")
     if args.save_tuning and rank == 0:
         from diffusers_amd import tuning
         tuning.save(args.save_tuning)
 
+    value = world * args.steps / elapsed
     result = {
         "metric": "images/sec @ SDXL-base 1024x1024 50-step EulerDiscrete CFG bf16",
-        "value": world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights, embeddings, latents)",
         "config": {"workload": "SDXL-base-1.0 U-Net (2567 M params) x 50 EulerDiscrete steps, CFG 5.0 (batch 2), "
                                "128x128 latents + AutoencoderKL decode to 1024x1024; 1 prompt per GPU"
                                if not args.tiny else "TINY plumbing config (not a benchmark)",
                    "global_batch": world, "parallelism": f"dp{world} (independent prompts, replicas)",
-                   "denoise_steps": args.denoise_steps, "hip_graph": state["graph"], "output_finite": finite},
+                   "denoise_steps": args.denoise_steps, "hip_graph": state["graph"], "output_finite": finite,
+                   "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+                   "images_per_s_per_rank": per_rank},
     }
 
     if rank == 0 and not args.tiny:
         if not args.no_roofline:
-            # dominant kernel = igemm_bf16_kernel (all Linear + Conv2d 3x3/1x1): MFMA-bound.
-            sch = pipe.scheduler
-            cond = pipe._static.get("cond")
-            lat = mine["latents"].clone()
-
-            def one_step():
-                sch.reset(0)
-                pipe._step(lat, cond, 5.0, True)
             log("roofline leg: one eager denoising step with HIP events around every igemm launch")
-            one_step()  # untimed warm pass
-            n, ms, fl = instrumented_gemm_pass(pipe, one_step)
-            ach = fl / (ms * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
-                                  "kernel": "igemm_bf16_kernel (Linear + Conv2d implicit GEMM)",
-                                  "launches_per_denoise_step": n, "avg_launch_us": 1000.0 * ms / max(n, 1),
-                                  "algorithmic_tflop_per_denoise_step": fl / 1e12,
-                                  "end_to_end_frac": (world * args.steps / elapsed) * TFLOP_PER_IMAGE / world / MFMA_PEAK_TFLOPS}
+            try:
+                result["roofline"] = roofline_leg(pipe, mine, world, value)
+            except Exception as e:  # never lose the measured line to a diagnostic leg
+                result["roofline"] = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": None, "traffic": None, "error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_reference:
+            full_u, full_v = dict(UD), dict(VD)
+            full_u.update(ucfg)
+            full_v.update(vcfg)
+            # the engine's own image / latents for the parity check: the same call as the timed one
+            eng_lat = one_image("latent").clone()
+            eng_img = one_image("raw")
+            parity, base, vs = reference_legs(eng_img, eng_lat, unet_sd, vae_sd, full_u, full_v, mine,
+                                              args.denoise_steps, value)
+            result["parity"], result["torch_rocm_baseline"], result["vs_torch_rocm"] = parity, base, vs
         if world == 1 and not args.no_cpu_baseline:
             full = dict(UD)
             full.update(ucfg)
@@ -261,10 +433,11 @@ def main():
             finally:
                 signal.alarm(0)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    return result
 
 
 if __name__ == "__main__":

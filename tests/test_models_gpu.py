@@ -96,7 +96,7 @@ def test_tiny_sdxl_pipeline_vs_reference(golden):
     ps = _psnr(img, torch.from_numpy(g["image"]))
     print(f"[parity] tiny SDXL pipeline: latents rel_rms={rr:.3e}  image PSNR vs reference fp32 = {ps:.1f} dB")
     assert rr < 4e-2
-    assert ps >= 35.0  # recurrent bf16 rounding over the loop; the bf16 reference itself sits at a similar floor
+    assert ps >= 40.0  # BASELINE.json target (measured 51-52 dB; the bf16 reference itself sits at the same floor)
 
 
 def test_sdxl_architecture_small_latents_vs_oracle():
@@ -175,7 +175,7 @@ def test_tiny_flux_pipeline_vs_reference(golden):
     ps = _psnr(img, torch.from_numpy(g["image"]))
     print(f"[parity] tiny Flux pipeline: latents rel_rms={rr:.3e}  image PSNR vs reference fp32 = {ps:.1f} dB")
     assert rr < 4e-2
-    assert ps >= 35.0
+    assert ps >= 40.0
 
 
 def test_sd15_head_geometry_vs_reference(golden):
@@ -254,7 +254,7 @@ def test_tiny_ddpm_unet_and_pipeline_vs_reference(golden):
     mse = float(((img - want) ** 2).mean())
     ps = 10 * np.log10(1.0 / max(mse, 1e-12))
     print(f"[parity] tiny DDPM pipeline (5 steps): image PSNR vs reference fp32 = {ps:.1f} dB, max abs {np.abs(img - want).max():.3f}")
-    assert ps >= 35.0
+    assert ps >= 40.0
 
 
 def test_tiny_wan_pipeline_unipc_vs_oracle(golden):
