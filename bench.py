@@ -104,7 +104,7 @@ def synth_inputs(n_prompts, tiny, device):
 
 def instrumented_gemm_pass(pipe, run_one_step):
     """Roofline leg: one eager denoising step with a HIP-event pair around every igemm launch (linear + conv), on the
-    stream the kernels are launched on.  Returns (launches, total_ms, total_algorithmic_flops)."""
+    stream the kernels are launched on.  Returns (launches, total_ms, total_algorithmic_flops, total_algorithmic_bytes)."""
     from diffusers_amd import ops
     records = []
     orig_linear, orig_conv = ops.linear, ops.conv2d_nhwc
@@ -123,11 +123,14 @@ def instrumented_gemm_pass(pipe, run_one_step):
         x, w = a[0], a[1]
         if x.shape[0] <= 8:
             return None  # skinny path: not the igemm kernel
-        return 2.0 * x.shape[0] * w.shape[0] * x.shape[1]
+        # (flops, algorithmic bytes = each operand and the output once)
+        return 2.0 * x.shape[0] * w.shape[0] * x.shape[1], 2.0 * (x.numel() + w.numel() + out.numel())
 
     def conv_flops(a, k, out):
-        w = a[1]
-        return 2.0 * out.shape[0] * out.shape[1] * out.shape[2] * w.shape[0] * w.shape[1]
+        x, w = a[0], a[1]
+        x2 = k.get("x2")
+        return (2.0 * out.shape[0] * out.shape[1] * out.shape[2] * w.shape[0] * w.shape[1],
+                2.0 * (x.numel() + (x2.numel() if x2 is not None else 0) + w.numel() + out.numel()))
 
     ops.linear, ops.conv2d_nhwc = timed(orig_linear, lin_flops), timed(orig_conv, conv_flops)
     try:
@@ -136,7 +139,7 @@ def instrumented_gemm_pass(pipe, run_one_step):
     finally:
         ops.linear, ops.conv2d_nhwc = orig_linear, orig_conv
     recs = [(e0.elapsed_time(e1), f) for e0, e1, f in records if f is not None]
-    return len(recs), sum(r[0] for r in recs), sum(r[1] for r in recs)
+    return len(recs), sum(r[0] for r in recs), sum(r[1][0] for r in recs), sum(r[1][1] for r in recs)
 
 
 def roofline_leg(pipe, mine, world, images_per_s):
@@ -155,7 +158,7 @@ def roofline_leg(pipe, mine, world, images_per_s):
         sch.reset(0)
         pipe._step(lat, cond, GUIDANCE, True)
     one_step()  # untimed warm pass
-    n, ms, fl = instrumented_gemm_pass(pipe, one_step)
+    n, ms, fl, nbytes = instrumented_gemm_pass(pipe, one_step)
     ach = fl / (ms * 1e-3) / 1e12
     traffic, note = None, "no committed PMC measurement (profiles/sdxl_traffic.json)"
     if TRAFFIC_FILE.exists():
@@ -169,6 +172,7 @@ def roofline_leg(pipe, mine, world, images_per_s):
             "kernel": "igemm_bf16_kernel (Linear + Conv2d implicit GEMM)",
             "launches_per_denoise_step": n, "avg_launch_us": 1000.0 * ms / max(n, 1),
             "algorithmic_tflop_per_denoise_step": fl / 1e12,
+            "algorithmic_bytes_per_launch": nbytes / max(n, 1),
             "end_to_end_frac": images_per_s * TFLOP_PER_IMAGE / world / MFMA_PEAK_TFLOPS}
 
 

@@ -196,6 +196,26 @@ class UNet2DConditionModel:
             aug = self._text_time_embedding(added_cond_kwargs, B)
         return {"kvs": kvs, "aug_emb": aug, "batch": B, "ehs_ptr": encoder_hidden_states.data_ptr()}
 
+    def _cached_conditioning(self, encoder_hidden_states, added_cond_kwargs):
+        """The drop-in path: an unchanged reference pipeline calls forward(sample, t, encoder_hidden_states=prompt_embeds,
+        added_cond_kwargs=...) with the SAME tensors on every step (pipeline_stable_diffusion_xl.py:1208-1217), so the
+        step-invariant work (140 K / V^T GEMMs + the text_time MLP for SDXL) is computed for the first call and reused
+        while those tensors are the same objects with the same in-place version counters."""
+        def ident(t):
+            return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+        added = added_cond_kwargs or {}
+        key = (ident(encoder_hidden_states), ident(added.get("text_embeds")), ident(added.get("time_ids")))
+        hit = getattr(self, "_cond_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        ehs = encoder_hidden_states
+        if ehs is not None and (ehs.dtype != bf16 or not ehs.is_cuda):
+            ehs = ehs.to(device=self.device, dtype=bf16)
+        cond = self.precompute_conditioning(ehs, added_cond_kwargs)
+        # the cache holds references to the keyed tensors, so their storage (and data_ptr) cannot be recycled under it
+        self._cond_cache = (key, cond, (encoder_hidden_states, added.get("text_embeds"), added.get("time_ids")))
+        return cond
+
     def _text_time_embedding(self, added_cond_kwargs, B):
         # unet_2d_condition.py:906-922
         if added_cond_kwargs is None or "text_embeds" not in added_cond_kwargs:
@@ -245,7 +265,7 @@ class UNet2DConditionModel:
         if H % (2 ** n_up) or W_ % (2 ** n_up):
             raise ValueError("sample height/width must be divisible by 2**(num_upsamplers)")
         if conditioning is None:
-            conditioning = self.precompute_conditioning(encoder_hidden_states, added_cond_kwargs)
+            conditioning = self._cached_conditioning(encoder_hidden_states, added_cond_kwargs)
         if conditioning["batch"] != B:
             raise ValueError("conditioning batch does not match sample batch")
         kvs = conditioning["kvs"]

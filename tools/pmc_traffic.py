@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""HBM-side traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE in one, WRITE_SIZE in the other: they do not fit
+one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") of `bench.py --no-graph --steps 1 --warmup 0 ...`.
+
+Corrections applied exactly as the guide's HBM section prescribes: FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950
+FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced streams (every load of these kernels is 16 B / lane),
+so fetched bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is taken as reported (uncalibrated, stated in the output).
+
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.md> <out.json> [algorithmic_bytes_per_igemm_launch]
+Writes the per-kernel-family table (markdown) and the JSON bench.py reads for roofline.traffic."""
+import csv
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+
+def family(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    for key in ("igemm_bf16_kernel", "attn_fwd_kernel", "layernorm_kernel", "gn_apply_kernel", "gn_stats_kernel",
+                "linear_small_m_kernel", "conv_thin_in_kernel", "conv_thin_out_kernel", "softmax_rows_kernel",
+                "euler_step_kernel", "euler_scale_input_kernel"):
+        if key in name:
+            return key
+    if "at::native" in name or name.startswith("at::"):
+        return "torch:*"
+    cut = name.find("(")
+    return (name if cut < 0 else name[:cut])[:60]
+
+
+def collect(root: Path, counter: str):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in root.rglob("*counter_collection.csv"):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] != counter:
+                    continue
+                a = acc[family(r["Kernel_Name"])]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch_dir, write_dir, out_md, out_json = (Path(p) for p in sys.argv[1:5])
+    algo = float(sys.argv[5]) if len(sys.argv) > 5 else None
+    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    fams = sorted(set(fe) | set(wr), key=lambda k: -(2 * fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1]))
+    lines = ["# HBM-side traffic per launch, SDXL bench (eager launches, rocprofv3 --pmc; FETCH and WRITE in separate passes)",
+             "",
+             "fetched = 2 x FETCH_SIZE KiB (gfx950 wide-stream correction, MI355X_MICROARCH.md HBM section); written = "
+             "WRITE_SIZE KiB as reported (uncalibrated).  Per launch = counter sum / dispatches of the family.", "",
+             "| kernel family | dispatches | fetched MB / launch | written MB / launch | total MB / launch | total GB (run) |",
+             "|---|---:|---:|---:|---:|---:|"]
+    rec = {}
+    for k in fams:
+        nf, sf = fe.get(k, [0, 0.0])
+        nw, sw = wr.get(k, [0, 0.0])
+        n = max(nf, nw)
+        if n == 0:
+            continue
+        fb = 2.0 * sf * 1024.0 / max(nf, 1)
+        wb = sw * 1024.0 / max(nw, 1)
+        rec[k] = {"dispatches": n, "fetched_bytes_per_launch": fb, "written_bytes_per_launch": wb}
+        if (2 * sf + sw) * 1024 < 1e6:
+            continue
+        lines.append(f"| `{k}` | {n} | {fb / 1e6:.3f} | {wb / 1e6:.3f} | {(fb + wb) / 1e6:.3f} | {(fb * nf + wb * nw) / 1e9:.2f} |")
+    ig = rec.get("igemm_bf16_kernel")
+    out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --no-graph --steps 1; "
+                     f"{out_md.name}", "unit": "bytes", "families": rec}
+    if ig:
+        tot = ig["fetched_bytes_per_launch"] + ig["written_bytes_per_launch"]
+        out["igemm_bytes_per_launch"] = tot
+        lines += ["", f"igemm_bf16_kernel: {tot / 1e6:.3f} MB of HBM-side traffic per launch"
+                  + (f" against {algo / 1e6:.3f} MB of algorithmic bytes (unique A + W + C per launch, averaged over the "
+                     f"launches of a denoising step): ratio {tot / algo:.2f}x" if algo else "")]
+        if algo:
+            out["igemm_algorithmic_bytes_per_launch"] = algo
+    out_md.write_text("\n".join(lines) + "\n")
+    out_json.write_text(json.dumps(out, indent=1) + "\n")
+    print("\n".join(lines[-3:]))
+
+
+if __name__ == "__main__":
+    main()
