@@ -19,6 +19,8 @@ TILE_NAMES = ("auto", "128x128", "64x128", "128x64", "64x64", "256x128", "128x25
 STAGE_REGISTER, STAGE_LDS_DIRECT, STAGE_LDS_DIRECT3, STAGE_LDS_DIRECT4, STAGE_LDS_DIRECT6, STAGE_LDS_DIRECT8 = range(6)
 RING_SLOTS = (2, 2, 3, 4, 6, 8)  # LDS ring depth per staging code
 DTYPE_BF16, DTYPE_F32 = 0, 1
+SPLITK_FLAGS = 4096          # DA_SPLITK_FLAGS
+SPLITK_ERR_SLOT = SPLITK_FLAGS - 1
 PRED_EPSILON, PRED_V, PRED_SAMPLE = 0, 1, 2
 PRED_TYPES = {"epsilon": PRED_EPSILON, "v_prediction": PRED_V, "sample": PRED_SAMPLE}
 
@@ -37,6 +39,7 @@ class GemmParams(C.Structure):
         ("Hin", C.c_int), ("Win", C.c_int), ("C1", C.c_int), ("C2", C.c_int),
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("pad", C.c_int),
         ("tile", C.c_int), ("staging", C.c_int), ("gate_f32", C.c_int),
+        ("split_k", C.c_int), ("workspace", C.c_void_p), ("sync_flags", C.c_void_p), ("workspace_bytes", C.c_longlong),
     ]
 
 
@@ -47,7 +50,7 @@ class AttentionParams(C.Structure):
         ("q_batch_stride", C.c_longlong), ("k_batch_stride", C.c_longlong),
         ("vt_batch_stride", C.c_longlong), ("o_batch_stride", C.c_longlong),
         ("q_row_stride", C.c_int), ("k_row_stride", C.c_int), ("vt_ld", C.c_int), ("o_row_stride", C.c_int),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("ring_slots", C.c_int),
     ]
 
 
@@ -58,8 +61,9 @@ SIGNATURES = {
     "da_version": (_i, []),
     "da_last_error": (C.c_char_p, []),
     "da_gemm_bf16": (_i, [C.POINTER(GemmParams), _vp]),
-    "da_gemm_tune": (_i, [C.POINTER(GemmParams), _vp, _i, _vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
-                          C.POINTER(C.c_float)]),
+    "da_gemm_pair_bf16": (_i, [C.POINTER(GemmParams), C.POINTER(GemmParams), _vp]),
+    "da_gemm_tune": (_i, [C.POINTER(GemmParams), C.POINTER(GemmParams), _vp, _i, _vp, C.c_size_t, C.POINTER(C.c_int),
+                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "da_attention_bf16": (_i, [C.POINTER(AttentionParams), _vp]),
     "da_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "da_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

@@ -66,8 +66,8 @@ class VaeAttention:
         S = H * W_
         res = x.view(B * S, C)
         h = self.group_norm(x).view(B * S, C)
-        qk = ops.linear(h, self.wqk, self.bqk)      # [B*S][2C]
-        vt = ops.linear(self.wv, h)                 # [C][B*S]  (bias folded into self.bo)
+        # [B*S][2C] and [C][B*S] (V bias folded into self.bo): one paired launch (layers.Attention)
+        qk, vt = ops.linear_pair({"x": h, "w": self.wqk, "bias": self.bqk}, {"x": self.wv, "w": h})
         if self.head_dim in (64, 96, 128, 160) and not self.force_gemm_path:
             o = ops.attention(qk, qk[:, self.inner:], vt, B=B, H=self.heads, D=self.head_dim, Sq=S, Skv=S, Skv_alloc=S,
                               q_row_stride=2 * self.inner, k_row_stride=2 * self.inner,

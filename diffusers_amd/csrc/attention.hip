@@ -15,8 +15,13 @@
 // lane^32 exchange, the online-softmax rescale is a per-lane scalar, and P never leaves registers: the MFMA K-index
 // permutation that the C/D layout imposes on P is simply applied to the V^T fragment reads as well.
 //
-// One block = 4 waves = 128 queries of one (batch, head); KV tiles of 64 in a 2-slot LDS ring filled by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, the next tile streams in under this tile's MFMAs / softmax).
+// One block = 4 waves = 128 queries of one (batch, head); KV tiles of 64 in an NS-slot LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers).  NS - 1 tiles are in flight while one is consumed and the wait in
+// front of each tile is a COUNTED s_waitcnt vmcnt((NS - 2) * LOADS) + raw s_barrier, so the K / V^T stream never
+// drains: with the 2-slot ring of the first version every tile paid one full L2 / HBM round trip (~1-2 k cycles)
+// against ~0.5 k cycles of MFMA work.  One rendezvous per tile orders both hazards: every wave has passed its wait
+// for tile j (tile j has landed for all readers) and has retired its LDS reads of tile j-1 (lgkmcnt(0)), whose slot the
+// DMA issued right after the barrier overwrites.
 #include "common.cuh"
 
 namespace {
@@ -45,9 +50,13 @@ __device__ __forceinline__ int k_swz(int row) {
   return 0;
 }
 
-template <int D>
+template <int D, int NS>
 __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
   using C = AttnCfg<D>;
+  constexpr int PD = NS - 1;                 // prefetch distance (tiles in flight ahead of the one being consumed)
+  constexpr int LOADS = C::KCH + C::VCH;     // LDS-DMA instructions per wave per tile
+  static_assert(NS >= 2 && NS <= 4 && (PD - 1) * LOADS <= 63, "vmcnt is a 6-bit counter");
+  static_assert(NS * C::STAGE <= 160 * 1024, "K / V^T ring exceeds the LDS of a CU");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -111,12 +120,19 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
                                        (__attribute__((address_space(3))) void*)(vb + (i * 4 + wave) * 1024), 16, 0, 0);
     }
   };
-  // all of this wave's LDS-DMA has landed and its LDS reads have retired, then rendezvous (raw barrier + compiler fence)
-  auto wait_all = [&]() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // wait until at most G of this wave's later tiles are still in flight (so tile j has landed) and this wave's LDS
+  // reads have retired, then rendezvous (raw barrier: __syncthreads would drain vmcnt to 0) + compiler fence
+#define DA_ATTN_VMCNT_CASE(G_) \
+  case G_: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G_) * LOADS <= 63 ? (G_) * LOADS : 63) : "memory"); break;
+  auto wait_tile = [&](int g) {
+    switch (g) {
+      DA_ATTN_VMCNT_CASE(1) DA_ATTN_VMCNT_CASE(2)
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+#undef DA_ATTN_VMCNT_CASE
 
   f32x16_t o[D / 32];
 #pragma unroll
@@ -130,13 +146,15 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
   const int ksw = k_swz<D>(l31);           // K fragment swizzle of this lane's row
   const int vsw = (l31 >> 1) & 7;          // V^T 16-byte chunk swizzle of this lane's row ((32*dt + l31) >> 1) & 7
 
-  issue(0, 0);
-  wait_all();
+#pragma unroll
+  for (int t0 = 0; t0 < PD; ++t0)
+    if (t0 < ntiles) issue(t0, t0);
 
+  int cur = 0, nxt = PD % NS;   // ring slot of tile j / of the tile issued in iteration j
   for (int j = 0; j < ntiles; ++j) {
-    const int cur = j & 1;
-    const bool more = (j + 1 < ntiles);
-    if (more) issue(j + 1, cur ^ 1);   // the other slot was last read in iteration j-1, behind that iteration's barrier
+    // issued so far: tiles 0 .. min(ntiles, j + PD) - 1; tile j must have landed -> the later ones may stay in flight
+    wait_tile(min(ntiles, j + PD) - j - 1);
+    if (j + PD < ntiles) issue(j + PD, nxt);   // slot of tile j - 1: every wave's reads of it retired before the barrier
     __builtin_amdgcn_sched_barrier(0);
 
     const unsigned char* kb = smem + cur * C::STAGE;
@@ -193,10 +211,14 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
         psum += e;
       }
     l_run = l_run * alpha + psum;  // per-half partial; halves are combined after the loop
+    // the O rescale is D/2 multiplies per lane per tile; once the running maxima have settled (after the first tiles)
+    // alpha == 1 in every lane and the pass is skipped wave-uniformly (x * 1.0f is exact: same bits either way)
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-    for (int i = 0; i < D / 32; ++i)
+      for (int i = 0; i < D / 32; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
 
     // ---- P^T fragments: MFMA u (K=16) takes registers 8*(u&1)..+7 of tile u>>1; packed two per v_cvt_pk_bf16_f32 ----
     bf16x8_t pf[4];
@@ -222,7 +244,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
       }
     }
 
-    if (more) wait_all();
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
   }
 
   // ---- epilogue ----
@@ -243,11 +266,11 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
   }
 }
 
-template <int D>
+template <int D, int NS>
 int launch_attn(const da_attention_params& p, hipStream_t s) {
   using C = AttnCfg<D>;
-  const size_t lds = 2 * C::STAGE;
-  auto kern = attn_fwd_kernel<D>;
+  const size_t lds = (size_t)NS * C::STAGE;
+  auto kern = attn_fwd_kernel<D, NS>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -263,6 +286,24 @@ int launch_attn(const da_attention_params& p, hipStream_t s) {
   return DA_OK;
 }
 
+// ring depth: p.ring_slots (2..4) when the caller pins it (A/B measurements, tests), else the default per head size:
+// the deepest ring that keeps the block count per CU (2 for D <= 64, 1 above) inside the 160 KiB of LDS
+template <int D>
+int launch_attn_ring(const da_attention_params& p, hipStream_t s) {
+  using C = AttnCfg<D>;
+  constexpr int per_cu = (D <= 64) ? 2 : 1;
+  constexpr int max_ns = (160 * 1024) / (C::STAGE * per_cu);
+  constexpr int def_ns = max_ns >= 4 ? 4 : (max_ns >= 3 ? 3 : 2);
+  int ns = p.ring_slots ? p.ring_slots : def_ns;
+  if (p.Skv <= 64) ns = 2;   // a single tile: nothing to pipeline
+  switch (ns) {
+    case 2: return launch_attn<D, 2>(p, s);
+    case 3: if constexpr (3 * C::STAGE <= 160 * 1024) return launch_attn<D, 3>(p, s); else return DA_ERR_UNSUPPORTED;
+    case 4: if constexpr (4 * C::STAGE <= 160 * 1024) return launch_attn<D, 4>(p, s); else return DA_ERR_UNSUPPORTED;
+  }
+  return DA_ERR_INVALID;
+}
+
 }  // namespace
 
 extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
@@ -271,15 +312,16 @@ extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
   if (!p.q || !p.k || !p.vt || !p.out) return DA_ERR_INVALID;
   if (p.B <= 0 || p.H <= 0 || p.Sq <= 0 || p.Skv <= 0) return DA_ERR_INVALID;
   if (p.Skv_alloc < p.Skv || (p.Skv_alloc & 7)) return DA_ERR_INVALID;
+  if (p.ring_slots != 0 && (p.ring_slots < 2 || p.ring_slots > 4)) return DA_ERR_INVALID;
   if ((p.q_row_stride & 7) || (p.k_row_stride & 7) || (p.vt_ld & 7) || (p.vt_batch_stride & 7) || (p.o_row_stride & 3))
     return DA_ERR_UNSUPPORTED;
   if ((p.q_batch_stride & 7) || (p.k_batch_stride & 7) || (p.o_batch_stride & 3)) return DA_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   switch (p.D) {
-    case 64: return launch_attn<64>(p, s);
-    case 96: return launch_attn<96>(p, s);
-    case 128: return launch_attn<128>(p, s);
-    case 160: return launch_attn<160>(p, s);
+    case 64: return launch_attn_ring<64>(p, s);
+    case 96: return launch_attn_ring<96>(p, s);
+    case 128: return launch_attn_ring<128>(p, s);
+    case 160: return launch_attn_ring<160>(p, s);
   }
   return DA_ERR_UNSUPPORTED;
 }

@@ -41,9 +41,29 @@ struct RowInfo {      // per staged activation row (implicit GEMM gather state)
 // bit 31 of it: beyond num_records, so the hardware range check writes zeros to LDS (the convention of
 // ck::amd_direct_load_global_to_lds); descriptor bases sit at the tile's first input row, which keeps offsets 31-bit on
 // tensors of any size.
-template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
+//
+// Two launch-level extensions (speed only for the first, a different fp32 summation order for the second):
+//  * PAIR: one launch may carry TWO independent problems (prob_a on blocks [0, grid_a), prob_b on the rest) -- e.g. the fused
+//    Q|K projection (160 tiles of 128x256 at SDXL's 1280-wide level) and the swapped V^T projection (80 tiles) of one
+//    self-attention layer, which separately fill 62 % and 31 % of the 256 CUs and together 94 %.  Each block runs
+//    exactly the code it would run in its own launch: results are bit-identical to two launches.
+//  * SPLIT-K (p.split_k > 1, nn.Linear only): the K slices of a tile are dealt to split_k blocks of the same XCD.
+//    Blocks 0 .. split_k-2 publish their fp32 accumulators to a workspace slot with write-through (sc1) stores, drain
+//    them and raise a flag; the LAST block (highest block id: dispatched after its producers) polls the flags, adds the
+//    slots in index order with sc1 loads and runs the epilogue.  That is the agent-scope hand-off of
+//    cdna_hip_programming.md Guideline 16 (R1: sc1 payload both sides, drained before a relaxed agent-scope flag, ONE
+//    polling lane, bounded spin); the consumer re-arms the flag for the next launch on the stream.  The sum order is
+//    fixed (own slices, then slot 0, 1, ...), so a given split_k is deterministic; different split_k differ in the
+//    last fp32 bit of the sum.  The host admits split-K only when every block of the launch is co-resident.
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_params prob_a, const int xcd_gx_a,
+                                                                  const da_gemm_params prob_b, const int xcd_gx_b,
+                                                                  const int grid_a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and cannot parse the buffer builtins)
+  const bool second = (int)blockIdx.x >= grid_a;          // wave-uniform: a scalar select between the two kernarg blocks
+  const da_gemm_params& p = second ? prob_b : prob_a;
+  const int xcd_gx = second ? xcd_gx_b : xcd_gx_a;
+  const int bid = second ? (int)blockIdx.x - grid_a : (int)blockIdx.x;
   constexpr bool GLDS = (SM != 0), BLDS = (SM == 2);
   constexpr int NW = WM * WN, NTHR = 64 * NW, RP = NTHR / 8;  // RP = tile rows staged per pass (one 1 KiB piece per wave)
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -74,9 +94,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   const int tiles_m = (p.M + BM - 1) / BM;
   const int gyn = 8 / xcd_gx;
   const int tm_per = (tiles_m + gyn - 1) / gyn, tn_per = (tiles_n + xcd_gx - 1) / xcd_gx;
-  const int xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
+  const int xcd = bid & 7, kblk = bid >> 3;       // grid_a is a multiple of 8: both problems see XCD = block id % 8
   const int gy = xcd / xcd_gx, gx = xcd - gy * xcd_gx;
-  const int lm = kblk / tn_per, ln = kblk - lm * tn_per;
+  // split-K: the split index is the slowest part of the per-XCD block index, so the split_k blocks of a tile share the
+  // tile's XCD (same L2 for the partial hand-off) and the reducer (last index) has the highest block id of the tile
+  // (SPLITK is a template parameter: the hand-off code costs ~50 VGPRs -- the accumulators are touched by VALU adds and
+  // buffer stores, not only by MFMAs -- which the unsplit instantiations must not pay)
+  const int split = (SPLITK && !CONV && p.split_k > 1) ? p.split_k : 1;
+  const int rect = tm_per * tn_per;
+  const int sidx = (split > 1) ? kblk / rect : 0;
+  const int kb2 = kblk - sidx * rect;
+  const int lm = kb2 / tn_per, ln = kb2 - lm * tn_per;
   const int tm = gy * tm_per + lm, tn = gx * tn_per + ln;
   if (tm >= tiles_m || tn >= tiles_n) return;  // ragged rectangle: the whole block leaves before any barrier
   const int m0 = tm * BM, n0 = tn * BN;
@@ -123,7 +151,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
     wrow[i] = (n < p.N) ? n : -1;
   }
 
-  const int nk = p.K >> 6;
+  // K slices of this block: all of them, or (split-K) the sidx-th of split nearly equal runs
+  const int nk_all = p.K >> 6;
+  const int nk_base = nk_all / split, nk_rem = nk_all - nk_base * split;
+  const int k_begin = sidx * nk_base + min(sidx, nk_rem);
+  const int nk = nk_base + (sidx < nk_rem ? 1 : 0);
   const int Ctot = CONV ? (p.C1 + p.C2) : 0;
 
   // buffer-addressed staging: descriptors over the block's operand panels, per-lane byte offsets in vo_*
@@ -147,7 +179,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   __amdgpu_buffer_rsrc_t rs_x2 = uniform_rsrc((CONV && A2) ? A2 + (size_t)pb * p.C2 : A, x2bytes);
   __amdgpu_buffer_rsrc_t rs_w = uniform_rsrc(Wt + (BLDS ? (size_t)n0 * p.ldw : 0), 0x7fffffff);
   int vo_x[XR], vo_x2[XR], vo_w[WR];
-  int bk_off = 0;  // byte offset of the cursor K slice inside a weight / activation row (scalar)
+  int bk_off = k_begin * 128;  // byte offset of the cursor K slice inside a weight / activation row (scalar)
   // conv: offsets of the activation rows for tap (kh, kw) -- called once per tap, not per K slice
   auto tap_offsets = [&](int kh, int kw) {
 #pragma unroll
@@ -187,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   // K-slice cursor of the NEXT slice to issue.  Slices are issued strictly in order, so the (tap, channel) position
   // of the implicit GEMM advances incrementally (no integer division in the loop): K index = tap * Ctot + c.
   int is_kh = 0, is_kw = 0, is_c0 = 0;  // conv: kernel row / column of the tap, first channel of the slice
-  size_t is_k = 0;                      // linear / weights: element offset of the slice inside a row
+  size_t is_k = (size_t)k_begin * 64;   // linear / weights: element offset of the slice inside a row
 
   // source pointer of activation row i for the cursor slice (a 128-byte line of zeros when the slot must be zero,
   // so every staging load is unconditional and the compiler keeps them all in flight)
@@ -408,6 +440,71 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
 #undef DA_STAGE_WAIT
 #undef DA_VMCNT_CASE
 
+  // ---- split-K hand-off (see the kernel header): producers publish and leave, the reducer gathers ----
+  if constexpr (SPLITK && !CONV) {
+    if (split > 1) {
+      constexpr int TILE_FLOATS = BM * BN;
+      float* ws = (float*)p.workspace;
+      int* flags = (int*)p.sync_flags;
+      const int slot0 = (tm * tiles_n + tn) * (split - 1);
+      if (sidx < split - 1) {
+        const int slot = slot0 + sidx;
+        __amdgpu_buffer_rsrc_t rs = uniform_rsrc(ws + (size_t)slot * TILE_FLOATS, (size_t)TILE_FLOATS * 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              u32x4_t v;
+              v.x = __float_as_uint(acc[i][j][4 * q + 0]); v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+              v.z = __float_as_uint(acc[i][j][4 * q + 2]); v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+              // lane-linear image: 16 B per lane, 64 lanes contiguous; sc1 = write-through past the XCD's L2
+              __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((((i * NT + j) * 4 + q) * NTHR) + t) * 16, 0, 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one sub-tile's accumulator reads at a time (VGPR budget, see the reducer)
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains before the flag
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      for (int sp = 0; sp < split - 1; ++sp) {
+        const int slot = slot0 + sp;
+        if (t == 0) {   // ONE lane polls ONE word, relaxed, with a bounded spin (a lost producer must not hang the GPU)
+          int spins = 0;
+          while (__hip_atomic_load(flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 20)) {
+              __hip_atomic_store(flags + DA_SPLITK_ERR_SLOT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+          __hip_atomic_store(flags + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        }
+        __syncthreads();
+        __amdgpu_buffer_rsrc_t rs = uniform_rsrc(ws + (size_t)slot * TILE_FLOATS, (size_t)TILE_FLOATS * 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            // one 32x32 sub-tile (4 x 16 B per lane in flight) at a time: without the fence the scheduler hoists every
+            // load of the slot above the first add and the kernel's VGPR budget grows by the whole partial tile
+            u32x4_t v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((((i * NT + j) * 4 + q) * NTHR) + t) * 16, 0, 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              acc[i][j][4 * q + 0] += __uint_as_float(v[q].x); acc[i][j][4 * q + 1] += __uint_as_float(v[q].y);
+              acc[i][j][4 * q + 2] += __uint_as_float(v[q].z); acc[i][j][4 * q + 3] += __uint_as_float(v[q].w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+    }
+  }
+
   // ---- epilogue: lane holds, for output row m (= lane&31 within the 32-tile), channels 8*(r>>2)+4*hi+(r&3) ----
   const uint16_t* __restrict__ bias = (const uint16_t*)p.bias;
   const uint16_t* __restrict__ rowvec = (const uint16_t*)p.rowvec;
@@ -540,14 +637,48 @@ inline int choose_xcd_gx(int tiles_m, int tiles_n, int BM, int BN) {
   return best;
 }
 
-template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM>
-int launch(const da_gemm_params& p, hipStream_t s) {
-  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+// CUs of the current device (256 on an MI355X), queried once
+inline int compute_units() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      return 256;
+    return cus;
+  }();
+  return n;
+}
+
+// blocks of one problem: 8 XCD rectangles x split_k
+template <int BM, int BN>
+inline int problem_grid(const da_gemm_params& p, int* gx_out) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int gx = choose_xcd_gx(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
-  const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
+  *gx_out = gx;
+  return 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx) * (p.split_k > 1 ? p.split_k : 1);
+}
+
+// pb == nullptr: one problem.  Otherwise both problems run in ONE launch (see the kernel header).
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false>
+int launch(const da_gemm_params& p, const da_gemm_params* pb, hipStream_t s) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  int gx_a = 1, gx_b = 1;
+  const int grid_a = problem_grid<BM, BN>(p, &gx_a);
+  const int grid_b = pb ? problem_grid<BM, BN>(*pb, &gx_b) : 0;
   const size_t lds = (size_t)(BM + BN) * 128 * STAGES;
-  auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, SM>;
+  if (!SPLITK && p.split_k > 1) return DA_ERR_UNSUPPORTED;
+  if (p.split_k > 1) {
+    // the reducer block of a tile spins on its producers: every block of the launch must be co-resident (LDS and the
+    // 1-2 blocks of 256 / 512 threads a CU takes at this kernel's register count bound it), and the workspace must
+    // hold (split_k - 1) fp32 tiles per output tile
+    if (CONV || pb) return DA_ERR_UNSUPPORTED;
+    const int per_cu = (int)((160 * 1024) / lds) >= 2 && WM * WN == 4 ? 2 : 1;
+    if (grid_a > compute_units() * per_cu) return DA_ERR_UNSUPPORTED;
+    const size_t tiles = (size_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (!p.workspace || !p.sync_flags || (p.K >> 6) < p.split_k) return DA_ERR_INVALID;
+    if (tiles * (p.split_k - 1) * BM * BN * 4 > (size_t)p.workspace_bytes) return DA_ERR_INVALID;
+    if (tiles * (p.split_k - 1) > DA_SPLITK_ERR_SLOT) return DA_ERR_INVALID;
+  }
+  auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, SM, SPLITK>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -556,7 +687,7 @@ int launch(const da_gemm_params& p, hipStream_t s) {
       attr_set = true;
     }
   }
-  DA_LAUNCH(kern, dim3(grid), dim3(64 * WM * WN), lds, s, p, gx);
+  DA_LAUNCH(kern, dim3(grid_a + grid_b), dim3(64 * WM * WN), lds, s, p, gx_a, pb ? *pb : p, gx_b, grid_a);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -584,16 +715,35 @@ inline bool buffer_staging_fits(const da_gemm_params& p) {
 
 // (tile, staging) -> kernel instantiation.  staging: 0 register staged (2 slots); 1..5 LDS-DMA with 2/3/4/6/8 ring slots.
 template <bool CONV>
-int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
+int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s, const da_gemm_params* pb = nullptr) {
   // LDS-DMA variants use the buffer-addressed mode whenever a tile's operand panels fit 31-bit byte offsets (always,
   // for the shapes of this engine); per-lane pointers (mode 1) are the fallback
-  const bool buf = !flat_staging_forced() && buffer_staging_fits(p);
+  const bool buf = !flat_staging_forced() && buffer_staging_fits(p) && (!pb || buffer_staging_fits(*pb));
+  if constexpr (!CONV) {
+    if (p.split_k > 1) {
+      // split-K instantiations: buffer-addressed staging only, the tiles that can be short of blocks (>= 128 wide)
+      if (!buf || pb) return DA_ERR_UNSUPPORTED;
+#define DA_SK(T_, ST_, WM_, WN_, MT_, NT_, NS_) \
+  if (tile == (T_) && staging == (ST_)) return launch<WM_, WN_, MT_, NT_, NS_, false, 2, true>(p, nullptr, s)
+      DA_SK(DA_TILE_128x128, DA_STAGE_LDS_DIRECT, 2, 2, 2, 2, 2);
+      DA_SK(DA_TILE_128x128, DA_STAGE_LDS_DIRECT3, 2, 2, 2, 2, 3);
+      DA_SK(DA_TILE_128x128, DA_STAGE_LDS_DIRECT4, 2, 2, 2, 2, 4);
+      DA_SK(DA_TILE_256x128, DA_STAGE_LDS_DIRECT, 4, 2, 2, 2, 2);
+      DA_SK(DA_TILE_256x128, DA_STAGE_LDS_DIRECT3, 4, 2, 2, 2, 3);
+      DA_SK(DA_TILE_128x256, DA_STAGE_LDS_DIRECT, 2, 4, 2, 2, 2);
+      DA_SK(DA_TILE_128x256, DA_STAGE_LDS_DIRECT3, 2, 4, 2, 2, 3);
+      DA_SK(DA_TILE_128x64, DA_STAGE_LDS_DIRECT3, 2, 2, 2, 1, 3);
+      DA_SK(DA_TILE_64x128, DA_STAGE_LDS_DIRECT3, 2, 2, 1, 2, 3);
+#undef DA_SK
+      return DA_ERR_UNSUPPORTED;
+    }
+  }
 #define DA_V(WM_, WN_, MT_, NT_, ST_, G_)                                                         \
   do {                                                                                            \
     if constexpr (G_) {                                                                           \
-      if (buf) return launch<WM_, WN_, MT_, NT_, ST_, CONV, 2>(p, s);                             \
+      if (buf) return launch<WM_, WN_, MT_, NT_, ST_, CONV, 2>(p, pb, s);                         \
     }                                                                                             \
-    return launch<WM_, WN_, MT_, NT_, ST_, CONV, (G_) ? 1 : 0>(p, s);                             \
+    return launch<WM_, WN_, MT_, NT_, ST_, CONV, (G_) ? 1 : 0>(p, pb, s);                         \
   } while (0)
   switch (staging) {
     case DA_STAGE_REGISTER:

@@ -255,8 +255,9 @@ class Attention:
                               q_batch_stride=seq * self.inner, k_batch_stride=kv.skv_alloc * self.inner,
                               vt_ld=batch * kv.skv_alloc, vt_batch_stride=kv.skv_alloc, scale=self.scale)
         else:
-            qk = ops.linear(x, self.wqk)       # [M][2*inner]
-            vt = ops.linear(self.wv, x)        # [inner][M]
+            # [M][2*inner] and [inner][M]: two problems, ONE launch (neither fills the 256 CUs alone at SDXL's sizes:
+            # 160 + 80 tiles of 128x256); bit-identical to two launches
+            qk, vt = ops.linear_pair({"x": x, "w": self.wqk}, {"x": self.wv, "w": x})
             o = ops.attention(qk, qk[:, self.inner:], vt, B=batch, H=Hh, D=D, Sq=seq, Skv=seq, Skv_alloc=seq,
                               q_row_stride=2 * self.inner, k_row_stride=2 * self.inner,
                               q_batch_stride=seq * 2 * self.inner, k_batch_stride=seq * 2 * self.inner,

@@ -21,14 +21,45 @@ DEFAULT_TILE = L.TILE_AUTO
 TUNING = True  # per-shape (tile, staging) from diffusers_amd.tuning when the caller does not pin them
 
 
+SPLITK_WS_BYTES = 64 << 20    # split-K workspace per (device, stream): 256 fp32 partial tiles of 256x256
+_splitk_ws = {}
+
+
+def splitk_workspace(device: torch.device, stream: int):
+    """(workspace, flags) of the in-launch split-K reduction (da_gemm_params.workspace / .sync_flags): one pair per
+    (device, stream) -- launches on one stream are ordered, so they can share it; the flags are zeroed ONCE here and
+    re-armed by the kernel.  Allocated on first use and kept (a HIP graph may have captured the addresses)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream)
+    ent = _splitk_ws.get(key)
+    if ent is None:
+        ent = (torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=device),
+               torch.zeros(L.SPLITK_FLAGS, dtype=torch.int32, device=device))
+        _splitk_ws[key] = ent
+    return ent
+
+
+def splitk_error(device=None) -> bool:
+    """True if any split-K reducer ever gave up waiting for a producer on this device (diagnostics / tests)."""
+    return any(bool(f[L.SPLITK_ERR_SLOT].item()) for (d, _), (_, f) in _splitk_ws.items()
+               if device is None or d == torch.device(device).index)
+
+
 def _select_variant(p: "L.GemmParams", tile: Optional[int], staging: Optional[int], stream: int,
-                    inplace: bool = False) -> None:
-    if (TUNING and tile is None and staging is None and DEFAULT_TILE == L.TILE_AUTO
-            and DEFAULT_STAGING == L.STAGE_LDS_DIRECT):
-        p.tile, p.staging = tuning.lookup(p, stream, inplace=inplace)
+                    inplace: bool = False, split_k: Optional[int] = None, device=None) -> None:
+    p.split_k = 1
+    auto = (TUNING and tile is None and staging is None and split_k is None and DEFAULT_TILE == L.TILE_AUTO
+            and DEFAULT_STAGING == L.STAGE_LDS_DIRECT)
+    want_ws = (not p.conv) and device is not None and ((auto and tuning.SPLIT_K) or (split_k or 1) > 1)
+    if want_ws and not inplace:
+        ws, flags = splitk_workspace(device, stream)
+        p.workspace, p.sync_flags, p.workspace_bytes = ws.data_ptr(), flags.data_ptr(), ws.numel()
+    if auto:
+        p.tile, p.staging, sk = tuning.lookup(p, stream, inplace=inplace)
+        p.split_k = sk if p.workspace else 1
     else:
         p.tile = DEFAULT_TILE if tile is None else tile
         p.staging = DEFAULT_STAGING if staging is None else staging
+        p.split_k = split_k or 1
 
 
 def _stream() -> int:
@@ -68,9 +99,50 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            residual: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
            alpha: float = 1.0, out_scale: float = 1.0, out: Optional[torch.Tensor] = None, out_f32: bool = False,
            bias_rows: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
-           tile: Optional[int] = None, staging: Optional[int] = None) -> torch.Tensor:
+           tile: Optional[int] = None, staging: Optional[int] = None, split_k: Optional[int] = None) -> torch.Tensor:
     """out[M][N] = epilogue(alpha * x[M][K] @ w[N][K]^T).  For act == GEGLU, w/bias are in the packed layout of
     :func:`pack_geglu` and the output has N/2 columns."""
+    p, st = _linear_params(x, w, bias, act=act, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch,
+                           alpha=alpha, out_scale=out_scale, out=out, out_f32=out_f32, bias_rows=bias_rows, gate=gate,
+                           tile=tile, staging=staging, split_k=split_k)
+    if p is None:
+        return st     # the skinny-M path ran
+    L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(linear)")
+    return p._out
+
+
+def linear_pair(a: dict, b: dict):
+    """Two independent nn.Linear problems in ONE launch (da_gemm_pair_bf16): ``a`` / ``b`` are keyword dicts of
+    :func:`linear` (x, w, bias, ...).  Bit-identical to two :func:`linear` calls; used where neither problem fills the
+    256 CUs on its own (the Q|K and V^T projections of a self-attention layer).  Falls back to two launches when the
+    paired variant is unknown and cannot be tuned now, or is not faster than the two separate launches."""
+    pa, st = _linear_params(**a)
+    pb, _ = _linear_params(**b)
+    if pa is None or pb is None:
+        raise ValueError("linear_pair: both problems must take the MFMA GEMM path (M > 8)")
+    lib = L.load()
+    pair = tuning.lookup_pair(pa, pb, st) if TUNING else None
+    if pair is not None:
+        sep = (tuning.table().get(tuning.key_of(pa)), tuning.table().get(tuning.key_of(pb)))
+        if all(sep) and pair[2] >= sep[0][2] + sep[1][2]:
+            pair = None
+    if pair is None:
+        L.check(lib.da_gemm_bf16(C.byref(pa), st), "da_gemm_bf16(linear)")
+        L.check(lib.da_gemm_bf16(C.byref(pb), st), "da_gemm_bf16(linear)")
+    else:
+        pa.tile, pa.staging, pa.split_k, pb.split_k = pair[0], pair[1], 1, 1
+        L.check(lib.da_gemm_pair_bf16(C.byref(pa), C.byref(pb), st), "da_gemm_pair_bf16")
+    return pa._out, pb._out
+
+
+def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
+                   residual: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
+                   rows_per_batch: int = 0, alpha: float = 1.0, out_scale: float = 1.0,
+                   out: Optional[torch.Tensor] = None, out_f32: bool = False, bias_rows: Optional[torch.Tensor] = None,
+                   gate: Optional[torch.Tensor] = None, tile: Optional[int] = None, staging: Optional[int] = None,
+                   split_k: Optional[int] = None):
+    """Checks + da_gemm_params of one nn.Linear problem; returns (params, stream), or (None, result) when the skinny-M
+    kernel handled it."""
     _req(x, "x"), _req(w, "w")
     M, K = x.shape
     N, Kw = w.shape
@@ -79,7 +151,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     n_out = N // 2 if act == L.ACT_GEGLU else N
     if M <= 8 and act in (L.ACT_NONE, L.ACT_SILU, L.ACT_GELU_TANH) and rowvec is None and not out_f32 \
             and alpha == 1.0 and out_scale == 1.0 and bias_rows is None and gate is None:
-        return linear_small_m(x, w, bias, act_out=act, residual=residual, out=out)
+        return None, linear_small_m(x, w, bias, act_out=act, residual=residual, out=out)
     if out is None:
         out = torch.empty((M, n_out), device=x.device, dtype=torch.float32 if out_f32 else bf16)
     p = L.GemmParams()
@@ -103,9 +175,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     p.rows_per_batch = rows_per_batch
     p.alpha, p.out_scale, p.act, p.out_f32, p.conv = alpha, out_scale, act, int(out_f32), 0
     st = _stream()
-    _select_variant(p, tile, staging, st, inplace=inplace)
-    L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(linear)")
-    return out
+    _select_variant(p, tile, staging, st, inplace=inplace, split_k=split_k, device=x.device)
+    p._out = out            # keeps the output (and through it nothing else) alive next to the raw pointers
+    p._keep = (x, w, bias, residual, rowvec, bias_rows, gate)
+    return p, st
 
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, ksize: int = 3,
@@ -211,7 +284,7 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: int, D: int, Sq: int, Skv: int,
               Skv_alloc: int, q_row_stride: int, k_row_stride: int, q_batch_stride: int, k_batch_stride: int,
               vt_ld: int, vt_batch_stride: int, scale: Optional[float] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, ring_slots: int = 0) -> torch.Tensor:
     """Flash attention over strided views; returns out [B*Sq][H*D]."""
     _req(q, "q"), _req(k, "k"), _req(vt, "vt")
     if out is None:
@@ -224,6 +297,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: 
     p.o_batch_stride = Sq * o_row_stride
     p.q_row_stride, p.k_row_stride, p.vt_ld, p.o_row_stride = q_row_stride, k_row_stride, vt_ld, o_row_stride
     p.scale = (D ** -0.5) if scale is None else scale
+    p.ring_slots = ring_slots
     L.check(L.load().da_attention_bf16(C.byref(p), _stream()), "da_attention_bf16")
     return out
 

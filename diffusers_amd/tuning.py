@@ -32,7 +32,7 @@ LIVE = os.environ.get("DIFFUSERS_AMD_TUNE", "1") != "0"
 ITERS = 3
 FLUSH_BYTES = 320 << 20  # > 256 MiB Infinity Cache: operands are timed at HBM latency, as inside the denoising loop
 
-_table: Dict[str, Tuple[int, int, float]] = {}
+_table: Dict[str, Tuple[int, int, float, int]] = {}   # key -> (tile, staging, microseconds, split_k)
 _loaded = False
 _dirty = False
 _scratch = {}
@@ -62,12 +62,12 @@ def _load() -> None:
         try:
             raw = json.loads(DB_PATH.read_text())
             for k, v in raw.get("entries", {}).items():
-                _table[k] = (int(v[0]), int(v[1]), float(v[2]))
+                _table[k] = (int(v[0]), int(v[1]), float(v[2]), int(v[3]) if len(v) > 3 else 1)
         except (ValueError, KeyError, TypeError) as e:  # a corrupt table must not break inference
             raise RuntimeError(f"diffusers_amd: unreadable tuning table {DB_PATH}: {e}") from e
 
 
-def table() -> Dict[str, Tuple[int, int, float]]:
+def table() -> Dict[str, Tuple[int, int, float, int]]:
     if not _loaded:
         _load()
     return _table
@@ -76,33 +76,43 @@ def table() -> Dict[str, Tuple[int, int, float]]:
 def save(path: Optional[os.PathLike] = None) -> Path:
     path = Path(path) if path is not None else DB_PATH
     path.parent.mkdir(parents=True, exist_ok=True)
-    ent = {k: [v[0], v[1], round(v[2], 2)] for k, v in sorted(table().items())}
-    path.write_text(json.dumps({"arch": "gfx950", "format": "key -> [tile, staging, microseconds]",
+    ent = {k: [v[0], v[1], round(v[2], 2)] + ([v[3]] if v[3] > 1 else []) for k, v in sorted(table().items())}
+    path.write_text(json.dumps({"arch": "gfx950", "format": "key -> [tile, staging, microseconds(, split_k if > 1)]",
                                 "tiles": list(L.TILE_NAMES), "entries": ent}, indent=0))
     return path
 
 
-def tune(p: "L.GemmParams", stream: int) -> Tuple[int, int, float]:
-    """Run da_gemm_tune for this problem (synchronises the stream) and remember the winner."""
+SPLIT_K = os.environ.get("DIFFUSERS_AMD_SPLITK", "1") != "0"   # let the tuner consider split-K variants (nn.Linear only)
+
+
+def pair_key(pa: "L.GemmParams", pb: "L.GemmParams") -> str:
+    return "pair:" + key_of(pa) + "|" + key_of(pb)
+
+
+def tune(p: "L.GemmParams", stream: int, pair: Optional["L.GemmParams"] = None) -> Tuple[int, int, float, int]:
+    """Run da_gemm_tune for this problem (synchronises the stream) and remember the winner.  ``pair``: the two problems
+    are timed as ONE launch (da_gemm_pair_bf16).  When ``p`` carries a split-K workspace the split factors 2..4 compete
+    with the unsplit variants."""
     global _dirty
-    bt, bs, us = C.c_int(0), C.c_int(0), C.c_float(0.0)
+    bt, bs, bk, us = C.c_int(0), C.c_int(0), C.c_int(1), C.c_float(0.0)
     dev = torch.cuda.current_device()
     if FLUSH_BYTES and dev not in _scratch:
         _scratch[dev] = torch.empty(FLUSH_BYTES, dtype=torch.uint8, device=f"cuda:{dev}")
     sp = _scratch[dev].data_ptr() if FLUSH_BYTES else None
     # a launch of more than ~2 TFLOP runs for milliseconds: one timed launch per variant is already stable
     iters = 1 if 2.0 * p.M * p.N * p.K > 2e12 else ITERS
-    L.check(L.load().da_gemm_tune(C.byref(p), stream, iters, sp, FLUSH_BYTES if sp else 0, C.byref(bt), C.byref(bs),
-                                  C.byref(us)), "da_gemm_tune")
-    ent = (bt.value, bs.value, us.value)
-    table()[key_of(p)] = ent
+    L.check(L.load().da_gemm_tune(C.byref(p), C.byref(pair) if pair is not None else None, stream, iters, sp,
+                                  FLUSH_BYTES if sp else 0, C.byref(bt), C.byref(bs), C.byref(bk), C.byref(us)),
+            "da_gemm_tune")
+    ent = (bt.value, bs.value, us.value, bk.value)
+    table()[pair_key(p, pair) if pair is not None else key_of(p)] = ent
     _dirty = True
     return ent
 
 
-def lookup(p: "L.GemmParams", stream: int, inplace: bool = False) -> Tuple[int, int]:
-    """(tile, staging) to launch this problem with.  ``inplace``: the output aliases the residual (accumulating launch),
-    so the repeated timing launches write to a scratch output instead of accumulating into the caller's tensor."""
+def lookup(p: "L.GemmParams", stream: int, inplace: bool = False) -> Tuple[int, int, int]:
+    """(tile, staging, split_k) to launch this problem with.  ``inplace``: the output aliases the residual (accumulating
+    launch), so the repeated timing launches write to a scratch output instead of accumulating into the caller's tensor."""
     ent = table().get(key_of(p))
     if ent is None:
         if LIVE and not torch.cuda.is_current_stream_capturing():
@@ -118,8 +128,19 @@ def lookup(p: "L.GemmParams", stream: int, inplace: bool = False) -> Tuple[int, 
             else:
                 ent = tune(p, stream)
         else:
-            return L.TILE_AUTO, L.STAGE_LDS_DIRECT
-    return ent[0], ent[1]
+            return L.TILE_AUTO, L.STAGE_LDS_DIRECT, 1
+    return ent[0], ent[1], ent[3]
+
+
+def lookup_pair(pa: "L.GemmParams", pb: "L.GemmParams", stream: int) -> Optional[Tuple[int, int, float]]:
+    """(tile, staging, microseconds) of the paired launch of two nn.Linear problems, or None when it is not known and
+    cannot be measured now (graph capture / live tuning off): the caller then launches them separately."""
+    ent = table().get(pair_key(pa, pb))
+    if ent is None:
+        if not (LIVE and not torch.cuda.is_current_stream_capturing()):
+            return None
+        ent = tune(pa, stream, pair=pb)
+    return ent[0], ent[1], ent[2]
 
 
 def _save_at_exit() -> None:

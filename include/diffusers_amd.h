@@ -100,9 +100,25 @@ typedef struct da_gemm_params {
   int staging; /* DA_STAGE_* */
   int gate_f32; /* 1: gate is float and out = residual + bf16(xW+b) * gate in fp32, rounded once
                    (WanTransformerBlock, transformer_wan.py:491,:502); 0: Flux rounding (gate product rounded to bf16) */
+  int split_k;  /* 0 / 1: every tile is computed by one block.  2..8 (nn.Linear only): the K range of each tile is dealt to
+                   split_k co-resident blocks that hand fp32 partial tiles over through `workspace` (in-launch reduction,
+                   fixed summation order: deterministic, but the last fp32 bit of a sum differs from split_k = 1).  For
+                   problems with fewer tiles than the 256 CUs (SDXL: M = 2048, N = 1280). */
+  void* workspace;          /* split_k > 1: caller-owned device buffer, >= tiles * (split_k - 1) * tile_rows * tile_cols * 4 B */
+  void* sync_flags;         /* split_k > 1: DA_SPLITK_FLAGS ints, zeroed ONCE by the caller; the kernel re-arms what it uses */
+  long long workspace_bytes;
 } da_gemm_params;
 
+#define DA_SPLITK_FLAGS 4096
+#define DA_SPLITK_ERR_SLOT (DA_SPLITK_FLAGS - 1) /* set to 1 by a reducer whose producer never arrived (bounded spin) */
+
 int da_gemm_bf16(const da_gemm_params* p, void* stream);
+
+/* Two independent nn.Linear problems in ONE launch (same tile / staging variant, taken from *a; split_k must be 0 / 1):
+ * blocks [0, grid_a) work on *a, the rest on *b, each exactly as in its own launch -- bit-identical results, better
+ * fill when neither problem has 256 tiles.  The engine pairs the fused Q|K projection with the swapped V^T projection of
+ * a self-attention layer (attention_processor.py:2743-2751: three F.linear calls on the same input). */
+int da_gemm_pair_bf16(const da_gemm_params* a, const da_gemm_params* b, void* stream);
 
 /* Times every (tile, staging) variant able to run *p on `stream` (HIP events; one warm launch + min of `iters` timed
  * launches each) and returns the fastest in *best_tile / *best_staging (and its time in *best_us, may be NULL).
@@ -112,8 +128,11 @@ int da_gemm_bf16(const da_gemm_params* p, void* stream);
  * changes speed only.  The library keeps no tuning state: the caller owns the table (diffusers_amd/tuning.py keeps
  * it per problem shape, the role torch's cublasLt/hipblasLt heuristic cache plays for F.linear / F.conv2d in the
  * reference).  Synchronises the stream; must not be called while the stream is being captured into a graph. */
-int da_gemm_tune(const da_gemm_params* p, void* stream, int iters, void* scratch, size_t scratch_bytes, int* best_tile,
-                 int* best_staging, float* best_us);
+/* `pair` (may be NULL): time the two problems as ONE da_gemm_pair_bf16 launch.  `best_split` (may be NULL): when given and
+ * p->workspace / p->sync_flags are set, split_k = 2, 3, 4 variants of every admissible tile are timed as well and the
+ * winner's split factor is returned (1 = unsplit); otherwise only split_k = 1 is considered. */
+int da_gemm_tune(const da_gemm_params* p, const da_gemm_params* pair, void* stream, int iters, void* scratch,
+                 size_t scratch_bytes, int* best_tile, int* best_staging, int* best_split, float* best_us);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * da_attention_bf16: out = softmax(scale * Q K^T) V, flash-style (no S x S tensor), no mask / dropout / causal.
@@ -136,6 +155,8 @@ typedef struct da_attention_params {
   long long q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride;
   int q_row_stride, k_row_stride, vt_ld, o_row_stride;
   float scale;
+  int ring_slots; /* K / V^T LDS ring depth: 0 = default for the head size (deepest that fits), 2..4 = pinned (speed only:
+                     every depth computes the same tiles in the same order -> bit-identical outputs) */
 } da_attention_params;
 
 int da_attention_bf16(const da_attention_params* p, void* stream);

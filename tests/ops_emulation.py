@@ -61,7 +61,7 @@ def conv2d_nhwc(x, w, bias=None, *, ksize=3, x2=None, stride=1, up=False, pad=No
 
 
 def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch=0, alpha=1.0, out_scale=1.0, out=None,
-           out_f32=False, bias_rows=None, gate=None, tile=None, staging=None):
+           out_f32=False, bias_rows=None, gate=None, tile=None, staging=None, split_k=None):
     assert x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: K % 64, N % 4"
     assert x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0, "C ABI: row strides % 8"
     y = alpha * (x.float() @ w.float().t())
@@ -90,6 +90,11 @@ def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch
     if residual is not None:
         y = y + residual.float()
     return _store(y * out_scale, out, torch.float32 if out_f32 else bf16)
+
+
+def linear_pair(a, b):
+    """da_gemm_pair_bf16: two independent problems, results identical to two linear() calls."""
+    return linear(**a), linear(**b)
 
 
 def linear_small_m(x, w, bias=None, *, act_in=0, act_out=0, residual=None, out=None):
@@ -380,7 +385,7 @@ def cast_f32_bf16(x, rep=1):
 
 def install(monkeypatch, ops_module):
     """Replace the kernels behind ``ops_module`` with the stand-ins above (pack_* helpers are pure torch and stay)."""
-    for name in ("conv2d_nhwc", "linear", "linear_small_m", "attention", "softmax_rows", "group_norm_nhwc", "layer_norm",
+    for name in ("conv2d_nhwc", "linear", "linear_pair", "linear_small_m", "attention", "softmax_rows", "group_norm_nhwc", "layer_norm",
                  "rmsnorm_rope_", "rmsnorm_channels", "timestep_embedding", "permute_0213", "frames_to_ncthw",
                  "conv_thin_in", "conv_thin_out", "bcast_add_f32", "patchify3d", "unpatchify3d", "transpose",
                  "mul_scalar", "cast_f32_bf16", "require_hip", "euler_scale_model_input", "euler_step", "x0_linear_step",

@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""Round-2 kernel experiments on the SDXL shapes that leave CUs idle (one JSON object per line, HIP-event timing on the
+launch stream, caches evicted before every timed launch unless a line says otherwise):
+  * split-K (in-launch reduction) vs the best unsplit variant          -> "op": "splitk"
+  * paired Q|K + V^T launch vs the two separate launches               -> "op": "pair"
+  * flash attention K / V^T ring depth 2 / 3 / 4                       -> "op": "attn_ring"
+  * operand residency diagnostic (cold / weights pre-touched / warm)   -> "op": "residency"
+Every variant is checked against the unsplit / unpaired / 2-slot result before it is timed."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from diffusers_amd import _lib as L  # noqa: E402
+from diffusers_amd import ops  # noqa: E402
+
+bf16 = torch.bfloat16
+DEV = "cuda"
+FLUSH = None
+
+
+def rnd(shape, scale=1.0):
+    return (torch.randn(shape, device=DEV) * scale).to(bf16)
+
+
+def timeit(fn, iters=10, warm=2, pre=None, flush=True):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if flush:
+            FLUSH.zero_()
+        if pre is not None:
+            pre()
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[0], ts[len(ts) // 2]
+
+
+def emit(rec):
+    print(json.dumps(rec), flush=True)
+
+
+def best_unsplit(x, w, **kw):
+    best = None
+    for tile in range(1, 8):
+        for st in range(1, 6):
+            try:
+                tmin, tmed = timeit(lambda: ops.linear(x, w, tile=tile, staging=st, **kw), iters=6, warm=1)
+            except RuntimeError:
+                continue
+            if best is None or tmin < best[0]:
+                best = (tmin, tmed, tile, st)
+    return best
+
+
+def main():
+    global FLUSH
+    FLUSH = torch.empty(320 << 20, dtype=torch.uint8, device=DEV)
+    lib = L.load()
+    shapes = [("to_out 1280", 2048, 1280, 1280, True), ("ff_down 1280", 2048, 1280, 5120, True),
+              ("q cross 1280", 2048, 1280, 1280, False), ("qk 1280", 2048, 2560, 1280, False),
+              ("to_out 640", 8192, 640, 640, True), ("ff_down 640", 8192, 640, 2560, True)]
+    split_variants = [(L.TILE_128x128, 1), (L.TILE_128x128, 2), (L.TILE_128x128, 3), (L.TILE_256x128, 1),
+                      (L.TILE_256x128, 2), (L.TILE_128x256, 1), (L.TILE_128x256, 2), (L.TILE_128x64, 2), (L.TILE_64x128, 2)]
+    for name, M, N, K, res in shapes:
+        x, w, b = rnd((M, K)), rnd((N, K), K ** -0.5), rnd((N,))
+        r = rnd((M, N)) if res else None
+        kw = dict(bias=b, residual=r)
+        flops = 2.0 * M * N * K
+        base = ops.linear(x, w, tile=L.TILE_128x128, staging=1, **kw)
+        ub = best_unsplit(x, w, **kw)
+        emit({"op": "splitk", "name": name, "split": 1, "tile": L.TILE_NAMES[ub[2]], "staging": ub[3], "us": round(ub[0], 1),
+              "us_med": round(ub[1], 1), "tflops": round(flops / ub[0] / 1e6, 1)})
+        for split in (2, 3, 4):
+            best = None
+            for tile, st in split_variants:
+                try:
+                    y = ops.linear(x, w, tile=tile, staging=st, split_k=split, **kw)
+                except RuntimeError:
+                    continue
+                err = float((y.float() - base.float()).abs().max() / base.float().abs().max())
+                if err > 2e-2:
+                    emit({"op": "splitk.WRONG", "name": name, "split": split, "tile": L.TILE_NAMES[tile], "staging": st, "err": err})
+                    continue
+                tmin, tmed = timeit(lambda: ops.linear(x, w, tile=tile, staging=st, split_k=split, **kw), iters=8, warm=1)
+                emit({"op": "splitk.var", "name": name, "split": split, "tile": L.TILE_NAMES[tile], "staging": st,
+                      "us": round(tmin, 1), "us_med": round(tmed, 1)})
+                if best is None or tmin < best[0]:
+                    best = (tmin, tmed, tile, st)
+            if best:
+                emit({"op": "splitk", "name": name, "split": split, "tile": L.TILE_NAMES[best[2]], "staging": best[3],
+                      "us": round(best[0], 1), "us_med": round(best[1], 1), "tflops": round(flops / best[0] / 1e6, 1),
+                      "speedup_vs_unsplit": round(ub[0] / best[0], 3)})
+        emit({"op": "splitk.err_word", "set": bool(ops.splitk_error())})
+        del x, w, r
+
+    # ---- paired Q|K + V^T ----
+    for name, M, C_ in [("self-attn 1280", 2048, 1280), ("self-attn 640", 8192, 640)]:
+        x, wqk, wv = rnd((M, C_)), rnd((2 * C_, C_), C_ ** -0.5), rnd((C_, C_), C_ ** -0.5)
+        ref_qk, ref_vt = ops.linear(x, wqk, tile=1, staging=1), ops.linear(wv, x, tile=1, staging=1)
+        bq = best_unsplit(x, wqk)
+        bv = best_unsplit(wv, x)
+        best = None
+        for tile in range(1, 8):
+            for st in range(1, 6):
+                pa, s_ = ops._linear_params(x, wqk, tile=tile, staging=st)
+                pb, _ = ops._linear_params(wv, x, tile=tile, staging=st)
+                if lib.da_gemm_pair_bf16(C.byref(pa), C.byref(pb), s_) != 0:
+                    continue
+                if not (torch.equal(pa._out, ref_qk) and torch.equal(pb._out, ref_vt)):
+                    emit({"op": "pair.WRONG", "name": name, "tile": L.TILE_NAMES[tile], "staging": st})
+                    continue
+                tmin, tmed = timeit(lambda: lib.da_gemm_pair_bf16(C.byref(pa), C.byref(pb), s_), iters=8, warm=1)
+                if best is None or tmin < best[0]:
+                    best = (tmin, tmed, tile, st)
+        emit({"op": "pair", "name": name, "qk_us": round(bq[0], 1), "qk_var": [L.TILE_NAMES[bq[2]], bq[3]],
+              "vt_us": round(bv[0], 1), "vt_var": [L.TILE_NAMES[bv[2]], bv[3]], "pair_us": round(best[0], 1),
+              "pair_us_med": round(best[1], 1), "pair_var": [L.TILE_NAMES[best[2]], best[3]],
+              "speedup": round((bq[0] + bv[0]) / best[0], 3)})
+
+    # ---- attention ring depth ----
+    for name, B, H, S, Skv, D in [("sdxl self 1024", 2, 20, 1024, 1024, 64), ("sdxl self 4096", 2, 10, 4096, 4096, 64),
+                                  ("sdxl cross 1024", 2, 20, 1024, 77, 64), ("sdxl cross 4096", 2, 10, 4096, 77, 64),
+                                  ("flux joint", 1, 24, 4608, 4608, 128), ("wan slice", 1, 12, 8192, 8192, 128)]:
+        inner = H * D
+        sa = ((Skv + 15) // 16) * 16
+        q, k, vt = rnd((B * S, inner)), rnd((B * sa, inner)), rnd((inner, B * sa))
+        def run(ring):
+            return ops.attention(q, k, vt, B=B, H=H, D=D, Sq=S, Skv=Skv, Skv_alloc=sa, q_row_stride=inner, k_row_stride=inner,
+                                 q_batch_stride=S * inner, k_batch_stride=sa * inner, vt_ld=B * sa, vt_batch_stride=sa,
+                                 ring_slots=ring)
+        ref = run(2)
+        flops = 4.0 * B * H * S * Skv * D
+        for ring in (2, 3, 4):
+            y = run(ring)
+            same = bool(torch.equal(y, ref))
+            tmin, tmed = timeit(lambda: run(ring), iters=8, warm=1)
+            tw, _ = timeit(lambda: run(ring), iters=8, warm=1, flush=False)
+            emit({"op": "attn_ring", "name": name, "ring": ring, "bit_identical_to_ring2": same, "us": round(tmin, 1),
+                  "us_med": round(tmed, 1), "us_warm": round(tw, 1), "tflops": round(flops / tmin / 1e6, 1)})
+
+    # ---- residency diagnostic: what would weights resident in the Infinity Cache buy? ----
+    for name, M, N, K in [("to_out 1280", 2048, 1280, 1280), ("ff_down 1280", 2048, 1280, 5120), ("geglu 1280", 2048, 10240, 1280)]:
+        act = L.ACT_GEGLU if "geglu" in name else 0
+        x, w = rnd((M, K)), rnd((N, K), K ** -0.5)
+        for tile, st in ((L.TILE_64x64, 1), (L.TILE_128x128, 1), (L.TILE_128x128, 3), (L.TILE_256x128, 2)):
+            if act and tile == L.TILE_64x64:
+                continue
+            fn = lambda: ops.linear(x, w, act=act, tile=tile, staging=st)  # noqa: E731
+            try:
+                cold, _ = timeit(fn, iters=6, warm=1)
+            except RuntimeError:
+                continue
+            wpre, _ = timeit(fn, iters=6, warm=1, pre=lambda: w.float().sum())   # weights re-read after the flush
+            xpre, _ = timeit(fn, iters=6, warm=1, pre=lambda: x.float().sum())   # activations re-read after the flush
+            warm, _ = timeit(fn, iters=6, warm=1, flush=False)
+            emit({"op": "residency", "name": name, "tile": L.TILE_NAMES[tile], "staging": st, "cold_us": round(cold, 1),
+                  "weights_touched_us": round(wpre, 1), "acts_touched_us": round(xpre, 1), "warm_us": round(warm, 1)})
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,25 @@ if [[ $WHAT == *fullsize* ]]; then
   timeout 900 python -m pytest tests/test_full_size_gpu.py -m gpu -q -s --timeout 600 > $O/pytest_fullsize.log 2>&1; echo "pytest fullsize rc=$?" | tee -a $O/pytest_fullsize.log
   grep -E "passed|failed|FAILED|Error|\[parity\]" $O/pytest_fullsize.log | tail -30
 fi
+if [[ $WHAT == *retune* ]]; then
+  # re-measure the variant choice (tile, ring depth, split-K, paired launches) of every SDXL shape with the current kernels
+  rm -f $O/tuned_sdxl_r2.json
+  DIFFUSERS_AMD_TUNE_DB=$O/none.json DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_sdxl_r2.json timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-reference > $O/retune.json 2> $O/retune.err; echo "retune rc=$?"
+  cut -c1-200 $O/retune.json
+  python - <<PYEOF
+import json
+a = json.load(open("$R/diffusers_amd/tuned/gfx950.json"))
+b = json.load(open("$O/tuned_sdxl_r2.json"))
+ch = sum(1 for k, v in b["entries"].items() if k in a["entries"] and a["entries"][k][:2] != v[:2])
+sp = sum(1 for v in b["entries"].values() if len(v) > 3)
+pr = sum(1 for k in b["entries"] if k.startswith("pair:"))
+a["entries"].update(b["entries"])
+a["format"] = b["format"]
+json.dump(a, open("$O/tuned_merged_r2.json", "w"), indent=0)
+print("retuned", len(b["entries"]), "shapes;", ch, "changed variant;", sp, "use split-K;", pr, "paired; table now", len(a["entries"]))
+PYEOF
+  export DIFFUSERS_AMD_TUNE_DB=$O/tuned_merged_r2.json
+fi
 if [[ $WHAT == *bench* ]]; then
   timeout 900 python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
   cat $O/bench.json; grep "^\[bench" $O/bench.err | tail -20
@@ -38,11 +57,29 @@ if [[ $WHAT == *traffic* ]]; then
   find $O/pmc_traffic -name '*counter_collection.csv' -size +8M -delete
   tail -3 $O/pmc_traffic/fetch.log | cut -c1-300
 fi
+if [[ $WHAT == *onestep* ]]; then
+  # per-launch HBM-side traffic from a SMALL eager workload (a few denoising steps): FETCH and WRITE in separate passes
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc_traffic; mkdir -p $O/pmc_traffic
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_traffic/fetch -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/fetch.log 2>&1; echo "pmc fetch rc=$?"
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_traffic/write -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/write.log 2>&1; echo "pmc write rc=$?"
+  cd $R
+  ALGO=$(python -c "import json;print(json.load(open('$O/bench.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null)
+  python tools/pmc_traffic.py $O/pmc_traffic/fetch $O/pmc_traffic/write $O/r02_sdxl_traffic.md $O/sdxl_traffic.json $ALGO
+  find $O/pmc_traffic -name '*kernel_trace*' -delete
+  find $O/pmc_traffic -name '*counter_collection.csv' -size +8M -delete
+  tail -4 $O/pmc_traffic/fetch.log | cut -c1-200
+fi
 if [[ $WHAT == *dropin* ]]; then
   timeout 400 python tools/dropin_loop.py > $O/dropin.json 2> $O/dropin.err; echo "dropin rc=$?"
   cat $O/dropin.json; tail -3 $O/dropin.err
 fi
 if [[ $WHAT == *kernels* ]]; then
   timeout 900 python tools/bench_kernels_r2.py > $O/kernels_r2.log 2>&1; echo "kernels rc=$?"
-  grep -E '^\{' $O/kernels_r2.log | cut -c1-260 | tail -80
+  grep -E '^\{' $O/kernels_r2.log | grep -v "splitk.var" | cut -c1-300 | tail -90
+  grep -vE '^\{' $O/kernels_r2.log | tail -15
+fi
+if [[ $WHAT == *newtests* ]]; then
+  timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -s --timeout 300 -k "pair_launch or split_k or sampler_round2 or flowmatch_fp32 or flash_attention or attention or torch_library" > $O/pytest_new.log 2>&1; echo "pytest new rc=$?" | tee -a $O/pytest_new.log
+  grep -E "passed|failed|FAILED|Error|split-K" $O/pytest_new.log | tail -30
 fi
