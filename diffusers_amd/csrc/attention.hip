@@ -286,14 +286,14 @@ int launch_attn(const da_attention_params& p, hipStream_t s) {
   return DA_OK;
 }
 
-// ring depth: p.ring_slots (2..4) when the caller pins it (A/B measurements, tests), else the default per head size:
-// the deepest ring that keeps the block count per CU (2 for D <= 64, 1 above) inside the 160 KiB of LDS
+// ring depth: p.ring_slots (2..4) when the caller pins it (A/B measurements, tests), else 2 for D <= 64 and 3 above.
+// Measured (profiles/r02b_kernel_experiments.md): the tile loop is bound by its VALU work (exp2 / max / packing), not by
+// the K / V^T stream -- a deeper ring changes nothing at D = 128 (S = 4608: 586 / 563 / 566 us for 2 / 3 / 4 slots) and
+// costs occupancy at D = 64 (S = 4096: 147 / 149 / 167 us)
 template <int D>
 int launch_attn_ring(const da_attention_params& p, hipStream_t s) {
   using C = AttnCfg<D>;
-  constexpr int per_cu = (D <= 64) ? 2 : 1;
-  constexpr int max_ns = (160 * 1024) / (C::STAGE * per_cu);
-  constexpr int def_ns = max_ns >= 4 ? 4 : (max_ns >= 3 ? 3 : 2);
+  constexpr int def_ns = (D <= 64 || 3 * C::STAGE > 160 * 1024) ? 2 : 3;
   int ns = p.ring_slots ? p.ring_slots : def_ns;
   if (p.Skv <= 64) ns = 2;   // a single tile: nothing to pipeline
   switch (ns) {

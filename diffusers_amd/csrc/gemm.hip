@@ -72,7 +72,6 @@ int validate(da_gemm_params& p) {
   if (p.act == DA_ACT_GEGLU && ((p.N & 127) || p.out_f32 || p.residual || p.rowvec || p.gate || p.bias_rows))
     return DA_ERR_UNSUPPORTED;
   if (p.split_k < 0 || p.split_k > 8) return DA_ERR_INVALID;
-  if (p.split_k > 1 && p.conv) return DA_ERR_UNSUPPORTED;
   return DA_OK;
 }
 
@@ -142,7 +141,7 @@ extern "C" int da_gemm_tune(const da_gemm_params* pp, const da_gemm_params* pair
   static const int stagings[] = {DA_STAGE_LDS_DIRECT, DA_STAGE_LDS_DIRECT3, DA_STAGE_LDS_DIRECT4, DA_STAGE_LDS_DIRECT6,
                                  DA_STAGE_LDS_DIRECT8};
   constexpr int n_stagings = sizeof(stagings) / sizeof(stagings[0]);
-  const int max_split = (best_split && !pair && !p.conv && p.workspace && p.sync_flags) ? 4 : 1;
+  const int max_split = (best_split && !pair && p.workspace && p.sync_flags) ? 4 : 1;
   for (int split = 1; split <= max_split; ++split) {
     p.split_k = split;
     for (int tile = 1; tile < kNumTiles; ++tile) {

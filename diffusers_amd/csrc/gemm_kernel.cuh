@@ -47,7 +47,7 @@ struct RowInfo {      // per staged activation row (implicit GEMM gather state)
 //    Q|K projection (160 tiles of 128x256 at SDXL's 1280-wide level) and the swapped V^T projection (80 tiles) of one
 //    self-attention layer, which separately fill 62 % and 31 % of the 256 CUs and together 94 %.  Each block runs
 //    exactly the code it would run in its own launch: results are bit-identical to two launches.
-//  * SPLIT-K (p.split_k > 1, nn.Linear only): the K slices of a tile are dealt to split_k blocks of the same XCD.
+//  * SPLIT-K (p.split_k > 1): the K slices of a tile are dealt to split_k blocks of the same XCD.
 //    Blocks 0 .. split_k-2 publish their fp32 accumulators to a workspace slot with write-through (sc1) stores, drain
 //    them and raise a flag; the LAST block (highest block id: dispatched after its producers) polls the flags, adds the
 //    slots in index order with sc1 loads and runs the epilogue.  That is the agent-scope hand-off of
@@ -60,7 +60,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
                                                                   const da_gemm_params prob_b, const int xcd_gx_b,
                                                                   const int grid_a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and cannot parse the buffer builtins)
-  const bool second = (int)blockIdx.x >= grid_a;          // wave-uniform: a scalar select between the two kernarg blocks
+  // wave-uniform: a scalar select between the two kernarg blocks (nn.Linear only: conv launches are never paired, and the
+  // select would cost the conv instantiations 24 bytes of scratch per lane)
+  const bool second = !CONV && (int)blockIdx.x >= grid_a;
   const da_gemm_params& p = second ? prob_b : prob_a;
   const int xcd_gx = second ? xcd_gx_b : xcd_gx_a;
   const int bid = second ? (int)blockIdx.x - grid_a : (int)blockIdx.x;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   // tile's XCD (same L2 for the partial hand-off) and the reducer (last index) has the highest block id of the tile
   // (SPLITK is a template parameter: the hand-off code costs ~50 VGPRs -- the accumulators are touched by VALU adds and
   // buffer stores, not only by MFMAs -- which the unsplit instantiations must not pay)
-  const int split = (SPLITK && !CONV && p.split_k > 1) ? p.split_k : 1;
+  const int split = (SPLITK && p.split_k > 1) ? p.split_k : 1;
   const int rect = tm_per * tn_per;
   const int sidx = (split > 1) ? kblk / rect : 0;
   const int kb2 = kblk - sidx * rect;
@@ -180,6 +182,18 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   __amdgpu_buffer_rsrc_t rs_w = uniform_rsrc(Wt + (BLDS ? (size_t)n0 * p.ldw : 0), 0x7fffffff);
   int vo_x[XR], vo_x2[XR], vo_w[WR];
   int bk_off = k_begin * 128;  // byte offset of the cursor K slice inside a weight / activation row (scalar)
+  // K-slice cursor of the NEXT slice to issue.  Slices are issued strictly in order, so the (tap, channel) position
+  // of the implicit GEMM advances incrementally (no integer division in the loop): K index = tap * Ctot + c.  A
+  // split-K block starts at slice k_begin: one division here (a slice never straddles taps: Ctot % 64 == 0).
+  int is_kh = 0, is_kw = 0, is_c0 = 0;  // conv: kernel row / column of the tap, first channel of the slice
+  if constexpr (CONV) {
+    if (k_begin > 0) {
+      const int tap = (k_begin * 64) / Ctot;
+      is_c0 = k_begin * 64 - tap * Ctot;
+      is_kh = tap / p.conv;
+      is_kw = tap - is_kh * p.conv;
+    }
+  }
   // conv: offsets of the activation rows for tap (kh, kw) -- called once per tap, not per K slice
   auto tap_offsets = [&](int kh, int kw) {
 #pragma unroll
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   };
   if constexpr (BLDS) {
     if constexpr (CONV) {
-      tap_offsets(0, 0);
+      tap_offsets(is_kh, is_kw);
     } else {
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
@@ -216,9 +230,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   uint4 xg0, xg1, xg2, xg3, wg0, wg1, wg2, wg3;  // named (not arrays) so they never land in scratch
   xg0 = xg1 = xg2 = xg3 = wg0 = wg1 = wg2 = wg3 = make_uint4(0, 0, 0, 0);
 
-  // K-slice cursor of the NEXT slice to issue.  Slices are issued strictly in order, so the (tap, channel) position
-  // of the implicit GEMM advances incrementally (no integer division in the loop): K index = tap * Ctot + c.
-  int is_kh = 0, is_kw = 0, is_c0 = 0;  // conv: kernel row / column of the tap, first channel of the slice
   size_t is_k = (size_t)k_begin * 64;   // linear / weights: element offset of the slice inside a row
 
   // source pointer of activation row i for the cursor slice (a 128-byte line of zeros when the slot must be zero,
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
 #undef DA_VMCNT_CASE
 
   // ---- split-K hand-off (see the kernel header): producers publish and leave, the reducer gathers ----
-  if constexpr (SPLITK && !CONV) {
+  if constexpr (SPLITK) {
     if (split > 1) {
       constexpr int TILE_FLOATS = BM * BN;
       float* ws = (float*)p.workspace;
@@ -670,7 +681,7 @@ int launch(const da_gemm_params& p, const da_gemm_params* pb, hipStream_t s) {
     // the reducer block of a tile spins on its producers: every block of the launch must be co-resident (LDS and the
     // 1-2 blocks of 256 / 512 threads a CU takes at this kernel's register count bound it), and the workspace must
     // hold (split_k - 1) fp32 tiles per output tile
-    if (CONV || pb) return DA_ERR_UNSUPPORTED;
+    if (pb) return DA_ERR_UNSUPPORTED;
     const int per_cu = (int)((160 * 1024) / lds) >= 2 && WM * WN == 4 ? 2 : 1;
     if (grid_a > compute_units() * per_cu) return DA_ERR_UNSUPPORTED;
     const size_t tiles = (size_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -719,24 +730,24 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s, cons
   // LDS-DMA variants use the buffer-addressed mode whenever a tile's operand panels fit 31-bit byte offsets (always,
   // for the shapes of this engine); per-lane pointers (mode 1) are the fallback
   const bool buf = !flat_staging_forced() && buffer_staging_fits(p) && (!pb || buffer_staging_fits(*pb));
-  if constexpr (!CONV) {
-    if (p.split_k > 1) {
-      // split-K instantiations: buffer-addressed staging only, the tiles that can be short of blocks (>= 128 wide)
-      if (!buf || pb) return DA_ERR_UNSUPPORTED;
+  if (p.split_k > 1) {
+    // split-K instantiations: buffer-addressed staging only, the tiles that can be short of blocks (>= 128 wide)
+    if (!buf || pb) return DA_ERR_UNSUPPORTED;
 #define DA_SK(T_, ST_, WM_, WN_, MT_, NT_, NS_) \
-  if (tile == (T_) && staging == (ST_)) return launch<WM_, WN_, MT_, NT_, NS_, false, 2, true>(p, nullptr, s)
-      DA_SK(DA_TILE_128x128, DA_STAGE_LDS_DIRECT, 2, 2, 2, 2, 2);
-      DA_SK(DA_TILE_128x128, DA_STAGE_LDS_DIRECT3, 2, 2, 2, 2, 3);
+  if (tile == (T_) && staging == (ST_)) return launch<WM_, WN_, MT_, NT_, NS_, CONV, 2, true>(p, nullptr, s)
+    DA_SK(DA_TILE_128x128, DA_STAGE_LDS_DIRECT, 2, 2, 2, 2, 2);
+    DA_SK(DA_TILE_128x128, DA_STAGE_LDS_DIRECT3, 2, 2, 2, 2, 3);
+    DA_SK(DA_TILE_256x128, DA_STAGE_LDS_DIRECT3, 4, 2, 2, 2, 3);
+    DA_SK(DA_TILE_128x256, DA_STAGE_LDS_DIRECT3, 2, 4, 2, 2, 3);
+    DA_SK(DA_TILE_128x64, DA_STAGE_LDS_DIRECT3, 2, 2, 2, 1, 3);
+    DA_SK(DA_TILE_64x128, DA_STAGE_LDS_DIRECT3, 2, 2, 1, 2, 3);
+    if constexpr (!CONV) {
       DA_SK(DA_TILE_128x128, DA_STAGE_LDS_DIRECT4, 2, 2, 2, 2, 4);
       DA_SK(DA_TILE_256x128, DA_STAGE_LDS_DIRECT, 4, 2, 2, 2, 2);
-      DA_SK(DA_TILE_256x128, DA_STAGE_LDS_DIRECT3, 4, 2, 2, 2, 3);
       DA_SK(DA_TILE_128x256, DA_STAGE_LDS_DIRECT, 2, 4, 2, 2, 2);
-      DA_SK(DA_TILE_128x256, DA_STAGE_LDS_DIRECT3, 2, 4, 2, 2, 3);
-      DA_SK(DA_TILE_128x64, DA_STAGE_LDS_DIRECT3, 2, 2, 2, 1, 3);
-      DA_SK(DA_TILE_64x128, DA_STAGE_LDS_DIRECT3, 2, 2, 1, 2, 3);
-#undef DA_SK
-      return DA_ERR_UNSUPPORTED;
     }
+#undef DA_SK
+    return DA_ERR_UNSUPPORTED;
   }
 #define DA_V(WM_, WN_, MT_, NT_, ST_, G_)                                                         \
   do {                                                                                            \

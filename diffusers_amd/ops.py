@@ -49,7 +49,7 @@ def _select_variant(p: "L.GemmParams", tile: Optional[int], staging: Optional[in
     p.split_k = 1
     auto = (TUNING and tile is None and staging is None and split_k is None and DEFAULT_TILE == L.TILE_AUTO
             and DEFAULT_STAGING == L.STAGE_LDS_DIRECT)
-    want_ws = (not p.conv) and device is not None and ((auto and tuning.SPLIT_K) or (split_k or 1) > 1)
+    want_ws = device is not None and ((auto and tuning.SPLIT_K) or (split_k or 1) > 1)
     if want_ws and not inplace:
         ws, flags = splitk_workspace(device, stream)
         p.workspace, p.sync_flags, p.workspace_bytes = ws.data_ptr(), flags.data_ptr(), ws.numel()
@@ -185,7 +185,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                 x2: Optional[torch.Tensor] = None, stride: int = 1, up: bool = False, pad: Optional[int] = None,
                 rowvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 out_scale: float = 1.0, act: int = L.ACT_NONE, tile: Optional[int] = None,
-                staging: Optional[int] = None, pad_after: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                staging: Optional[int] = None, pad_after: int = 0, out: Optional[torch.Tensor] = None,
+                split_k: Optional[int] = None) -> torch.Tensor:
     """Implicit-GEMM Conv2d on channels-last tensors.  x: [B][H][W][C1] (x2: [B][H][W][C2] = fused channel concat),
     w: [Cout][k][k][C1+C2] flattened to [Cout][k*k*(C1+C2)].  up=True fuses a nearest 2x upsample of the input.
     rowvec [B][Cout] is added per batch (time embedding); residual is [B][Hout][Wout][Cout].  ``out`` (contiguous
@@ -236,7 +237,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     p.Hin, p.Win, p.C1, p.C2, p.Hout, p.Wout = H, W_, C1, C2, Hout, Wout
     p.stride, p.up, p.pad = stride, int(up), pad
     st = _stream()
-    _select_variant(p, tile, staging, st, inplace=inplace)
+    _select_variant(p, tile, staging, st, inplace=inplace, split_k=split_k, device=x.device)
     L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(conv)")
     return out
 

@@ -82,7 +82,10 @@ def save(path: Optional[os.PathLike] = None) -> Path:
     return path
 
 
-SPLIT_K = os.environ.get("DIFFUSERS_AMD_SPLITK", "1") != "0"   # let the tuner consider split-K variants (nn.Linear only)
+# Let the tuner consider split-K variants.  OFF by default: on every SDXL shape that leaves CUs idle the in-launch
+# reduction measured SLOWER than the best unsplit variant (profiles/r02b_kernel_experiments.md: 0.59-0.85x; the fp32
+# partial-tile hand-off costs more than the idle CUs), and a split factor changes the fp32 summation order.
+SPLIT_K = os.environ.get("DIFFUSERS_AMD_SPLITK", "0") == "1"
 
 
 def pair_key(pa: "L.GemmParams", pb: "L.GemmParams") -> str:

@@ -100,10 +100,10 @@ typedef struct da_gemm_params {
   int staging; /* DA_STAGE_* */
   int gate_f32; /* 1: gate is float and out = residual + bf16(xW+b) * gate in fp32, rounded once
                    (WanTransformerBlock, transformer_wan.py:491,:502); 0: Flux rounding (gate product rounded to bf16) */
-  int split_k;  /* 0 / 1: every tile is computed by one block.  2..8 (nn.Linear only): the K range of each tile is dealt to
+  int split_k;  /* 0 / 1: every tile is computed by one block.  2..8: the K range of each tile is dealt to
                    split_k co-resident blocks that hand fp32 partial tiles over through `workspace` (in-launch reduction,
                    fixed summation order: deterministic, but the last fp32 bit of a sum differs from split_k = 1).  For
-                   problems with fewer tiles than the 256 CUs (SDXL: M = 2048, N = 1280). */
+                   problems with fewer tiles than the 256 CUs (SDXL: M = 2048, N = 1280 Linear and the 1280-channel convs). */
   void* workspace;          /* split_k > 1: caller-owned device buffer, >= tiles * (split_k - 1) * tile_rows * tile_cols * 4 B */
   void* sync_flags;         /* split_k > 1: DA_SPLITK_FLAGS ints, zeroed ONCE by the caller; the kernel re-arms what it uses */
   long long workspace_bytes;

@@ -35,7 +35,7 @@ def _act(y, act):
 
 
 def conv2d_nhwc(x, w, bias=None, *, ksize=3, x2=None, stride=1, up=False, pad=None, rowvec=None, residual=None,
-                out_scale=1.0, act=0, tile=None, staging=None, pad_after=0, out=None):
+                out_scale=1.0, act=0, tile=None, staging=None, pad_after=0, out=None, split_k=None):
     assert x.is_contiguous() and x.shape[-1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: conv channels % 64, N % 4"
     if x2 is not None:
         assert x2.is_contiguous() and x2.shape[-1] % 64 == 0 and x2.shape[:3] == x.shape[:3]

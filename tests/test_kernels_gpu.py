@@ -153,6 +153,44 @@ def test_gemm_split_k_in_launch_reduction(M, N, K):
     assert not ops.splitk_error()
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,Co,stride,up", [(2, 32, 32, 1280, 0, 1280, 1, False), (2, 16, 16, 640, 320, 640, 1, False),
+                                                     (1, 16, 16, 320, 0, 320, 2, False), (1, 8, 8, 256, 0, 128, 1, True)])
+def test_conv_split_k(B, H, W, C1, C2, Co, stride, up):
+    """split-K on the implicit GEMM: a block starts in the middle of the (tap, channel) walk (cursor initialised from its
+    first K slice), for plain, two-source (skip concat), strided and upsampling convs, with bias + time-embedding row
+    vector + residual applied once by the reducer.  Deterministic, and within one bf16 ulp of the unsplit kernel."""
+    ops, L = _ops()
+    x1 = rnd((B, H, W, C1), 41)
+    x2 = rnd((B, H, W, C2), 42) if C2 else None
+    K = 9 * (C1 + C2)
+    w, b = rnd((Co, K), 43, K ** -0.5), rnd((Co,), 44)
+    Ho, Wo = ((2 * H if up else H) // stride, (2 * W if up else W) // stride)
+    rv, res = rnd((B, Co), 45), rnd((B, Ho, Wo, Co), 46)
+    kw = dict(ksize=3, x2=x2, stride=stride, up=up, rowvec=rv, residual=res)
+    base = ops.conv2d_nhwc(x1, w, b, tile=L.TILE_128x128, staging=L.STAGE_LDS_DIRECT, **kw)
+    ran = 0
+    for split in (2, 3, 4):
+        first = None
+        for tile, st in ((L.TILE_128x128, L.STAGE_LDS_DIRECT), (L.TILE_128x128, L.STAGE_LDS_DIRECT3),
+                         (L.TILE_256x128, L.STAGE_LDS_DIRECT3), (L.TILE_128x256, L.STAGE_LDS_DIRECT3),
+                         (L.TILE_128x64, L.STAGE_LDS_DIRECT3), (L.TILE_64x128, L.STAGE_LDS_DIRECT3)):
+            for rep in range(2):
+                try:
+                    y = ops.conv2d_nhwc(x1, w, b, tile=tile, staging=st, split_k=split, **kw)
+                except RuntimeError as e:
+                    assert "UNSUPPORTED" in str(e)
+                    y = None
+                    break
+                if first is None:
+                    first = y.clone()
+                assert torch.equal(y, first), f"conv split {split} tile {tile}/{st} rep {rep}: not deterministic"
+            ran += y is not None
+        if first is not None:
+            ulp = (first.float() - base.float()).abs() / base.float().abs().clamp_min(2.0 ** -8)
+            assert float(ulp.max()) <= 2.0 ** -7, f"conv split {split}: more than one bf16 ulp from the unsplit kernel"
+    assert ran >= 4 and not ops.splitk_error()
+
+
 def test_conv_all_variants_bit_identical():
     ops, L = _ops()
     B, H, W, C1, C2, Cout = 2, 24, 20, 64, 128, 192
@@ -192,12 +230,17 @@ def test_gemm_tuner_picks_a_valid_variant(tmp_path, monkeypatch):
     y_ref = ops.linear(x, w, tile=L.TILE_128x128, staging=L.STAGE_REGISTER)
     y = ops.linear(x, w)  # tunes live
     assert torch.equal(y, y_ref)
-    (key, (tile, staging, us)), = tuning.table().items()
-    assert 1 <= tile <= 7 and 1 <= staging <= 5 and us > 0
+    (key, (tile, staging, us, split)), = tuning.table().items()
+    assert 1 <= tile <= 7 and 1 <= staging <= 5 and us > 0 and split == 1   # split-K is opt-in (DIFFUSERS_AMD_SPLITK=1)
     print(f"[tune] {key} -> tile {L.TILE_NAMES[tile]} staging {staging}: {us:.1f} us")
     assert torch.equal(ops.linear(x, w), y_ref)  # table hit
     out = tuning.save(tmp_path / "t.json")
     assert "lin:M2048:N1280:K640" in out.read_text()
+    # a paired launch is tuned as ONE problem and stored under its own key; same bits as two launches
+    wv = rnd((640, 640), 53, scale=640 ** -0.5)
+    qk, vt = ops.linear_pair({"x": x, "w": w}, {"x": wv, "w": x})
+    assert torch.equal(qk, y_ref) and torch.equal(vt, ops.linear(wv, x, tile=L.TILE_128x128, staging=L.STAGE_REGISTER))
+    assert any(k.startswith("pair:") for k in tuning.table())
 
 
 @pytest.mark.parametrize("staging", [0, 1])
