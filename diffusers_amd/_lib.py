@@ -40,6 +40,8 @@ class GemmParams(C.Structure):
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("pad", C.c_int),
         ("tile", C.c_int), ("staging", C.c_int), ("gate_f32", C.c_int),
         ("split_k", C.c_int), ("workspace", C.c_void_p), ("sync_flags", C.c_void_p), ("workspace_bytes", C.c_longlong),
+        ("stats_out", C.c_void_p), ("stats_ld", C.c_int), ("ln_stats", C.c_void_p), ("ln_stats_ld", C.c_int),
+        ("ln_parts", C.c_int), ("ln_s", C.c_void_p), ("ln_c", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 
@@ -62,6 +64,7 @@ SIGNATURES = {
     "da_last_error": (C.c_char_p, []),
     "da_gemm_bf16": (_i, [C.POINTER(GemmParams), _vp]),
     "da_gemm_pair_bf16": (_i, [C.POINTER(GemmParams), C.POINTER(GemmParams), _vp]),
+    "da_gemm_stats_parts": (_i, [C.POINTER(GemmParams)]),
     "da_gemm_tune": (_i, [C.POINTER(GemmParams), C.POINTER(GemmParams), _vp, _i, _vp, C.c_size_t, C.POINTER(C.c_int),
                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "da_attention_bf16": (_i, [C.POINTER(AttentionParams), _vp]),

@@ -72,7 +72,17 @@ int validate(da_gemm_params& p) {
   if (p.act == DA_ACT_GEGLU && ((p.N & 127) || p.out_f32 || p.residual || p.rowvec || p.gate || p.bias_rows))
     return DA_ERR_UNSUPPORTED;
   if (p.split_k < 0 || p.split_k > 8) return DA_ERR_INVALID;
+  if (p.stats_out && (p.conv || p.out_f32 || p.act == DA_ACT_GEGLU || p.stats_ld <= 0 || (p.stats_ld & 1)))
+    return DA_ERR_UNSUPPORTED;
+  if (p.ln_stats && (p.conv || !p.ln_s || !p.ln_c || p.ln_parts <= 0 || p.ln_stats_ld < 2 * p.ln_parts || (p.ln_stats_ld & 1)))
+    return DA_ERR_INVALID;
   return DA_OK;
+}
+
+constexpr int kWavesN[] = {0, 2, 2, 2, 2, 2, 4, 4};   // WN of each DA_TILE_*
+
+int stats_parts(const da_gemm_params& p, int tile) {
+  return ((p.N + kTiles[tile].bn - 1) / kTiles[tile].bn) * kWavesN[tile];
 }
 
 bool tile_ok(const da_gemm_params& p, int tile) {
@@ -97,7 +107,16 @@ extern "C" int da_gemm_bf16(const da_gemm_params* pp, void* stream) {
   int tile = p.tile;
   if (tile == DA_TILE_AUTO) tile = pick_tile(p);
   if (!tile_ok(p, tile)) return DA_ERR_UNSUPPORTED;
+  if (p.stats_out && p.stats_ld < 2 * stats_parts(p, tile)) return DA_ERR_INVALID;
   return run(p, tile, p.staging, (hipStream_t)stream);
+}
+
+extern "C" int da_gemm_stats_parts(const da_gemm_params* pp) {
+  if (!pp || pp->N <= 0) return 0;
+  int tile = pp->tile;
+  if (tile == DA_TILE_AUTO) tile = pick_tile(*pp);
+  if (tile <= 0 || tile >= kNumTiles) return 0;
+  return stats_parts(*pp, tile);
 }
 
 extern "C" int da_gemm_pair_bf16(const da_gemm_params* pa, const da_gemm_params* pb, void* stream) {

@@ -426,6 +426,33 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
       if (s == 0) DA_STAGE_COMMIT(0);
     }
   }
+  // LayerNorm fold, consumer side: mean / rstd of this lane's MT output rows from the producer's partials -- loaded
+  // here, while the first K slices are in flight (the one-time vmcnt(0) these plain loads imply costs nothing: slice 0
+  // has to land before the first MFMA anyway).  Lane halves sum the even / odd parts, then combine: fixed order.
+  float ln_mu[MT], ln_rs[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) ln_mu[i] = 0.f, ln_rs[i] = 1.f;
+  if constexpr (!CONV) {
+    if (p.ln_stats) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = min(m0 + (wm * MT + i) * 32 + l31, p.M - 1);
+        const float* sp = p.ln_stats + (size_t)m * p.ln_stats_ld;
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = hi; q < p.ln_parts; q += 2) {
+          const float2 v = *(const float2*)(sp + 2 * q);
+          s1 += v.x;
+          s2 += v.y;
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float inv_c = 1.0f / (float)p.K;          // the normalised dimension is this GEMM's K
+        const float mean = s1 * inv_c;
+        ln_mu[i] = mean;
+        ln_rs[i] = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + p.ln_eps);
+      }
+    }
+  }
   {
     const int g0 = min(nk, PD) - 1;  // slices still allowed in flight once slice 0 is needed
     DA_STAGE_WAIT(g0);
@@ -545,6 +572,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
             for (int e = 0; e < 4; ++e) {
               float hv = acc[i][2 * jp][4 * g + e] * p.alpha;
               float gv = acc[i][2 * jp + 1][4 * g + e] * p.alpha;
+              if (!CONV && p.ln_stats) {   // LayerNorm fold (see da_gemm_params): both halves of the projection
+                hv = ln_rs[i] * (hv - ln_mu[i] * p.ln_s[nv + e]) + p.ln_c[nv + e];
+                gv = ln_rs[i] * (gv - ln_mu[i] * p.ln_s[nv + 32 + e]) + p.ln_c[nv + 32 + e];
+              }
               if (bias) {
                 hv += bf2f(bias[nv + e]);
                 gv += bf2f(bias[nv + 32 + e]);
@@ -563,6 +594,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
       }
       continue;
     }
+    float st1 = 0.f, st2 = 0.f;   // LayerNorm fold, producer side: this lane's share of the row's (sum, sum of squares)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -572,6 +604,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * p.alpha;
+        if (!CONV && p.ln_stats) {
+          const float4 sv = *(const float4*)(p.ln_s + n), cv = *(const float4*)(p.ln_c + n);
+          o[0] = ln_rs[i] * (o[0] - ln_mu[i] * sv.x) + cv.x;
+          o[1] = ln_rs[i] * (o[1] - ln_mu[i] * sv.y) + cv.y;
+          o[2] = ln_rs[i] * (o[2] - ln_mu[i] * sv.z) + cv.z;
+          o[3] = ln_rs[i] * (o[3] - ln_mu[i] * sv.w) + cv.w;
+        }
         if (bias) {
           const uint2 bv = *(const uint2*)(bias + n);
           o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y);
@@ -622,8 +661,18 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
           pk.x = pack_bf2(o[0], o[1]);
           pk.y = pack_bf2(o[2], o[3]);
           *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + n) = pk;
+          if (!CONV && p.stats_out) {   // statistics of the STORED (bf16-rounded) values, as a LayerNorm kernel would see them
+            const float r0 = bf_lo(pk.x), r1 = bf_hi(pk.x), r2 = bf_lo(pk.y), r3 = bf_hi(pk.y);
+            st1 += (r0 + r1) + (r2 + r3);
+            st2 += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+          }
         }
       }
+    }
+    if (!CONV && p.stats_out) {
+      st1 += __shfl_xor(st1, 32, 64);
+      st2 += __shfl_xor(st2, 32, 64);
+      if (hi == 0) *(float2*)(p.stats_out + (size_t)m * p.stats_ld + 2 * (tn * WN + wn)) = make_float2(st1, st2);
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__

@@ -245,11 +245,17 @@ class Attention:
         vt = ops.linear(self.wv, ehs_pad)  # [inner][batch*skv_alloc] = V^T
         return CrossKV(k, vt, skv, skv_alloc, batch)
 
-    def __call__(self, x, batch: int, seq: int, residual, kv: Optional[CrossKV] = None):
-        """x: [batch*seq][C] (already normalised); returns to_out(attn) + residual."""
+    def fold_norm(self, norm: "LayerNorm") -> None:
+        """Cross-attention only: fold the LayerNorm in front of the block (attention.py:1030) into to_q."""
+        self.wq_ln, self.fold = ops.fold_layernorm(self.wq, norm.weight, norm.bias, norm.eps)
+
+    def __call__(self, x, batch: int, seq: int, residual, kv: Optional[CrossKV] = None, stats=None, stats_out=None):
+        """x: [batch*seq][C], already normalised -- or, with ``stats`` (ops.RowStats of x), the un-normalised tokens of a
+        cross-attention whose norm was folded into to_q; returns to_out(attn) + residual (``stats_out``: the row statistics
+        of that result, for the next folded norm)."""
         Hh, D = self.heads, self.kdim
         if self.cross:
-            q = ops.linear(x, self.wq)
+            q = ops.linear(x, self.wq_ln, ln=(stats, self.fold)) if stats is not None else ops.linear(x, self.wq)
             o = ops.attention(q, kv.k, kv.vt, B=batch, H=Hh, D=D, Sq=seq, Skv=kv.skv, Skv_alloc=kv.skv_alloc,
                               q_row_stride=self.inner, k_row_stride=self.inner,
                               q_batch_stride=seq * self.inner, k_batch_stride=kv.skv_alloc * self.inner,
@@ -262,21 +268,38 @@ class Attention:
                               q_row_stride=2 * self.inner, k_row_stride=2 * self.inner,
                               q_batch_stride=seq * 2 * self.inner, k_batch_stride=seq * 2 * self.inner,
                               vt_ld=batch * seq, vt_batch_stride=seq, scale=self.scale)
-        return self.to_out(o, residual=residual)
+        return self.to_out(o, residual=residual, stats_out=stats_out)
 
 
 class FeedForwardGEGLU:
     """models/attention.py:1682-1742 with activation_fn="geglu" (activations.py:93-124): GEGLU fused into the up
-    projection's epilogue, bias + residual fused into the down projection's."""
+    projection's epilogue, bias + residual fused into the down projection's.  ``norm`` (the LayerNorm in front of the
+    block, attention.py:1056): folded into the up projection -- ``w1_ln`` is (gamma o W1) in the packed GEGLU row order and
+    ``fold`` carries the matching s / c vectors (ops.fold_layernorm), so ``__call__(x, ..., stats=)`` takes the
+    UN-normalised tokens plus their row statistics."""
 
-    def __init__(self, w: Weights, prefix: str):
-        wp, bp = ops.pack_geglu(w.get(prefix + ".net.0.proj.weight"), w.opt(prefix + ".net.0.proj.bias"))
+    def __init__(self, w: Weights, prefix: str, norm: Optional["LayerNorm"] = None):
+        w1, b1 = w.get(prefix + ".net.0.proj.weight"), w.opt(prefix + ".net.0.proj.bias")
+        wp, bp = ops.pack_geglu(w1, b1)
         self.w1, self.b1 = wp, bp
         self.out = Linear(w, prefix + ".net.2")
+        self.w1_ln = self.fold = None
+        if norm is not None:
+            wl, fold = ops.fold_layernorm(w1, norm.weight, norm.bias, norm.eps)
+            wl, _ = ops.pack_geglu(wl, None)
+            n = w1.shape[0] // 2
+            idx = torch.arange(n, device=w1.device).view(n // 32, 32)
+            order = torch.cat([idx, idx + n], dim=1).reshape(-1)            # the row order of pack_geglu
+            self.w1_ln = wl
+            self.fold = ops.LNFold(fold.s.index_select(0, order).contiguous(), fold.c.index_select(0, order).contiguous(),
+                                   fold.eps)
 
-    def __call__(self, x, residual):
-        h = ops.linear(x, self.w1, self.b1, act=L.ACT_GEGLU)
-        return self.out(h, residual=residual)
+    def __call__(self, x, residual, stats=None, stats_out=None):
+        if stats is not None:
+            h = ops.linear(x, self.w1_ln, self.b1, act=L.ACT_GEGLU, ln=(stats, self.fold))
+        else:
+            h = ops.linear(x, self.w1, self.b1, act=L.ACT_GEGLU)
+        return self.out(h, residual=residual, stats_out=stats_out)
 
 
 class BasicTransformerBlock:
@@ -288,13 +311,22 @@ class BasicTransformerBlock:
         self.norm2 = LayerNorm(w, prefix + ".norm2")
         self.attn2 = Attention(w, prefix + ".attn2", heads, cross=True)
         self.norm3 = LayerNorm(w, prefix + ".norm3")
-        self.ff = FeedForwardGEGLU(w, prefix + ".ff")
+        self.ff = FeedForwardGEGLU(w, prefix + ".ff", norm=self.norm3)
+        self.attn2.fold_norm(self.norm2)
 
     def __call__(self, x, batch, seq, kv: CrossKV):
-        x = self.attn1(self.norm1(x), batch, seq, residual=x)
-        x = self.attn2(self.norm2(x), batch, seq, residual=x, kv=kv)
-        x = self.ff(self.norm3(x), residual=x)
-        return x
+        if not ops.LN_FOLD:
+            x = self.attn1(self.norm1(x), batch, seq, residual=x)
+            x = self.attn2(self.norm2(x), batch, seq, residual=x, kv=kv)
+            return self.ff(self.norm3(x), residual=x)
+        # norm2 and norm3 never run as kernels: attn1.to_out / attn2.to_out also write the row statistics of the
+        # residual stream they produce, and attn2.to_q / the GEGLU projection apply the normalisation in their epilogue
+        # (ops.linear(ln=)).  norm1 stays a kernel: its consumers are the Q|K projection AND the swapped V^T product,
+        # where the normalised tokens are the column operand.
+        st1, st2 = ops.RowStats(x.shape[0], x.device), ops.RowStats(x.shape[0], x.device)
+        x = self.attn1(self.norm1(x), batch, seq, residual=x, stats_out=st1)
+        x = self.attn2(x, batch, seq, residual=x, kv=kv, stats=st1, stats_out=st2)
+        return self.ff(x, residual=x, stats=st2)
 
 
 class Transformer2DModel:

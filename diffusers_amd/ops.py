@@ -44,6 +44,39 @@ def splitk_error(device=None) -> bool:
                if device is None or d == torch.device(device).index)
 
 
+LN_FOLD = True   # BasicTransformerBlock folds norm2 / norm3 into the GEMMs either side of them (see linear(ln=...))
+STATS_MAX_PARTS = 64
+
+
+class RowStats:
+    """Per-row (sum, sum of squares) partials of a GEMM output, written by the producing launch (``linear(stats_out=)``)
+    and consumed by the GEMM that reads LayerNorm of that output (``linear(ln=)``): fp32 [M][STATS_MAX_PARTS][2], of which
+    the first ``parts`` pairs of every row are valid."""
+
+    __slots__ = ("buf", "parts")
+
+    def __init__(self, rows: int, device):
+        self.buf = torch.empty((rows, STATS_MAX_PARTS, 2), device=device, dtype=torch.float32)
+        self.parts = 0
+
+
+class LNFold:
+    """What the consumer GEMM of a folded LayerNorm needs besides the pre-scaled weight: s[n] = sum_k (gamma o W)[n, k]
+    and c[n] = sum_k beta[k] W[n, k] (fp32), and eps.  Built once at load time by :func:`fold_layernorm`."""
+
+    def __init__(self, s, c, eps):
+        self.s, self.c, self.eps = s, c, eps
+
+
+def fold_layernorm(w: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float):
+    """(W', LNFold) for LN(x; gamma, beta) @ W^T == rstd * (x @ W'^T - mu * s) + c   (W' = bf16(gamma o W))."""
+    wf = w.float()
+    wp = (wf * gamma.float()[None, :]).to(bf16) if gamma is not None else w
+    s = wp.float().sum(dim=1).contiguous()
+    c = (wf @ beta.float()).contiguous() if beta is not None else torch.zeros_like(s)
+    return wp.contiguous(), LNFold(s, c, float(eps))
+
+
 def _select_variant(p: "L.GemmParams", tile: Optional[int], staging: Optional[int], stream: int,
                     inplace: bool = False, split_k: Optional[int] = None, device=None) -> None:
     p.split_k = 1
@@ -99,12 +132,17 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            residual: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
            alpha: float = 1.0, out_scale: float = 1.0, out: Optional[torch.Tensor] = None, out_f32: bool = False,
            bias_rows: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
-           tile: Optional[int] = None, staging: Optional[int] = None, split_k: Optional[int] = None) -> torch.Tensor:
+           tile: Optional[int] = None, staging: Optional[int] = None, split_k: Optional[int] = None,
+           stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None) -> torch.Tensor:
     """out[M][N] = epilogue(alpha * x[M][K] @ w[N][K]^T).  For act == GEGLU, w/bias are in the packed layout of
-    :func:`pack_geglu` and the output has N/2 columns."""
+    :func:`pack_geglu` and the output has N/2 columns.
+
+    LayerNorm fold: ``stats_out`` (a :class:`RowStats`) makes this launch also write the row statistics of its output;
+    ``ln=(RowStats, LNFold)`` makes it compute LN(x) @ w^T from the UN-normalised ``x`` whose statistics another launch
+    wrote (``w`` pre-scaled by :func:`fold_layernorm`)."""
     p, st = _linear_params(x, w, bias, act=act, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch,
                            alpha=alpha, out_scale=out_scale, out=out, out_f32=out_f32, bias_rows=bias_rows, gate=gate,
-                           tile=tile, staging=staging, split_k=split_k)
+                           tile=tile, staging=staging, split_k=split_k, stats_out=stats_out, ln=ln)
     if p is None:
         return st     # the skinny-M path ran
     L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(linear)")
@@ -140,7 +178,7 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
                    rows_per_batch: int = 0, alpha: float = 1.0, out_scale: float = 1.0,
                    out: Optional[torch.Tensor] = None, out_f32: bool = False, bias_rows: Optional[torch.Tensor] = None,
                    gate: Optional[torch.Tensor] = None, tile: Optional[int] = None, staging: Optional[int] = None,
-                   split_k: Optional[int] = None):
+                   split_k: Optional[int] = None, stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None):
     """Checks + da_gemm_params of one nn.Linear problem; returns (params, stream), or (None, result) when the skinny-M
     kernel handled it."""
     _req(x, "x"), _req(w, "w")
@@ -150,7 +188,7 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         raise ValueError(f"linear: K mismatch {K} vs {Kw}")
     n_out = N // 2 if act == L.ACT_GEGLU else N
     if M <= 8 and act in (L.ACT_NONE, L.ACT_SILU, L.ACT_GELU_TANH) and rowvec is None and not out_f32 \
-            and alpha == 1.0 and out_scale == 1.0 and bias_rows is None and gate is None:
+            and alpha == 1.0 and out_scale == 1.0 and bias_rows is None and gate is None and stats_out is None and ln is None:
         return None, linear_small_m(x, w, bias, act_out=act, residual=residual, out=out)
     if out is None:
         out = torch.empty((M, n_out), device=x.device, dtype=torch.float32 if out_f32 else bf16)
@@ -175,9 +213,22 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     p.rows_per_batch = rows_per_batch
     p.alpha, p.out_scale, p.act, p.out_f32, p.conv = alpha, out_scale, act, int(out_f32), 0
     st = _stream()
+    if ln is not None:
+        rs, fold = ln
+        if rs.parts <= 0 or rs.buf.shape[0] != M or fold.s.numel() != N or fold.c.numel() != N:
+            raise ValueError("linear(ln=): statistics / fold vectors do not match this problem (was the producer run?)")
+        p.ln_stats, p.ln_stats_ld, p.ln_parts = rs.buf.data_ptr(), rs.buf.shape[1] * 2, rs.parts
+        p.ln_s, p.ln_c, p.ln_eps = fold.s.data_ptr(), fold.c.data_ptr(), fold.eps
     _select_variant(p, tile, staging, st, inplace=inplace, split_k=split_k, device=x.device)
+    if stats_out is not None:
+        if act == L.ACT_GEGLU or out_f32 or stats_out.buf.shape[0] != M:
+            raise ValueError("linear(stats_out=): bf16 non-GEGLU outputs only, one statistics row per output row")
+        p.stats_out, p.stats_ld = stats_out.buf.data_ptr(), stats_out.buf.shape[1] * 2
+        stats_out.parts = int(L.load().da_gemm_stats_parts(C.byref(p)))
+        if not 0 < stats_out.parts <= stats_out.buf.shape[1]:
+            raise ValueError(f"linear(stats_out=): {stats_out.parts} partials per row do not fit the statistics buffer")
     p._out = out            # keeps the output (and through it nothing else) alive next to the raw pointers
-    p._keep = (x, w, bias, residual, rowvec, bias_rows, gate)
+    p._keep = (x, w, bias, residual, rowvec, bias_rows, gate, stats_out, ln)
     return p, st
 
 

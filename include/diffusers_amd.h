@@ -107,7 +107,26 @@ typedef struct da_gemm_params {
   void* workspace;          /* split_k > 1: caller-owned device buffer, >= tiles * (split_k - 1) * tile_rows * tile_cols * 4 B */
   void* sync_flags;         /* split_k > 1: DA_SPLITK_FLAGS ints, zeroed ONCE by the caller; the kernel re-arms what it uses */
   long long workspace_bytes;
+  /* ---- LayerNorm folded into the GEMMs either side of it (nn.Linear, bf16 output; attention.py:1030,:1056: norm2 ->
+   * attn2.to_q, norm3 -> ff.net.0.proj).  LN(x) W^T = rstd (x (gamma o W)^T - mu s^T) + c^T with s[n] = sum_k (gamma o W)[n,k],
+   * c[n] = sum_k beta[k] W[n,k]: the normalised tensor is never written or read.
+   *   PRODUCER (the GEMM that writes x): stats_out != NULL -> besides C, every (column tile, wave column) writes the partial
+   *     (sum, sum of squares) of ITS columns of each row of the bf16-rounded output: float2 stats_out[m * stats_ld + 2 * part],
+   *     part = column_tile * waves_n + wave_n  (da_gemm_stats_parts() = number of parts for *p; no atomics: deterministic).
+   *   CONSUMER (the GEMM that reads LN(x)): ln_stats != NULL -> each row's mean / rstd are formed from its ln_parts partials
+   *     (fixed order) while the first K slices are in flight, and the epilogue applies the identity above to alpha * acc
+   *     before bias / activation (both GEGLU halves included).  W must be the pre-scaled (gamma o W) in bf16. */
+  float* stats_out;
+  int stats_ld;             /* floats per row of stats_out (>= 2 * parts) */
+  const float* ln_stats;    /* partials written by the producer of this GEMM's A operand */
+  int ln_stats_ld, ln_parts;
+  const float* ln_s;        /* [N] fp32 */
+  const float* ln_c;        /* [N] fp32 */
+  float ln_eps;
 } da_gemm_params;
+
+/* number of stats partials per row the launch *p (tile resolved as da_gemm_bf16 resolves it) writes to stats_out */
+int da_gemm_stats_parts(const da_gemm_params* p);
 
 #define DA_SPLITK_FLAGS 4096
 #define DA_SPLITK_ERR_SLOT (DA_SPLITK_FLAGS - 1) /* set to 1 by a reducer whose producer never arrived (bounded spin) */

@@ -61,10 +61,17 @@ def conv2d_nhwc(x, w, bias=None, *, ksize=3, x2=None, stride=1, up=False, pad=No
 
 
 def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch=0, alpha=1.0, out_scale=1.0, out=None,
-           out_f32=False, bias_rows=None, gate=None, tile=None, staging=None, split_k=None):
+           out_f32=False, bias_rows=None, gate=None, tile=None, staging=None, split_k=None, stats_out=None, ln=None):
     assert x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: K % 64, N % 4"
     assert x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0, "C ABI: row strides % 8"
     y = alpha * (x.float() @ w.float().t())
+    if ln is not None:      # LayerNorm fold, consumer: rstd * (x W'^T - mu s) + c from the producer's partial sums
+        rs, fold = ln
+        assert rs.parts > 0 and rs.buf.shape[0] == x.shape[0]
+        tot = rs.buf[:, :rs.parts].sum(dim=1)
+        mean = tot[:, 0] / x.shape[1]
+        rstd = torch.rsqrt((tot[:, 1] / x.shape[1] - mean * mean).clamp_min(0) + fold.eps)
+        y = rstd[:, None] * (y - mean[:, None] * fold.s[None, :]) + fold.c[None, :]
     if bias is not None:
         y = y + bias.float()
     if bias_rows is not None:
@@ -89,7 +96,16 @@ def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch
             y = y.to(bf16).float()
     if residual is not None:
         y = y + residual.float()
-    return _store(y * out_scale, out, torch.float32 if out_f32 else bf16)
+    res = _store(y * out_scale, out, torch.float32 if out_f32 else bf16)
+    if stats_out is not None:   # LayerNorm fold, producer: partial (sum, sum of squares) of the STORED values; the stand-in
+        assert act != ACT_GEGLU and not out_f32 and stats_out.buf.shape[0] == M     # writes two parts (column halves)
+        r = res.float()
+        h = r.shape[1] // 2
+        stats_out.parts = 2
+        for q, blk in enumerate((r[:, :h], r[:, h:])):
+            stats_out.buf[:, q, 0] = blk.sum(dim=1)
+            stats_out.buf[:, q, 1] = (blk * blk).sum(dim=1)
+    return res
 
 
 def linear_pair(a, b):

@@ -191,6 +191,62 @@ def test_conv_split_k(B, H, W, C1, C2, Co, stride, up):
     assert ran >= 4 and not ops.splitk_error()
 
 
+@pytest.mark.parametrize("M,C,N", [(2048, 1280, 1280), (520, 320, 384), (8192, 640, 640)])
+def test_layernorm_fold_producer_and_consumers(M, C, N):
+    """LayerNorm folded into the GEMMs either side of it (da_gemm_params.stats_out / ln_*):
+      * PRODUCER: every tile variant writes per-row partial (sum, sum of squares) of its bf16 output; their sum equals the
+        row statistics of the stored tensor (fp32 tolerance), the output itself is bit-identical to the launch without
+        statistics, and da_gemm_stats_parts() is the number of partials written;
+      * CONSUMER: linear(x, W', ln=...) == linear(layer_norm(x), W) within the bf16 tolerance of one GEMM (the fold skips
+        the bf16 rounding of the normalised tensor and rounds gamma o W instead), for a plain epilogue (+bias) and for the
+        GEGLU epilogue, for every tile variant; rows with a large mean (|mu| = 8 sigma) included."""
+    ops, L = _ops()
+    a, wprod, res = rnd((M, 192), 61), rnd((C, 192), 62, 192 ** -0.5), rnd((M, C), 63)
+    res = res + 8.0 * (torch.arange(M, device=DEV) % 3 == 0).to(bf16)[:, None]       # a third of the rows: mean ~ 8 sigma
+    gamma, beta = rnd((C,), 64) * 0.3 + 1.0, rnd((C,), 65) * 0.2
+    w, b = rnd((N, C), 66, C ** -0.5), rnd((N,), 67)
+    w1 = rnd((2 * max(N // 128, 1) * 128, C), 68, C ** -0.5)
+    b1 = rnd((w1.shape[0],), 69)
+    x_plain = ops.linear(a, wprod, residual=res, tile=L.TILE_128x128, staging=1)
+    xf = x_plain.float()
+    ln_ref = F.layer_norm(xf, (C,), gamma.float(), beta.float(), 1e-5)
+    ref = ln_ref @ w.float().t() + b.float()
+    g = ln_ref @ w1.float().t() + b1.float()
+    h_, g_ = g.chunk(2, dim=-1)
+    ref_geglu = h_ * F.gelu(g_)
+    wl, fold = ops.fold_layernorm(w, gamma, beta, 1e-5)
+    w1l, fold1 = ops.fold_layernorm(w1, gamma, beta, 1e-5)
+    w1p, b1p = ops.pack_geglu(w1l, b1)
+    n2 = w1.shape[0] // 2
+    idx = torch.arange(n2, device=DEV).view(n2 // 32, 32)
+    order = torch.cat([idx, idx + n2], dim=1).reshape(-1)
+    fold1p = ops.LNFold(fold1.s[order].contiguous(), fold1.c[order].contiguous(), fold1.eps)
+    n_prod = 0
+    for tile in range(1, 8):
+        st = ops.RowStats(M, DEV)
+        st.buf.fill_(float("nan"))
+        try:
+            x = ops.linear(a, wprod, residual=res, tile=tile, staging=1, stats_out=st)
+        except RuntimeError:
+            continue
+        n_prod += 1
+        assert torch.equal(x, x_plain), f"tile {tile}: statistics changed the output"
+        tot = st.buf[:, :st.parts].sum(dim=1)
+        assert torch.isfinite(tot).all() and torch.isnan(st.buf[:, st.parts:]).all(), f"tile {tile}: wrong number of partials"
+        assert torch.allclose(tot[:, 0], xf.sum(dim=1), rtol=1e-5, atol=1e-2)
+        assert torch.allclose(tot[:, 1], (xf * xf).sum(dim=1), rtol=1e-5, atol=1e-2)
+        for ctile in range(1, 8):
+            try:
+                y = ops.linear(x, wl, b, tile=ctile, staging=1, ln=(st, fold))
+            except RuntimeError:
+                continue
+            assert_close_bf16(y, ref, f"LN fold, producer tile {tile} -> consumer tile {ctile}", rel_rms_max=6e-3)
+            if ctile in (L.TILE_128x128, L.TILE_256x128, L.TILE_64x128) and tile == 1:
+                yg = ops.linear(x, w1p, b1p, act=L.ACT_GEGLU, tile=ctile, staging=1, ln=(st, fold1p))
+                assert_close_bf16(yg, ref_geglu, f"LN fold + GEGLU, consumer tile {ctile}", rel_rms_max=8e-3)
+    assert n_prod >= 6
+
+
 def test_conv_all_variants_bit_identical():
     ops, L = _ops()
     B, H, W, C1, C2, Cout = 2, 24, 20, 64, 128, 192
