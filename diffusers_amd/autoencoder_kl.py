@@ -13,6 +13,7 @@ import torch
 
 from . import ops
 from .config_utils import check_to
+from .loading import PretrainedMixin
 from .layers import GroupNorm, ResnetBlock2D, Upsample2D, Weights
 from .unet_2d_condition import FrozenConfig
 
@@ -87,7 +88,7 @@ class VaeAttention:
         return y.view(B, H, W_, C)
 
 
-class AutoencoderKL:
+class AutoencoderKL(PretrainedMixin):
     """Drop-in for the reference ``AutoencoderKL`` decode path (inference, bf16, HIP device only)."""
 
     def __init__(self, **kwargs):

@@ -28,6 +28,7 @@ import torch
 
 from . import ops
 from .config_utils import check_to
+from .loading import PretrainedMixin
 from .autoencoder_kl import DecoderOutput
 from .layers import Weights
 from .unet_2d_condition import FrozenConfig
@@ -191,7 +192,7 @@ class Resample:
         return ops.conv2d_nhwc(x, self.w, self.b, ksize=3, up=True)
 
 
-class AutoencoderKLWan:
+class AutoencoderKLWan(PretrainedMixin):
     """Drop-in for the reference ``AutoencoderKLWan`` decode path (inference, bf16, HIP device only)."""
 
     def __init__(self, **kwargs):

@@ -51,7 +51,7 @@ def _walk(obj, path: str, visit, seen: set) -> None:
         items = list(enumerate(obj))
         get = lambda k: obj[k]                      # noqa: E731
     elif hasattr(obj, "__dict__"):
-        items = [(k, v) for k, v in vars(obj).items() if k not in ("config", "_rope_cache", "_graph", "_static")]
+        items = [(k, v) for k, v in vars(obj).items() if k not in ("config", "_rope_cache", "_graph", "_static", "_cond_cache", "_source", "_lora")]
         get = lambda k: getattr(obj, k)             # noqa: E731
     else:
         return

@@ -27,6 +27,7 @@ import torch
 
 from . import _lib as L
 from .config_utils import check_to
+from .loading import PretrainedMixin
 from . import ops
 from .layers import Linear, TimestepEmbedding, Weights
 from .unet_2d_condition import FrozenConfig
@@ -91,7 +92,7 @@ class _SingleBlock:
         self.norm_q, self.norm_k = w.get(p + ".attn.norm_q.weight"), w.get(p + ".attn.norm_k.weight")
 
 
-class FluxTransformer2DModel:
+class FluxTransformer2DModel(PretrainedMixin):
     """Drop-in for the reference ``FluxTransformer2DModel`` (inference, bf16, HIP device only)."""
 
     def __init__(self, **kwargs):

@@ -20,6 +20,7 @@ import torch
 
 from . import _lib as L
 from .config_utils import check_to
+from .loading import PretrainedMixin
 from . import ops
 from .layers import LayerNorm, Linear, TimestepEmbedding, Weights
 from .transformer_flux import Transformer2DModelOutput
@@ -71,7 +72,7 @@ class _Block:
         self.table = w.get_f32(p + ".scale_shift_table").reshape(-1).contiguous()     # fp32 [6*dim]
 
 
-class WanTransformer3DModel:
+class WanTransformer3DModel(PretrainedMixin):
     """Drop-in for the reference ``WanTransformer3DModel`` (T2V, inference, bf16, HIP device only)."""
 
     def __init__(self, **kwargs):

@@ -16,6 +16,7 @@ import torch
 
 from . import ops
 from .config_utils import check_to
+from .loading import PretrainedMixin
 from .autoencoder_kl import VaeAttention
 from .layers import Downsample2D, GroupNorm, ResnetBlock2D, TimestepEmbedding, Upsample2D, Weights
 from .unet_2d_condition import FrozenConfig
@@ -40,7 +41,7 @@ _DEFAULTS = dict(
 )
 
 
-class UNet2DModel:
+class UNet2DModel(PretrainedMixin):
     """Drop-in for the reference ``UNet2DModel`` (inference, bf16, HIP device only)."""
 
     def __init__(self, **kwargs):

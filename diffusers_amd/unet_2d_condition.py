@@ -14,6 +14,7 @@ import torch
 
 from . import ops
 from .config_utils import check_to
+from .loading import PretrainedMixin
 from .layers import (Downsample2D, GroupNorm, ResnetBlock2D, TimestepEmbedding, Transformer2DModel,
                      Upsample2D, Weights, pad_encoder_states)
 
@@ -56,7 +57,7 @@ def _tup(v, n):
     return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
 
 
-class UNet2DConditionModel:
+class UNet2DConditionModel(PretrainedMixin):
     """Drop-in for the reference ``UNet2DConditionModel`` (inference, bf16, HIP device only)."""
 
     def __init__(self, **kwargs):
