@@ -74,7 +74,8 @@ int validate(da_gemm_params& p) {
   if (p.split_k < 0 || p.split_k > 8) return DA_ERR_INVALID;
   if (p.stats_out && (p.conv || p.out_f32 || p.act == DA_ACT_GEGLU || p.stats_ld <= 0 || (p.stats_ld & 1)))
     return DA_ERR_UNSUPPORTED;
-  if (p.ln_stats && (p.conv || !p.ln_s || !p.ln_c || p.ln_parts <= 0 || p.ln_stats_ld < 2 * p.ln_parts || (p.ln_stats_ld & 1)))
+  if (p.ln_stats && (p.conv || !p.ln_s || !p.ln_c || p.ln_parts <= 0 || p.ln_parts > DA_LN_MAX_PARTS ||
+                     p.ln_stats_ld < 2 * DA_LN_MAX_PARTS || (p.ln_stats_ld & 3)))
     return DA_ERR_INVALID;
   return DA_OK;
 }

@@ -438,11 +438,24 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
       for (int i = 0; i < MT; ++i) {
         const int m = min(m0 + (wm * MT + i) * 32 + l31, p.M - 1);
         const float* sp = p.ln_stats + (size_t)m * p.ln_stats_ld;
+        // Two partials per 16-byte load; lane half `hi` takes the pairs hi, hi + 2, ...  The loads of a batch are
+        // UNCONDITIONAL (the row always holds DA_LN_MAX_PARTS slots; slots past ln_parts are masked after the load), so
+        // the compiler issues all eight back to back: one L2 round trip per batch instead of one per partial (a
+        // runtime-trip-count loop of dependent load -> add steps cost ~10 us per launch, more than the LayerNorm kernel
+        // this fold removes).
         float s1 = 0.f, s2 = 0.f;
-        for (int q = hi; q < p.ln_parts; q += 2) {
-          const float2 v = *(const float2*)(sp + 2 * q);
-          s1 += v.x;
-          s2 += v.y;
+#pragma unroll
+        for (int batch = 0; batch < DA_LN_MAX_PARTS / 32; ++batch) {
+          if (batch * 32 >= p.ln_parts) break;   // wave-uniform
+          float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(sp + 4 * (16 * batch + hi + 2 * u));
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int q = 2 * (16 * batch + hi + 2 * u);
+            s1 += (q < p.ln_parts ? v[u].x : 0.f) + (q + 1 < p.ln_parts ? v[u].z : 0.f);
+            s2 += (q < p.ln_parts ? v[u].y : 0.f) + (q + 1 < p.ln_parts ? v[u].w : 0.f);
+          }
         }
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);

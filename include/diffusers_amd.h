@@ -118,7 +118,9 @@ typedef struct da_gemm_params {
    *     before bias / activation (both GEGLU halves included).  W must be the pre-scaled (gamma o W) in bf16. */
   float* stats_out;
   int stats_ld;             /* floats per row of stats_out (>= 2 * parts) */
-  const float* ln_stats;    /* partials written by the producer of this GEMM's A operand */
+  const float* ln_stats;    /* partials written by the producer of this GEMM's A operand; every row must hold
+                               DA_LN_MAX_PARTS (sum, sum of squares) slots (ln_stats_ld >= 2 * DA_LN_MAX_PARTS): the
+                               kernel loads whole 16-byte pairs of slots and masks the ones past ln_parts */
   int ln_stats_ld, ln_parts;
   const float* ln_s;        /* [N] fp32 */
   const float* ln_c;        /* [N] fp32 */
@@ -128,6 +130,7 @@ typedef struct da_gemm_params {
 /* number of stats partials per row the launch *p (tile resolved as da_gemm_bf16 resolves it) writes to stats_out */
 int da_gemm_stats_parts(const da_gemm_params* p);
 
+#define DA_LN_MAX_PARTS 64
 #define DA_SPLITK_FLAGS 4096
 #define DA_SPLITK_ERR_SLOT (DA_SPLITK_FLAGS - 1) /* set to 1 by a reducer whose producer never arrived (bounded spin) */
 
