@@ -74,16 +74,14 @@ int validate(da_gemm_params& p) {
   if (p.split_k < 0 || p.split_k > 8) return DA_ERR_INVALID;
   if (p.stats_out && (p.conv || p.out_f32 || p.act == DA_ACT_GEGLU || p.stats_ld <= 0 || (p.stats_ld & 1)))
     return DA_ERR_UNSUPPORTED;
-  if (p.ln_stats && (p.conv || !p.ln_s || !p.ln_c || p.ln_parts <= 0 || p.ln_parts > DA_LN_MAX_PARTS ||
+  if (p.ln_stats && (p.conv || !p.ln_s || !p.ln_c || p.ln_parts <= 0 || p.ln_parts > 4 * DA_LN_PAIR_LOADS ||
                      p.ln_stats_ld < 2 * DA_LN_MAX_PARTS || (p.ln_stats_ld & 3)))
     return DA_ERR_INVALID;
   return DA_OK;
 }
 
-constexpr int kWavesN[] = {0, 2, 2, 2, 2, 2, 4, 4};   // WN of each DA_TILE_*
-
-int stats_parts(const da_gemm_params& p, int tile) {
-  return ((p.N + kTiles[tile].bn - 1) / kTiles[tile].bn) * kWavesN[tile];
+int stats_parts(const da_gemm_params& p, int tile) {   // one partial per column tile
+  return (p.N + kTiles[tile].bn - 1) / kTiles[tile].bn;
 }
 
 bool tile_ok(const da_gemm_params& p, int tile) {

@@ -417,6 +417,22 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
 #undef DA_SG_MF
   };
 
+  // LayerNorm fold, consumer side, part 1: ONE batch of unconditional 16-byte loads of this lane's rows' partials (every
+  // row holds DA_LN_MAX_PARTS slots; slots past ln_parts are masked in part 2).  DA_LN_PAIR_LOADS pairs per lane half
+  // cover 4 * DA_LN_PAIR_LOADS partials per row -- the host refuses more.
+  float4 ln_v[MT][DA_LN_PAIR_LOADS];
+  if constexpr (!CONV) {
+    if (p.ln_stats) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = min(m0 + (wm * MT + i) * 32 + l31, p.M - 1);
+        const float* sp = p.ln_stats + (size_t)m * p.ln_stats_ld;
+#pragma unroll
+        for (int u = 0; u < DA_LN_PAIR_LOADS; ++u) ln_v[i][u] = *(const float4*)(sp + 4 * (hi + 2 * u));
+      }
+    }
+  }
+
   // ---- main loop: LDS ring of STAGES slices, one rendezvous per K slice ----
   // prologue: slices 0 .. min(PD, nk) - 1 go to ring slots 0 .. ; then slice 0 must have landed
 #pragma unroll
@@ -426,9 +442,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
       if (s == 0) DA_STAGE_COMMIT(0);
     }
   }
-  // LayerNorm fold, consumer side: mean / rstd of this lane's MT output rows from the producer's partials -- loaded
-  // here, while the first K slices are in flight (the one-time vmcnt(0) these plain loads imply costs nothing: slice 0
-  // has to land before the first MFMA anyway).  Lane halves sum the even / odd parts, then combine: fixed order.
+  // LayerNorm fold, consumer side, part 2: mean / rstd of this lane's MT output rows (the loads were issued BEFORE the
+  // staging prologue, so their round trip overlaps the first K slices' flight; the compiler's vmcnt for them leaves the
+  // LDS-DMA issued since in flight).  Lane halves sum alternate 16-byte pairs of partials, then combine: fixed order.
   float ln_mu[MT], ln_rs[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) ln_mu[i] = 0.f, ln_rs[i] = 1.f;
@@ -436,26 +452,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
     if (p.ln_stats) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int m = min(m0 + (wm * MT + i) * 32 + l31, p.M - 1);
-        const float* sp = p.ln_stats + (size_t)m * p.ln_stats_ld;
-        // Two partials per 16-byte load; lane half `hi` takes the pairs hi, hi + 2, ...  The loads of a batch are
-        // UNCONDITIONAL (the row always holds DA_LN_MAX_PARTS slots; slots past ln_parts are masked after the load), so
-        // the compiler issues all eight back to back: one L2 round trip per batch instead of one per partial (a
-        // runtime-trip-count loop of dependent load -> add steps cost ~10 us per launch, more than the LayerNorm kernel
-        // this fold removes).
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int batch = 0; batch < DA_LN_MAX_PARTS / 32; ++batch) {
-          if (batch * 32 >= p.ln_parts) break;   // wave-uniform
-          float4 v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(sp + 4 * (16 * batch + hi + 2 * u));
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int q = 2 * (16 * batch + hi + 2 * u);
-            s1 += (q < p.ln_parts ? v[u].x : 0.f) + (q + 1 < p.ln_parts ? v[u].z : 0.f);
-            s2 += (q < p.ln_parts ? v[u].y : 0.f) + (q + 1 < p.ln_parts ? v[u].w : 0.f);
-          }
+        for (int u = 0; u < DA_LN_PAIR_LOADS; ++u) {
+          const int q = 2 * (hi + 2 * u);
+          s1 += (q < p.ln_parts ? ln_v[i][u].x : 0.f) + (q + 1 < p.ln_parts ? ln_v[i][u].z : 0.f);
+          s2 += (q < p.ln_parts ? ln_v[i][u].y : 0.f) + (q + 1 < p.ln_parts ? ln_v[i][u].w : 0.f);
         }
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
@@ -563,6 +565,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
   const uint16_t* __restrict__ gate = (const uint16_t*)p.gate;
   const bool geglu = (p.act == DA_ACT_GEGLU);
+  float st_sum[MT], st_sq[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) st_sum[i] = 0.f, st_sq[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + (wm * MT + i) * 32 + l31;
@@ -581,13 +586,21 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
             const int no = (n0 >> 1) + (wn * (NT / 2) + jp) * 32 + cin;       // output column
             if (nv >= p.N) continue;
             float o[4];
+            float lsv[4] = {0.f, 0.f, 0.f, 0.f}, lcv[4] = {0.f, 0.f, 0.f, 0.f}, lsg[4] = {0.f, 0.f, 0.f, 0.f}, lcg[4] = {0.f, 0.f, 0.f, 0.f};
+            const bool fold = !CONV && p.ln_stats != nullptr;
+            if (fold) {   // LayerNorm fold (see da_gemm_params): s / c of the value and the gate rows, 16 bytes each
+              const float4 a = *(const float4*)(p.ln_s + nv), b = *(const float4*)(p.ln_c + nv);
+              const float4 c = *(const float4*)(p.ln_s + nv + 32), d = *(const float4*)(p.ln_c + nv + 32);
+              lsv[0] = a.x; lsv[1] = a.y; lsv[2] = a.z; lsv[3] = a.w; lcv[0] = b.x; lcv[1] = b.y; lcv[2] = b.z; lcv[3] = b.w;
+              lsg[0] = c.x; lsg[1] = c.y; lsg[2] = c.z; lsg[3] = c.w; lcg[0] = d.x; lcg[1] = d.y; lcg[2] = d.z; lcg[3] = d.w;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float hv = acc[i][2 * jp][4 * g + e] * p.alpha;
               float gv = acc[i][2 * jp + 1][4 * g + e] * p.alpha;
-              if (!CONV && p.ln_stats) {   // LayerNorm fold (see da_gemm_params): both halves of the projection
-                hv = ln_rs[i] * (hv - ln_mu[i] * p.ln_s[nv + e]) + p.ln_c[nv + e];
-                gv = ln_rs[i] * (gv - ln_mu[i] * p.ln_s[nv + 32 + e]) + p.ln_c[nv + 32 + e];
+              if (fold) {
+                hv = ln_rs[i] * (hv - ln_mu[i] * lsv[e]) + lcv[e];
+                gv = ln_rs[i] * (gv - ln_mu[i] * lsg[e]) + lcg[e];
               }
               if (bias) {
                 hv += bf2f(bias[nv + e]);
@@ -683,9 +696,34 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
       }
     }
     if (!CONV && p.stats_out) {
-      st1 += __shfl_xor(st1, 32, 64);
-      st2 += __shfl_xor(st2, 32, 64);
-      if (hi == 0) *(float2*)(p.stats_out + (size_t)m * p.stats_ld + 2 * (tn * WN + wn)) = make_float2(st1, st2);
+      st_sum[i] = st1;
+      st_sq[i] = st2;
+    }
+  }
+  // LayerNorm fold, producer side: ONE partial per (row, column tile).  The WN waves of a block row hold disjoint column
+  // ranges of the same rows: combine them through LDS (the ring is free once every wave has left the main loop) in wave
+  // order -- fixed summation order, no atomics -- and let thread r write row r's pair.
+  if constexpr (!CONV) {
+    if (p.stats_out) {
+      float2* red = (float2*)smem;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float a = st_sum[i] + __shfl_xor(st_sum[i], 32, 64);
+        const float b = st_sq[i] + __shfl_xor(st_sq[i], 32, 64);
+        if (hi == 0) red[((wm * MT + i) * 32 + l31) * WN + wn] = make_float2(a, b);
+      }
+      __syncthreads();
+      if (t < BM && m0 + t < p.M) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) {
+          const float2 v = red[t * WN + w];
+          a += v.x;
+          b += v.y;
+        }
+        *(float2*)(p.stats_out + (size_t)(m0 + t) * p.stats_ld + 2 * tn) = make_float2(a, b);
+      }
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__

@@ -45,7 +45,8 @@ def splitk_error(device=None) -> bool:
 
 
 LN_FOLD = True   # BasicTransformerBlock folds norm2 / norm3 into the GEMMs either side of them (see linear(ln=...))
-STATS_MAX_PARTS = 64
+STATS_MAX_PARTS = 64          # DA_LN_MAX_PARTS: slots per row of a statistics buffer
+STATS_MAX_CONSUMED = 24       # 4 * DA_LN_PAIR_LOADS: partials per row a consumer launch reads
 
 
 class RowStats:
@@ -225,8 +226,14 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
             raise ValueError("linear(stats_out=): bf16 non-GEGLU outputs only, one statistics row per output row")
         p.stats_out, p.stats_ld = stats_out.buf.data_ptr(), stats_out.buf.shape[1] * 2
         stats_out.parts = int(L.load().da_gemm_stats_parts(C.byref(p)))
-        if not 0 < stats_out.parts <= stats_out.buf.shape[1]:
-            raise ValueError(f"linear(stats_out=): {stats_out.parts} partials per row do not fit the statistics buffer")
+        if stats_out.parts > STATS_MAX_CONSUMED and tile is None:
+            # too many narrow column tiles for the consumer's one-batch read: take a 128- / 256-wide tile instead (every
+            # tile computes the same bits, so this is a speed decision only)
+            p.tile, p.staging, p.split_k = (L.TILE_128x128 if N <= 128 * STATS_MAX_CONSUMED else L.TILE_128x256), L.STAGE_LDS_DIRECT, 1
+            stats_out.parts = int(L.load().da_gemm_stats_parts(C.byref(p)))
+        if not 0 < stats_out.parts <= min(stats_out.buf.shape[1], STATS_MAX_CONSUMED):
+            raise ValueError(f"linear(stats_out=): {stats_out.parts} column tiles: the consumer reads at most "
+                             f"{STATS_MAX_CONSUMED} partials per row (use a wider tile for this producer)")
     p._out = out            # keeps the output (and through it nothing else) alive next to the raw pointers
     p._keep = (x, w, bias, residual, rowvec, bias_rows, gate, stats_out, ln)
     return p, st

@@ -110,9 +110,10 @@ typedef struct da_gemm_params {
   /* ---- LayerNorm folded into the GEMMs either side of it (nn.Linear, bf16 output; attention.py:1030,:1056: norm2 ->
    * attn2.to_q, norm3 -> ff.net.0.proj).  LN(x) W^T = rstd (x (gamma o W)^T - mu s^T) + c^T with s[n] = sum_k (gamma o W)[n,k],
    * c[n] = sum_k beta[k] W[n,k]: the normalised tensor is never written or read.
-   *   PRODUCER (the GEMM that writes x): stats_out != NULL -> besides C, every (column tile, wave column) writes the partial
-   *     (sum, sum of squares) of ITS columns of each row of the bf16-rounded output: float2 stats_out[m * stats_ld + 2 * part],
-   *     part = column_tile * waves_n + wave_n  (da_gemm_stats_parts() = number of parts for *p; no atomics: deterministic).
+   *   PRODUCER (the GEMM that writes x): stats_out != NULL -> besides C, every column tile writes the partial (sum, sum of
+   *     squares) of ITS columns of each row of the bf16-rounded output: float2 stats_out[m * stats_ld + 2 * column_tile]
+   *     (da_gemm_stats_parts() = number of column tiles for *p; combined across a block's waves in LDS in fixed order, no
+   *     atomics: deterministic).
    *   CONSUMER (the GEMM that reads LN(x)): ln_stats != NULL -> each row's mean / rstd are formed from its ln_parts partials
    *     (fixed order) while the first K slices are in flight, and the epilogue applies the identity above to alpha * acc
    *     before bias / activation (both GEGLU halves included).  W must be the pre-scaled (gamma o W) in bf16. */
@@ -130,7 +131,8 @@ typedef struct da_gemm_params {
 /* number of stats partials per row the launch *p (tile resolved as da_gemm_bf16 resolves it) writes to stats_out */
 int da_gemm_stats_parts(const da_gemm_params* p);
 
-#define DA_LN_MAX_PARTS 64
+#define DA_LN_MAX_PARTS 64   /* slots per row of a statistics buffer */
+#define DA_LN_PAIR_LOADS 6   /* 16-byte loads per lane half in the consumer: rows with up to 24 partials (N <= 24 column tiles) */
 #define DA_SPLITK_FLAGS 4096
 #define DA_SPLITK_ERR_SLOT (DA_SPLITK_FLAGS - 1) /* set to 1 by a reducer whose producer never arrived (bounded spin) */
 
