@@ -29,6 +29,10 @@ _EXPORTS = {
     "StableDiffusionPipeline": "pipelines",
     "StableDiffusionXLPipeline": "pipelines",
     "from_reference_config": "config_utils",
+    "CLIPTextModel": "text_encoders",
+    "CLIPTextModelWithProjection": "text_encoders",
+    "T5EncoderModel": "text_encoders",
+    "UMT5EncoderModel": "text_encoders",
 }
 
 __all__ = sorted(_EXPORTS)

@@ -13,7 +13,7 @@ LIB_PATH = _PKG / "_C" / "libdiffusers_amd.so"
 # ---- constants mirrored from include/diffusers_amd.h ----
 DA_OK = 0
 ERRORS = {1: "DA_ERR_INVALID", 2: "DA_ERR_LAUNCH", 3: "DA_ERR_UNSUPPORTED"}
-ACT_NONE, ACT_GEGLU, ACT_GELU_TANH, ACT_SILU, ACT_GELU_ERF = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GEGLU, ACT_GELU_TANH, ACT_SILU, ACT_GELU_ERF, ACT_QUICK_GELU, ACT_GEGLU_TANH = 0, 1, 2, 3, 4, 5, 6
 TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64, TILE_256x128, TILE_128x256, TILE_256x256 = range(8)
 TILE_NAMES = ("auto", "128x128", "64x128", "128x64", "64x64", "256x128", "128x256", "256x256")
 STAGE_REGISTER, STAGE_LDS_DIRECT, STAGE_LDS_DIRECT3, STAGE_LDS_DIRECT4, STAGE_LDS_DIRECT6, STAGE_LDS_DIRECT8 = range(6)
@@ -53,6 +53,8 @@ class AttentionParams(C.Structure):
         ("vt_batch_stride", C.c_longlong), ("o_batch_stride", C.c_longlong),
         ("q_row_stride", C.c_int), ("k_row_stride", C.c_int), ("vt_ld", C.c_int), ("o_row_stride", C.c_int),
         ("scale", C.c_float), ("ring_slots", C.c_int),
+        ("bias", C.c_void_p), ("bias_batch_stride", C.c_longlong), ("bias_head_stride", C.c_longlong),
+        ("bias_row_stride", C.c_int), ("bias_f32", C.c_int), ("causal", C.c_int),
     ]
 
 
@@ -70,6 +72,7 @@ SIGNATURES = {
     "da_attention_bf16": (_i, [C.POINTER(AttentionParams), _vp]),
     "da_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "da_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "da_rmsnorm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "da_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "da_rmsnorm_rope_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_void_p), _f, _vp, _vp,
                                   _i, _i, _vp]),

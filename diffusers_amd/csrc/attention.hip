@@ -50,7 +50,9 @@ __device__ __forceinline__ int k_swz(int row) {
   return 0;
 }
 
-template <int D, int NS>
+// MASKED (D = 64 instantiations only): causal mask and / or an additive score bias -- the text encoders (CLIP: causal;
+// T5 / UMT5: relative position bias + key padding, scale 1).  The unmasked instantiations carry none of this code.
+template <int D, int NS, bool MASKED = false>
 __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
   using C = AttnCfg<D>;
   constexpr int PD = NS - 1;                 // prefetch distance (tiles in flight ahead of the one being consumed)
@@ -193,6 +195,40 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
           if (kv >= p.Skv) s[st][r] = -1e30f;
         }
     }
+    if constexpr (MASKED) {
+      const int qi = q0 + l31;                                   // this lane's query
+      if (p.bias) {
+        // s_eff = s + bias / scale, so that s_eff * scale = scale * q.k + bias; 4 consecutive keys per load
+        const float inv_scale = 1.0f / p.scale;
+        const size_t boff = (size_t)b * p.bias_batch_stride + (size_t)h * p.bias_head_stride +
+                            (size_t)min(qi, p.Sq - 1) * p.bias_row_stride;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int kvb = kv0 + 32 * st + 8 * rg + 4 * hi;
+            float bv[4];
+            if (p.bias_f32) {
+              const float4 t4 = *(const float4*)((const float*)p.bias + boff + kvb);
+              bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
+            } else {
+              const uint2 t2 = *(const uint2*)((const uint16_t*)p.bias + boff + kvb);
+              bv[0] = bf_lo(t2.x); bv[1] = bf_hi(t2.x); bv[2] = bf_lo(t2.y); bv[3] = bf_hi(t2.y);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              s[st][4 * rg + e] = (bv[e] <= -1e29f || s[st][4 * rg + e] <= -1e29f)   // masked by the bias / past Skv
+                                      ? -1e30f : __builtin_fmaf(bv[e], inv_scale, s[st][4 * rg + e]);
+          }
+      }
+      if (p.causal) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kv0 + 32 * st + (r & 3) + 8 * (r >> 2) + 4 * hi > qi) s[st][r] = -1e30f;
+      }
+    }
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -206,7 +242,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sl2, -m_new));
+        float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sl2, -m_new));
+        if constexpr (MASKED) e = (s[st][r] <= -1e29f) ? 0.f : e;   // a fully masked tile must contribute nothing
         s[st][r] = e;
         psum += e;
       }
@@ -266,11 +303,11 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
   }
 }
 
-template <int D, int NS>
+template <int D, int NS, bool MASKED = false>
 int launch_attn(const da_attention_params& p, hipStream_t s) {
   using C = AttnCfg<D>;
   const size_t lds = (size_t)NS * C::STAGE;
-  auto kern = attn_fwd_kernel<D, NS>;
+  auto kern = attn_fwd_kernel<D, NS, MASKED>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -294,6 +331,10 @@ template <int D>
 int launch_attn_ring(const da_attention_params& p, hipStream_t s) {
   using C = AttnCfg<D>;
   constexpr int def_ns = (D <= 64 || 3 * C::STAGE > 160 * 1024) ? 2 : 3;
+  if (p.bias || p.causal) {
+    if constexpr (D == 64) return launch_attn<64, 2, true>(p, s);
+    else return DA_ERR_UNSUPPORTED;
+  }
   int ns = p.ring_slots ? p.ring_slots : def_ns;
   if (p.Skv <= 64) ns = 2;   // a single tile: nothing to pipeline
   switch (ns) {
@@ -313,6 +354,9 @@ extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
   if (p.B <= 0 || p.H <= 0 || p.Sq <= 0 || p.Skv <= 0) return DA_ERR_INVALID;
   if (p.Skv_alloc < p.Skv || (p.Skv_alloc & 7)) return DA_ERR_INVALID;
   if (p.ring_slots != 0 && (p.ring_slots < 2 || p.ring_slots > 4)) return DA_ERR_INVALID;
+  if (p.bias && (p.bias_row_stride < ((p.Skv + 63) & ~63) || (p.bias_row_stride & 3) || (p.bias_batch_stride & 3) ||
+                 (p.bias_head_stride & 3) || p.scale == 0.0f))
+    return DA_ERR_INVALID;
   if ((p.q_row_stride & 7) || (p.k_row_stride & 7) || (p.vt_ld & 7) || (p.vt_batch_stride & 7) || (p.o_row_stride & 3))
     return DA_ERR_UNSUPPORTED;
   if ((p.q_batch_stride & 7) || (p.k_batch_stride & 7) || (p.o_batch_stride & 3)) return DA_ERR_UNSUPPORTED;

@@ -39,7 +39,7 @@ int pick_tile(const da_gemm_params& p) {
   auto nblk = [&](int t) {
     return (long)((p.M + kTiles[t].bm - 1) / kTiles[t].bm) * ((p.N + kTiles[t].bn - 1) / kTiles[t].bn);
   };
-  const bool geglu = (p.act == DA_ACT_GEGLU);
+  const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
   const bool narrow = !geglu && ((p.N & 127) != 0) && ((p.N % 128) <= 64);
   if (narrow) return (nblk(DA_TILE_128x64) >= 200) ? DA_TILE_128x64 : DA_TILE_64x64;
   if (nblk(DA_TILE_256x128) >= 480) return DA_TILE_256x128;
@@ -69,10 +69,12 @@ int validate(da_gemm_params& p) {
   } else {
     if ((p.lda & 7) || (p.ldw & 7)) return DA_ERR_UNSUPPORTED;
   }
-  if (p.act == DA_ACT_GEGLU && ((p.N & 127) || p.out_f32 || p.residual || p.rowvec || p.gate || p.bias_rows))
+  if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) &&
+      ((p.N & 127) || p.out_f32 || p.residual || p.rowvec || p.gate || p.bias_rows))
     return DA_ERR_UNSUPPORTED;
+  if (p.act < 0 || p.act > DA_ACT_GEGLU_TANH) return DA_ERR_INVALID;
   if (p.split_k < 0 || p.split_k > 8) return DA_ERR_INVALID;
-  if (p.stats_out && (p.conv || p.out_f32 || p.act == DA_ACT_GEGLU || p.stats_ld <= 0 || (p.stats_ld & 1)))
+  if (p.stats_out && (p.conv || p.out_f32 || p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH || p.stats_ld <= 0 || (p.stats_ld & 1)))
     return DA_ERR_UNSUPPORTED;
   if (p.ln_stats && (p.conv || !p.ln_s || !p.ln_c || p.ln_parts <= 0 || p.ln_parts > 4 * DA_LN_PAIR_LOADS ||
                      p.ln_stats_ld < 2 * DA_LN_MAX_PARTS || (p.ln_stats_ld & 3)))
@@ -87,7 +89,7 @@ int stats_parts(const da_gemm_params& p, int tile) {   // one partial per column
 bool tile_ok(const da_gemm_params& p, int tile) {
   if (tile <= 0 || tile >= kNumTiles) return false;
   // GEGLU pairs (value, gate) 32-column tiles inside one wave: the wave must own an even number of them
-  if (p.act == DA_ACT_GEGLU && (tile == DA_TILE_128x64 || tile == DA_TILE_64x64)) return false;
+  if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) && (tile == DA_TILE_128x64 || tile == DA_TILE_64x64)) return false;
   return true;
 }
 

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
   const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
   const uint16_t* __restrict__ gate = (const uint16_t*)p.gate;
-  const bool geglu = (p.act == DA_ACT_GEGLU);
+  const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
   float st_sum[MT], st_sq[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) st_sum[i] = 0.f, st_sq[i] = 0.f;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
               // reference rounds the projection to bf16 before chunk/gelu/mul (activations.py:113-124)
               hv = bf2f(f2bf(hv));
               gv = bf2f(f2bf(gv));
-              o[e] = hv * bf2f(f2bf(gelu_erf_f(gv)));
+              o[e] = hv * bf2f(f2bf(p.act == DA_ACT_GEGLU ? gelu_erf_f(gv) : gelu_tanh_f(gv)));
             }
             uint2 pk;
             pk.x = pack_bf2(o[0], o[1]);
@@ -658,6 +658,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         } else if (p.act == DA_ACT_GELU_ERF) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(bf2f(f2bf(o[e])));
+        } else if (p.act == DA_ACT_QUICK_GELU) {
+          // x * sigmoid(1.702 * x), each torch op rounded to bf16 as the reference's elementwise chain rounds it
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xv = bf2f(f2bf(o[e]));
+            const float tv = bf2f(f2bf(1.702f * xv));
+            o[e] = xv * bf2f(f2bf(1.0f / (1.0f + __expf(-tv))));
+          }
         }
         if (gate && p.gate_f32) {
           // WanTransformerBlock: hidden.float() + Linear(x) (bf16) * gate (fp32), rounded once at the store

@@ -499,6 +499,61 @@ extern "C" int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
   return DA_OK;
 }
 
+// T5LayerNorm: one wave per row, the row in registers (as layernorm_kernel); no mean, no bias, two bf16 roundings.
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma,
+                                                           uint16_t* __restrict__ y, int M, int C, int ldx, int ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunks = C >> 3;
+  float v[NCH][8];
+  const uint16_t* xr = x + (size_t)row * ldx;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunks) {
+      unpack8(*(const uint4*)(xr + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sq += v[i][e] * v[i][e];
+    }
+  }
+  sq = wave_sum(sq);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+  uint16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunks) {
+      float g[8], o[8];
+      unpack8(*(const uint4*)(gamma + ch * 8), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(v[i][e] * rstd));
+      *(uint4*)(yr + ch * 8) = pack8(o);
+    }
+  }
+}
+
+extern "C" int da_rmsnorm_bf16(const void* x, const void* gamma, void* y, int M, int C, int ldx, int ldy, float eps,
+                               void* stream) {
+  if (!x || !gamma || !y) return DA_ERR_INVALID;
+  if (M <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7)) return DA_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = (C / 8 + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+#define DA_RMS(N) \
+  DA_LAUNCH(rmsnorm_rows_kernel<N>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, M, C, ldx, ldy, eps)
+  if (nch <= 1) DA_RMS(1);
+  else if (nch <= 2) DA_RMS(2);
+  else if (nch <= 4) DA_RMS(4);
+  else if (nch <= 8) DA_RMS(8);
+  else return DA_ERR_UNSUPPORTED;
+#undef DA_RMS
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
 extern "C" int da_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, const void* mod_scale,
                                  const void* mod_shift, int mod_ld, int mod_f32, int rows_per_batch, int M, int C,
                                  int ldx, int ldy, float eps, void* stream) {

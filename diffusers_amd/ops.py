@@ -343,8 +343,11 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: int, D: int, Sq: int, Skv: int,
               Skv_alloc: int, q_row_stride: int, k_row_stride: int, q_batch_stride: int, k_batch_stride: int,
               vt_ld: int, vt_batch_stride: int, scale: Optional[float] = None,
-              out: Optional[torch.Tensor] = None, ring_slots: int = 0) -> torch.Tensor:
-    """Flash attention over strided views; returns out [B*Sq][H*D]."""
+              out: Optional[torch.Tensor] = None, ring_slots: int = 0, causal: bool = False,
+              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Flash attention over strided views; returns out [B*Sq][H*D].  ``causal`` / ``bias`` (D = 64 only): the masked
+    variant for the text encoders -- ``bias`` is [B or 1][H or 1][Sq][>= ceil64(Skv)] (bf16 or fp32), added to
+    scale * q.k^T; entries <= -1e29 mask a key."""
     _req(q, "q"), _req(k, "k"), _req(vt, "vt")
     if out is None:
         out = torch.empty((B * Sq, H * D), device=q.device, dtype=bf16)
@@ -357,6 +360,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: 
     p.q_row_stride, p.k_row_stride, p.vt_ld, p.o_row_stride = q_row_stride, k_row_stride, vt_ld, o_row_stride
     p.scale = (D ** -0.5) if scale is None else scale
     p.ring_slots = ring_slots
+    p.causal = int(causal)
+    if bias is not None:
+        _req(bias, "bias", None)
+        if bias.dtype not in (bf16, torch.float32) or bias.dim() != 4 or bias.stride(3) != 1 or bias.shape[2] < Sq:
+            raise ValueError("attention: bias must be a bf16 / fp32 [B|1][H|1][Sq][>= ceil64(Skv)] tensor, last dim contiguous")
+        if bias.shape[0] not in (1, B) or bias.shape[1] not in (1, H):
+            raise ValueError("attention: bias batch / head dims must be 1 or match")
+        p.bias, p.bias_f32 = bias.data_ptr(), int(bias.dtype == torch.float32)
+        p.bias_batch_stride = bias.stride(0) if bias.shape[0] > 1 else 0
+        p.bias_head_stride = bias.stride(1) if bias.shape[1] > 1 else 0
+        p.bias_row_stride = bias.stride(2)
     L.check(L.load().da_attention_bf16(C.byref(p), _stream()), "da_attention_bf16")
     return out
 
@@ -400,6 +414,16 @@ def group_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gr
     L.check(lib.da_groupnorm_nhwc_bf16(x.data_ptr(), _ptr(x2), C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                        ws.data_ptr(), B, HW, Ctot, groups, eps, L.ACT_SILU if silu else L.ACT_NONE,
                                        _stream()), "da_groupnorm_nhwc_bf16")
+    return y
+
+
+def rms_norm(x: torch.Tensor, gamma: torch.Tensor, eps: float) -> torch.Tensor:
+    """T5LayerNorm over the last dim of a token matrix [M][C] (da_rmsnorm_bf16)."""
+    _req(x, "x"), _req(gamma, "gamma")
+    M, Cc = x.shape
+    y = torch.empty((M, Cc), device=x.device, dtype=bf16)
+    L.check(L.load().da_rmsnorm_bf16(x.data_ptr(), gamma.data_ptr(), y.data_ptr(), M, Cc, _rows2d(x, "x"), Cc, eps, _stream()),
+            "da_rmsnorm_bf16")
     return y
 
 

@@ -33,6 +33,9 @@ extern "C" {
 #define DA_ACT_GELU_TANH 2 /* activations.py:60-90 (approximate="tanh"), Flux / Wan feed-forward */
 #define DA_ACT_SILU 3
 #define DA_ACT_GELU_ERF 4
+#define DA_ACT_QUICK_GELU 5  /* x * sigmoid(1.702 x): transformers ACT2FN["quick_gelu"], the CLIP-L text encoder's MLP */
+#define DA_ACT_GEGLU_TANH 6  /* DA_ACT_GEGLU with the tanh GELU on the gate rows: T5 / UMT5 "gated-gelu" feed-forward
+                                (gelu_new(wi_0 x) * (wi_1 x), modeling_t5.py T5DenseGatedActDense); rows packed [32 wi_1 | 32 wi_0] */
 
 #define DA_TILE_AUTO 0
 #define DA_TILE_128x128 1
@@ -181,6 +184,14 @@ typedef struct da_attention_params {
   float scale;
   int ring_slots; /* K / V^T LDS ring depth: 0 = default for the head size (deepest that fits), 2..4 = pinned (speed only:
                      every depth computes the same tiles in the same order -> bit-identical outputs) */
+  /* ---- masked variant (D = 64 only; the text encoders either side of the hot path) ----
+   * causal != 0: key j is visible to query i iff j <= i (CLIP text transformer, modeling_clip.py create_causal_mask).
+   * bias != NULL: scores = scale * q.k^T + bias[b][h][i][j] before the softmax: T5 / UMT5 relative position bias with
+   *   scale = 1 (modeling_t5.py T5Attention: no 1/sqrt(d)), optionally with a key-padding mask folded in (entries <= -1e29
+   *   are treated as -inf).  Element type bf16 (bias_f32 == 0) or fp32; rows of bias_row_stride >= ceil64(Skv) elements. */
+  const void* bias;
+  long long bias_batch_stride, bias_head_stride; /* elements; 0 = shared across batches / heads */
+  int bias_row_stride, bias_f32, causal;
 } da_attention_params;
 
 int da_attention_bf16(const da_attention_params* p, void* stream);
@@ -211,6 +222,9 @@ int da_attention_bf16(const da_attention_params* p, void* stream);
 size_t da_groupnorm_workspace_bytes(int B, int HW, int C, int G);
 int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const void* gamma, const void* beta, void* y,
                            void* workspace, int B, int HW, int C, int G, float eps, int act, void* stream);
+/* T5LayerNorm (modeling_t5.py: no mean subtraction, no bias): y = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * gamma), the two
+ * roundings of the reference's fp32 -> weight-dtype cast followed by the bf16 multiply. */
+int da_rmsnorm_bf16(const void* x, const void* gamma, void* y, int M, int C, int ldx, int ldy, float eps, void* stream);
 int da_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, const void* mod_scale,
                       const void* mod_shift, int mod_ld, int mod_f32, int rows_per_batch, int M, int C, int ldx, int ldy,
                       float eps, void* stream);

@@ -18,7 +18,7 @@ def _store(val, out, dtype=bf16):
     return out
 
 
-ACT_NONE, ACT_GEGLU, ACT_GELU_TANH, ACT_SILU, ACT_GELU_ERF = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GEGLU, ACT_GELU_TANH, ACT_SILU, ACT_GELU_ERF, ACT_QUICK_GELU, ACT_GEGLU_TANH = 0, 1, 2, 3, 4, 5, 6
 
 
 def _act(y, act):
@@ -31,6 +31,8 @@ def _act(y, act):
         return F.gelu(y, approximate="tanh")
     if act == ACT_GELU_ERF:
         return F.gelu(y)
+    if act == ACT_QUICK_GELU:
+        return y * torch.sigmoid((1.702 * y).to(bf16).float()).to(bf16).float()
     raise AssertionError(f"activation {act}")
 
 
@@ -83,10 +85,11 @@ def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch
         bidx = torch.arange(M) // rows_per_batch
     if rowvec is not None:
         y = y + rowvec.float()[bidx]
-    if act == ACT_GEGLU:                          # packed rows: per 64 = [32 value | 32 gate] (ops.pack_geglu)
+    if act in (ACT_GEGLU, ACT_GEGLU_TANH):        # packed rows: per 64 = [32 value | 32 gate] (ops.pack_geglu)
         assert w.shape[0] % 128 == 0 and residual is None and gate is None and rowvec is None and not out_f32
         g = y.to(bf16).float().view(M, -1, 2, 32)
-        y = (g[:, :, 0] * F.gelu(g[:, :, 1]).to(bf16).float()).reshape(M, -1)
+        gl = F.gelu(g[:, :, 1]) if act == ACT_GEGLU else F.gelu(g[:, :, 1], approximate="tanh")
+        y = (g[:, :, 0] * gl.to(bf16).float()).reshape(M, -1)
     else:
         y = _act(y, act)
     if gate is not None:
@@ -130,16 +133,32 @@ def linear_small_m(x, w, bias=None, *, act_in=0, act_out=0, residual=None, out=N
 
 
 def attention(q, k, vt, *, B, H, D, Sq, Skv, Skv_alloc, q_row_stride, k_row_stride, q_batch_stride, k_batch_stride,
-              vt_ld, vt_batch_stride, scale=None, out=None):
+              vt_ld, vt_batch_stride, scale=None, out=None, ring_slots=0, causal=False, bias=None):
     assert D in (64, 96, 128, 160) and Skv_alloc % 8 == 0 and Skv_alloc >= Skv
     for s_ in (q_row_stride, k_row_stride, q_batch_stride, k_batch_stride, vt_ld, vt_batch_stride):
         assert s_ % 8 == 0, "C ABI: attention strides % 8"
     qq = q.as_strided((B, H, Sq, D), (q_batch_stride, D, q_row_stride, 1)).float()
     kk = k.as_strided((B, H, Skv, D), (k_batch_stride, D, k_row_stride, 1)).float()
     vv = vt.as_strided((B, H, D, Skv), (vt_batch_stride, D * vt_ld, vt_ld, 1)).float()
-    p = torch.softmax(qq @ kk.transpose(2, 3) * (D ** -0.5 if scale is None else scale), dim=-1)
+    sc = qq @ kk.transpose(2, 3) * (D ** -0.5 if scale is None else scale)
+    if bias is not None or causal:
+        assert D == 64, "C ABI: the masked attention variant exists for D = 64"
+    if bias is not None:
+        assert bias.dim() == 4 and bias.stride(3) == 1 and bias.shape[3] >= ((Skv + 63) // 64) * 64 and bias.stride(2) % 4 == 0
+        bb = bias[:, :, :Sq, :Skv].float()
+        sc = torch.where(bb <= -1e29, torch.full_like(sc, float("-inf")), sc + bb)
+    if causal:
+        keep = torch.arange(Skv)[None, :] <= torch.arange(Sq)[:, None]
+        sc = sc.masked_fill(~keep, float("-inf"))
+    p = torch.softmax(sc, dim=-1)
     o = (p @ vv.transpose(2, 3)).permute(0, 2, 1, 3).reshape(B * Sq, H * D)
     return _store(o, out)
+
+
+def rms_norm(x, gamma, eps):
+    """da_rmsnorm_bf16: T5LayerNorm with its two roundings."""
+    xf = x.float()
+    return (gamma.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(bf16).float()).to(bf16)
 
 
 def group_norm_nhwc(x, gamma, beta, groups, eps, silu=False, x2=None):
@@ -401,7 +420,7 @@ def cast_f32_bf16(x, rep=1):
 
 def install(monkeypatch, ops_module):
     """Replace the kernels behind ``ops_module`` with the stand-ins above (pack_* helpers are pure torch and stay)."""
-    for name in ("conv2d_nhwc", "linear", "linear_pair", "linear_small_m", "attention", "softmax_rows", "group_norm_nhwc", "layer_norm",
+    for name in ("conv2d_nhwc", "linear", "linear_pair", "linear_small_m", "rms_norm", "attention", "softmax_rows", "group_norm_nhwc", "layer_norm",
                  "rmsnorm_rope_", "rmsnorm_channels", "timestep_embedding", "permute_0213", "frames_to_ncthw",
                  "conv_thin_in", "conv_thin_out", "bcast_add_f32", "patchify3d", "unpatchify3d", "transpose",
                  "mul_scalar", "cast_f32_bf16", "require_hip", "euler_scale_model_input", "euler_step", "x0_linear_step",

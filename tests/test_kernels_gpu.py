@@ -1153,3 +1153,71 @@ def test_torch_library_ops_run_the_kernels_and_trace():
     want = block(x, w, b)
     got = torch.compile(block, backend="aot_eager", fullgraph=True)(x, w, b)
     assert torch.equal(got, want)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# kernels behind the text encoders (diffusers_amd/text_encoders.py)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,S,causal,with_bias,mask", [(2, 2, 77, True, False, False), (1, 12, 77, True, False, False),
+                                                         (2, 4, 512, False, True, False), (2, 3, 200, False, True, True),
+                                                         (1, 2, 130, True, True, False)])
+def test_masked_flash_attention(B, H, S, causal, with_bias, mask):
+    """The MASKED variant (D = 64): causal (CLIP), additive bias with scale 1 (T5 relative position bias), key padding
+    folded into the bias (UMT5 / Wan), and both at once -- vs fp32 softmax(scale q k^T + bias + mask) v."""
+    ops, L = _ops()
+    D, inner = 64, H * 64
+    g = torch.Generator("cpu").manual_seed(S + H)
+    q, k, v = ((torch.randn((B, S, inner), generator=g) * 0.7).to(bf16) for _ in range(3))
+    sa = ((S + 15) // 16) * 16
+    pad = lambda t: torch.cat([t, torch.zeros((B, sa - S, inner), dtype=bf16)], 1).reshape(B * sa, inner).to(DEV)  # noqa: E731
+    qp, kp, vp = pad(q), pad(k), pad(v)
+    vt = vp.view(B, sa, inner).permute(2, 0, 1).reshape(inner, B * sa).contiguous()
+    scale = 1.0 if with_bias else D ** -0.5
+    bias = None
+    sc = torch.einsum("bqhd,bkhd->bhqk", q.float().view(B, S, H, D), k.float().view(B, S, H, D)) * scale
+    if with_bias:
+        ld = ((S + 63) // 64) * 64
+        bz = torch.zeros((B if mask else 1, H, S, ld))
+        bz[..., :S] = torch.randn((1, H, S, S), generator=g) * 0.5
+        if mask:
+            keep = torch.ones((B, S), dtype=torch.bool)
+            keep[0, S // 2:] = False
+            keep[1, S - 7:] = False
+            bz[..., :S].masked_fill_(~keep[:, None, None, :], -1e30)
+        bias = (bz.to(bf16) if S == 512 else bz).to(DEV)          # both element types of the C ABI
+        bb = bias.float().cpu()[..., :S]
+        sc = torch.where(bb <= -1e29, torch.full_like(sc, float("-inf")), sc + bb)
+    if causal:
+        sc = sc.masked_fill(torch.arange(S)[None, :] > torch.arange(S)[:, None], float("-inf"))
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), v.float().view(B, S, H, D)).reshape(B, S, inner)
+    for b in range(B):        # padded batches: one launch per batch, as text_encoders._SelfAttention does
+        o = torch.zeros((S, inner), device=DEV, dtype=bf16)
+        ops.attention(qp[b * sa:], kp[b * sa:], vt[:, b * sa:], B=1, H=H, D=D, Sq=S, Skv=S, Skv_alloc=sa, q_row_stride=inner,
+                      k_row_stride=inner, q_batch_stride=sa * inner, k_batch_stride=sa * inner, vt_ld=B * sa, vt_batch_stride=sa,
+                      scale=scale, causal=causal, bias=None if bias is None else (bias[b:b + 1] if bias.shape[0] > 1 else bias),
+                      out=o)
+        assert_close_bf16(o, ref[b], f"masked attention B{B} H{H} S{S} causal={causal} bias={with_bias} mask={mask} [batch {b}]",
+                          rel_rms_max=6e-3)
+
+
+def test_text_encoder_epilogues_and_rmsnorm():
+    """DA_ACT_QUICK_GELU (CLIP-L MLP), DA_ACT_GEGLU_TANH (T5 gated-GELU feed-forward) and da_rmsnorm_bf16 (T5LayerNorm) vs the
+    torch ops of the transformers modules they replace."""
+    ops, L = _ops()
+    M, K, N = 154, 768, 3072
+    x, w, b = rnd((M, K), 71), rnd((N, K), 72, K ** -0.5), rnd((N,), 73)
+    y = ops.linear(x, w, b, act=L.ACT_QUICK_GELU)
+    pre = (x.float() @ w.float().t() + b.float()).to(bf16).float()
+    assert_close_bf16(y, pre * torch.sigmoid(1.702 * pre), "fc1 + quick_gelu")
+    wi0, wi1 = rnd((1024, K), 74, K ** -0.5), rnd((1024, K), 75, K ** -0.5)
+    wp, _ = ops.pack_geglu(torch.cat([wi1, wi0], 0), None)
+    for tile in (L.TILE_128x128, L.TILE_64x128, L.TILE_256x128):
+        yg = ops.linear(x, wp, act=L.ACT_GEGLU_TANH, tile=tile, staging=1)
+        want = F.gelu(x.float() @ wi0.float().t(), approximate="tanh") * (x.float() @ wi1.float().t())
+        assert_close_bf16(yg, want, f"gated tanh-GELU, tile {tile}", rtol=2.5e-2, atol_rms=2.5e-2)
+    for C in (768, 4096, 128):
+        xr, gm = rnd((77, C), 76, 3.0), rnd((C,), 77) * 0.2 + 1.0
+        got = ops.rms_norm(xr, gm, 1e-6)
+        xf = xr.float()
+        want = gm.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(bf16).float()
+        assert torch.equal(got, want.to(bf16)) or float((got.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())

@@ -83,6 +83,10 @@ if [[ $WHAT == *lnfold* ]]; then
   timeout 300 python tools/bench_lnfold.py > $O/lnfold.log 2>&1; echo "lnfold rc=$?"; grep -E '^\{' $O/lnfold.log | cut -c1-220; grep -vE '^\{' $O/lnfold.log | tail -5
   timeout 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q -s --timeout 200 -k "layernorm_fold or conv_split_k" > $O/pytest_ln.log 2>&1; echo "pytest ln rc=$?"; grep -E "passed|failed|FAILED|Error" $O/pytest_ln.log | tail -5
 fi
+if [[ $WHAT == *textenc* ]]; then
+  timeout 600 python -m pytest tests/test_text_encoders.py tests/test_kernels_gpu.py -m gpu -q -s --timeout 300 -k "text_encoder or masked_flash or clip or t5 or layernorm_fold" > $O/pytest_textenc.log 2>&1; echo "pytest textenc rc=$?" | tee -a $O/pytest_textenc.log
+  grep -E "passed|failed|FAILED|Error|\[parity\] (CLIP|T5|UMT5|masked)" $O/pytest_textenc.log | tail -30
+fi
 if [[ $WHAT == *newtests* ]]; then
   timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -s --timeout 300 -k "pair_launch or split_k or sampler_round2 or flowmatch_fp32 or flash_attention or attention or torch_library" > $O/pytest_new.log 2>&1; echo "pytest new rc=$?" | tee -a $O/pytest_new.log
   grep -E "passed|failed|FAILED|Error|split-K" $O/pytest_new.log | tail -30
