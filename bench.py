@@ -253,14 +253,19 @@ def reference_pipeline_on_device(unet_sd, vae_sd, ucfg, vcfg, inp, steps, dtype,
             x = sch.step(u + GUIDANCE * (c - u), x)
         return x
 
-    t_start = time.perf_counter()
     with torch.no_grad():
-        x = loop(2)                                              # warm-up: library handles, MIOpen / hipBLASLt solutions
+        # warm-up: library handles, MIOpen / hipBLASLt solution search -- a ONE-TIME cost that has been seen to take from 2 s
+        # to 100 s on otherwise identical boxes, so it is not what the budget is judged on ...
+        x = loop(2)
         R.vae_decode(vsd, vcfg, x / vcfg["scaling_factor"])
         torch.cuda.synchronize()
-        warm_s = time.perf_counter() - t_start
-        if warm_s * steps / 2 > budget_s:
-            raise TimeoutError(f"2 warm steps + decode took {warm_s:.1f} s: the {steps}-step run would exceed {budget_s:.0f} s")
+        # ... the steady state is: two more steps, timed
+        t1 = time.perf_counter()
+        loop(2)
+        torch.cuda.synchronize()
+        per_step = (time.perf_counter() - t1) / 2
+        if per_step * steps > budget_s:
+            raise TimeoutError(f"{per_step:.2f} s per warm denoising step: the {steps}-step run would exceed {budget_s:.0f} s")
         t0 = time.perf_counter()
         x = loop(steps)
         img = R.vae_decode(vsd, vcfg, x / vcfg["scaling_factor"])

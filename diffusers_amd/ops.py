@@ -6,6 +6,7 @@ gfx950 kernel in ``csrc/``.  Nothing in this module has a CPU or PyTorch fallbac
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -44,7 +45,10 @@ def splitk_error(device=None) -> bool:
                if device is None or d == torch.device(device).index)
 
 
-LN_FOLD = True   # BasicTransformerBlock folds norm2 / norm3 into the GEMMs either side of them (see linear(ln=...))
+# BasicTransformerBlock can fold norm2 / norm3 into the GEMMs either side of them (linear(stats_out=) / linear(ln=)).  OFF by
+# default: measured on an MI355X (profiles/r02d_layernorm_fold.md) the folded consumers cost +4.5 us (to_q) and +15 us (GEGLU
+# projection) against the 8.6 us LayerNorm launch + ~1.5 us boundary they remove -- a wash for norm2, a loss for norm3.
+LN_FOLD = os.environ.get("DIFFUSERS_AMD_LN_FOLD", "0") == "1"
 STATS_MAX_PARTS = 64          # DA_LN_MAX_PARTS: slots per row of a statistics buffer
 STATS_MAX_CONSUMED = 24       # 4 * DA_LN_PAIR_LOADS: partials per row a consumer launch reads
 
@@ -187,7 +191,7 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     N, Kw = w.shape
     if K != Kw:
         raise ValueError(f"linear: K mismatch {K} vs {Kw}")
-    n_out = N // 2 if act == L.ACT_GEGLU else N
+    n_out = N // 2 if act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH) else N
     if M <= 8 and act in (L.ACT_NONE, L.ACT_SILU, L.ACT_GELU_TANH) and rowvec is None and not out_f32 \
             and alpha == 1.0 and out_scale == 1.0 and bias_rows is None and gate is None and stats_out is None and ln is None:
         return None, linear_small_m(x, w, bias, act_out=act, residual=residual, out=out)
@@ -222,7 +226,7 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         p.ln_s, p.ln_c, p.ln_eps = fold.s.data_ptr(), fold.c.data_ptr(), fold.eps
     _select_variant(p, tile, staging, st, inplace=inplace, split_k=split_k, device=x.device)
     if stats_out is not None:
-        if act == L.ACT_GEGLU or out_f32 or stats_out.buf.shape[0] != M:
+        if act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH) or out_f32 or stats_out.buf.shape[0] != M:
             raise ValueError("linear(stats_out=): bf16 non-GEGLU outputs only, one statistics row per output row")
         p.stats_out, p.stats_ld = stats_out.buf.data_ptr(), stats_out.buf.shape[1] * 2
         stats_out.parts = int(L.load().da_gemm_stats_parts(C.byref(p)))

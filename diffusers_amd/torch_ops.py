@@ -37,7 +37,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: in
 
 @gemm.register_fake
 def _(x, w, bias, act):
-    n = w.shape[0] // 2 if act == 1 else w.shape[0]
+    n = w.shape[0] // 2 if act in (1, 6) else w.shape[0]   # DA_ACT_GEGLU / DA_ACT_GEGLU_TANH
     return x.new_empty((x.shape[0], n))
 
 

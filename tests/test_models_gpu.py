@@ -19,9 +19,11 @@ def t(g, k, dtype=bf16):
     return torch.from_numpy(g[k]).to(dtype).to(DEV)
 
 
+@pytest.mark.parametrize("fold", [False, True])
 @pytest.mark.parametrize("name,added", [("tiny_unet_sdxl", True), ("tiny_unet_sd15", False)])
-def test_tiny_unet_vs_reference(golden, name, added):
-    from diffusers_amd import factory, init as dinit
+def test_tiny_unet_vs_reference(golden, name, added, fold, monkeypatch):
+    from diffusers_amd import factory, init as dinit, ops
+    monkeypatch.setattr(ops, "LN_FOLD", fold)     # the opt-in LayerNorm fold must hold the same parity bound
     cfg = dinit.TINY_SDXL_UNET if added else dinit.TINY_SD15_UNET
     g = golden(name)
     unet, _ = factory.build_unet(cfg, seed=0, device=DEV)
