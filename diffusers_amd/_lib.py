@@ -14,8 +14,9 @@ LIB_PATH = _PKG / "_C" / "libdiffusers_amd.so"
 DA_OK = 0
 ERRORS = {1: "DA_ERR_INVALID", 2: "DA_ERR_LAUNCH", 3: "DA_ERR_UNSUPPORTED"}
 ACT_NONE, ACT_GEGLU, ACT_GELU_TANH, ACT_SILU, ACT_GELU_ERF, ACT_QUICK_GELU, ACT_GEGLU_TANH = 0, 1, 2, 3, 4, 5, 6
-TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64, TILE_256x128, TILE_128x256, TILE_256x256 = range(8)
-TILE_NAMES = ("auto", "128x128", "64x128", "128x64", "64x64", "256x128", "128x256", "256x256")
+(TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64, TILE_256x128, TILE_128x256, TILE_256x256,
+ TILE_128x128_W8) = range(9)
+TILE_NAMES = ("auto", "128x128", "64x128", "128x64", "64x64", "256x128", "128x256", "256x256", "128x128w8")
 STAGE_REGISTER, STAGE_LDS_DIRECT, STAGE_LDS_DIRECT3, STAGE_LDS_DIRECT4, STAGE_LDS_DIRECT6, STAGE_LDS_DIRECT8 = range(6)
 RING_SLOTS = (2, 2, 3, 4, 6, 8)  # LDS ring depth per staging code
 DTYPE_BF16, DTYPE_F32 = 0, 1
@@ -54,7 +55,7 @@ class AttentionParams(C.Structure):
         ("q_row_stride", C.c_int), ("k_row_stride", C.c_int), ("vt_ld", C.c_int), ("o_row_stride", C.c_int),
         ("scale", C.c_float), ("ring_slots", C.c_int),
         ("bias", C.c_void_p), ("bias_batch_stride", C.c_longlong), ("bias_head_stride", C.c_longlong),
-        ("bias_row_stride", C.c_int), ("bias_f32", C.c_int), ("causal", C.c_int),
+        ("bias_row_stride", C.c_int), ("bias_f32", C.c_int), ("causal", C.c_int), ("q_block", C.c_int),
     ]
 
 

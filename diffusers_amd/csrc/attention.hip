@@ -28,14 +28,14 @@ namespace {
 
 __device__ uint4 g_zero_chunk[1];  // 16 B of zeros: the source of every K / V^T chunk past the end of the sequence
 
-template <int D>
+template <int D, int NW = 4>
 struct AttnCfg {
   static constexpr int CPR = D / 8;              // 16-byte chunks per K row
   static constexpr int KBYTES = 64 * D * 2;      // K tile  [64][D]
   static constexpr int VBYTES = D * 128;         // V^T tile [D][64]
   static constexpr int STAGE = KBYTES + VBYTES;
-  static constexpr int KCH = (64 * CPR) / 256;   // K chunks staged per thread
-  static constexpr int VCH = (D * 8) / 256;      // V^T chunks staged per thread
+  static constexpr int KCH = (64 * CPR) / (64 * NW);   // K chunks staged per thread (NW waves share the tile)
+  static constexpr int VCH = (D * 8) / (64 * NW);      // V^T chunks staged per thread
 };
 
 // 16-byte-slot XOR applied to a K row so the 16 rows of a ds_read_b128 lane group spread over the LDS bank row.  The XOR
@@ -52,9 +52,13 @@ __device__ __forceinline__ int k_swz(int row) {
 
 // MASKED (D = 64 instantiations only): causal mask and / or an additive score bias -- the text encoders (CLIP: causal;
 // T5 / UMT5: relative position bias + key padding, scale 1).  The unmasked instantiations carry none of this code.
-template <int D, int NS, bool MASKED = false>
-__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
-  using C = AttnCfg<D>;
+// NW = waves per block = 32-query groups per block (4: 128 queries; 2: 64 queries -- for problems with fewer than two
+// 128-query blocks per CU, e.g. SDXL's 1024-token level: 320 blocks of 128 leave 192 CUs with one block and 64 with two,
+// 640 blocks of 64 spread the same work at finer grain).
+template <int D, int NS, bool MASKED = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
+  using C = AttnCfg<D, NW>;
+  constexpr int QT = 32 * NW;                // queries per block
   constexpr int PD = NS - 1;                 // prefetch distance (tiles in flight ahead of the one being consumed)
   constexpr int LOADS = C::KCH + C::VCH;     // LDS-DMA instructions per wave per tile
   static_assert(NS >= 2 && NS <= 4 && (PD - 1) * LOADS <= 63, "vmcnt is a 6-bit counter");
@@ -65,12 +69,12 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
   // XCD-aware mapping (speed only): block id -> (XCD = id % 8, slot = id / 8).  All query tiles of one (batch, head)
   // pair go to ONE XCD, so its K / V^T (1 MB at S = 4096, D = 64; a 17 MB stream for Wan) is pulled into a single L2
   // and shared by the blocks that walk it side by side, instead of being fetched by all eight XCDs.
-  const int qtiles = (p.Sq + 127) >> 7;
+  const int qtiles = (p.Sq + QT - 1) / QT;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int pair = (slot / qtiles) * 8 + xcd;            // (batch, head) pairs are dealt round-robin to the XCDs
   if (pair >= p.B * p.H) return;                          // ragged last round: leaves before any barrier
   const int b = pair / p.H, h = pair - b * p.H;
-  const int q0 = (slot % qtiles) * 128 + wave * 32;
+  const int q0 = (slot % qtiles) * QT + wave * 32;
 
   const uint16_t* __restrict__ Q = (const uint16_t*)p.q + (size_t)b * p.q_batch_stride + (size_t)h * D;
   const uint16_t* __restrict__ K = (const uint16_t*)p.k + (size_t)b * p.k_batch_stride + (size_t)h * D;
@@ -103,23 +107,23 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
     unsigned char* vb = kb + C::KBYTES;
 #pragma unroll
     for (int i = 0; i < C::KCH; ++i) {
-      const int pch = (i * 4 + wave) * 64 + lane;
+      const int pch = (i * NW + wave) * 64 + lane;
       const int row = pch / C::CPR, slot = pch % C::CPR;
       const int c = slot ^ k_swz<D>(row);
       const int kv = kv0 + row;
       const uint16_t* src = (kv < p.Skv_alloc) ? K + (size_t)kv * p.k_row_stride + c * 8 : zsrc;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(kb + (i * 4 + wave) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(kb + (i * NW + wave) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < C::VCH; ++i) {
-      const int pch = (i * 4 + wave) * 64 + lane;
+      const int pch = (i * NW + wave) * 64 + lane;
       const int d = pch >> 3, slot = pch & 7;
       const int c = slot ^ ((d >> 1) & 7);
       const int kv = kv0 + c * 8;
       const uint16_t* src = (kv < p.Skv_alloc) ? VT + (size_t)d * p.vt_ld + kv : zsrc;  // Skv_alloc % 8 == 0
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(vb + (i * 4 + wave) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(vb + (i * NW + wave) * 1024), 16, 0, 0);
     }
   };
   // wait until at most G of this wave's later tiles are still in flight (so tile j has landed) and this wave's LDS
@@ -303,11 +307,11 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const 
   }
 }
 
-template <int D, int NS, bool MASKED = false>
+template <int D, int NS, bool MASKED = false, int NW = 4>
 int launch_attn(const da_attention_params& p, hipStream_t s) {
-  using C = AttnCfg<D>;
+  using C = AttnCfg<D, NW>;
   const size_t lds = (size_t)NS * C::STAGE;
-  auto kern = attn_fwd_kernel<D, NS, MASKED>;
+  auto kern = attn_fwd_kernel<D, NS, MASKED, NW>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -316,9 +320,9 @@ int launch_attn(const da_attention_params& p, hipStream_t s) {
       attr_set = true;
     }
   }
-  const int qtiles = (p.Sq + 127) / 128, rounds = (p.B * p.H + 7) / 8;
+  const int qtiles = (p.Sq + 32 * NW - 1) / (32 * NW), rounds = (p.B * p.H + 7) / 8;
   dim3 grid(8 * rounds * qtiles);
-  DA_LAUNCH(kern, grid, dim3(256), lds, s, p);
+  DA_LAUNCH(kern, grid, dim3(64 * NW), lds, s, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -337,6 +341,12 @@ int launch_attn_ring(const da_attention_params& p, hipStream_t s) {
   }
   int ns = p.ring_slots ? p.ring_slots : def_ns;
   if (p.Skv <= 64) ns = 2;   // a single tile: nothing to pipeline
+  if constexpr (D == 64) {
+    // fewer than two 128-query blocks per CU: 64-query blocks balance the CUs better (same tiles, same order, same bits)
+    const long blocks128 = (long)((p.B * p.H + 7) / 8) * 8 * ((p.Sq + 127) / 128);
+    const bool q64 = p.q_block ? p.q_block == 64 : (blocks128 < 2 * 256 && p.Sq >= 256 && p.Skv >= 256);
+    if (q64 && ns == 2) return launch_attn<64, 2, false, 2>(p, s);
+  }
   switch (ns) {
     case 2: return launch_attn<D, 2>(p, s);
     case 3: if constexpr (3 * C::STAGE <= 160 * 1024) return launch_attn<D, 3>(p, s); else return DA_ERR_UNSUPPORTED;
@@ -354,6 +364,7 @@ extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
   if (p.B <= 0 || p.H <= 0 || p.Sq <= 0 || p.Skv <= 0) return DA_ERR_INVALID;
   if (p.Skv_alloc < p.Skv || (p.Skv_alloc & 7)) return DA_ERR_INVALID;
   if (p.ring_slots != 0 && (p.ring_slots < 2 || p.ring_slots > 4)) return DA_ERR_INVALID;
+  if (p.q_block != 0 && p.q_block != 64 && p.q_block != 128) return DA_ERR_INVALID;
   if (p.bias && (p.bias_row_stride < ((p.Skv + 63) & ~63) || (p.bias_row_stride & 3) || (p.bias_batch_stride & 3) ||
                  (p.bias_head_stride & 3) || p.scale == 0.0f))
     return DA_ERR_INVALID;

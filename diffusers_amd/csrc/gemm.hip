@@ -29,8 +29,8 @@ namespace {
 struct TileShape {
   int bm, bn, waves;
 };
-constexpr TileShape kTiles[] = {{0, 0, 0},      {128, 128, 4}, {64, 128, 4},  {128, 64, 4},
-                                {64, 64, 4},    {256, 128, 8}, {128, 256, 8}, {256, 256, 8}};
+constexpr TileShape kTiles[] = {{0, 0, 0},      {128, 128, 4}, {64, 128, 4},  {128, 64, 4}, {64, 64, 4},
+                                {256, 128, 8},  {128, 256, 8}, {256, 256, 8}, {128, 128, 8}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 // Untuned fallback: fewest bytes staged per flop among the tiles that still give every CU a block; output-channel
@@ -89,7 +89,9 @@ int stats_parts(const da_gemm_params& p, int tile) {   // one partial per column
 bool tile_ok(const da_gemm_params& p, int tile) {
   if (tile <= 0 || tile >= kNumTiles) return false;
   // GEGLU pairs (value, gate) 32-column tiles inside one wave: the wave must own an even number of them
-  if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) && (tile == DA_TILE_128x64 || tile == DA_TILE_64x64)) return false;
+  if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) &&
+      (tile == DA_TILE_128x64 || tile == DA_TILE_64x64 || tile == DA_TILE_128x128_W8))
+    return false;
   return true;
 }
 

@@ -882,6 +882,7 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s, cons
         case DA_TILE_256x128: DA_V(4, 2, 2, 2, 2, true);
         case DA_TILE_128x256: DA_V(2, 4, 2, 2, 2, true);
         case DA_TILE_256x256: DA_V(2, 4, 4, 2, 2, true);
+        case DA_TILE_128x128_W8: DA_V(2, 4, 2, 1, 2, true);
       }
       return DA_ERR_UNSUPPORTED;
     case DA_STAGE_LDS_DIRECT3:
@@ -892,6 +893,7 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s, cons
         case DA_TILE_64x64: DA_V(2, 2, 1, 1, 3, true);
         case DA_TILE_256x128: DA_V(4, 2, 2, 2, 3, true);
         case DA_TILE_128x256: DA_V(2, 4, 2, 2, 3, true);
+        case DA_TILE_128x128_W8: DA_V(2, 4, 2, 1, 3, true);
       }
       return DA_ERR_UNSUPPORTED;  // 256x256 x 3 slots would need 192 KiB of LDS
     case DA_STAGE_LDS_DIRECT4:
@@ -900,6 +902,7 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s, cons
         case DA_TILE_64x128: DA_V(2, 2, 1, 2, 4, true);
         case DA_TILE_128x64: DA_V(2, 2, 2, 1, 4, true);
         case DA_TILE_64x64: DA_V(2, 2, 1, 1, 4, true);
+        case DA_TILE_128x128_W8: DA_V(2, 4, 2, 1, 4, true);
       }
       return DA_ERR_UNSUPPORTED;
     case DA_STAGE_LDS_DIRECT6:

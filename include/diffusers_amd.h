@@ -45,6 +45,9 @@ extern "C" {
 #define DA_TILE_256x128 5 /* 8 waves (4x2); LDS-direct staging only */
 #define DA_TILE_128x256 6 /* 8 waves (2x4); LDS-direct staging only */
 #define DA_TILE_256x256 7 /* 8 waves (2x4), 128x64 per wave; LDS-direct, 2-stage only */
+#define DA_TILE_128x128_W8 8 /* 128x128 computed by 8 waves (2x4, 64x32 per wave): twice the waves per staged byte of
+                                DA_TILE_128x128, for problems with fewer tiles than CUs where ONE block per CU has to hide the
+                                fill latency on its own; LDS-direct, 2 / 3 / 4 ring slots; not for GEGLU epilogues */
 
 #define DA_STAGE_REGISTER 0   /* global_load_dwordx4 -> ds_write_b128 */
 /* LDS-DMA variants: buffer-addressed (buffer_load_dwordx4 ... offen lds: descriptor base at the tile's first operand row,
@@ -192,6 +195,9 @@ typedef struct da_attention_params {
   const void* bias;
   long long bias_batch_stride, bias_head_stride; /* elements; 0 = shared across batches / heads */
   int bias_row_stride, bias_f32, causal;
+  int q_block; /* queries per workgroup: 0 = chosen from the grid size, 128 (four waves) or 64 (two waves; D = 64, unmasked,
+                  ring depth 2 only -- for grids of fewer than two 128-query workgroups per CU).  Speed only: each wave
+                  owns 32 queries and walks the same K / V^T tiles in the same order either way -> bit-identical outputs */
 } da_attention_params;
 
 int da_attention_bf16(const da_attention_params* p, void* stream);

@@ -311,3 +311,26 @@ def test_sdxl_pipeline_without_cfg():
     rr = _rel(lat, x)
     print(f"[host] tiny SDXL pipeline without CFG: latents rel rms vs fp32 oracle loop = {rr:.3e}")
     assert rr < 4e-2
+
+
+def test_flux_rope_cache_distinguishes_portrait_from_landscape():
+    """an (h, w) and a (w, h) latent grid have the same id-tensor shape AND the same coordinate sum, so a
+    RoPE cache keyed on (shape, sum) handed the second image the first one's cos / sin tables.  The key is now a digest of the
+    id values: tables differ, each equals a fresh computation, and a repeated grid still hits the cache."""
+    from diffusers_amd.pipelines import FluxPipeline
+    from diffusers_amd.transformer_flux import FluxTransformer2DModel, rope_tables
+    tr = FluxTransformer2DModel(**dinit.TINY_FLUX)
+    tr.load_state_dict(dinit.random_state_dict(dinit.flux_param_shapes(tr.config), seed=5), device="cpu")
+    pooled = torch.zeros((1, tr.config.pooled_projection_dim), dtype=bf16)
+    txt = torch.zeros(8, 3)
+    a_ids, b_ids = FluxPipeline._prepare_latent_image_ids(4, 6), FluxPipeline._prepare_latent_image_ids(6, 4)
+    assert a_ids.shape == b_ids.shape and float(a_ids.sum()) == float(b_ids.sum())       # the collision the old key had
+    ca = tr.precompute_conditioning(pooled, a_ids, txt)
+    cos_a = ca["cos"].clone()
+    cb = tr.precompute_conditioning(pooled, b_ids, txt)
+    assert not torch.equal(cos_a, cb["cos"]), "portrait grid reused the landscape tables"
+    for ids, got in ((a_ids, cos_a), (b_ids, cb["cos"])):
+        want, _ = rope_tables(torch.cat((txt, ids), dim=0), tr.config.axes_dims_rope)
+        assert torch.equal(got, want)
+    again = tr.precompute_conditioning(pooled, b_ids, txt)
+    assert again["cos"] is cb["cos"], "an identical grid must hit the cache"

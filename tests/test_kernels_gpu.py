@@ -44,10 +44,11 @@ def test_gemm_plain(M, N, K, tile, staging):
     assert_close_bf16(y, ref, f"gemm {M}x{N}x{K} tile={tile} stage={staging}", rtol=8e-3, atol_rms=4e-3)
 
 
-# every (tile, staging) variant the C ABI exposes: tiles 1..7 x staging 0 (register) / 1..5 (LDS-DMA ring of 2/3/4/6/8
-# slots); combinations whose ring does not fit the 160 KiB LDS return DA_ERR_UNSUPPORTED.  25 are valid.
-ALL_VARIANTS = [(1, 0)] + [(t, s) for s in range(0, 6) for t in range(1, 8) if (t, s) != (1, 0)]
-N_VALID_VARIANTS = 25
+# every (tile, staging) variant the C ABI exposes: tiles 1..8 x staging 0 (register) / 1..5 (LDS-DMA ring of 2/3/4/6/8
+# slots); combinations whose ring does not fit the 160 KiB LDS return DA_ERR_UNSUPPORTED.  28 are valid (25 of round 1 + the
+# 8-wave 128x128 tile with 2 / 3 / 4 slots).
+ALL_VARIANTS = [(1, 0)] + [(t, s) for s in range(0, 6) for t in range(1, 9) if (t, s) != (1, 0)]
+N_VALID_VARIANTS = 28
 
 
 def _run_variants(fn, what, geglu=False):
@@ -95,7 +96,7 @@ def test_gemm_pair_launch_is_bit_identical_to_two_launches():
         ref_qk = ops.linear(x, wqk, bias, tile=L.TILE_128x128, staging=L.STAGE_LDS_DIRECT)
         ref_vt = ops.linear(wv, x, tile=L.TILE_128x128, staging=L.STAGE_LDS_DIRECT)
         n_ok = 0
-        for tile in range(1, 8):
+        for tile in range(1, 9):
             for st in range(1, 6):
                 pa, s_ = ops._linear_params(x, wqk, bias, tile=tile, staging=st)
                 pb, _ = ops._linear_params(wv, x, tile=tile, staging=st)
@@ -222,7 +223,7 @@ def test_layernorm_fold_producer_and_consumers(M, C, N):
     order = torch.cat([idx, idx + n2], dim=1).reshape(-1)
     fold1p = ops.LNFold(fold1.s[order].contiguous(), fold1.c[order].contiguous(), fold1.eps)
     n_prod = 0
-    for tile in range(1, 8):
+    for tile in range(1, 9):
         st = ops.RowStats(M, DEV)
         st.buf.fill_(float("nan"))
         try:
@@ -235,7 +236,7 @@ def test_layernorm_fold_producer_and_consumers(M, C, N):
         assert torch.isfinite(tot).all() and torch.isnan(st.buf[:, st.parts:]).all(), f"tile {tile}: wrong number of partials"
         assert torch.allclose(tot[:, 0], xf.sum(dim=1), rtol=1e-5, atol=1e-2)
         assert torch.allclose(tot[:, 1], (xf * xf).sum(dim=1), rtol=1e-5, atol=1e-2)
-        for ctile in range(1, 8):
+        for ctile in range(1, 9):
             try:
                 y = ops.linear(x, wl, b, tile=ctile, staging=1, ln=(st, fold))
             except RuntimeError:
@@ -422,6 +423,30 @@ def test_flash_attention(B, H, D, Sq, Skv):
                       k_batch_stride=skv_alloc * C, vt_ld=B * skv_alloc, vt_batch_stride=skv_alloc)
     ref = _attn_ref(q, k, v, H).view(B * Sq, C)
     assert_close_bf16(o, ref, f"flash attn B{B} H{H} D{D} Sq{Sq} Skv{Skv}", rtol=1.6e-2, atol_rms=1.6e-2)
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv", [(2, 3, 256, 256), (1, 2, 200, 333), (1, 5, 1024, 1024), (2, 2, 130, 77)])
+def test_flash_attention_query_block_sizes_are_bit_identical(B, H, Sq, Skv):
+    """da_attention_params.q_block: 64-query (two-wave) and 128-query (four-wave) workgroups walk the same tiles in the same
+    order per wave, so the choice -- made from the grid size when q_block = 0 -- must not change a single bit."""
+    ops, L = _ops()
+    D, C = 64, H * 64
+    q, k, v = rnd((B, Sq, C), 36), rnd((B, Skv, C), 37), rnd((B, Skv, C), 38)
+    sa = ((Skv + 15) // 16) * 16
+    kp = torch.zeros((B, sa, C), device=DEV, dtype=bf16)
+    kp[:, :Skv] = k
+    vt = torch.zeros((C, B * sa), device=DEV, dtype=bf16)
+    vt.view(C, B, sa)[:, :, :Skv] = v.permute(2, 0, 1)
+    def run(qb):
+        return ops.attention(q.view(B * Sq, C), kp.view(B * sa, C), vt, B=B, H=H, D=D, Sq=Sq, Skv=Skv, Skv_alloc=sa,
+                             q_row_stride=C, k_row_stride=C, q_batch_stride=Sq * C, k_batch_stride=sa * C,
+                             vt_ld=B * sa, vt_batch_stride=sa, q_block=qb)
+    o128, o64, oauto = run(128), run(64), run(0)
+    assert torch.equal(o128, o64) and torch.equal(oauto, o128)
+    assert_close_bf16(o64, _attn_ref(q, k, v, H).view(B * Sq, C), f"flash attn q_block=64 B{B} H{H} Sq{Sq} Skv{Skv}",
+                      rtol=1.6e-2, atol_rms=1.6e-2)
+    with pytest.raises(RuntimeError):
+        run(32)
 
 
 def test_flash_attention_rescale_branch():

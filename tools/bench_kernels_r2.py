@@ -54,7 +54,7 @@ def emit(rec):
 
 def best_unsplit(x, w, **kw):
     best = None
-    for tile in range(1, 8):
+    for tile in range(1, 9):
         for st in range(1, 6):
             try:
                 tmin, tmed = timeit(lambda: ops.linear(x, w, tile=tile, staging=st, **kw), iters=6, warm=1)
@@ -113,7 +113,7 @@ def main():
         bq = best_unsplit(x, wqk)
         bv = best_unsplit(wv, x)
         best = None
-        for tile in range(1, 8):
+        for tile in range(1, 9):
             for st in range(1, 6):
                 pa, s_ = ops._linear_params(x, wqk, tile=tile, staging=st)
                 pb, _ = ops._linear_params(wv, x, tile=tile, staging=st)

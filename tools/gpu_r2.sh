@@ -91,3 +91,9 @@ if [[ $WHAT == *newtests* ]]; then
   timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -s --timeout 300 -k "pair_launch or split_k or sampler_round2 or flowmatch_fp32 or flash_attention or attention or torch_library" > $O/pytest_new.log 2>&1; echo "pytest new rc=$?" | tee -a $O/pytest_new.log
   grep -E "passed|failed|FAILED|Error|split-K" $O/pytest_new.log | tail -30
 fi
+if [[ $WHAT == *r2b* ]]; then
+  timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -s --timeout 300 -k "bit_identical or query_block or tuner or flash_attention" > $O/pytest_r2b.log 2>&1; echo "pytest r2b rc=$?" | tee -a $O/pytest_r2b.log
+  grep -E "passed|failed|FAILED|Error" $O/pytest_r2b.log | tail -12
+  timeout 600 python tools/bench_kernels_r2b.py > $O/kernels_r2b.log 2>&1; echo "kernels r2b rc=$?"
+  grep -E '^\{' $O/kernels_r2b.log | cut -c1-400; grep -vE '^\{' $O/kernels_r2b.log | tail -8
+fi
