@@ -52,9 +52,7 @@ __device__ __forceinline__ int k_swz(int row) {
 
 // MASKED (D = 64 instantiations only): causal mask and / or an additive score bias -- the text encoders (CLIP: causal;
 // T5 / UMT5: relative position bias + key padding, scale 1).  The unmasked instantiations carry none of this code.
-// NW = waves per block = 32-query groups per block (4: 128 queries; 2: 64 queries -- for problems with fewer than two
-// 128-query blocks per CU, e.g. SDXL's 1024-token level: 320 blocks of 128 leave 192 CUs with one block and 64 with two,
-// 640 blocks of 64 spread the same work at finer grain).
+// NW = waves per block = 32-query groups per block (4: 128 queries, the default; 2: 64 queries, da_attention_params.q_block).
 template <int D, int NS, bool MASKED = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
   using C = AttnCfg<D, NW>;
@@ -342,9 +340,9 @@ int launch_attn_ring(const da_attention_params& p, hipStream_t s) {
   int ns = p.ring_slots ? p.ring_slots : def_ns;
   if (p.Skv <= 64) ns = 2;   // a single tile: nothing to pipeline
   if constexpr (D == 64) {
-    // fewer than two 128-query blocks per CU: 64-query blocks balance the CUs better (same tiles, same order, same bits)
-    const long blocks128 = (long)((p.B * p.H + 7) / 8) * 8 * ((p.Sq + 127) / 128);
-    const bool q64 = p.q_block ? p.q_block == 64 : (blocks128 < 2 * 256 && p.Sq >= 256 && p.Skv >= 256);
+    // 64-query workgroups only on request: measured (profiles/r02e_kernel_experiments.md) they do not help even where 128-query
+    // workgroups leave CUs with one block (SDXL S = 1024: 34.9 vs 36.1 us) and cost 1.3-1.5x at S = 4096
+    const bool q64 = p.q_block == 64;
     if (q64 && ns == 2) return launch_attn<64, 2, false, 2>(p, s);
   }
   switch (ns) {

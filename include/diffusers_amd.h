@@ -195,9 +195,9 @@ typedef struct da_attention_params {
   const void* bias;
   long long bias_batch_stride, bias_head_stride; /* elements; 0 = shared across batches / heads */
   int bias_row_stride, bias_f32, causal;
-  int q_block; /* queries per workgroup: 0 = chosen from the grid size, 128 (four waves) or 64 (two waves; D = 64, unmasked,
-                  ring depth 2 only -- for grids of fewer than two 128-query workgroups per CU).  Speed only: each wave
-                  owns 32 queries and walks the same K / V^T tiles in the same order either way -> bit-identical outputs */
+  int q_block; /* queries per workgroup: 0 / 128 = four waves (default), 64 = two waves (D = 64, unmasked, ring depth 2
+                  only; other cases run 128).  Speed only: each wave owns 32 queries and walks the same K / V^T tiles in
+                  the same order either way -> bit-identical outputs */
 } da_attention_params;
 
 int da_attention_bf16(const da_attention_params* p, void* stream);

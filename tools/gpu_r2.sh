@@ -97,3 +97,16 @@ if [[ $WHAT == *r2b* ]]; then
   timeout 600 python tools/bench_kernels_r2b.py > $O/kernels_r2b.log 2>&1; echo "kernels r2b rc=$?"
   grep -E '^\{' $O/kernels_r2b.log | cut -c1-400; grep -vE '^\{' $O/kernels_r2b.log | tail -8
 fi
+if [[ $WHAT == *ksweep* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/ksweep; mkdir -p $O/ksweep
+  DIFFUSERS_AMD_TUNE=0 timeout 400 rocprofv3 --kernel-trace -f csv -d $O/ksweep -o ks -- python $R/tools/ksweep.py $O/ksweep/manifest.json > $O/ksweep/run.log 2>&1; echo "ksweep rc=$?"
+  cd $R
+  python tools/ksweep_report.py $O/ksweep/manifest.json $(find $O/ksweep -name '*kernel_trace.csv' | head -1) > $O/ksweep_report.md 2>> $O/ksweep/run.log
+  find $O/ksweep -name '*kernel_trace*' -delete
+  grep -A40 "K sweep" $O/ksweep_report.md; tail -3 $O/ksweep/run.log
+fi
+if [[ $WHAT == *twostream* ]]; then
+  DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_batch1.json timeout 800 python tools/bench_two_stream.py > $O/two_stream.log 2>&1; echo "twostream rc=$?"
+  grep -E '^\{' $O/two_stream.log; grep -vE '^\{' $O/two_stream.log | tail -8
+fi
