@@ -433,6 +433,60 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
     }
   }
 
+  // Residual prefetch: ONE batch of unconditional 8-byte loads of every residual fragment this lane will add in the
+  // epilogue, issued before the staging prologue so the round trip hides under the K loop.  Left in the epilogue's
+  // per-fragment loop the loads sit behind the activation branches and retire one L2 round trip at a time: + 3-5 us on
+  // a launch whose K loop is 8 us (profiles/r02e_kernel_experiments.md).  Rows / columns past the edge are clamped to
+  // valid addresses (their values are never stored).  In-place accumulation (residual == C, the temporal taps of a
+  // causal Conv3d) is unaffected: each element is read and later written by the same lane.
+  // (Not for the 4 x 2 wave tile, whose accumulators already fill the register file, nor for split-K builds.)
+  constexpr bool RES_PF = (MT * NT < 8) && !SPLITK;
+  uint2 res_v[RES_PF ? MT : 1][RES_PF ? NT : 1][4];
+  if constexpr (RES_PF) {
+    const uint16_t* __restrict__ resid_pf = (const uint16_t*)p.residual;
+    if (resid_pf) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = min(m0 + (wm * MT + i) * 32 + l31, p.M - 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = min(n0 + (wn * NT + j) * 32 + 8 * g + 4 * hi, p.N - 4);
+            res_v[i][j][g] = *(const uint2*)(resid_pf + (size_t)m * p.ldr + n);
+          }
+      }
+    }
+  }
+  // Same for the bias (one 8-byte load per 4 output channels, shared by the MT row tiles) and the per-batch channel
+  // vector (ResnetBlock2D's time embedding): in the epilogue loop each sat in front of its fragment's arithmetic.
+  uint2 bias_v[NT][4], rowvec_v[RES_PF ? MT : 1][RES_PF ? NT : 1][4];
+  {
+    const uint16_t* __restrict__ bias_pf = (const uint16_t*)p.bias;
+    if (bias_pf && p.act != DA_ACT_GEGLU && p.act != DA_ACT_GEGLU_TANH) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          bias_v[j][g] = *(const uint2*)(bias_pf + min(n0 + (wn * NT + j) * 32 + 8 * g + 4 * hi, p.N - 4));
+    }
+    if constexpr (RES_PF) {
+      const uint16_t* __restrict__ rowvec_pf = (const uint16_t*)p.rowvec;
+      if (rowvec_pf) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = min(m0 + (wm * MT + i) * 32 + l31, p.M - 1);
+          const size_t ro = (size_t)(m / p.rows_per_batch) * p.ld_rowvec;
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              rowvec_v[i][j][g] = *(const uint2*)(rowvec_pf + ro + min(n0 + (wn * NT + j) * 32 + 8 * g + 4 * hi, p.N - 4));
+        }
+      }
+    }
+  }
+
   // ---- main loop: LDS ring of STAGES slices, one rendezvous per K slice ----
   // prologue: slices 0 .. min(PD, nk) - 1 go to ring slots 0 .. ; then slice 0 must have landed
 #pragma unroll
@@ -638,7 +692,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
           o[3] = ln_rs[i] * (o[3] - ln_mu[i] * sv.w) + cv.w;
         }
         if (bias) {
-          const uint2 bv = *(const uint2*)(bias + n);
+          const uint2 bv = bias_v[j][g];
           o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y);
         }
         if (bias_rows) {
@@ -646,7 +700,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
           for (int e = 0; e < 4; ++e) o[e] += brow;
         }
         if (rowvec) {
-          const uint2 rv = *(const uint2*)(rowvec + (size_t)bidx * p.ld_rowvec + n);
+          uint2 rv;
+          if constexpr (RES_PF) rv = rowvec_v[i][j][g];
+          else rv = *(const uint2*)(rowvec + (size_t)bidx * p.ld_rowvec + n);
           o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
         }
         if (p.act == DA_ACT_GELU_TANH) {
@@ -681,7 +737,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
           o[3] = bf2f(f2bf(bf2f(f2bf(o[3])) * bf_hi(gv.y)));
         }
         if (resid) {
-          const uint2 rv = *(const uint2*)(resid + (size_t)m * p.ldr + n);
+          uint2 rv;
+          if constexpr (RES_PF) rv = res_v[i][j][g];
+          else rv = *(const uint2*)(resid + (size_t)m * p.ldr + n);
           o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
         }
         if (p.out_scale != 1.0f) {

@@ -291,7 +291,7 @@ def test_gemm_tuner_picks_a_valid_variant(tmp_path, monkeypatch):
     y = ops.linear(x, w)  # tunes live
     assert torch.equal(y, y_ref)
     (key, (tile, staging, us, split)), = tuning.table().items()
-    assert 1 <= tile <= 7 and 1 <= staging <= 5 and us > 0 and split == 1   # split-K is opt-in (DIFFUSERS_AMD_SPLITK=1)
+    assert 1 <= tile <= 8 and 1 <= staging <= 5 and us > 0 and split == 1   # split-K is opt-in (DIFFUSERS_AMD_SPLITK=1)
     print(f"[tune] {key} -> tile {L.TILE_NAMES[tile]} staging {staging}: {us:.1f} us")
     assert torch.equal(ops.linear(x, w), y_ref)  # table hit
     out = tuning.save(tmp_path / "t.json")
