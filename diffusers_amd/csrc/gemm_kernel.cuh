@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   uint2 bias_v[NT][4], rowvec_v[RES_PF ? MT : 1][RES_PF ? NT : 1][4];
   {
     const uint16_t* __restrict__ bias_pf = (const uint16_t*)p.bias;
-    if (bias_pf && p.act != DA_ACT_GEGLU && p.act != DA_ACT_GEGLU_TANH) {
+    if (bias_pf) {   // GEGLU: sub-tile 2jp holds the value rows, 2jp + 1 the gate rows (= value + 32): same formula
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -657,8 +657,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
                 gv = ln_rs[i] * (gv - ln_mu[i] * lsg[e]) + lcg[e];
               }
               if (bias) {
-                hv += bf2f(bias[nv + e]);
-                gv += bf2f(bias[nv + 32 + e]);
+                const uint2 bh = bias_v[2 * jp][g], bg = bias_v[2 * jp + 1][g];
+                hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
+                gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
               }
               // reference rounds the projection to bf16 before chunk/gelu/mul (activations.py:113-124)
               hv = bf2f(f2bf(hv));
