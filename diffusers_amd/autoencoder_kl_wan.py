@@ -46,6 +46,14 @@ _DEFAULTS = dict(
 )
 
 
+# Skip the MFMA steps over zero channel padding (da_gemm_params.k_valid).  Speed only; the switch exists for A/B timing.
+K_SKIP = True
+
+
+def _kv(c: int) -> int:
+    return c if K_SKIP else 0
+
+
 def _pad64(c: int) -> int:
     return (c + 63) // 64 * 64
 
@@ -67,19 +75,20 @@ class CausalConv3d:
         b = w.get(prefix + ".bias")
         cout, cin, kt, k, _ = wt.shape
         self.kt, self.k = kt, k
-        self.cin_p, self.cout_p = _pad64(cin), cout_pad or _pad64(cout)
+        self.cin, self.cin_p, self.cout_p = cin, _pad64(cin), cout_pad or _pad64(cout)
         wt = _pad_to(wt, (self.cout_p, self.cin_p, kt, k, k))
         self.bias = _pad_to(b, (self.cout_p,))
         self.taps = [ops.pack_conv_weight(wt[:, :, i].contiguous()) if k == 3
                      else wt[:, :, i, 0, 0].contiguous() for i in range(kt)]
 
     def _one(self, x, wt, bias, residual, out):
+        # k_valid: the zero channels that pad Cin up to the K granule (96 -> 128 at full size) are skipped, not multiplied
         if self.k == 3:
-            return ops.conv2d_nhwc(x, wt, bias, ksize=3, residual=residual, out=out)
+            return ops.conv2d_nhwc(x, wt, bias, ksize=3, residual=residual, out=out, k_valid=_kv(self.cin))
         T, H, W_, C = x.shape
         y = ops.linear(x.view(T * H * W_, C), wt, bias,
                        residual=None if residual is None else residual.view(T * H * W_, self.cout_p),
-                       out=None if out is None else out.view(T * H * W_, self.cout_p))
+                       out=None if out is None else out.view(T * H * W_, self.cout_p), k_valid=_kv(self.cin))
         return y.view(T, H, W_, self.cout_p)
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -166,7 +175,7 @@ class Resample:
     def __init__(self, w: Weights, p: str, temporal: bool):
         wt = w.get(p + ".resample.1.weight")                                 # Conv2d(dim, dim // 2, 3, padding=1)
         cout, cin = wt.shape[:2]
-        self.cin_p, self.cout_p = _pad64(cin), _pad64(cout)
+        self.cin, self.cin_p, self.cout_p = cin, _pad64(cin), _pad64(cout)
         self.w = ops.pack_conv_weight(_pad_to(wt, (self.cout_p, self.cin_p, 3, 3)))
         self.b = _pad_to(w.get(p + ".resample.1.bias"), (self.cout_p,))
         self.time = None
@@ -189,7 +198,7 @@ class Resample:
             x2[0].copy_(x[0])                                                # the "Rep" frame passes through
             ops.permute_0213(y.view(T - 1, H * W_, 2, cp), out=x2[1:])       # [T-1][HW][2][cp] -> [T-1][2][HW][cp]
             x = x2
-        return ops.conv2d_nhwc(x, self.w, self.b, ksize=3, up=True)
+        return ops.conv2d_nhwc(x, self.w, self.b, ksize=3, up=True, k_valid=_kv(self.cin))
 
 
 class AutoencoderKLWan(PretrainedMixin):

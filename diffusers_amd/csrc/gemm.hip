@@ -74,6 +74,7 @@ int validate(da_gemm_params& p) {
     return DA_ERR_UNSUPPORTED;
   if (p.act < 0 || p.act > DA_ACT_GEGLU_TANH) return DA_ERR_INVALID;
   if (p.split_k < 0 || p.split_k > 8) return DA_ERR_INVALID;
+  if (p.k_valid < 0 || (p.k_valid > 0 && (p.k_valid > (p.conv ? p.C1 : p.K) || (p.conv && p.C2 != 0)))) return DA_ERR_INVALID;
   if (p.stats_out && (p.conv || p.out_f32 || p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH || p.stats_ld <= 0 || (p.stats_ld & 1)))
     return DA_ERR_UNSUPPORTED;
   if (p.ln_stats && (p.conv || !p.ln_s || !p.ln_c || p.ln_parts <= 0 || p.ln_parts > 4 * DA_LN_PAIR_LOADS ||

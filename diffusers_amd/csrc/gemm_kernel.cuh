@@ -55,7 +55,7 @@ struct RowInfo {      // per staged activation row (implicit GEMM gather state)
 //    polling lane, bounded spin); the consumer re-arms the flag for the next launch on the stream.  The sum order is
 //    fixed (own slices, then slot 0, 1, ...), so a given split_k is deterministic; different split_k differ in the
 //    last fp32 bit of the sum.  The host admits split-K only when every block of the launch is co-resident.
-template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false>
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false, bool KSKIP = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_params prob_a, const int xcd_gx_a,
                                                                   const da_gemm_params prob_b, const int xcd_gx_b,
                                                                   const int grid_a) {
@@ -370,7 +370,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   const int fsw = (l31 >> 1) & 7;
   const int frow = l31 * 128;
 
-  auto compute = [&](int buf) {
+  // `full` (KSKIP builds only): false = the slice's upper 32 K elements are channel padding (da_gemm_params.k_valid): its
+  // k-steps 2 and 3 are not run.  Without KSKIP the body is one straight-line region of 4 k-steps.
+  auto compute = [&](int buf, bool full) {
     const unsigned char* xb = smem + buf * STAGE + (wm * MT * 32) * 128 + frow;
     const unsigned char* wb = smem + buf * STAGE + XBYTES + (wn * NT * 32) * 128 + frow;
     // two fragment register sets: the ds_reads of k-step ks+1 are issued before the MFMAs of k-step ks, so the LDS
@@ -383,23 +385,18 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
 #pragma unroll
       for (int i = 0; i < MT; ++i) xf[set][i] = *(const bf16x8_t*)(xb + i * 32 * 128 + off);
     };
-    frag(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) frag((ks + 1) & 1, ks + 1);
+    auto mfmas = [&](int ks) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
-    }
-    // The order above is only a wish: without these directives the scheduler folds both fragment sets back into one
+    };
+    // The program order below is only a wish: without the directives the scheduler folds both fragment sets back into one
     // (read, wait, multiply).  Pin it: first set, then each step's MFMAs interleaved with the NEXT step's ds_reads.
 #define DA_SG_DS(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
 #define DA_SG_MF(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
-    DA_SG_DS(MT + NT);
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
+    auto pin_step = [&]() {   // one k-step's MFMAs over the next step's MT + NT fragment reads
       if constexpr (MT * NT == 4) {         // 4 reads under 4 MFMAs
         DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1);
       } else if constexpr (MT * NT == 2) {  // 3 reads, 2 MFMAs
@@ -411,8 +408,36 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         DA_SG_DS(1); DA_SG_MF(2); DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1);
         DA_SG_DS(1); DA_SG_MF(2); DA_SG_DS(1); DA_SG_MF(1); DA_SG_DS(1); DA_SG_MF(1);
       }
+    };
+    if constexpr (!KSKIP) {
+      frag(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) frag((ks + 1) & 1, ks + 1);
+        mfmas(ks);
+      }
+      DA_SG_DS(MT + NT);
+      pin_step(); pin_step(); pin_step();
+      DA_SG_MF(MT * NT);
+    } else {
+      // k-steps 0 and 1, with step 2's fragments fetched under step 1's MFMAs whether or not they will be used (a half
+      // slice's upper bytes are staged like any others), then ONE wave-uniform branch around steps 2 and 3
+      frag(0, 0);
+      frag(1, 1);
+      mfmas(0);
+      frag(0, 2);
+      mfmas(1);
+      DA_SG_DS(MT + NT);
+      pin_step(); pin_step();
+      __builtin_amdgcn_sched_barrier(0);
+      if (full) {
+        frag(1, 3);
+        mfmas(2);
+        mfmas(3);
+        pin_step();
+        DA_SG_MF(MT * NT);
+      }
     }
-    DA_SG_MF(MT * NT);
 #undef DA_SG_DS
 #undef DA_SG_MF
   };
@@ -460,7 +485,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   }
   // Same for the bias (one 8-byte load per 4 output channels, shared by the MT row tiles) and the per-batch channel
   // vector (ResnetBlock2D's time embedding): in the epilogue loop each sat in front of its fragment's arithmetic.
-  uint2 bias_v[NT][4], rowvec_v[RES_PF ? MT : 1][RES_PF ? NT : 1][4];
+  constexpr bool RV_PF = RES_PF && !KSKIP;   // the k_valid builds sit at the 256-register line of 2 waves per SIMD
+  uint2 bias_v[NT][4], rowvec_v[RV_PF ? MT : 1][RV_PF ? NT : 1][4];
   {
     const uint16_t* __restrict__ bias_pf = (const uint16_t*)p.bias;
     if (bias_pf) {   // GEGLU: sub-tile 2jp holds the value rows, 2jp + 1 the gate rows (= value + 32): same formula
@@ -470,7 +496,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         for (int g = 0; g < 4; ++g)
           bias_v[j][g] = *(const uint2*)(bias_pf + min(n0 + (wn * NT + j) * 32 + 8 * g + 4 * hi, p.N - 4));
     }
-    if constexpr (RES_PF) {
+    if constexpr (RV_PF) {
       const uint16_t* __restrict__ rowvec_pf = (const uint16_t*)p.rowvec;
       if (rowvec_pf) {
 #pragma unroll
@@ -528,11 +554,26 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   }
   int cur = 0;          // ring slot of slice kt
   int nxt = PD;         // ring slot the next issued slice goes to (STAGES == PD + 1)
+  // KSKIP: position of the slice being COMPUTED inside its K period (a kernel tap's channels / the whole K of a Linear)
+  const int kper = CONV ? Ctot : p.K;
+  int cpos = (KSKIP && p.k_valid > 0 && k_begin > 0) ? (k_begin * 64) % kper : 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = (kt + PD < nk);
     if (more) DA_STAGE_ISSUE(nxt);
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in flight under this slice's MFMAs
-    compute(cur);
+    if constexpr (KSKIP) {
+      int live = 64;                    // valid K elements of this slice (wave-uniform)
+      if (p.k_valid > 0) {
+        live = p.k_valid - cpos;
+        cpos += 64;
+        if (cpos >= kper) cpos = 0;
+      }
+      // a slice whose upper half is padding runs k-steps 0 and 1 only, one that is all padding none (the padded operand
+      // values are zeros by contract, so any other split just multiplies some of them)
+      if (live > 0) compute(cur, live > 32);
+    } else {
+      compute(cur, true);
+    }
     if (kt + 1 < nk) {
       if (more) DA_STAGE_COMMIT(nxt);
       // issued so far: min(nk, kt + PD + 1) slices; slices 0 .. kt+1 must have landed before the next iteration
@@ -702,7 +743,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         }
         if (rowvec) {
           uint2 rv;
-          if constexpr (RES_PF) rv = rowvec_v[i][j][g];
+          if constexpr (RV_PF) rv = rowvec_v[i][j][g];
           else rv = *(const uint2*)(rowvec + (size_t)bidx * p.ld_rowvec + n);
           o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
         }
@@ -836,7 +877,7 @@ inline int problem_grid(const da_gemm_params& p, int* gx_out) {
 }
 
 // pb == nullptr: one problem.  Otherwise both problems run in ONE launch (see the kernel header).
-template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false>
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false, bool KSKIP = false>
 int launch(const da_gemm_params& p, const da_gemm_params* pb, hipStream_t s) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   int gx_a = 1, gx_b = 1;
@@ -856,7 +897,7 @@ int launch(const da_gemm_params& p, const da_gemm_params* pb, hipStream_t s) {
     if (tiles * (p.split_k - 1) * BM * BN * 4 > (size_t)p.workspace_bytes) return DA_ERR_INVALID;
     if (tiles * (p.split_k - 1) > DA_SPLITK_ERR_SLOT) return DA_ERR_INVALID;
   }
-  auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, SM, SPLITK>;
+  auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, SM, SPLITK, KSKIP>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -915,6 +956,21 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s, cons
     }
 #undef DA_SK
     return DA_ERR_UNSUPPORTED;
+  }
+  if (p.k_valid > 0 && buf && !pb) {
+    // instantiations that skip the MFMA steps over channel padding (the tiles the large video convs use); any other
+    // variant runs the problem too -- it multiplies the zeros
+#define DA_KS(T_, ST_, WM_, WN_, MT_, NT_, NS_) \
+  if (tile == (T_) && staging == (ST_)) return launch<WM_, WN_, MT_, NT_, NS_, CONV, 2, false, true>(p, nullptr, s)
+    DA_KS(DA_TILE_128x128, DA_STAGE_LDS_DIRECT, 2, 2, 2, 2, 2);
+    DA_KS(DA_TILE_128x64, DA_STAGE_LDS_DIRECT, 2, 2, 2, 1, 2);
+    DA_KS(DA_TILE_64x128, DA_STAGE_LDS_DIRECT, 2, 2, 1, 2, 2);
+    DA_KS(DA_TILE_256x128, DA_STAGE_LDS_DIRECT3, 4, 2, 2, 2, 3);
+    DA_KS(DA_TILE_128x256, DA_STAGE_LDS_DIRECT3, 2, 4, 2, 2, 3);
+    DA_KS(DA_TILE_256x256, DA_STAGE_LDS_DIRECT, 2, 4, 4, 2, 2);
+    DA_KS(DA_TILE_128x128_W8, DA_STAGE_LDS_DIRECT, 2, 4, 2, 1, 2);
+    DA_KS(DA_TILE_128x128_W8, DA_STAGE_LDS_DIRECT3, 2, 4, 2, 1, 3);
+#undef DA_KS
   }
 #define DA_V(WM_, WN_, MT_, NT_, ST_, G_)                                                         \
   do {                                                                                            \

@@ -138,16 +138,17 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            alpha: float = 1.0, out_scale: float = 1.0, out: Optional[torch.Tensor] = None, out_f32: bool = False,
            bias_rows: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
            tile: Optional[int] = None, staging: Optional[int] = None, split_k: Optional[int] = None,
-           stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None) -> torch.Tensor:
+           stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None, k_valid: int = 0) -> torch.Tensor:
     """out[M][N] = epilogue(alpha * x[M][K] @ w[N][K]^T).  For act == GEGLU, w/bias are in the packed layout of
-    :func:`pack_geglu` and the output has N/2 columns.
+    :func:`pack_geglu` and the output has N/2 columns.  ``k_valid`` > 0: columns k >= k_valid of BOTH operands are
+    zero padding (da_gemm_params.k_valid): the kernel skips the MFMA steps that would multiply them.
 
     LayerNorm fold: ``stats_out`` (a :class:`RowStats`) makes this launch also write the row statistics of its output;
     ``ln=(RowStats, LNFold)`` makes it compute LN(x) @ w^T from the UN-normalised ``x`` whose statistics another launch
     wrote (``w`` pre-scaled by :func:`fold_layernorm`)."""
     p, st = _linear_params(x, w, bias, act=act, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch,
                            alpha=alpha, out_scale=out_scale, out=out, out_f32=out_f32, bias_rows=bias_rows, gate=gate,
-                           tile=tile, staging=staging, split_k=split_k, stats_out=stats_out, ln=ln)
+                           tile=tile, staging=staging, split_k=split_k, stats_out=stats_out, ln=ln, k_valid=k_valid)
     if p is None:
         return st     # the skinny-M path ran
     L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(linear)")
@@ -183,7 +184,8 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
                    rows_per_batch: int = 0, alpha: float = 1.0, out_scale: float = 1.0,
                    out: Optional[torch.Tensor] = None, out_f32: bool = False, bias_rows: Optional[torch.Tensor] = None,
                    gate: Optional[torch.Tensor] = None, tile: Optional[int] = None, staging: Optional[int] = None,
-                   split_k: Optional[int] = None, stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None):
+                   split_k: Optional[int] = None, stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None,
+                   k_valid: int = 0):
     """Checks + da_gemm_params of one nn.Linear problem; returns (params, stream), or (None, result) when the skinny-M
     kernel handled it."""
     _req(x, "x"), _req(w, "w")
@@ -217,6 +219,9 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         raise ValueError("linear: an aliased residual must have the output's row stride")
     p.rows_per_batch = rows_per_batch
     p.alpha, p.out_scale, p.act, p.out_f32, p.conv = alpha, out_scale, act, int(out_f32), 0
+    if not 0 <= k_valid <= K:
+        raise ValueError(f"linear: k_valid {k_valid} outside [0, K = {K}]")
+    p.k_valid = 0 if k_valid == K else k_valid
     st = _stream()
     if ln is not None:
         rs, fold = ln
@@ -248,12 +253,14 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                 rowvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 out_scale: float = 1.0, act: int = L.ACT_NONE, tile: Optional[int] = None,
                 staging: Optional[int] = None, pad_after: int = 0, out: Optional[torch.Tensor] = None,
-                split_k: Optional[int] = None) -> torch.Tensor:
+                split_k: Optional[int] = None, k_valid: int = 0) -> torch.Tensor:
     """Implicit-GEMM Conv2d on channels-last tensors.  x: [B][H][W][C1] (x2: [B][H][W][C2] = fused channel concat),
     w: [Cout][k][k][C1+C2] flattened to [Cout][k*k*(C1+C2)].  up=True fuses a nearest 2x upsample of the input.
     rowvec [B][Cout] is added per batch (time embedding); residual is [B][Hout][Wout][Cout].  ``out`` (contiguous
     [B][Hout][Wout][Cout]) may be the SAME tensor as ``residual``: every output element is read and written by one
-    lane, which is how the temporal taps of a causal Conv3d accumulate in place (autoencoder_kl_wan.py)."""
+    lane, which is how the temporal taps of a causal Conv3d accumulate in place (autoencoder_kl_wan.py).
+    ``k_valid`` > 0 (single source only): channels >= k_valid of x AND of every tap of w are zero padding up to the 64-wide
+    K granule; the kernel skips the MFMA steps that would multiply them (da_gemm_params.k_valid)."""
     _req(x, "x"), _req(w, "w")
     B, H, W_, C1 = x.shape
     C2 = 0
@@ -298,6 +305,9 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     p.alpha, p.out_scale, p.act, p.out_f32, p.conv = 1.0, out_scale, act, 0, ksize
     p.Hin, p.Win, p.C1, p.C2, p.Hout, p.Wout = H, W_, C1, C2, Hout, Wout
     p.stride, p.up, p.pad = stride, int(up), pad
+    if not 0 <= k_valid <= C1 or (k_valid and C2):
+        raise ValueError(f"conv2d_nhwc: k_valid {k_valid} outside [0, C1 = {C1}] (or given with a second source)")
+    p.k_valid = 0 if k_valid == C1 else k_valid
     st = _stream()
     _select_variant(p, tile, staging, st, inplace=inplace, split_k=split_k, device=x.device)
     L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(conv)")

@@ -49,10 +49,11 @@ def _m_key(m: int) -> int:
 
 def key_of(p: "L.GemmParams") -> str:
     """Shape key: everything that changes the kernel's work or its memory pattern, nothing that is a pointer."""
+    kv = f":v{p.k_valid}" if p.k_valid else ""   # valid K elements per period: changes the work per slice
     if p.conv:
         return (f"conv{p.conv}:M{_m_key(int(p.M))}:N{p.N}:C{p.C1}+{p.C2}:H{p.Hin}x{p.Win}:s{p.stride}:u{p.up}:a{p.act}"
-                f":r{int(bool(p.residual))}")
-    return f"lin:M{_m_key(int(p.M))}:N{p.N}:K{p.K}:a{p.act}:f{p.out_f32}:r{int(bool(p.residual))}"
+                f":r{int(bool(p.residual))}{kv}")
+    return f"lin:M{_m_key(int(p.M))}:N{p.N}:K{p.K}:a{p.act}:f{p.out_f32}:r{int(bool(p.residual))}{kv}"
 
 
 def _load() -> None:

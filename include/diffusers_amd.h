@@ -132,6 +132,12 @@ typedef struct da_gemm_params {
   const float* ln_s;        /* [N] fp32 */
   const float* ln_c;        /* [N] fp32 */
   float ln_eps;
+  int k_valid; /* 0: every K element counts.  > 0: only the first k_valid elements of every K PERIOD are non-zero -- a period is
+                  one kernel tap's channels (C1, conv with C2 == 0) or the whole K (Linear) -- because the channel count was
+                  zero-padded up to the 64-wide K granule (AutoencoderKLWan's 96-channel stage: k_valid = 96 in periods of
+                  128).  The operand values past k_valid MUST be zeros in both operands' layouts (activation channels and
+                  weight columns); the kernel then runs half the MFMA steps on a slice that is half padding and none on a
+                  slice that is all padding.  Results equal k_valid = 0 (adding products of zeros changes nothing). */
 } da_gemm_params;
 
 /* number of stats partials per row the launch *p (tile resolved as da_gemm_bf16 resolves it) writes to stats_out */

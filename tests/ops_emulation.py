@@ -37,8 +37,11 @@ def _act(y, act):
 
 
 def conv2d_nhwc(x, w, bias=None, *, ksize=3, x2=None, stride=1, up=False, pad=None, rowvec=None, residual=None,
-                out_scale=1.0, act=0, tile=None, staging=None, pad_after=0, out=None, split_k=None):
+                out_scale=1.0, act=0, tile=None, staging=None, pad_after=0, out=None, split_k=None, k_valid=0):
     assert x.is_contiguous() and x.shape[-1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: conv channels % 64, N % 4"
+    if k_valid:   # the contract of da_gemm_params.k_valid: everything past it is zero padding in both operands
+        assert x2 is None and 0 < k_valid <= x.shape[-1]
+        assert not x[..., k_valid:].any() and not w.view(w.shape[0], ksize * ksize, -1)[..., k_valid:].any()
     if x2 is not None:
         assert x2.is_contiguous() and x2.shape[-1] % 64 == 0 and x2.shape[:3] == x.shape[:3]
         x = torch.cat([x, x2], -1)
@@ -63,8 +66,11 @@ def conv2d_nhwc(x, w, bias=None, *, ksize=3, x2=None, stride=1, up=False, pad=No
 
 
 def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch=0, alpha=1.0, out_scale=1.0, out=None,
-           out_f32=False, bias_rows=None, gate=None, tile=None, staging=None, split_k=None, stats_out=None, ln=None):
+           out_f32=False, bias_rows=None, gate=None, tile=None, staging=None, split_k=None, stats_out=None, ln=None,
+           k_valid=0):
     assert x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: K % 64, N % 4"
+    if k_valid:
+        assert 0 < k_valid <= x.shape[1] and not x[:, k_valid:].any() and not w[:, k_valid:].any()
     assert x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0, "C ABI: row strides % 8"
     y = alpha * (x.float() @ w.float().t())
     if ln is not None:      # LayerNorm fold, consumer: rstd * (x W'^T - mu s) + c from the producer's partial sums

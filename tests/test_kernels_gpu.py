@@ -81,6 +81,47 @@ def test_gemm_all_variants_bit_identical(M, N, K):
     assert_close_bf16(y, ref, f"gemm {M}x{N}x{K} all variants", rtol=8e-3, atol_rms=4e-3)
 
 
+@pytest.mark.parametrize("kind,Cp,Cv", [("linear", 128, 96), ("linear", 64, 32), ("linear", 192, 160), ("conv", 128, 96),
+                                        ("conv", 64, 32), ("conv", 128, 80)])
+def test_k_valid_skips_the_channel_padding(kind, Cp, Cv):
+    """da_gemm_params.k_valid: with zero padding past k_valid in both operands every variant must return what k_valid = 0
+    returns.  Where a whole half-slice is padding (valid % 64 == 32) the skipping instantiations really skip the MFMA
+    steps over it: junk planted there no longer reaches the output."""
+    ops, L = _ops()
+    if kind == "linear":
+        M, N = 700, 192
+        x, w = torch.zeros((M, Cp), device=DEV, dtype=bf16), torch.zeros((N, Cp), device=DEV, dtype=bf16)
+        x[:, :Cv], w[:, :Cv] = rnd((M, Cv), 61), rnd((N, Cv), 62, Cv ** -0.5)
+        b, r = rnd((N,), 63), rnd((M, N), 64)
+        run = lambda t, st, kv, xx=x, ww=w: ops.linear(xx, ww, b, residual=r, tile=t, staging=st, k_valid=kv)  # noqa: E731
+        ref = x.float() @ w.float().t() + b.float() + r.float()
+    else:
+        B, H, W_, N = 2, 20, 24, 96
+        x = torch.zeros((B, H, W_, Cp), device=DEV, dtype=bf16)
+        x[..., :Cv] = rnd((B, H, W_, Cv), 61)
+        w4 = torch.zeros((N, Cp, 3, 3), device=DEV, dtype=bf16)
+        w4[:, :Cv] = rnd((N, Cv, 3, 3), 62, (9 * Cv) ** -0.5)
+        w, b = ops.pack_conv_weight(w4), rnd((N,), 63)
+        run = lambda t, st, kv, xx=x, ww=w: ops.conv2d_nhwc(xx, ww, b, ksize=3, tile=t, staging=st, k_valid=kv)  # noqa: E731
+        ref = _conv_ref(x, w4, b)
+    full = run(1, 1, 0)
+    y = _run_variants(lambda t, st: run(t, st, Cv), f"{kind} C{Cp} k_valid {Cv}")
+    assert torch.equal(y, full)
+    assert_close_bf16(y, ref, f"{kind} C{Cp} k_valid {Cv}", rtol=8e-3, atol_rms=4e-3)
+    if Cv % 64 == 32:   # the padding is exactly the upper half of the last slice of every period
+        xj, wj = x.clone(), w.clone()
+        if kind == "linear":
+            xj[:, Cv:], wj[:, Cv:] = 7.0, 5.0
+        else:
+            xj[..., Cv:] = 7.0
+            wj.view(N, 9, Cp)[..., Cv:] = 5.0
+        # the instantiations that skip (gemm_kernel.cuh dispatch, DA_KS): tile / ring depth pairs of the large video convs
+        for t, st in [(1, 1), (3, 1), (2, 1), (5, 2), (6, 2), (7, 1), (8, 1), (8, 2)]:
+            assert torch.equal(run(t, st, Cv, xj, wj), full), f"tile {t} staging {st}: padding still multiplied"
+    with pytest.raises((RuntimeError, ValueError)):
+        run(1, 1, Cp + 8)
+
+
 def test_gemm_pair_launch_is_bit_identical_to_two_launches():
     """da_gemm_pair_bf16: the fused Q|K projection and the swapped V^T projection of a self-attention layer in ONE launch
     (blocks [0, grid_a) on problem a, the rest on problem b), for every tile / ring depth both problems can run:

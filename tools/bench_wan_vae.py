@@ -56,19 +56,30 @@ def main():
     vae, _ = factory.build_wan_vae(cfg, seed=21, device=dev, init_device=str(dev))
     g = torch.Generator("cpu").manual_seed(4321)
     lat = torch.randn((1, 16, 21, 60, 104), generator=g).to(dev)                     # fp32, as the UniPC loop leaves them
-    res, out = [], None
-    for i in range(3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        out = vae.decode(lat, denormalize=True, return_dict=False)[0]
-        torch.cuda.synchronize()
-        res.append(time.perf_counter() - t0)
-        print(f"[bench_wan_vae] decode {i}: {res[-1]:.3f} s", file=sys.stderr, flush=True)
-    best = min(res[1:])
+    from diffusers_amd import autoencoder_kl_wan as wan
+    best_by, outs = {}, {}
+    for skip in (False, True):          # A/B of da_gemm_params.k_valid (zero channel padding skipped vs multiplied)
+        wan.K_SKIP = skip
+        res = []
+        for i in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = vae.decode(lat, denormalize=True, return_dict=False)[0]
+            torch.cuda.synchronize()
+            res.append(time.perf_counter() - t0)
+            print(f"[bench_wan_vae] k_skip={skip} decode {i}: {res[-1]:.3f} s", file=sys.stderr, flush=True)
+        best_by[skip], outs[skip] = min(res[1:]), out
+        if not skip:
+            first = res[0]
+    best = best_by[True]
+    same = bool(torch.equal(outs[False], outs[True]))
+    out = outs[True]
+    res = [first]
     alg = decode_flops(cfg, 21, 60, 104) / 1e12
     exe = decode_flops(cfg, 21, 60, 104, pad=lambda c: (c + 63) // 64 * 64 if c > 4 else 4) / 1e12
     rec = {"op": "wan_vae_decode_81x480x832", "s_per_decode": round(best, 3), "algorithmic_tflop": round(alg, 1),
            "executed_tflop": round(exe, 1), "algorithmic_tflops": round(alg / best, 1), "executed_tflops": round(exe / best, 1),
+           "s_per_decode_padding_multiplied": round(best_by[False], 3), "k_skip_output_identical": same,
            "first_call_s": round(res[0], 2), "finite": bool(torch.isfinite(out.float()).all()), "shape": list(out.shape),
            "mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
     print(json.dumps(rec), flush=True)

@@ -110,3 +110,10 @@ if [[ $WHAT == *twostream* ]]; then
   DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_batch1.json timeout 800 python tools/bench_two_stream.py > $O/two_stream.log 2>&1; echo "twostream rc=$?"
   grep -E '^\{' $O/two_stream.log; grep -vE '^\{' $O/two_stream.log | tail -8
 fi
+if [[ $WHAT == *wanvae* ]]; then
+  timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_models_gpu.py -m gpu -q -s --timeout 300 -k "k_valid or wan_vae or decodes_video or all_variants" > $O/pytest_wan.log 2>&1; echo "pytest wan rc=$?" | tee -a $O/pytest_wan.log
+  grep -E "passed|failed|FAILED|Error|\[parity\]" $O/pytest_wan.log | tail -12
+  # every shape of the decoder re-tuned with the current kernels (empty table), with and without k_valid
+  DIFFUSERS_AMD_TUNE_DB=$O/none.json DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_wan_vae.json timeout 900 python tools/bench_wan_vae.py > $O/wan_vae.log 2>&1; echo "wanvae rc=$?"
+  grep -E '^\{|bench_wan_vae' $O/wan_vae.log | tail -8; grep -vE '^\{|bench_wan_vae' $O/wan_vae.log | tail -5
+fi
