@@ -93,6 +93,8 @@ bool tile_ok(const da_gemm_params& p, int tile) {
   if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) &&
       (tile == DA_TILE_128x64 || tile == DA_TILE_64x64 || tile == DA_TILE_128x128_W8))
     return false;
+  // the 4 x 2 wave tile has no registers for the LayerNorm fold (either side)
+  if (tile == DA_TILE_256x256 && (p.stats_out || p.ln_stats)) return false;
   return true;
 }
 

@@ -1,10 +1,21 @@
 // Shared kernel template of the bf16 MFMA GEMM / implicit-GEMM conv (instantiated by gemm.hip for nn.Linear and by
 // gemm_conv.hip for nn.Conv2d so the two halves compile in parallel).  See gemm.hip for the design notes.
 #pragma once
+#include <type_traits>
+
 #include "common.cuh"
 #include "diffusers_amd.h"
 
 namespace da_gemm {
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 static __device__ uint4 g_zero_line[8];  // 128 B of zeros: source for out-of-bounds rows in the direct-to-LDS path
 
@@ -69,6 +80,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   constexpr bool GLDS = (SM != 0), BLDS = (SM == 2);
   constexpr int NW = WM * WN, NTHR = 64 * NW, RP = NTHR / 8;  // RP = tile rows staged per pass (one 1 KiB piece per wave)
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  // LayerNorm fold (both sides) and the epilogue operand prefetch need registers the 4 x 2 wave tile (256x256) does not
+  // have: with them it spills (round 1: 178 VGPRs, no scratch).  The host refuses stats_out / ln_stats for that tile.
+  constexpr bool LNF = !CONV && (MT * NT < 8);
   constexpr int XR = BM / RP, WR = BN / RP;  // staged rows per thread
   constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
   constexpr int PD = STAGES - 1;             // prefetch distance
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   // row holds DA_LN_MAX_PARTS slots; slots past ln_parts are masked in part 2).  DA_LN_PAIR_LOADS pairs per lane half
   // cover 4 * DA_LN_PAIR_LOADS partials per row -- the host refuses more.
   float4 ln_v[MT][DA_LN_PAIR_LOADS];
-  if constexpr (!CONV) {
+  if constexpr (LNF) {
     if (p.ln_stats) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -486,10 +500,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   // Same for the bias (one 8-byte load per 4 output channels, shared by the MT row tiles) and the per-batch channel
   // vector (ResnetBlock2D's time embedding): in the epilogue loop each sat in front of its fragment's arithmetic.
   constexpr bool RV_PF = RES_PF && !KSKIP;   // the k_valid builds sit at the 256-register line of 2 waves per SIMD
-  uint2 bias_v[NT][4], rowvec_v[RV_PF ? MT : 1][RV_PF ? NT : 1][4];
+  uint2 bias_v[RES_PF ? NT : 1][4], rowvec_v[RV_PF ? MT : 1][RV_PF ? NT : 1][4];
   {
     const uint16_t* __restrict__ bias_pf = (const uint16_t*)p.bias;
-    if (bias_pf) {   // GEGLU: sub-tile 2jp holds the value rows, 2jp + 1 the gate rows (= value + 32): same formula
+    if constexpr (RES_PF) if (bias_pf) {   // GEGLU: sub-tile 2jp holds the value rows, 2jp + 1 the gate rows (= value + 32): same formula
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   float ln_mu[MT], ln_rs[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) ln_mu[i] = 0.f, ln_rs[i] = 1.f;
-  if constexpr (!CONV) {
+  if constexpr (LNF) {
     if (p.ln_stats) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -663,10 +677,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   float st_sum[MT], st_sq[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) st_sum[i] = 0.f, st_sq[i] = 0.f;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  // (a lambda over a compile-time row-tile index, not a loop: the 4 x 2 wave tile's loop was not unrolled any more once the
+  // body grew, and its dynamically indexed accumulators went through 512 B of scratch per lane)
+  auto epilogue_rows = [&](auto i_c) {
+    constexpr int i = decltype(i_c)::value;
     const int m = m0 + (wm * MT + i) * 32 + l31;
-    if (m >= p.M) continue;
+    if (m >= p.M) return;
     const int bidx = (rowvec != nullptr || gate != nullptr) ? (m / p.rows_per_batch) : 0;
     const float brow = bias_rows ? bf2f(bias_rows[m]) : 0.f;
     if (geglu) {
@@ -682,7 +698,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
             if (nv >= p.N) continue;
             float o[4];
             float lsv[4] = {0.f, 0.f, 0.f, 0.f}, lcv[4] = {0.f, 0.f, 0.f, 0.f}, lsg[4] = {0.f, 0.f, 0.f, 0.f}, lcg[4] = {0.f, 0.f, 0.f, 0.f};
-            const bool fold = !CONV && p.ln_stats != nullptr;
+            const bool fold = LNF && p.ln_stats != nullptr;
             if (fold) {   // LayerNorm fold (see da_gemm_params): s / c of the value and the gate rows, 16 bytes each
               const float4 a = *(const float4*)(p.ln_s + nv), b = *(const float4*)(p.ln_c + nv);
               const float4 c = *(const float4*)(p.ln_s + nv + 32), d = *(const float4*)(p.ln_c + nv + 32);
@@ -698,7 +714,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
                 gv = ln_rs[i] * (gv - ln_mu[i] * lsg[e]) + lcg[e];
               }
               if (bias) {
-                const uint2 bh = bias_v[2 * jp][g], bg = bias_v[2 * jp + 1][g];
+                uint2 bh, bg;
+                if constexpr (RES_PF) {
+                  bh = bias_v[2 * jp][g], bg = bias_v[2 * jp + 1][g];
+                } else {
+                  bh = *(const uint2*)(bias + nv), bg = *(const uint2*)(bias + nv + 32);
+                }
                 hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
                 gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
               }
@@ -714,7 +735,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
           }
         }
       }
-      continue;
+      return;
     }
     float st1 = 0.f, st2 = 0.f;   // LayerNorm fold, producer side: this lane's share of the row's (sum, sum of squares)
 #pragma unroll
@@ -726,7 +747,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * p.alpha;
-        if (!CONV && p.ln_stats) {
+        if (LNF && p.ln_stats) {
           const float4 sv = *(const float4*)(p.ln_s + n), cv = *(const float4*)(p.ln_c + n);
           o[0] = ln_rs[i] * (o[0] - ln_mu[i] * sv.x) + cv.x;
           o[1] = ln_rs[i] * (o[1] - ln_mu[i] * sv.y) + cv.y;
@@ -734,7 +755,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
           o[3] = ln_rs[i] * (o[3] - ln_mu[i] * sv.w) + cv.w;
         }
         if (bias) {
-          const uint2 bv = bias_v[j][g];
+          uint2 bv;
+          if constexpr (RES_PF) bv = bias_v[j][g];
+          else bv = *(const uint2*)(bias + n);
           o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y);
         }
         if (bias_rows) {
@@ -795,7 +818,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
           pk.x = pack_bf2(o[0], o[1]);
           pk.y = pack_bf2(o[2], o[3]);
           *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + n) = pk;
-          if (!CONV && p.stats_out) {   // statistics of the STORED (bf16-rounded) values, as a LayerNorm kernel would see them
+          if (LNF && p.stats_out) {   // statistics of the STORED (bf16-rounded) values, as a LayerNorm kernel would see them
             const float r0 = bf_lo(pk.x), r1 = bf_hi(pk.x), r2 = bf_lo(pk.y), r3 = bf_hi(pk.y);
             st1 += (r0 + r1) + (r2 + r3);
             st2 += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
@@ -803,15 +826,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         }
       }
     }
-    if (!CONV && p.stats_out) {
+    if (LNF && p.stats_out) {
       st_sum[i] = st1;
       st_sq[i] = st2;
     }
-  }
+  };
+  static_for<MT>(epilogue_rows);
   // LayerNorm fold, producer side: ONE partial per (row, column tile).  The WN waves of a block row hold disjoint column
   // ranges of the same rows: combine them through LDS (the ring is free once every wave has left the main loop) in wave
   // order -- fixed summation order, no atomics -- and let thread r write row r's pair.
-  if constexpr (!CONV) {
+  if constexpr (LNF) {
     if (p.stats_out) {
       float2* red = (float2*)smem;
       __syncthreads();

@@ -117,3 +117,18 @@ if [[ $WHAT == *wanvae* ]]; then
   DIFFUSERS_AMD_TUNE_DB=$O/none.json DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_wan_vae.json timeout 900 python tools/bench_wan_vae.py > $O/wan_vae.log 2>&1; echo "wanvae rc=$?"
   grep -E '^\{|bench_wan_vae' $O/wan_vae.log | tail -8; grep -vE '^\{|bench_wan_vae' $O/wan_vae.log | tail -5
 fi
+if [[ $WHAT == *others* ]]; then
+  # the other BASELINE configs, every GEMM / conv shape re-tuned with the current kernels (empty table) and saved
+  for cfg in flux sd15 ddpm wan; do
+    DIFFUSERS_AMD_TUNE_DB=$O/none.json DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_$cfg.json timeout 900 python tools/bench_$cfg.py > $O/$cfg.log 2>&1; echo "$cfg rc=$?"
+    grep -E '^\{' $O/$cfg.log | cut -c1-400; grep -vE '^\{' $O/$cfg.log | grep -v amdgpu.ids | tail -2
+  done
+fi
+if [[ $WHAT == *fluxprof* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/prof_flux
+  timeout 420 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_flux -o flux -- python $R/tools/bench_flux.py > $O/prof_flux.log 2>&1; echo "fluxprof rc=$?"
+  find $O/prof_flux -name '*kernel_trace*' -size +30M -delete
+  cd $R
+  python tools/prof_summary.py $(find $O/prof_flux -name '*kernel_stats.csv' | head -1) "flux-schnell (tools/bench_flux.py)" > $O/prof_flux_summary.md 2>> $O/prof_flux.log; head -28 $O/prof_flux_summary.md
+fi

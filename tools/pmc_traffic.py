@@ -66,8 +66,9 @@ def main():
             continue
         lines.append(f"| `{k}` | {n} | {fb / 1e6:.3f} | {wb / 1e6:.3f} | {(fb + wb) / 1e6:.3f} | {(fb * nf + wb * nw) / 1e9:.2f} |")
     ig = rec.get("igemm_bf16_kernel")
-    out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --no-graph --steps 1; "
-                     f"{out_md.name}", "unit": "bytes", "families": rec}
+    out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 2x FETCH_SIZE correction) on the SDXL "
+                     f"denoising-step kernels launched eagerly (tools/pmc_one_step.py); profiles/{out_md.name}",
+           "unit": "bytes", "families": rec}
     if ig:
         tot = ig["fetched_bytes_per_launch"] + ig["written_bytes_per_launch"]
         out["igemm_bytes_per_launch"] = tot
