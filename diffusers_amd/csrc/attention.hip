@@ -22,6 +22,8 @@
 // against ~0.5 k cycles of MFMA work.  One rendezvous per tile orders both hazards: every wave has passed its wait
 // for tile j (tile j has landed for all readers) and has retired its LDS reads of tile j-1 (lgkmcnt(0)), whose slot the
 // DMA issued right after the barrier overwrites.
+#include <type_traits>
+
 #include "common.cuh"
 
 namespace {
@@ -53,8 +55,13 @@ __device__ __forceinline__ int k_swz(int row) {
 // MASKED (D = 64 instantiations only): causal mask and / or an additive score bias -- the text encoders (CLIP: causal;
 // T5 / UMT5: relative position bias + key padding, scale 1).  The unmasked instantiations carry none of this code.
 // NW = waves per block = 32-query groups per block (4: 128 queries, the default; 2: 64 queries, da_attention_params.q_block).
-template <int D, int NS, bool MASKED = false, int NW = 4>
+// PIPE (unmasked, NS = 3): the P.V product of tile j - 1 is issued AFTER the Q.K^T product of tile j, so its MFMAs run
+// under tile j's softmax arithmetic instead of behind it (one more P fragment set and one more ring slot -- tile j - 1's V^T
+// stays resident while tile j + 1 lands).  Same operations on the same values in the same order per accumulator:
+// bit-identical to the unpipelined kernel.
+template <int D, int NS, bool MASKED = false, int NW = 4, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
+  static_assert(!PIPE || (NS == 3 && !MASKED), "the pipelined loop is the unmasked 3-slot variant");
   using C = AttnCfg<D, NW>;
   constexpr int QT = 32 * NW;                // queries per block
   constexpr int PD = NS - 1;                 // prefetch distance (tiles in flight ahead of the one being consumed)
@@ -150,6 +157,162 @@ __global__ __launch_bounds__(64 * NW, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(co
   const int ksw = k_swz<D>(l31);           // K fragment swizzle of this lane's row
   const int vsw = (l31 >> 1) & 7;          // V^T 16-byte chunk swizzle of this lane's row ((32*dt + l31) >> 1) & 7
 
+  if constexpr (PIPE) {
+    bf16x8_t pf[4];            // P^T fragments of the previous tile, consumed one iteration late
+    auto pv = [&](const unsigned char* vb) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt) {
+          const unsigned char* vrow = vb + (32 * dt + l31) * 128;
+          const uint2 a0 = *(const uint2*)(vrow + (((2 * u) ^ vsw) << 4) + 8 * hi);
+          const uint2 a1 = *(const uint2*)(vrow + (((2 * u + 1) ^ vsw) << 4) + 8 * hi);
+          const uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), pf[u], o[dt], 0, 0, 0);
+        }
+      }
+    };
+    issue(0, 0);
+    int cur = 0, prv = 2, nxt = 1;   // ring slots of tile j, tile j - 1, tile j + 1
+    // One iteration.  HAS_PREV: tile j - 1's product is pending; RAGGED: tile j may reach past Skv.  Both are compile-time
+    // so that [Q.K^T(j), P.V(j-1), softmax(j), pack P(j)] is ONE branch-free scheduling region: the directives at its end
+    // put each P.V MFMA in front of its share of the softmax VALU work (the in-order issue would otherwise run all 16
+    // MFMAs first and the softmax behind them).
+    auto iter = [&](int j, auto has_prev_c, auto ragged_c) {
+      constexpr bool HAS_PREV = decltype(has_prev_c)::value, RAGGED = decltype(ragged_c)::value;
+      // only tile j is outstanding here; after the rendezvous every wave has finished iteration j - 1, i.e. its reads
+      // of tile j - 2's V^T -- the slot tile j + 1 now goes to
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (j + 1 < ntiles) issue(j + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* kb = smem + cur * C::STAGE;
+
+      f32x16_t s[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+      {
+        const unsigned char* krow0 = kb + l31 * (2 * D);
+        const unsigned char* krow1 = kb + (32 + l31) * (2 * D);
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+          const int off = ((2 * ks + hi) ^ ksw) << 4;
+          const bf16x8_t kf0 = *(const bf16x8_t*)(krow0 + off);
+          const bf16x8_t kf1 = *(const bf16x8_t*)(krow1 + off);
+          s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s[0], 0, 0, 0);
+          s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s[1], 0, 0, 0);
+        }
+      }
+      // ragged last tile: select, not branch
+      const int kv0 = j * 64;
+      if constexpr (RAGGED) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = kv0 + 32 * st + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            s[st][r] = (kv >= p.Skv) ? -1e30f : s[st][r];
+          }
+      }
+      // The softmax of tile j in 8 slices, each fenced behind ONE (D = 128: two) MFMA of O^T += V^T(j-1) . P^T(j-1): the
+      // wave issues in order, so a P.V MFMA only runs under softmax VALU work that FOLLOWS it in the instruction stream.
+      // (sched_group_barrier could not express this: the scheduler kept all 16 MFMAs in front of the first v_max.)
+      float mx = -1e30f, m_new = 0.f, alpha = 1.f, psum = 0.f;
+      bf16x8_t pn[4];
+      auto slice = [&](int sl) {
+        if (sl == 1) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][r]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          m_new = fmaxf(m_run, mx * sl2);
+          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+        } else if (sl >= 2 && sl <= 5) {
+          const int st = (sl - 2) >> 1, r0 = 8 * ((sl - 2) & 1);
+#pragma unroll
+          for (int r = r0; r < r0 + 8; ++r) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sl2, -m_new));
+            s[st][r] = e;
+            psum += e;
+          }
+        } else if (sl >= 6) {
+          if (sl == 6) l_run = l_run * alpha + psum;
+#pragma unroll
+          for (int u = 2 * (sl - 6); u < 2 * (sl - 6) + 2; ++u) {
+            const int b8 = 8 * (u & 1);
+            const uint4 pk = make_uint4(pack_bf2(s[u >> 1][b8 + 0], s[u >> 1][b8 + 1]), pack_bf2(s[u >> 1][b8 + 2], s[u >> 1][b8 + 3]),
+                                        pack_bf2(s[u >> 1][b8 + 4], s[u >> 1][b8 + 5]), pack_bf2(s[u >> 1][b8 + 6], s[u >> 1][b8 + 7]));
+            pn[u] = __builtin_bit_cast(bf16x8_t, pk);
+          }
+        }
+      };
+      if constexpr (HAS_PREV) {
+        constexpr int DT = D / 32, NPV = 4 * DT, PER = NPV / 8;   // P.V MFMAs per slice
+        const unsigned char* vb = smem + prv * C::STAGE + C::KBYTES;
+        auto vload = [&](int k) {
+          const int u = k / DT, dt = k % DT;
+          const unsigned char* vrow = vb + (32 * dt + l31) * 128;
+          const uint2 a0 = *(const uint2*)(vrow + (((2 * u) ^ vsw) << 4) + 8 * hi);
+          const uint2 a1 = *(const uint2*)(vrow + (((2 * u + 1) ^ vsw) << 4) + 8 * hi);
+          return __builtin_bit_cast(bf16x8_t, make_uint4(a0.x, a0.y, a1.x, a1.y));
+        };
+        bf16x8_t av[PER], an[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) av[q] = vload(q);
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+#pragma unroll
+          for (int q = 0; q < PER; ++q)
+            if (sl < 7) an[q] = vload((sl + 1) * PER + q);          // next slice's V^T fragments fly under this slice
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const int k = sl * PER + q;
+            o[k % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q], pf[k / DT], o[k % DT], 0, 0, 0);
+          }
+          slice(sl);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < PER; ++q) av[q] = an[q];
+        }
+      } else {
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) slice(sl);
+      }
+      // the packed P must exist HERE: otherwise the compiler sinks the exponentials below the rescale branch and the
+      // P.V MFMAs above are left with nothing to run over
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(pn[u]));
+      __builtin_amdgcn_sched_barrier(0);
+      // rescale AFTER tile j - 1's product has been added: O_j-1 complete, then * alpha_j, then (next iteration) + P_j V_j
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pf[u] = pn[u];
+      const int t3 = prv;
+      prv = cur;
+      cur = nxt;
+      nxt = t3;
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (ntiles == 1) {
+      iter(0, F_{}, T_{});
+    } else {
+      iter(0, F_{}, F_{});
+      for (int j = 1; j < ntiles - 1; ++j) iter(j, T_{}, F_{});
+      iter(ntiles - 1, T_{}, T_{});
+    }
+    pv(smem + prv * C::STAGE + C::KBYTES);   // the last tile's product (its slot was not refilled: no tile ntiles + 1)
+  } else {
 #pragma unroll
   for (int t0 = 0; t0 < PD; ++t0)
     if (t0 < ntiles) issue(t0, t0);
@@ -286,6 +449,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(co
     cur = (cur + 1 == NS) ? 0 : cur + 1;
     nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
   }
+  }  // !PIPE
 
   // ---- epilogue ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -305,11 +469,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(co
   }
 }
 
-template <int D, int NS, bool MASKED = false, int NW = 4>
+template <int D, int NS, bool MASKED = false, int NW = 4, bool PIPE = false>
 int launch_attn(const da_attention_params& p, hipStream_t s) {
   using C = AttnCfg<D, NW>;
   const size_t lds = (size_t)NS * C::STAGE;
-  auto kern = attn_fwd_kernel<D, NS, MASKED, NW>;
+  auto kern = attn_fwd_kernel<D, NS, MASKED, NW, PIPE>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -329,6 +493,9 @@ int launch_attn(const da_attention_params& p, hipStream_t s) {
 // Measured (profiles/r02b_kernel_experiments.md): the tile loop is bound by its VALU work (exp2 / max / packing), not by
 // the K / V^T stream -- a deeper ring changes nothing at D = 128 (S = 4608: 586 / 563 / 566 us for 2 / 3 / 4 slots) and
 // costs occupancy at D = 64 (S = 4096: 147 / 149 / 167 us)
+// Default of da_attention_params.pv_delay, measured (profiles/r02g_attention_pv_delay.md): + 3-6 % at D = 64 on long key
+// sequences, - 6 % at D = 128 (Flux), nothing on the 77-key cross attention -- the tile loop is bound by its VALU instruction
+// count (exp2 at quarter rate, max / sum, packing), which both loops share, not by MFMA time waiting behind VALU time.
 template <int D>
 int launch_attn_ring(const da_attention_params& p, hipStream_t s) {
   using C = AttnCfg<D>;
@@ -344,6 +511,12 @@ int launch_attn_ring(const da_attention_params& p, hipStream_t s) {
     // workgroups leave CUs with one block (SDXL S = 1024: 34.9 vs 36.1 us) and cost 1.3-1.5x at S = 4096
     const bool q64 = p.q_block == 64;
     if (q64 && ns == 2) return launch_attn<64, 2, false, 2>(p, s);
+  }
+  // PV-delayed loop: on request, for the head sizes it is built for; by default where it measured faster (see above)
+  if constexpr (D == 64 || D == 128) {
+    const bool delay = p.pv_delay ? p.pv_delay > 0 : (D == 64 && p.Skv >= 512);
+    if (delay && p.Skv > 64 && (p.ring_slots == 0 || p.ring_slots == 3) && p.q_block != 64)
+      return launch_attn<D, 3, false, 4, true>(p, s);
   }
   switch (ns) {
     case 2: return launch_attn<D, 2>(p, s);
@@ -363,6 +536,7 @@ extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
   if (p.Skv_alloc < p.Skv || (p.Skv_alloc & 7)) return DA_ERR_INVALID;
   if (p.ring_slots != 0 && (p.ring_slots < 2 || p.ring_slots > 4)) return DA_ERR_INVALID;
   if (p.q_block != 0 && p.q_block != 64 && p.q_block != 128) return DA_ERR_INVALID;
+  if (p.pv_delay < -1 || p.pv_delay > 1) return DA_ERR_INVALID;
   if (p.bias && (p.bias_row_stride < ((p.Skv + 63) & ~63) || (p.bias_row_stride & 3) || (p.bias_batch_stride & 3) ||
                  (p.bias_head_stride & 3) || p.scale == 0.0f))
     return DA_ERR_INVALID;

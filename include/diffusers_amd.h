@@ -204,6 +204,9 @@ typedef struct da_attention_params {
   int q_block; /* queries per workgroup: 0 / 128 = four waves (default), 64 = two waves (D = 64, unmasked, ring depth 2
                   only; other cases run 128).  Speed only: each wave owns 32 queries and walks the same K / V^T tiles in
                   the same order either way -> bit-identical outputs */
+  int pv_delay; /* 0 = default for the head size, 1 = on, -1 = off.  On (D = 64 / 128, unmasked, 3 ring slots): the P.V
+                   product of K / V tile j - 1 is issued after the Q.K^T product of tile j so that it runs under tile j's
+                   softmax arithmetic.  Speed only: the same operations in the same order per accumulator. */
 } da_attention_params;
 
 int da_attention_bf16(const da_attention_params* p, void* stream);

@@ -490,6 +490,30 @@ def test_flash_attention_query_block_sizes_are_bit_identical(B, H, Sq, Skv):
         run(32)
 
 
+@pytest.mark.parametrize("B,H,D,Sq,Skv", [(2, 3, 64, 256, 256), (1, 2, 64, 200, 333), (1, 5, 64, 1024, 1024), (2, 2, 64, 130, 77),
+                                         (1, 2, 64, 96, 64), (1, 2, 128, 192, 320), (1, 2, 128, 520, 1030), (2, 1, 128, 64, 129)])
+def test_flash_attention_pv_delay_is_bit_identical(B, H, D, Sq, Skv):
+    """da_attention_params.pv_delay: the loop that issues tile j - 1's P.V product under tile j's softmax performs the same
+    operations in the same order per accumulator -- not one bit may differ from the plain loop (and it must be right)."""
+    ops, L = _ops()
+    C = H * D
+    q, k, v = rnd((B, Sq, C), 36), rnd((B, Skv, C), 37), rnd((B, Skv, C), 38)
+    k[0, Skv // 2] = q[0, 5] * 3.0          # a late jump of the running maximum: the rescale branch runs mid-sequence
+    sa = ((Skv + 15) // 16) * 16
+    kp = torch.zeros((B, sa, C), device=DEV, dtype=bf16)
+    kp[:, :Skv] = k
+    vt = torch.zeros((C, B * sa), device=DEV, dtype=bf16)
+    vt.view(C, B, sa)[:, :, :Skv] = v.permute(2, 0, 1)
+    def run(pd):
+        return ops.attention(q.view(B * Sq, C), kp.view(B * sa, C), vt, B=B, H=H, D=D, Sq=Sq, Skv=Skv, Skv_alloc=sa,
+                             q_row_stride=C, k_row_stride=C, q_batch_stride=Sq * C, k_batch_stride=sa * C,
+                             vt_ld=B * sa, vt_batch_stride=sa, pv_delay=pd)
+    plain, delayed, auto = run(-1), run(1), run(0)
+    assert torch.equal(plain, delayed) and torch.equal(auto, plain)
+    assert_close_bf16(delayed, _attn_ref(q, k, v, H).view(B * Sq, C), f"flash attn pv_delay B{B} H{H} D{D} Sq{Sq} Skv{Skv}",
+                      rtol=1.6e-2, atol_rms=1.6e-2)
+
+
 def test_flash_attention_rescale_branch():
     """Force the online-softmax running max to jump late: one key matches one query far more than the others."""
     ops, L = _ops()

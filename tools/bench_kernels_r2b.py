@@ -57,5 +57,33 @@ def main():
         print(json.dumps(rec), flush=True)
 
 
+def attn_pv_delay():
+    K.FLUSH = torch.empty(320 << 20, dtype=torch.uint8, device="cuda")
+    for name, B, H, S, Skv, D in [("sdxl self 1024", 2, 20, 1024, 1024, 64), ("sdxl self 4096", 2, 10, 4096, 4096, 64),
+                                  ("sdxl cross 1024", 2, 20, 1024, 77, 64), ("sdxl cross 4096", 2, 10, 4096, 77, 64),
+                                  ("sd15 self 4096 (d40->64)", 2, 8, 4096, 4096, 64), ("flux joint", 1, 24, 4608, 4608, 128),
+                                  ("wan slice", 1, 12, 8192, 8192, 128)]:
+        inner = H * D
+        sa = ((Skv + 15) // 16) * 16
+        q, k, vt = rnd((B * S, inner)), rnd((B * sa, inner)), rnd((inner, B * sa))
+        def run(pd):
+            return ops.attention(q, k, vt, B=B, H=H, D=D, Sq=S, Skv=Skv, Skv_alloc=sa, q_row_stride=inner, k_row_stride=inner,
+                                 q_batch_stride=S * inner, k_batch_stride=sa * inner, vt_ld=B * sa, vt_batch_stride=sa,
+                                 pv_delay=pd)
+        ref = run(-1)
+        rec = {"op": "attn_pv_delay", "name": name, "tflop": round(4.0 * B * H * S * Skv * D / 1e12, 4),
+               "same": bool(torch.equal(run(1), ref))}
+        for rep in range(2):            # interleaved A/B
+            for pd in (-1, 1):
+                tmin, tmed = timeit(lambda: run(pd), iters=10, warm=2)
+                key = "plain_us" if pd < 0 else "delayed_us"
+                rec[key] = round(min(rec.get(key, 1e9), tmin), 1)
+        rec["speedup"] = round(rec["plain_us"] / rec["delayed_us"], 3)
+        print(json.dumps(rec), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "attn":
+        attn_pv_delay()
+    else:
+        main()

@@ -132,3 +132,9 @@ if [[ $WHAT == *fluxprof* ]]; then
   cd $R
   python tools/prof_summary.py $(find $O/prof_flux -name '*kernel_stats.csv' | head -1) "flux-schnell (tools/bench_flux.py)" > $O/prof_flux_summary.md 2>> $O/prof_flux.log; head -28 $O/prof_flux_summary.md
 fi
+if [[ $WHAT == *pvdelay* ]]; then
+  timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_full_size_gpu.py -m gpu -q -s --timeout 300 -k "flash_attention or attention" > $O/pytest_pv.log 2>&1; echo "pytest pv rc=$?" | tee -a $O/pytest_pv.log
+  grep -E "passed|failed|FAILED|Error" $O/pytest_pv.log | tail -8
+  timeout 600 python tools/bench_kernels_r2b.py attn > $O/attn_pv.log 2>&1; echo "attn pv rc=$?"
+  grep -E '^\{' $O/attn_pv.log | cut -c1-300; grep -vE '^\{' $O/attn_pv.log | tail -5
+fi
