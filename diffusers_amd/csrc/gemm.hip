@@ -74,6 +74,7 @@ int validate(da_gemm_params& p) {
     return DA_ERR_UNSUPPORTED;
   if (p.act < 0 || p.act > DA_ACT_GEGLU_TANH) return DA_ERR_INVALID;
   if (p.split_k < 0 || p.split_k > 8) return DA_ERR_INVALID;
+  if (p.split_k > 1 && (p.stats_out || p.ln_stats)) return DA_ERR_UNSUPPORTED;   // no split-K build of the LayerNorm fold
   if (p.k_valid < 0 || (p.k_valid > 0 && (p.k_valid > (p.conv ? p.C1 : p.K) || (p.conv && p.C2 != 0)))) return DA_ERR_INVALID;
   if (p.stats_out && (p.conv || p.out_f32 || p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH || p.stats_ld <= 0 || (p.stats_ld & 1)))
     return DA_ERR_UNSUPPORTED;

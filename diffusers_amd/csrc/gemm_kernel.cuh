@@ -66,7 +66,8 @@ struct RowInfo {      // per staged activation row (implicit GEMM gather state)
 //    polling lane, bounded spin); the consumer re-arms the flag for the next launch on the stream.  The sum order is
 //    fixed (own slices, then slot 0, 1, ...), so a given split_k is deterministic; different split_k differ in the
 //    last fp32 bit of the sum.  The host admits split-K only when every block of the launch is co-resident.
-template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false, bool KSKIP = false>
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false, bool KSKIP = false,
+          bool LNFOLD = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_params prob_a, const int xcd_gx_a,
                                                                   const da_gemm_params prob_b, const int xcd_gx_b,
                                                                   const int grid_a) {
@@ -80,9 +81,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
   constexpr bool GLDS = (SM != 0), BLDS = (SM == 2);
   constexpr int NW = WM * WN, NTHR = 64 * NW, RP = NTHR / 8;  // RP = tile rows staged per pass (one 1 KiB piece per wave)
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
-  // LayerNorm fold (both sides) and the epilogue operand prefetch need registers the 4 x 2 wave tile (256x256) does not
-  // have: with them it spills (round 1: 178 VGPRs, no scratch).  The host refuses stats_out / ln_stats for that tile.
-  constexpr bool LNF = !CONV && (MT * NT < 8);
+  // LayerNorm fold (da_gemm_params.stats_out / ln_*): its own instantiations (LNFOLD) -- carried by every kernel it cost the
+  // register-heaviest 4-wave tile 5-9 % (128x128, 2 slots: SDXL GEGLU projection 88 -> 80 us without it), and the fold
+  // itself measured slower than the LayerNorm kernel it replaces (profiles/r02d_layernorm_fold.md).
+  constexpr bool LNF = LNFOLD && !CONV && (MT * NT < 8);
   constexpr int XR = BM / RP, WR = BN / RP;  // staged rows per thread
   constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
   constexpr int PD = STAGES - 1;             // prefetch distance
@@ -901,7 +903,8 @@ inline int problem_grid(const da_gemm_params& p, int* gx_out) {
 }
 
 // pb == nullptr: one problem.  Otherwise both problems run in ONE launch (see the kernel header).
-template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false, bool KSKIP = false>
+template <int WM, int WN, int MT, int NT, int STAGES, bool CONV, int SM, bool SPLITK = false, bool KSKIP = false,
+          bool LNFOLD = false>
 int launch(const da_gemm_params& p, const da_gemm_params* pb, hipStream_t s) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   int gx_a = 1, gx_b = 1;
@@ -921,7 +924,7 @@ int launch(const da_gemm_params& p, const da_gemm_params* pb, hipStream_t s) {
     if (tiles * (p.split_k - 1) * BM * BN * 4 > (size_t)p.workspace_bytes) return DA_ERR_INVALID;
     if (tiles * (p.split_k - 1) > DA_SPLITK_ERR_SLOT) return DA_ERR_INVALID;
   }
-  auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, SM, SPLITK, KSKIP>;
+  auto kern = igemm_bf16_kernel<WM, WN, MT, NT, STAGES, CONV, SM, SPLITK, KSKIP, LNFOLD>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -980,6 +983,29 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s, cons
     }
 #undef DA_SK
     return DA_ERR_UNSUPPORTED;
+  }
+  if (p.stats_out || p.ln_stats || (pb && (pb->stats_out || pb->ln_stats))) {
+    // LayerNorm-fold instantiations (nn.Linear, buffer-addressed staging): every 4- and 8-wave tile with 2 ring slots, the
+    // three 3-slot variants the SDXL shapes use
+    if constexpr (CONV) {
+      return DA_ERR_UNSUPPORTED;
+    } else {
+      if (!buf || pb || p.split_k > 1) return DA_ERR_UNSUPPORTED;
+#define DA_LN(T_, ST_, WM_, WN_, MT_, NT_, NS_) \
+  if (tile == (T_) && staging == (ST_)) return launch<WM_, WN_, MT_, NT_, NS_, false, 2, false, false, true>(p, nullptr, s)
+      DA_LN(DA_TILE_128x128, DA_STAGE_LDS_DIRECT, 2, 2, 2, 2, 2);
+      DA_LN(DA_TILE_64x128, DA_STAGE_LDS_DIRECT, 2, 2, 1, 2, 2);
+      DA_LN(DA_TILE_128x64, DA_STAGE_LDS_DIRECT, 2, 2, 2, 1, 2);
+      DA_LN(DA_TILE_64x64, DA_STAGE_LDS_DIRECT, 2, 2, 1, 1, 2);
+      DA_LN(DA_TILE_256x128, DA_STAGE_LDS_DIRECT, 4, 2, 2, 2, 2);
+      DA_LN(DA_TILE_128x256, DA_STAGE_LDS_DIRECT, 2, 4, 2, 2, 2);
+      DA_LN(DA_TILE_128x128_W8, DA_STAGE_LDS_DIRECT, 2, 4, 2, 1, 2);
+      DA_LN(DA_TILE_128x64, DA_STAGE_LDS_DIRECT3, 2, 2, 2, 1, 3);
+      DA_LN(DA_TILE_256x128, DA_STAGE_LDS_DIRECT3, 4, 2, 2, 2, 3);
+      DA_LN(DA_TILE_128x256, DA_STAGE_LDS_DIRECT3, 2, 4, 2, 2, 3);
+#undef DA_LN
+      return DA_ERR_UNSUPPORTED;
+    }
   }
   if (p.k_valid > 0 && buf && !pb) {
     // instantiations that skip the MFMA steps over channel padding (the tiles the large video convs use); any other

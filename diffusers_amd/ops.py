@@ -229,13 +229,19 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
             raise ValueError("linear(ln=): statistics / fold vectors do not match this problem (was the producer run?)")
         p.ln_stats, p.ln_stats_ld, p.ln_parts = rs.buf.data_ptr(), rs.buf.shape[1] * 2, rs.parts
         p.ln_s, p.ln_c, p.ln_eps = fold.s.data_ptr(), fold.c.data_ptr(), fold.eps
+    tile_given = tile is not None
+    if (stats_out is not None or ln is not None) and tile is None:
+        # the LayerNorm fold lives in its own kernel instantiations (a subset of the variants; the per-shape table knows
+        # nothing about them): fixed choices that measured best on the SDXL shapes (profiles/r02d_layernorm_fold.md)
+        tile, staging, split_k = ((L.TILE_128x128, L.STAGE_LDS_DIRECT) if act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH)
+                                  else (L.TILE_128x64, L.STAGE_LDS_DIRECT3)) + (1,)
     _select_variant(p, tile, staging, st, inplace=inplace, split_k=split_k, device=x.device)
     if stats_out is not None:
         if act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH) or out_f32 or stats_out.buf.shape[0] != M:
             raise ValueError("linear(stats_out=): bf16 non-GEGLU outputs only, one statistics row per output row")
         p.stats_out, p.stats_ld = stats_out.buf.data_ptr(), stats_out.buf.shape[1] * 2
         stats_out.parts = int(L.load().da_gemm_stats_parts(C.byref(p)))
-        if stats_out.parts > STATS_MAX_CONSUMED and tile is None:
+        if stats_out.parts > STATS_MAX_CONSUMED and not tile_given:
             # too many narrow column tiles for the consumer's one-batch read: take a 128- / 256-wide tile instead (every
             # tile computes the same bits, so this is a speed decision only)
             p.tile, p.staging, p.split_k = (L.TILE_128x128 if N <= 128 * STATS_MAX_CONSUMED else L.TILE_128x256), L.STAGE_LDS_DIRECT, 1
