@@ -177,10 +177,11 @@ class Upsample2D:
 class CrossKV:
     """Step-invariant cross-attention keys / transposed values of one attention layer (hoisted out of the loop)."""
 
-    __slots__ = ("k", "vt", "skv", "skv_alloc", "batch")
+    __slots__ = ("k", "vt", "skv", "skv_alloc", "batch", "bias")
 
-    def __init__(self, k, vt, skv, skv_alloc, batch):
+    def __init__(self, k, vt, skv, skv_alloc, batch, bias=None):
         self.k, self.vt, self.skv, self.skv_alloc, self.batch = k, vt, skv, skv_alloc, batch
+        self.bias = bias   # [batch][1][1][ceil64(skv)] additive key mask (encoder_attention_mask), or None
 
 
 KERNEL_HEAD_DIMS = (64, 96, 128, 160)  # head sizes of the flash kernel (csrc/attention.hip)
@@ -239,11 +240,15 @@ class Attention:
         self.to_out.weight = pad_head_cols(self.to_out.weight, heads, d, dp)
         self.scale = self.head_dim ** -0.5
 
-    def precompute_kv(self, ehs_pad: torch.Tensor, batch: int, skv: int, skv_alloc: int) -> CrossKV:
-        """ehs_pad: [batch*skv_alloc][cross_dim], zero rows beyond skv in every batch."""
+    def precompute_kv(self, ehs_pad: torch.Tensor, batch: int, skv: int, skv_alloc: int, bias=None) -> CrossKV:
+        """ehs_pad: [batch*skv_alloc][cross_dim], zero rows beyond skv in every batch.  ``bias``: the additive key mask
+        built from ``encoder_attention_mask`` (see :func:`encoder_mask_bias`); it needs the masked flash kernel (D = 64)."""
+        if bias is not None and self.kdim != 64:
+            raise ValueError(f"encoder_attention_mask: the masked attention kernel exists for head sizes <= 64 "
+                             f"(this layer: {self.head_dim})")
         k = ops.linear(ehs_pad, self.wk)
         vt = ops.linear(self.wv, ehs_pad)  # [inner][batch*skv_alloc] = V^T
-        return CrossKV(k, vt, skv, skv_alloc, batch)
+        return CrossKV(k, vt, skv, skv_alloc, batch, bias)
 
     def fold_norm(self, norm: "LayerNorm") -> None:
         """Cross-attention only: fold the LayerNorm in front of the block (attention.py:1030) into to_q."""
@@ -259,7 +264,7 @@ class Attention:
             o = ops.attention(q, kv.k, kv.vt, B=batch, H=Hh, D=D, Sq=seq, Skv=kv.skv, Skv_alloc=kv.skv_alloc,
                               q_row_stride=self.inner, k_row_stride=self.inner,
                               q_batch_stride=seq * self.inner, k_batch_stride=kv.skv_alloc * self.inner,
-                              vt_ld=batch * kv.skv_alloc, vt_batch_stride=kv.skv_alloc, scale=self.scale)
+                              vt_ld=batch * kv.skv_alloc, vt_batch_stride=kv.skv_alloc, scale=self.scale, bias=kv.bias)
         else:
             # [M][2*inner] and [inner][M]: two problems, ONE launch (neither fills the 256 CUs alone at SDXL's sizes:
             # 160 + 80 tiles of 128x256); bit-identical to two launches
@@ -343,8 +348,8 @@ class Transformer2DModel:
         self.proj_out_w = pw.reshape(pw.shape[0], -1).contiguous()
         self.proj_out_b = w.opt(prefix + ".proj_out.bias")
 
-    def precompute_kv(self, ehs_pad, batch, skv, skv_alloc):
-        return [blk.attn2.precompute_kv(ehs_pad, batch, skv, skv_alloc) for blk in self.blocks]
+    def precompute_kv(self, ehs_pad, batch, skv, skv_alloc, bias=None):
+        return [blk.attn2.precompute_kv(ehs_pad, batch, skv, skv_alloc, bias) for blk in self.blocks]
 
     def __call__(self, x, kvs):
         B, H, W_, C = x.shape
@@ -375,6 +380,24 @@ class TimestepEmbedding:
     @property
     def linear_2(self) -> Linear:
         return self.l2
+
+
+def encoder_mask_bias(mask: torch.Tensor, batch: int, skv: int) -> torch.Tensor:
+    """``encoder_attention_mask`` of the reference forward -> the attention kernel's additive key bias.
+    unet_2d_condition.py:1071-1073 / transformer_2d.py:395-398: a [batch][key_tokens] mask (1 = keep, 0 = discard) becomes
+    ``(1 - mask) * -10000`` in the sample dtype, broadcast over heads and queries; a 3-D [batch][1][key_tokens] tensor is
+    taken as that bias already.  Returns bf16 [batch][1][1][ceil64(skv)] (one row for every query)."""
+    if mask.dim() == 2:
+        bias = (1 - mask.to(bf16)) * -10000.0
+    elif mask.dim() == 3 and mask.shape[1] == 1:
+        bias = mask[:, 0].to(bf16)
+    else:
+        raise ValueError("encoder_attention_mask must be [batch][key_tokens] or a [batch][1][key_tokens] bias")
+    if bias.shape[0] != batch or bias.shape[1] != skv:
+        raise ValueError(f"encoder_attention_mask shape {tuple(mask.shape)} does not match ({batch}, {skv}) text tokens")
+    out = torch.zeros((batch, 1, 1, (skv + 63) // 64 * 64), device=mask.device, dtype=bf16)
+    out[:, 0, 0, :skv] = bias
+    return out
 
 
 def pad_encoder_states(ehs: torch.Tensor):

@@ -385,14 +385,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: 
     p.causal = int(causal)
     if bias is not None:
         _req(bias, "bias", None)
-        if bias.dtype not in (bf16, torch.float32) or bias.dim() != 4 or bias.stride(3) != 1 or bias.shape[2] < Sq:
-            raise ValueError("attention: bias must be a bf16 / fp32 [B|1][H|1][Sq][>= ceil64(Skv)] tensor, last dim contiguous")
+        if bias.dtype not in (bf16, torch.float32) or bias.dim() != 4 or bias.stride(3) != 1 or \
+                (bias.shape[2] != 1 and bias.shape[2] < Sq):
+            raise ValueError("attention: bias must be a bf16 / fp32 [B|1][H|1][Sq|1][>= ceil64(Skv)] tensor, last dim contiguous")
         if bias.shape[0] not in (1, B) or bias.shape[1] not in (1, H):
             raise ValueError("attention: bias batch / head dims must be 1 or match")
         p.bias, p.bias_f32 = bias.data_ptr(), int(bias.dtype == torch.float32)
         p.bias_batch_stride = bias.stride(0) if bias.shape[0] > 1 else 0
         p.bias_head_stride = bias.stride(1) if bias.shape[1] > 1 else 0
-        p.bias_row_stride = bias.stride(2)
+        p.bias_row_stride = bias.stride(2) if bias.shape[2] > 1 else 0   # one row for every query (key-padding mask)
     L.check(L.load().da_attention_bf16(C.byref(p), _stream()), "da_attention_bf16")
     return out
 

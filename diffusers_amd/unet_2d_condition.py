@@ -16,7 +16,7 @@ from . import ops
 from .config_utils import check_to
 from .loading import PretrainedMixin
 from .layers import (Downsample2D, GroupNorm, ResnetBlock2D, TimestepEmbedding, Transformer2DModel,
-                     Upsample2D, Weights, pad_encoder_states)
+                     Upsample2D, Weights, encoder_mask_bias, pad_encoder_states)
 
 bf16 = torch.bfloat16
 
@@ -186,18 +186,22 @@ class UNet2DConditionModel(PretrainedMixin):
         return out
 
     def precompute_conditioning(self, encoder_hidden_states: torch.Tensor,
-                                added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, Any]:
+                                added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
+                                encoder_attention_mask: Optional[torch.Tensor] = None) -> Dict[str, Any]:
         """Everything in forward() that does not depend on the timestep or the latents."""
         ops.require_hip(encoder_hidden_states, "encoder_hidden_states")
         B = encoder_hidden_states.shape[0]
         ehs_pad, skv, skv_alloc = pad_encoder_states(encoder_hidden_states.contiguous())
-        kvs = [tr.precompute_kv(ehs_pad, B, skv, skv_alloc) for tr in self._transformers()]
+        bias = None
+        if encoder_attention_mask is not None:
+            bias = encoder_mask_bias(encoder_attention_mask.to(encoder_hidden_states.device), B, skv)
+        kvs = [tr.precompute_kv(ehs_pad, B, skv, skv_alloc, bias) for tr in self._transformers()]
         aug = None
         if self.config.addition_embed_type == "text_time":
             aug = self._text_time_embedding(added_cond_kwargs, B)
         return {"kvs": kvs, "aug_emb": aug, "batch": B, "ehs_ptr": encoder_hidden_states.data_ptr()}
 
-    def _cached_conditioning(self, encoder_hidden_states, added_cond_kwargs):
+    def _cached_conditioning(self, encoder_hidden_states, added_cond_kwargs, encoder_attention_mask=None):
         """The drop-in path: an unchanged reference pipeline calls forward(sample, t, encoder_hidden_states=prompt_embeds,
         added_cond_kwargs=...) with the SAME tensors on every step (pipeline_stable_diffusion_xl.py:1208-1217), so the
         step-invariant work (140 K / V^T GEMMs + the text_time MLP for SDXL) is computed for the first call and reused
@@ -205,17 +209,28 @@ class UNet2DConditionModel(PretrainedMixin):
         def ident(t):
             return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
         added = added_cond_kwargs or {}
-        key = (ident(encoder_hidden_states), ident(added.get("text_embeds")), ident(added.get("time_ids")))
+        key = (ident(encoder_hidden_states), ident(added.get("text_embeds")), ident(added.get("time_ids")),
+               ident(encoder_attention_mask))
         hit = getattr(self, "_cond_cache", None)
         if hit is not None and hit[0] == key:
             return hit[1]
         ehs = encoder_hidden_states
         if ehs is not None and (ehs.dtype != bf16 or not ehs.is_cuda):
             ehs = ehs.to(device=self.device, dtype=bf16)
-        cond = self.precompute_conditioning(ehs, added_cond_kwargs)
+        cond = self.precompute_conditioning(ehs, added_cond_kwargs, encoder_attention_mask)
         # the cache holds references to the keyed tensors, so their storage (and data_ptr) cannot be recycled under it
-        self._cond_cache = (key, cond, (encoder_hidden_states, added.get("text_embeds"), added.get("time_ids")))
+        self._cond_cache = (key, cond, (encoder_hidden_states, added.get("text_embeds"), added.get("time_ids"),
+                                        encoder_attention_mask))
         return cond
+
+    @staticmethod
+    def _nhwc(r: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+        """A reference-layout (NCHW) residual as a channels-last bf16 tensor shaped like ``like``."""
+        ops.require_hip(r, "additional residual", (bf16, torch.float16, torch.float32))
+        if r.dim() != 4 or tuple(r.shape) != (like.shape[0], like.shape[3], like.shape[1], like.shape[2]):
+            raise ValueError(f"additional residual of shape {tuple(r.shape)} does not match the activation "
+                             f"{(like.shape[0], like.shape[3], like.shape[1], like.shape[2])} (NCHW)")
+        return r.to(bf16).permute(0, 2, 3, 1).contiguous()
 
     def _text_time_embedding(self, added_cond_kwargs, B):
         # unet_2d_condition.py:906-922
@@ -248,17 +263,29 @@ class UNet2DConditionModel(PretrainedMixin):
                 conditioning: Optional[Dict[str, Any]] = None, sampler_table=None, step_idx=None):
         """Same signature as the reference forward (unet_2d_condition.py:979-994) plus two engine extensions:
         ``conditioning`` (result of :meth:`precompute_conditioning`) and ``sampler_table``/``step_idx`` (read the
-        timestep from the device-resident sampler table so the call is HIP-graph replayable)."""
+        timestep from the device-resident sampler table so the call is HIP-graph replayable).
+
+        Handled like the reference: ``encoder_attention_mask`` (key-padding mask of the text tokens, :1071-1073, through the
+        masked flash kernel), ``down_block_additional_residuals`` / ``mid_block_additional_residual`` (ControlNet, :1178-1222:
+        added to the skip connections / the mid-block output), ``cross_attention_kwargs`` that change nothing
+        (``None``, ``{}``, ``{"scale": 1.0}``).  Refused loudly: what has no engine path (self-attention ``attention_mask``,
+        ``class_labels``, ``timestep_cond``, T2I-Adapter intra-block residuals, GLIGEN, a LoRA ``scale`` != 1 -- fuse the
+        adapter with ``fuse_lora(scale)`` instead)."""
         if not self._built:
             raise RuntimeError("UNet2DConditionModel: call load_state_dict() first")
         for name, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond),
-                        ("attention_mask", attention_mask), ("cross_attention_kwargs", cross_attention_kwargs),
-                        ("down_block_additional_residuals", down_block_additional_residuals),
-                        ("mid_block_additional_residual", mid_block_additional_residual),
-                        ("down_intrablock_additional_residuals", down_intrablock_additional_residuals),
-                        ("encoder_attention_mask", encoder_attention_mask)):
+                        ("attention_mask", attention_mask),
+                        ("down_intrablock_additional_residuals", down_intrablock_additional_residuals)):
             if v is not None:
                 raise ValueError(f"diffusers_amd UNet2DConditionModel.forward: `{name}` is not supported on the HIP path")
+        if cross_attention_kwargs:
+            extra = {k: v for k, v in cross_attention_kwargs.items() if not (k == "scale" and float(v) == 1.0)}
+            if extra:
+                raise ValueError(f"diffusers_amd UNet2DConditionModel.forward: cross_attention_kwargs {sorted(extra)} are not "
+                                 "supported on the HIP path (LoRA scales: fuse_lora(scale) packs them into the weights)")
+        if (down_block_additional_residuals is None) != (mid_block_additional_residual is None):
+            raise ValueError("ControlNet residuals: pass both down_block_additional_residuals and "
+                             "mid_block_additional_residual (unet_2d_condition.py:1104)")
         ops.require_hip(sample, "sample")
         c = self.config
         B, Cin, H, W_ = sample.shape
@@ -266,7 +293,9 @@ class UNet2DConditionModel(PretrainedMixin):
         if H % (2 ** n_up) or W_ % (2 ** n_up):
             raise ValueError("sample height/width must be divisible by 2**(num_upsamplers)")
         if conditioning is None:
-            conditioning = self._cached_conditioning(encoder_hidden_states, added_cond_kwargs)
+            conditioning = self._cached_conditioning(encoder_hidden_states, added_cond_kwargs, encoder_attention_mask)
+        elif encoder_attention_mask is not None:
+            raise ValueError("pass encoder_attention_mask to precompute_conditioning() when `conditioning` is given")
         if conditioning["batch"] != B:
             raise ValueError("conditioning batch does not match sample batch")
         kvs = conditioning["kvs"]
@@ -302,11 +331,21 @@ class UNet2DConditionModel(PretrainedMixin):
                 x = st["down"](x)
                 skips.append(x)
 
+        if down_block_additional_residuals is not None:
+            # ControlNet (:1191-1200): one residual per skip connection, NCHW like every reference activation; the sum is a
+            # bf16 add as in the reference (torch glue on the device: not part of the captured hot loop)
+            if len(down_block_additional_residuals) != len(skips):
+                raise ValueError(f"down_block_additional_residuals: expected {len(skips)} tensors, got "
+                                 f"{len(down_block_additional_residuals)}")
+            skips = [s_ + self._nhwc(r, s_) for s_, r in zip(skips, down_block_additional_residuals)]
+
         # 4. mid
         x = self.mid["resnets"][0](x, emb)
         x = self.mid["attns"][0](x, kvs[ki])
         ki += 1
         x = self.mid["resnets"][1](x, emb)
+        if mid_block_additional_residual is not None:
+            x = x + self._nhwc(mid_block_additional_residual, x)             # :1220-1222
 
         # 5. up (skip concat fused into the resnets)
         for st in self.up:

@@ -197,7 +197,9 @@ typedef struct da_attention_params {
    * causal != 0: key j is visible to query i iff j <= i (CLIP text transformer, modeling_clip.py create_causal_mask).
    * bias != NULL: scores = scale * q.k^T + bias[b][h][i][j] before the softmax: T5 / UMT5 relative position bias with
    *   scale = 1 (modeling_t5.py T5Attention: no 1/sqrt(d)), optionally with a key-padding mask folded in (entries <= -1e29
-   *   are treated as -inf).  Element type bf16 (bias_f32 == 0) or fp32; rows of bias_row_stride >= ceil64(Skv) elements. */
+   *   are treated as -inf).  Element type bf16 (bias_f32 == 0) or fp32; rows of bias_row_stride >= ceil64(Skv) elements,
+   *   or bias_row_stride == 0: ONE row shared by every query (a key-padding mask such as UNet2DConditionModel's
+   *   encoder_attention_mask, unet_2d_condition.py:1071-1073: 0 for kept keys, -10000 for discarded ones). */
   const void* bias;
   long long bias_batch_stride, bias_head_stride; /* elements; 0 = shared across batches / heads */
   int bias_row_stride, bias_f32, causal;

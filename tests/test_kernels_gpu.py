@@ -1290,6 +1290,37 @@ def test_masked_flash_attention(B, H, S, causal, with_bias, mask):
                           rel_rms_max=6e-3)
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv", [(2, 5, 256, 77), (2, 2, 1000, 77), (1, 3, 64, 130)])
+def test_cross_attention_key_padding_mask_shared_by_all_queries(B, H, Sq, Skv):
+    """bias_row_stride = 0: ONE bias row per batch for every head and query -- UNet2DConditionModel's encoder_attention_mask
+    (unet_2d_condition.py:1071-1073: 0 keep, -10000 discard, added to the scaled scores) -- vs fp32 SDPA with that mask."""
+    ops, L = _ops()
+    from diffusers_amd.layers import encoder_mask_bias
+    D, inner = 64, H * 64
+    q, k, v = rnd((B, Sq, inner), 71, 0.7), rnd((B, Skv, inner), 72, 0.7), rnd((B, Skv, inner), 73)
+    keep = torch.ones((B, Skv), dtype=torch.long, device=DEV)
+    keep[0, Skv // 2:] = 0
+    keep[-1, Skv - 3:] = 0
+    bias = encoder_mask_bias(keep, B, Skv)
+    assert bias.shape == (B, 1, 1, (Skv + 63) // 64 * 64)
+    sa = ((Skv + 15) // 16) * 16
+    kp = torch.zeros((B, sa, inner), device=DEV, dtype=bf16)
+    kp[:, :Skv] = k
+    vt = torch.zeros((inner, B * sa), device=DEV, dtype=bf16)
+    vt.view(inner, B, sa)[:, :, :Skv] = v.permute(2, 0, 1)
+    o = ops.attention(q.view(B * Sq, inner), kp.view(B * sa, inner), vt, B=B, H=H, D=D, Sq=Sq, Skv=Skv, Skv_alloc=sa,
+                      q_row_stride=inner, k_row_stride=inner, q_batch_stride=Sq * inner, k_batch_stride=sa * inner,
+                      vt_ld=B * sa, vt_batch_stride=sa, bias=bias)
+    qh, kh, vh = (t.float().cpu().view(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+    add = ((1 - keep.float().cpu()) * -10000.0)[:, None, None, :]
+    ref = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=add).transpose(1, 2).reshape(B * Sq, inner)
+    assert_close_bf16(o, ref, f"cross attention with a key-padding mask B{B} H{H} Sq{Sq} Skv{Skv}", rel_rms_max=6e-3)
+    unmasked = ops.attention(q.view(B * Sq, inner), kp.view(B * sa, inner), vt, B=B, H=H, D=D, Sq=Sq, Skv=Skv, Skv_alloc=sa,
+                             q_row_stride=inner, k_row_stride=inner, q_batch_stride=Sq * inner, k_batch_stride=sa * inner,
+                             vt_ld=B * sa, vt_batch_stride=sa)
+    assert not torch.equal(o, unmasked)
+
+
 def test_text_encoder_epilogues_and_rmsnorm():
     """DA_ACT_QUICK_GELU (CLIP-L MLP), DA_ACT_GEGLU_TANH (T5 gated-GELU feed-forward) and da_rmsnorm_bf16 (T5LayerNorm) vs the
     torch ops of the transformers modules they replace."""

@@ -355,3 +355,52 @@ def test_engine_under_the_reference_sd_pipeline(ref, emulated_kernels):
     ps = _psnr(got, want)
     print(f"[drop-in] engine under the reference SD pipeline (DDIM): PSNR {ps:.1f} dB")
     assert got.shape == want.shape and ps >= 40.0
+
+
+def test_unet_forward_handles_controlnet_residuals_and_the_encoder_mask(ref, emulated_kernels):
+    """Reference-forward arguments beyond the BASELINE call (unet_2d_condition.py:979-994) that the mirror HANDLES:
+    ControlNet residuals (:1191-1222), ``encoder_attention_mask`` (:1071-1073) and no-op ``cross_attention_kwargs`` --
+    against the live reference U-Net on the same weights; the rest must be refused loudly, never ignored."""
+    import diffusers_amd as da
+    torch.manual_seed(0)
+    from diffusers_amd import init as dinit
+    runet = ref.UNet2DConditionModel(**_as_lists(dinit.TINY_SDXL_UNET)).eval()
+    unet = da.from_reference_config(da.UNet2DConditionModel, runet.config)
+    unet.load_state_dict(runet.state_dict(), device="cpu")
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    sample = torch.randn(B, 4, 16, 16, generator=g)
+    ehs = torch.randn(B, 7, 64, generator=g)
+    added = {"text_embeds": torch.randn(B, 64, generator=g), "time_ids": torch.tensor([[16., 16., 0., 0., 16., 16.]] * B)}
+    t = torch.tensor(500.0)
+    mask = torch.tensor([[1, 1, 1, 1, 1, 0, 0], [1, 1, 1, 0, 0, 0, 0]])
+    with torch.no_grad():
+        plain = runet(sample, t, ehs, added_cond_kwargs=added).sample
+        # residual shapes = the reference's skip connections (conv_in, each resnet / downsampler output) and the mid block
+        shapes = [(B, 64, 16, 16), (B, 64, 16, 16), (B, 64, 8, 8), (B, 128, 8, 8)]
+        down = [0.3 * torch.randn(s, generator=g) for s in shapes]
+        mid = 0.3 * torch.randn(B, 128, 8, 8, generator=g)
+        want_cn = runet(sample, t, ehs, added_cond_kwargs=added, down_block_additional_residuals=tuple(down),
+                        mid_block_additional_residual=mid).sample
+        want_mask = runet(sample, t, ehs, added_cond_kwargs=added, encoder_attention_mask=mask).sample
+    to = lambda x: x.to(torch.bfloat16)  # noqa: E731
+    addb = {k: to(v) if k == "text_embeds" else v for k, v in added.items()}
+
+    def rel(a, b):
+        return float((a.float() - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    got_plain = unet(to(sample), t, to(ehs), added_cond_kwargs=addb, cross_attention_kwargs={"scale": 1.0}).sample
+    got_cn = unet(to(sample), t, to(ehs), added_cond_kwargs=addb, down_block_additional_residuals=tuple(to(d) for d in down),
+                  mid_block_additional_residual=to(mid)).sample
+    got_mask = unet(to(sample), t, to(ehs), added_cond_kwargs=addb, encoder_attention_mask=mask).sample
+    e0, e1, e2 = rel(got_plain, plain), rel(got_cn, want_cn), rel(got_mask, want_mask)
+    print(f"[drop-in] UNet forward extras vs the live reference: plain {e0:.2e}, ControlNet residuals {e1:.2e}, "
+          f"encoder_attention_mask {e2:.2e}; the extras move the output by {rel(want_cn, plain):.2e} / {rel(want_mask, plain):.2e}")
+    assert max(e0, e1, e2) < 2.5e-2
+    assert rel(want_cn, plain) > 10 * e1 and rel(want_mask, plain) > 3 * e2      # the checks above are not vacuous
+    for bad in (dict(attention_mask=torch.ones(B, 256)), dict(class_labels=torch.zeros(B)), dict(timestep_cond=torch.zeros(B, 8)),
+                dict(cross_attention_kwargs={"scale": 0.5}), dict(cross_attention_kwargs={"gligen": {}}),
+                dict(down_block_additional_residuals=tuple(to(d) for d in down)),
+                dict(down_block_additional_residuals=tuple(to(d) for d in down[:-1]), mid_block_additional_residual=to(mid)),
+                dict(down_intrablock_additional_residuals=[to(down[0])]), dict(encoder_attention_mask=torch.ones(B, 5))):
+        with pytest.raises(ValueError):
+            unet(to(sample), t, to(ehs), added_cond_kwargs=addb, **bad)
