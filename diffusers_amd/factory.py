@@ -3,8 +3,6 @@ from __future__ import annotations
 
 from typing import Optional
 
-import torch
-
 from . import init as dinit
 from .autoencoder_kl import AutoencoderKL
 from .autoencoder_kl_wan import AutoencoderKLWan
