@@ -316,10 +316,17 @@ class BasicTransformerBlock:
         self.norm2 = LayerNorm(w, prefix + ".norm2")
         self.attn2 = Attention(w, prefix + ".attn2", heads, cross=True)
         self.norm3 = LayerNorm(w, prefix + ".norm3")
-        self.ff = FeedForwardGEGLU(w, prefix + ".ff", norm=self.norm3)
-        self.attn2.fold_norm(self.norm2)
+        # the folded copies (a second GEGLU up-projection, a second to_q, fp32 s / c vectors: ~1.7 GB for SDXL) exist only
+        # when the opt-in fold was on at LOAD time; it is part of the packed-cache fingerprint (loading.py)
+        self.folded = bool(ops.LN_FOLD)
+        self.ff = FeedForwardGEGLU(w, prefix + ".ff", norm=self.norm3 if self.folded else None)
+        if self.folded:
+            self.attn2.fold_norm(self.norm2)
 
     def __call__(self, x, batch, seq, kv: CrossKV):
+        if ops.LN_FOLD and not self.folded:
+            raise RuntimeError("ops.LN_FOLD was switched on after this model was loaded: the folded weights are built at "
+                               "load_state_dict() time (set DIFFUSERS_AMD_LN_FOLD=1 / ops.LN_FOLD before loading)")
         if not ops.LN_FOLD:
             x = self.attn1(self.norm1(x), batch, seq, residual=x)
             x = self.attn2(self.norm2(x), batch, seq, residual=x, kv=kv)

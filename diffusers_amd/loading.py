@@ -70,40 +70,63 @@ class LazyCheckpoint(Mapping):
         return key in self._where
 
 
-def _lora_pairs(lora_sd: Mapping, prefixes=("unet.", "transformer.", "")) -> Dict[str, dict]:
+COMPONENT_PREFIXES = ("unet.", "transformer.", "text_encoder.", "text_encoder_2.", "text_encoder_3.")
+_LORA_TAGS = ((".lora_A.weight", ".lora_B.weight"), (".lora_A.default.weight", ".lora_B.default.weight"),
+              (".lora.down.weight", ".lora.up.weight"), ("_lora.down.weight", "_lora.up.weight"),
+              (".lora_down.weight", ".lora_up.weight"))
+
+
+def _lora_pairs(lora_sd: Mapping, prefixes=("unet.", "transformer.")) -> Dict[str, dict]:
     """module path -> {"A": [r][in...], "B": [out][r...], "alpha": float | None} from a LoRA state dict in PEFT
-    (``lora_A.weight`` / ``lora_B.weight``), legacy diffusers (``lora.down.weight`` / ``lora.up.weight``,
-    ``to_q_lora.down.weight``) or kohya-after-conversion naming; component prefixes (``unet.``) are stripped."""
+    (``lora_A.weight`` / ``lora_B.weight``), legacy diffusers (``lora.down.weight`` / ``lora.up.weight``, attention-processor
+    ``to_q_lora.down.weight``) or kohya-after-conversion naming.
+
+    Component filter, as ``load_lora_adapter`` does it (loaders/peft.py:194-195): when the dict carries component prefixes
+    (a pipeline-level file: ``unet.`` / ``transformer.`` / ``text_encoder.`` ...), only the keys under one of ``prefixes``
+    (this model's) are kept, with the prefix removed; the other components' keys are ignored, not an error.  A dict with no
+    component prefix at all is taken to be this model's own."""
     out: Dict[str, dict] = {}
+    keys = list(lora_sd)
+    prefixed = any(k.startswith(COMPONENT_PREFIXES) for k in keys)
 
-    def strip(k: str) -> str:
+    def strip(k: str):
+        if not prefixed:
+            return k
         for p in prefixes:
-            if p and k.startswith(p):
+            if k.startswith(p):
                 return k[len(p):]
-        return k
+        return None            # another component's weight
 
-    for k in lora_sd:
-        base = None
-        for a_tag, b_tag in ((".lora_A.weight", ".lora_B.weight"), (".lora.down.weight", ".lora.up.weight"),
-                             ("_lora.down.weight", "_lora.up.weight"), (".lora_down.weight", ".lora_up.weight"),
-                             (".lora_A.default.weight", ".lora_B.default.weight")):
-            if k.endswith(a_tag):
-                base, which = k[: -len(a_tag)], "A"
-            elif k.endswith(b_tag):
-                base, which = k[: -len(b_tag)], "B"
+    for k in keys:
+        name = strip(k)
+        if name is None:
+            continue
+        base = which = None
+        for a_tag, b_tag in _LORA_TAGS:
+            if name.endswith(a_tag):
+                base, which, legacy = name[: -len(a_tag)], "A", a_tag.startswith("_lora")
+            elif name.endswith(b_tag):
+                base, which, legacy = name[: -len(b_tag)], "B", b_tag.startswith("_lora")
             else:
                 continue
             break
         if base is None:
-            if k.endswith(".alpha"):
-                out.setdefault(strip(k[: -len(".alpha")]), {})["alpha"] = float(torch.as_tensor(lora_sd[k]).item())
+            if name.endswith(".alpha"):
+                out.setdefault(name[: -len(".alpha")], {})["alpha"] = float(torch.as_tensor(lora_sd[k]).item())
             continue
-        name = strip(base)
-        name = name.replace(".processor.", ".").replace("to_out_lora", "to_out.0").replace("_lora", "")
-        out.setdefault(name, {})[which] = lora_sd[k]
+        if legacy:
+            # LoRAAttnProcessor naming: `<attn>.processor.to_q_lora.down.weight` -> `<attn>.to_q`; its output projection is
+            # `to_out_lora`, which lives at `<attn>.to_out.0` in the model
+            base = base.replace(".processor.", ".")
+            if base.endswith(".to_out"):
+                base += ".0"
+        out.setdefault(base, {})[which] = lora_sd[k]
     bad = [m for m, v in out.items() if "A" not in v or "B" not in v]
     if bad:
         raise ValueError(f"LoRA state dict has unpaired matrices for {bad[:4]}")
+    if prefixed and not out:
+        raise ValueError(f"No LoRA keys found under {prefixes} (loaders/peft.py:359-366); the file's components are "
+                         f"{sorted({k.split('.', 1)[0] for k in keys})}")
     return out
 
 
@@ -230,7 +253,9 @@ class PretrainedMixin:
         files = _weight_files(d, variant)
         cfg = read_config(d)
         cfg.update(config_overrides)
-        fp = checkpoint_fingerprint(files, extra=cls.__name__ + json.dumps(cfg, sort_keys=True, default=str))
+        from . import ops
+        fp = checkpoint_fingerprint(files, extra=cls.__name__ + json.dumps(cfg, sort_keys=True, default=str)
+                                    + ("+lnfold" if ops.LN_FOLD else ""))   # the fold changes the packed inventory
         cdir = Path(cache_dir) if cache_dir is not None else d / PACKED_DIR
         cfile = cdir / f"{cls.__name__}-{fp}.safetensors"
         model = None

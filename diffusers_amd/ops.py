@@ -160,6 +160,10 @@ def linear_pair(a: dict, b: dict):
     :func:`linear` (x, w, bias, ...).  Bit-identical to two :func:`linear` calls; used where neither problem fills the
     256 CUs on its own (the Q|K and V^T projections of a self-attention layer).  Falls back to two launches when the
     paired variant is unknown and cannot be tuned now, or is not faster than the two separate launches."""
+    if a["x"].shape[0] <= 8 or b["x"].shape[0] <= 8:
+        # a skinny problem (a 1x1 / 2x2-token mid block) belongs to the GEMV-style kernel: two ordinary launches, decided
+        # BEFORE any parameter block is built (building one would already run the skinny kernel)
+        return linear(**a), linear(**b)
     pa, st = _linear_params(**a)
     pb, _ = _linear_params(**b)
     if pa is None or pb is None:

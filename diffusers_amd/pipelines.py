@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from .autoencoder_kl import AutoencoderKL
-from .schedulers import (DDPMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler,
+from .schedulers import (DDIMScheduler, DDPMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler,
                          UniPCMultistepScheduler)
 from .transformer_flux import FluxTransformer2DModel
 from .transformer_wan import WanTransformer3DModel
@@ -91,6 +91,18 @@ class _LatentDiffusionBase:
         sch.step_cfg(eps, latents, guidance_scale, out=latents, cfg=do_cfg, **kw)
         return latents
 
+    def _make_graph_key(self, latents, cond, guidance_scale, do_cfg):
+        """Everything a captured step depends on besides the contents of its static buffers."""
+        sch = self.scheduler
+        if isinstance(sch, DDIMScheduler):
+            # set_timesteps() invalidated the coefficient table; rebuild it for THIS call's eta before the key reads its
+            # address (reading `device_table` first would rebuild it in place for eta = 0, and a replayed graph would
+            # then run deterministic DDIM whatever eta the caller passed)
+            sch._ensure(self._eta, sch.timesteps[0])
+        return (tuple(latents.shape), float(guidance_scale), bool(do_cfg), cond["kvs"][0][0].skv if cond["kvs"] else 0,
+                sch.device_table.data_ptr(), sch.device_step.data_ptr(),
+                self._noise_table.data_ptr() if self._noise_table is not None else 0, float(self._eta))
+
     def _denoise(self, latents, cond, num_steps, guidance_scale, do_cfg, use_graph):
         sch = self.scheduler
         sch.reset(0)
@@ -98,9 +110,7 @@ class _LatentDiffusionBase:
             for _ in range(num_steps):
                 self._step(latents, cond, guidance_scale, do_cfg)
             return latents
-        key = (tuple(latents.shape), float(guidance_scale), bool(do_cfg), cond["kvs"][0][0].skv if cond["kvs"] else 0,
-               sch.device_table.data_ptr(), sch.device_step.data_ptr(),
-               self._noise_table.data_ptr() if self._noise_table is not None else 0)
+        key = self._make_graph_key(latents, cond, guidance_scale, do_cfg)
         if self._graph is None or self._graph_key != key:
             # warm-up on a side stream (lazy one-time driver calls must not happen during capture), then capture
             saved = latents.clone()

@@ -326,6 +326,8 @@ class T5EncoderModel:
         x = x.view(B * S_alloc, c.d_model)
         eps = c.layer_norm_epsilon
         bias = None
+        # transformers' T5Stack: hidden_states = (embeddings, every block's output ..., the FINAL-NORMED last state)
+        hidden = [x.view(B, S_alloc, -1)[:, :S].clone()] if output_hidden_states else None
         for i, blk in enumerate(self.blocks):
             if blk["rel"] is not None and (bias is None or self.per_layer_bias):
                 bias = self._position_bias(blk["rel"], S, S_alloc, mask, i)
@@ -334,8 +336,12 @@ class T5EncoderModel:
             h = ops.rms_norm(x, blk["ln1"], eps)
             h = ops.linear(h, blk["wff"], act=L.ACT_GEGLU_TANH)
             x = ops.linear(h, blk["wo"], residual=x)
+            if output_hidden_states and i + 1 < len(self.blocks):
+                hidden.append(x.view(B, S_alloc, -1)[:, :S].clone())
         last = ops.rms_norm(x, self.final_ln, eps).view(B, S_alloc, -1)[:, :S]
-        out = ModelOutput(last_hidden_state=last)
+        if output_hidden_states:
+            hidden.append(last)
+        out = ModelOutput(last_hidden_state=last, hidden_states=tuple(hidden) if output_hidden_states else None)
         return out if return_dict else out.to_tuple()
 
 

@@ -110,6 +110,7 @@ class UNet2DConditionModel(PretrainedMixin):
         c = self.config
         w = Weights(state_dict, device)
         self.device = torch.device(device)
+        self._cond_cache = None   # hoisted K / V^T of the previous weights must not outlive them
         n = len(c.block_out_channels)
         boc = tuple(c.block_out_channels)
         groups, eps = c.norm_num_groups, c.norm_eps
@@ -207,17 +208,27 @@ class UNet2DConditionModel(PretrainedMixin):
         step-invariant work (140 K / V^T GEMMs + the text_time MLP for SDXL) is computed for the first call and reused
         while those tensors are the same objects with the same in-place version counters."""
         def ident(t):
-            return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+            if t is None:
+                return None
+            if t.is_inference():
+                # tensors made under torch.inference_mode() have no version counter (reading it raises): an in-place edit
+                # could not be seen, so such a call is never served from the cache
+                return False
+            return (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
         added = added_cond_kwargs or {}
         key = (ident(encoder_hidden_states), ident(added.get("text_embeds")), ident(added.get("time_ids")),
                ident(encoder_attention_mask))
+        cacheable = not any(k is False for k in key)
         hit = getattr(self, "_cond_cache", None)
-        if hit is not None and hit[0] == key:
+        if cacheable and hit is not None and hit[0] == key:
             return hit[1]
         ehs = encoder_hidden_states
         if ehs is not None and (ehs.dtype != bf16 or not ehs.is_cuda):
             ehs = ehs.to(device=self.device, dtype=bf16)
         cond = self.precompute_conditioning(ehs, added_cond_kwargs, encoder_attention_mask)
+        if not cacheable:
+            self._cond_cache = None
+            return cond
         # the cache holds references to the keyed tensors, so their storage (and data_ptr) cannot be recycled under it
         self._cond_cache = (key, cond, (encoder_hidden_states, added.get("text_embeds"), added.get("time_ids"),
                                         encoder_attention_mask))

@@ -47,6 +47,29 @@ def test_unet2d_condition(golden, name, added, fold, monkeypatch):
     assert y.shape == g["out"].shape and rr < TOL
 
 
+def test_unet_forward_under_inference_mode_and_cache_reset_on_reload(golden):
+    """the drop-in forward keyed its conditioning cache on `tensor._version`, which raises for tensors
+    created under torch.inference_mode() (a common wrapper around pipelines); and the cache survived a second
+    load_state_dict() on the same instance (stale hoisted K / V^T)."""
+    from diffusers_amd.unet_2d_condition import UNet2DConditionModel
+    g = golden("tiny_unet_sd15")
+    unet = UNet2DConditionModel(**dinit.TINY_SD15_UNET)
+    unet.load_state_dict(dinit.random_state_dict(dinit.unet_param_shapes(unet.config), seed=0), device="cpu")
+    y0 = unet(_t(g, "sample"), torch.tensor(float(g["t"])), _t(g, "ehs")).sample
+    assert unet._cond_cache is not None
+    with torch.inference_mode():
+        ehs = _t(g, "ehs") * 1.0                     # an inference tensor: no version counter
+        y1 = unet(_t(g, "sample"), torch.tensor(float(g["t"])), ehs).sample
+    assert torch.equal(y0, y1) and unet._cond_cache is None
+    ehs = _t(g, "ehs")
+    unet(_t(g, "sample"), torch.tensor(float(g["t"])), ehs)
+    assert unet._cond_cache is not None
+    unet.load_state_dict(dinit.random_state_dict(dinit.unet_param_shapes(unet.config), seed=1), device="cpu")
+    assert unet._cond_cache is None
+    y2 = unet(_t(g, "sample"), torch.tensor(float(g["t"])), ehs).sample        # same `ehs` object: must not hit a stale entry
+    assert not torch.equal(y0, y2)
+
+
 def test_unet_sd15_head_padding(golden):
     """SD1.5's 8 heads of 40 / 80 / 160 channels: zero-padded to the flash kernel's 64 / 96 / 160."""
     from diffusers_amd.unet_2d_condition import UNet2DConditionModel
@@ -280,6 +303,27 @@ def test_sd15_pipeline_no_cfg_eta_and_v_prediction_vs_oracle_loop(guidance, eta,
     ps = _psnr01((img.float() * 0.5 + 0.5).clamp(0, 1), (want * 0.5 + 0.5).clamp(0, 1))
     print(f"[host] tiny SD1.5 pipeline guidance={guidance} eta={eta} {pred}: PSNR vs fp32 oracle loop = {ps:.1f} dB")
     assert img.shape == want.shape and ps >= 35.0
+
+
+def test_ddim_eta_survives_the_graph_key_of_a_second_call():
+    """every __call__ runs set_timesteps(), which invalidates the DDIM coefficient table; the HIP-graph
+    key then read `device_table`, which rebuilt it IN PLACE for eta = 0 at the same address -- the replay branch was taken
+    and the captured kernel read kn = 0 (deterministic DDIM).  The key now rebuilds the table for the call's eta first and
+    carries eta itself."""
+    from diffusers_amd import factory
+    pipe = factory.build_sd15_pipeline(device="cpu", tiny=True, seed=0)
+    sch = pipe.scheduler
+    lat = torch.zeros((1, 4, 16, 16), dtype=bf16)
+    cond = {"kvs": []}
+    keys = []
+    for eta in (0.4, 0.4, 0.0):
+        sch.set_timesteps(4, device="cpu")   # what every pipeline call does first
+        sch.reset(0)
+        pipe._eta = eta
+        keys.append(pipe._make_graph_key(lat, cond, 7.5, True))
+        kn = sch._table[:, 5].float().cpu().numpy()
+        assert (kn[:-1] > 0).all() if eta > 0 else (kn == 0).all(), (eta, kn)
+    assert keys[0] == keys[1] and keys[0] != keys[2]
 
 
 def test_sdxl_pipeline_without_cfg():

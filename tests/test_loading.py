@@ -140,6 +140,39 @@ def test_fuse_lora_repacks_in_place(tmp_path, fmt):
         model.fuse_lora({"unet.mid_block.attentions.0.proj_in.lora_A.weight": torch.zeros(2, 4)})
 
 
+def test_lora_files_with_other_components_and_legacy_processor_names(tmp_path):
+    """(a) a pipeline-level LoRA file also carries `text_encoder.*` keys -- `load_lora_adapter` keeps only the
+    keys under the model's prefix (loaders/peft.py:194-195), it does not raise; (b) the legacy attention-processor naming
+    `<attn>.processor.to_out_lora.down.weight` targets `<attn>.to_out.0`; (c) no blanket `_lora` removal from module names."""
+    from diffusers_amd.loading import _lora_pairs
+    d, cfg, sd = _tiny_unet_checkpoint(tmp_path)
+    model = UNet2DConditionModel.from_pretrained(d, device="cpu")
+    attn = "down_blocks.1.attentions.0.transformer_blocks.0.attn1"
+    lora, dense = _lora_for(sd, [attn + ".to_q", attn + ".to_out.0"])
+    legacy = {}
+    for k, v in lora.items():                       # PEFT keys -> LoRAAttnProcessor keys
+        k = k.replace(".to_q.lora_A.weight", ".processor.to_q_lora.down.weight").replace(".to_q.lora_B.weight", ".processor.to_q_lora.up.weight")
+        k = k.replace(".to_out.0.lora_A.weight", ".processor.to_out_lora.down.weight").replace(".to_out.0.lora_B.weight", ".processor.to_out_lora.up.weight")
+        legacy[k] = v
+    legacy = {k: v for k, v in legacy.items() if not k.endswith(".alpha")}
+    legacy["text_encoder.text_model.encoder.layers.0.self_attn.q_proj.lora_A.weight"] = torch.zeros(4, 8)
+    legacy["text_encoder.text_model.encoder.layers.0.self_attn.q_proj.lora_B.weight"] = torch.zeros(8, 4)
+    pairs = _lora_pairs(legacy)
+    assert sorted(pairs) == sorted([attn + ".to_q", attn + ".to_out.0"])
+    model.fuse_lora(legacy, lora_scale=1.0)
+    fused_sd = dict(sd)
+    for n, dl in dense.items():                    # no alpha in the legacy file: scale = 1 (alpha / r was 2 in `dense`)
+        fused_sd[n + ".weight"] = (sd[n + ".weight"].float() + 0.5 * dl).to(sd[n + ".weight"].dtype)
+    want = UNet2DConditionModel(**cfg)
+    want.load_state_dict(fused_sd, device="cpu")
+    _same_packed(model, want)
+    # a module whose own name contains "_lora" is not renamed
+    assert list(_lora_pairs({"unet.my_lora_block.proj.lora_A.weight": torch.zeros(2, 4),
+                             "unet.my_lora_block.proj.lora_B.weight": torch.zeros(4, 2)})) == ["my_lora_block.proj"]
+    with pytest.raises(ValueError, match="No LoRA keys"):
+        _lora_pairs({"text_encoder.x.lora_A.weight": torch.zeros(2, 4), "text_encoder.x.lora_B.weight": torch.zeros(4, 2)})
+
+
 def test_in_memory_models_need_a_base_for_lora():
     cfg = dict(dinit.TINY_SDXL_UNET)
     sd = dinit.random_state_dict(dinit.unet_param_shapes(UNet2DConditionModel(**cfg).config), seed=0)

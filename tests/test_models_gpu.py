@@ -419,3 +419,25 @@ def test_flux_and_wan_pipelines_accept_prompts_with_caller_text_encoders(golden)
     wpe, wne = encode_prompt_wan(tok2, wpipe.text_encoder, "a cat on the mat", "red", device=DEV, max_sequence_length=16)
     wb = wpipe(prompt_embeds=wpe, negative_prompt_embeds=wne, latents=t(gw, "latents"), **wkw).images
     assert wpe.shape == (1, 16, 64) and torch.isfinite(wa.float()).all() and torch.equal(wa, wb)
+
+
+def test_sd15_ddim_eta_graph_replay_keeps_the_variance_noise():
+    """with use_graph=True the SECOND eta > 0 call replayed the captured step against a coefficient table
+    that set_timesteps() + the graph key had rebuilt for eta = 0 (kn = 0: deterministic DDIM).  Every call, graphed or not,
+    must give the eager eta > 0 result for its own seed; and an eta = 0 call in between must not inherit the noise."""
+    from diffusers_amd import factory
+    pipe = factory.build_sd15_pipeline(device=DEV, tiny=True, seed=0)
+    gen = torch.Generator().manual_seed(6)
+    lat0 = torch.randn((1, 4, 16, 16), generator=gen).to(bf16).to(DEV)
+    pe = torch.randn((1, 7, 64), generator=gen).to(bf16).to(DEV)
+    ne = torch.randn((1, 7, 64), generator=gen).to(bf16).to(DEV)
+
+    def run(eta, seed, graph):
+        return pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat0.clone(), num_inference_steps=4, guidance_scale=7.5,
+                    eta=eta, generator=torch.Generator().manual_seed(seed), height=32, width=32, output_type="latent",
+                    use_graph=graph).images.clone()
+    want = {(eta, seed): run(eta, seed, False) for eta, seed in [(0.4, 1), (0.4, 2), (0.0, 1)]}
+    assert not torch.equal(want[(0.4, 1)], want[(0.0, 1)]) and not torch.equal(want[(0.4, 1)], want[(0.4, 2)])
+    for eta, seed in [(0.4, 1), (0.4, 2), (0.0, 1), (0.4, 1)]:     # capture, replay, re-key for eta = 0, back to eta > 0
+        got = run(eta, seed, True)
+        assert torch.equal(got, want[(eta, seed)]), f"graphed DDIM call eta={eta} seed={seed} differs from the eager loop"

@@ -106,6 +106,13 @@ def check_t5(dev, umt5, masked):
     rr = _rel(got.last_hidden_state.cpu()[valid], want[valid])          # padded positions are trimmed by the pipelines
     print(f"[parity] {'UMT5' if umt5 else 'T5'} encoder (mask={masked}) on {dev}: last_hidden_state rel_rms {rr:.3e}")
     assert rr < TOL
+    # output_hidden_states: T5Stack's tuple = (embeddings, each block's output ..., the final-normed last state)
+    with torch.no_grad():
+        wh = ref(ids, attention_mask=mask if masked else None, output_hidden_states=True).hidden_states
+    gh = eng(ids.to(dev), attention_mask=mask.to(dev) if masked else None, output_hidden_states=True).hidden_states
+    assert len(gh) == len(wh) == cfg.num_layers + 1
+    for a, b in zip(gh, wh):
+        assert _rel(a.cpu()[valid], b[valid]) < TOL
 
 
 @pytest.fixture
