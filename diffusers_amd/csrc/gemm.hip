@@ -19,9 +19,13 @@
 // through a per-tile descriptor, or global_load_lds_dwordx4 with per-lane pointers; swizzle applied on the per-lane SOURCE
 // offset, LDS image lane-linear) -- see the staging-mode notes in gemm_kernel.cuh.
 #include "gemm_kernel.cuh"
+#include "gemm2_kernel.cuh"
 
 namespace da_gemm {
 int dispatch_conv(const da_gemm_params& p, int tile, int staging, hipStream_t s);  // gemm_conv.hip
+}
+namespace da_gemm2 {
+int dispatch_conv(const da_gemm_params& p, int tile, int staging, hipStream_t s);  // gemm2_conv.hip
 }
 
 namespace {
@@ -30,7 +34,11 @@ struct TileShape {
   int bm, bn, waves;
 };
 constexpr TileShape kTiles[] = {{0, 0, 0},      {128, 128, 4}, {64, 128, 4},  {128, 64, 4}, {64, 64, 4},
-                                {256, 128, 8},  {128, 256, 8}, {256, 256, 8}, {128, 128, 8}};
+                                {256, 128, 8},  {128, 256, 8}, {256, 256, 8}, {128, 128, 8},
+                                // K2 family (gemm2_kernel.cuh)
+                                {128, 128, 8},  {128, 80, 8},  {128, 160, 8}, {80, 128, 8}, {128, 64, 8}};
+static_assert(sizeof(kTiles) / sizeof(kTiles[0]) == DA_TILE_COUNT, "kTiles / DA_TILE_* mismatch");
+inline bool is_k2(int tile) { return tile >= DA_TILE_K2_128x128; }
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 // Untuned fallback: fewest bytes staged per flop among the tiles that still give every CU a block; output-channel
@@ -90,6 +98,11 @@ int stats_parts(const da_gemm_params& p, int tile) {   // one partial per column
 
 bool tile_ok(const da_gemm_params& p, int tile) {
   if (tile <= 0 || tile >= kNumTiles) return false;
+  if (is_k2(tile)) {
+    const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
+    return !p.stats_out && !p.ln_stats && p.split_k <= 1 && (!geglu || tile == DA_TILE_K2_128x128) &&
+           !(p.conv && tile == DA_TILE_K2_80x128);
+  }
   // GEGLU pairs (value, gate) 32-column tiles inside one wave: the wave must own an even number of them
   if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) &&
       (tile == DA_TILE_128x64 || tile == DA_TILE_64x64 || tile == DA_TILE_128x128_W8))
@@ -100,6 +113,10 @@ bool tile_ok(const da_gemm_params& p, int tile) {
 }
 
 int run(const da_gemm_params& p, int tile, int staging, hipStream_t s, const da_gemm_params* pb = nullptr) {
+  if (is_k2(tile)) {
+    if (pb) return DA_ERR_UNSUPPORTED;
+    return p.conv ? da_gemm2::dispatch_conv(p, tile, staging, s) : da_gemm2::dispatch<false>(p, tile, staging, s);
+  }
   if (p.conv) return pb ? DA_ERR_UNSUPPORTED : da_gemm::dispatch_conv(p, tile, staging, s);
   return da_gemm::dispatch<false>(p, tile, staging, s, pb);
 }

@@ -1,0 +1,627 @@
+// Second GEMM / implicit-GEMM family ("K2"): 8 waves per workgroup = 2 K-GROUPS x (WM x WN) waves, v_mfma_f32_16x16x32_bf16.
+//
+// Why it exists (profiles/r03a_ceiling_table.md, r02e_kernel_experiments.md).  The first family (gemm_kernel.cuh) is a
+// 4-wave tile with one rendezvous per 64-wide K slice: a workgroup ALONE on its CU spends ~900-1500 cycles per slice for
+// 128-512 cycles of MFMA work (the slice's ds_read latency, the barrier and the wait for the LDS-DMA sit in front of the
+// MFMAs of every slice), so it only approaches the matrix pipe's rate when 2-3 workgroups share a CU -- and the SDXL
+// shapes (M = 2048 tokens) do not have the tiles for that: 2048 x 1280 is 320 tiles of 128 x 64 on 256 CUs.  This family
+// is built for ONE workgroup per CU:
+//   * tile shapes in 16-column steps (128 x 80: 2048 x 1280 = exactly 256 tiles, one per CU; 128 x 160 for the 640-wide
+//     level; 128 x 128 for the GEGLU projection: 5 per CU);
+//   * the two K-groups take alternate K slices of the SAME output tile (even / odd), each with its own accumulators, so a
+//     SIMD always holds two waves with independent MFMA streams; their partial sums meet once, through LDS, after the loop,
+//     and each group finishes half of the tile's rows (both halves of the epilogue run in parallel);
+//   * K slices are staged in PAIRS (one per group) and there is ONE rendezvous per pair, placed in the MIDDLE of the
+//     pair's MFMAs: k-step 0 | wait + s_barrier + LDS-DMA of a later pair + ds_reads of the next pair's k-step 0 | k-step 1.
+//     At the rendezvous every fragment of the current pair is already in registers, so (a) its ring slot is free at once
+//     and (b) the next pair's first fragments arrive under this pair's second-half MFMAs: the matrix stream of a wave is
+//     continuous across slices, there is no per-slice bubble.
+// Staging, LDS image, swizzle and the implicit-GEMM addressing are those of gemm_kernel.cuh (buffer-addressed LDS-DMA,
+// 1 KiB pieces of 8 rows x 128 B, 16-byte slots XOR-swizzled with (row >> 1) & 7 on the SOURCE side): the same image is
+// conflict-free for the 16 x 16 x 32 fragment reads (lane = row & 15, 16-byte chunk (lane >> 4) + 4 * k-step).
+//
+// Numerics: fp32 accumulation, K summed as (even slices) + (odd slices); every K2 tile shape gives bit-identical results
+// to every other K2 shape; against the first family the fp32 summation order differs (last-bit differences before the
+// bf16 rounding of the output).
+#pragma once
+#include <type_traits>
+
+#include "common.cuh"
+#include "diffusers_amd.h"
+
+namespace da_gemm2 {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, size_t bytes) {
+  const uint64_t v = (uint64_t)base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+#endif
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// One 4-channel group of one output row: the fused epilogue of gemm_kernel.cuh (bias, per-row bias, per-batch channel
+// vector, activation, gate, residual, output scale) with the same rounding points.  o[] in, o[] out (fp32).
+__device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int m, int n, int bidx, float brow, bool has_bias,
+                                          uint2 bv, bool has_rowvec, uint2 rv, bool has_res, uint2 resv) {
+  if (has_bias) { o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y); }
+  if (p.bias_rows) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] += brow;
+  }
+  if (has_rowvec) { o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y); }
+  if (p.act == DA_ACT_GELU_TANH) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gelu_tanh_f(bf2f(f2bf(o[e])));
+  } else if (p.act == DA_ACT_SILU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = silu_f(bf2f(f2bf(o[e])));
+  } else if (p.act == DA_ACT_GELU_ERF) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(bf2f(f2bf(o[e])));
+  } else if (p.act == DA_ACT_QUICK_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xv = bf2f(f2bf(o[e]));
+      const float tv = bf2f(f2bf(1.702f * xv));
+      o[e] = xv * bf2f(f2bf(1.0f / (1.0f + __expf(-tv))));
+    }
+  }
+  if (p.gate && p.gate_f32) {
+    const float4 gv = *(const float4*)((const float*)p.gate + (size_t)bidx * p.ld_gate + n);
+    o[0] = bf2f(f2bf(o[0])) * gv.x; o[1] = bf2f(f2bf(o[1])) * gv.y;
+    o[2] = bf2f(f2bf(o[2])) * gv.z; o[3] = bf2f(f2bf(o[3])) * gv.w;
+  } else if (p.gate) {
+    const uint2 gv = *(const uint2*)((const uint16_t*)p.gate + (size_t)bidx * p.ld_gate + n);
+    o[0] = bf2f(f2bf(bf2f(f2bf(o[0])) * bf_lo(gv.x)));
+    o[1] = bf2f(f2bf(bf2f(f2bf(o[1])) * bf_hi(gv.x)));
+    o[2] = bf2f(f2bf(bf2f(f2bf(o[2])) * bf_lo(gv.y)));
+    o[3] = bf2f(f2bf(bf2f(f2bf(o[3])) * bf_hi(gv.y)));
+  }
+  if (has_res) { o[0] += bf_lo(resv.x); o[1] += bf_hi(resv.x); o[2] += bf_lo(resv.y); o[3] += bf_hi(resv.y); }
+  if (p.out_scale != 1.0f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] *= p.out_scale;
+  }
+}
+
+// WM x WN waves per K-group (WM * WN == 4), each wave owns MT x NT tiles of 16 x 16  ->  block tile (16*MT*WM) x (16*NT*WN).
+// NSLOT = ring depth in slice PAIRS (2 or 3).
+template <int WM, int WN, int MT, int NT, int NSLOT, bool CONV>
+__global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(WM * WN == 4, "a K-group is four waves");
+  constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+  constexpr int PX = BM / 8, PW = BN / 8;                 // 1 KiB pieces (8 rows x 128 B) per slice
+  constexpr int XBYTES = BM * 128, SLICE = (BM + BN) * 128, PAIR = 2 * SLICE;
+  constexpr int XI = (2 * PX + 7) / 8, WI = (2 * PW + 7) / 8;   // LDS-DMA instructions per wave per pair (upper bound)
+  constexpr int XRAG = (2 * PX) % 8 ? 1 : 0, WRAG = (2 * PW) % 8 ? 1 : 0;   // a last row of pieces only some waves own
+  static_assert(NSLOT == 2 || NSLOT == 3, "ring of 2 or 3 slice pairs");
+  constexpr int DUMP = (XRAG || WRAG) ? 1024 : 0;          // where the out-of-range pieces of ragged tiles write their zeros
+  static_assert(NSLOT * PAIR + DUMP <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
+  static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows are staged in 8-row pieces");
+  static_assert(!CONV || (PX % 4) == 0, "conv: the slice parity of an activation piece must be a compile-time constant");
+  static_assert((NSLOT - 1) * (XI + WI) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(MT * NT * 1024 * 4 <= NSLOT * PAIR, "partial-sum exchange does not fit the ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = wave >> 2, wq = wave & 3;                 // K-group, position inside the group
+  const int wm = wq / WN, wn = wq - wm * WN;
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  // ---- XCD-aware tile mapping (as gemm_kernel.cuh: block b runs on XCD b % 8, each XCD owns a rectangle of tiles) ----
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int gyn = 8 / xcd_gx;
+  const int tm_per = (tiles_m + gyn - 1) / gyn, tn_per = (tiles_n + xcd_gx - 1) / xcd_gx;
+  const int bid = (int)blockIdx.x;
+  const int xcd = bid & 7, kblk = bid >> 3;
+  const int gy = xcd / xcd_gx, gx = xcd - gy * xcd_gx;
+  const int lm = kblk / tn_per, ln = kblk - lm * tn_per;
+  const int tm = gy * tm_per + lm, tn = gx * tn_per + ln;
+  if (tm >= tiles_m || tn >= tiles_n) return;             // ragged rectangle: the whole block leaves before any barrier
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const uint16_t* __restrict__ A = (const uint16_t*)p.A;
+  const uint16_t* __restrict__ A2 = (const uint16_t*)p.A2;
+  const uint16_t* __restrict__ Wt = (const uint16_t*)p.W;
+  const int nk = p.K >> 6;                                // K slices
+  const int nk2 = (nk + 1) >> 1;                          // slice pairs
+  const int Ctot = CONV ? (p.C1 + p.C2) : 0;
+  const int Hv = CONV ? (p.Hin << p.up) : 0, Wv = CONV ? (p.Win << p.up) : 0;
+
+  // ---- staging assignment: wave w stages pieces q = i * 8 + w of the pair's 2 * PX activation and 2 * PW weight pieces ----
+  // piece q -> slice parity h = q / P, piece r = q % P inside the slice; lane -> row 8 r + (lane >> 3), 16-byte slot lane & 7
+  int x_h[XI], x_r[XI], w_h[WI], w_r[WI];
+  bool x_ok[XI], w_ok[WI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int q = i * 8 + wave;
+    // compile-time constants wherever all eight waves of a row i agree (so the unrolled issue code has no branch / select)
+    x_ok[i] = (i * 8 + 7 < 2 * PX) ? true : (q < 2 * PX);
+    x_h[i] = (i * 8 >= PX) ? 1 : (i * 8 + 7 < PX) ? 0 : (q >= PX ? 1 : 0);
+    x_r[i] = q - x_h[i] * PX;
+    if (!x_ok[i]) x_h[i] = 0, x_r[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int q = i * 8 + wave;
+    w_ok[i] = (i * 8 + 7 < 2 * PW) ? true : (q < 2 * PW);
+    w_h[i] = (i * 8 >= PW) ? 1 : (i * 8 + 7 < PW) ? 0 : (q >= PW ? 1 : 0);
+    w_r[i] = q - w_h[i] * PW;
+    if (!w_ok[i]) w_h[i] = 0, w_r[i] = 0;
+  }
+  constexpr int my_loads = XI + WI;                       // LDS-DMA instructions per wave per pair (ragged pieces included)
+
+  // conv: per staged activation row, the output pixel it belongs to
+  int xr_base[XI], xr_oy[XI], xr_ox[XI];
+  if constexpr (CONV) {
+    const int hw = p.Hout * p.Wout;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int m = m0 + x_r[i] * 8 + (lane >> 3);
+      if (m < p.M) {
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int oy = rem / p.Wout;
+        xr_base[i] = b * p.Hin;
+        xr_oy[i] = oy * p.stride - p.pad;
+        xr_ox[i] = (rem - oy * p.Wout) * p.stride - p.pad;
+      } else {
+        xr_base[i] = 0;
+        xr_oy[i] = -100000;
+        xr_ox[i] = -100000;
+      }
+    }
+  }
+
+  // buffer descriptors over the block's operand panels (see gemm_kernel.cuh, staging mode 2)
+  size_t xbase = 0, xbytes = 0x7fffffff, x2bytes = 0x7fffffff;
+  int pb = 0;
+  if constexpr (CONV) {
+    const int hw = p.Hout * p.Wout;
+    const int b0 = m0 / hw;
+    const int oy0 = (m0 - b0 * hw) / p.Wout;
+    pb = __builtin_amdgcn_readfirstlane((b0 * p.Hin + (max(0, oy0 * p.stride - p.pad) >> p.up)) * p.Win);
+    const size_t pix_left = (size_t)(p.M / hw) * p.Hin * p.Win - (size_t)pb;
+    xbytes = min(pix_left * p.C1 * 2, (size_t)0x7fffffff);
+    x2bytes = min(pix_left * p.C2 * 2, (size_t)0x7fffffff);
+  } else {
+    xbase = (size_t)m0 * p.lda;
+  }
+  __amdgpu_buffer_rsrc_t rs_x = uniform_rsrc(A + (CONV ? (size_t)pb * p.C1 : xbase), xbytes);
+  __amdgpu_buffer_rsrc_t rs_x2 = uniform_rsrc((CONV && A2) ? A2 + (size_t)pb * p.C2 : A, x2bytes);
+  __amdgpu_buffer_rsrc_t rs_w = uniform_rsrc(Wt + (size_t)n0 * p.ldw, 0x7fffffff);
+
+  int vo_x[XI], vo_x2[XI], vo_w[WI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int row = x_r[i] * 8 + (lane >> 3);
+    const int sc = (lane & 7) ^ ((row >> 1) & 7);
+    if constexpr (!CONV) vo_x[i] = (min(row, p.M - 1 - m0) * p.lda + sc * 8) * 2;
+    else vo_x[i] = 0;
+    vo_x2[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int row = w_r[i] * 8 + (lane >> 3);
+    const int sc = (lane & 7) ^ ((row >> 1) & 7);
+    vo_w[i] = (min(row, p.N - 1 - n0) * p.ldw + sc * 8) * 2;
+  }
+  // conv: one (kernel row, kernel column, first channel) cursor per slice parity; the per-lane offsets of the pieces of a
+  // parity are recomputed only when its tap changes.  Pairs are staged strictly in order, so the state below always
+  // describes the NEXT pair to stage (`st_pr`); it is advanced right after a pair's loads were issued, i.e. the address
+  // arithmetic of pair n + 1 runs under the MFMAs that follow the issue of pair n and the issue itself is straight-line.
+  int c_kh[2] = {0, 0}, c_kw[2] = {0, 0}, c_c0[2] = {0, 0};
+  int st_pr = 0;                                          // next pair to stage
+  int st_s[2] = {0, nk > 1 ? 1 : 0};                      // slice (clamped to nk - 1) each parity stages next
+  // a slice of the next pair that lies past K is staged as zeros (bit 31 of the per-lane offset: beyond num_records)
+  int st_zero[2] = {0, (nk > 1) ? 0 : (int)0x80000000};
+  auto tap_offsets = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      if ((i >= XI / 2 ? 1 : 0) != h) continue;           // CONV: PX % 4 == 0, so pieces i < XI / 2 are parity 0
+      const int row = x_r[i] * 8 + (lane >> 3);
+      const int sc = (lane & 7) ^ ((row >> 1) & 7);
+      const int iy = xr_oy[i] + c_kh[h], ix = xr_ox[i] + c_kw[h];
+      const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+      const int rel = (xr_base[i] + (iy >> p.up)) * p.Win + (ix >> p.up) - pb;
+      vo_x[i] = ok ? (rel * p.C1 + sc * 8) * 2 : (int)0x80000000;
+      vo_x2[i] = ok ? (rel * p.C2 + sc * 8) * 2 : (int)0x80000000;
+    }
+  };
+  auto cursor_step = [&](int h) {                         // advance parity h's cursor by one slice (wave-uniform)
+    c_c0[h] += 64;
+    if (c_c0[h] >= Ctot) {
+      c_c0[h] = 0;
+      if (++c_kw[h] >= p.conv) {
+        c_kw[h] = 0;
+        ++c_kh[h];
+      }
+    }
+  };
+  if constexpr (CONV) {
+    if (nk > 1) cursor_step(1);                           // parity 1 starts on slice 1
+    tap_offsets(0);
+    tap_offsets(1);
+  }
+
+#define DA2_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
+  // Issue the LDS-DMA of the next slice pair into ring slot `slot` (straight-line code).  A slice past the end of K (odd
+  // slice count; the pairs "staged" by the last NSLOT rendezvous) is staged as ZEROS (bit 31 of the per-lane offset: beyond
+  // num_records, the range check writes zeros to LDS without touching memory), so an odd slice count makes group 1 multiply
+  // zeros once, every rendezvous issues the same number of loads (one vmcnt immediate) and the loop body has no branch.
+  // Pieces only some waves own (ragged tiles) go first: their wave-uniform branch then sits in front of the straight-line part.
+  auto stage_issue = [&](int slot) {
+    unsigned char* base = smem + slot * PAIR;
+    auto issue_x = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int h = x_h[i];
+      // (h may be a run-time value on ragged tiles: select, never index.)  A piece this wave does not own (ragged last row)
+      // is issued all the same, out of range (zeros, no memory traffic) into the dump KiB behind the ring: every wave issues
+      // the same loads, the loop body stays ONE basic block and the compiler's lgkmcnt / vmcnt bookkeeping stays exact.
+      const int z = x_ok[i] ? (h ? st_zero[1] : st_zero[0]) : (int)0x80000000;
+      unsigned char* dst = x_ok[i] ? base + h * SLICE + x_r[i] * 1024 : smem + NSLOT * PAIR;
+      if constexpr (CONV) {
+        const int c0 = h ? c_c0[1] : c_c0[0];
+        if (p.C2 > 0 && c0 >= p.C1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, DA2_LDS(dst), 16, vo_x2[i] | z, (c0 - p.C1) * 2, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, DA2_LDS(dst), 16, vo_x[i] | z, c0 * 2, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, DA2_LDS(dst), 16, vo_x[i] | z, (h ? st_s[1] : st_s[0]) * 128, 0, 0);
+      }
+    };
+    auto issue_w = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int h = w_h[i];
+      const int z = w_ok[i] ? (h ? st_zero[1] : st_zero[0]) : (int)0x80000000;
+      unsigned char* dst = w_ok[i] ? base + h * SLICE + XBYTES + w_r[i] * 1024 : smem + NSLOT * PAIR;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DA2_LDS(dst), 16, vo_w[i] | z, (h ? st_s[1] : st_s[0]) * 128, 0, 0);
+    };
+    static_for<XI>(issue_x);
+    static_for<WI>(issue_w);
+  };
+  // Move the staging state to the following pair (scalar arithmetic; conv: a tap change recomputes that parity's offsets).
+  auto stage_advance = [&]() {
+    ++st_pr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int want = min(2 * st_pr + h, nk - 1);
+      if constexpr (CONV) {
+        const int kh0 = c_kh[h], kw0 = c_kw[h];
+        while (st_s[h] < want) {
+          cursor_step(h);
+          ++st_s[h];
+        }
+        if (c_kh[h] != kh0 || c_kw[h] != kw0) tap_offsets(h);
+      } else {
+        st_s[h] = want;
+      }
+    }
+    st_zero[0] = (2 * st_pr < nk) ? 0 : (int)0x80000000;
+    st_zero[1] = (2 * st_pr + 1 < nk) ? 0 : (int)0x80000000;
+  };
+  // wait until at most PAIRS later pairs of THIS wave's LDS-DMA are in flight (a compile-time immediate)
+#define DA2_WAIT_PAIRS(PAIRS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PAIRS) * my_loads) : "memory")
+
+  // ---- epilogue operands of the half tile this wave will finish: fetched BEFORE the K loop (their round trip hides there) ----
+  // After the loop group g keeps the row tiles [g * MH, (g + 1) * MH) (column tiles when MT is odd) and sends the rest.
+  constexpr bool SPLIT_M = (MT % 2) == 0;
+  static_assert(SPLIT_M || (NT % 2) == 0, "one of the wave tile's dimensions must split between the two K-groups");
+  constexpr int MH = SPLIT_M ? MT / 2 : MT, NH = SPLIT_M ? NT : NT / 2;
+  const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
+  auto row_of = [&](int ih) { return m0 + (wm * MT + (SPLIT_M ? g * MH : 0) + ih) * 16 + r16; };
+  auto col_of = [&](int jh) { return n0 + (wn * NT + (SPLIT_M ? 0 : g * NH) + jh) * 16 + 4 * kq; };
+  uint2 res_v[MH][NH], bias_v[NH], rowvec_v[MH][NH];
+#pragma unroll
+  for (int ih = 0; ih < MH; ++ih)
+#pragma unroll
+    for (int jh = 0; jh < NH; ++jh) res_v[ih][jh] = rowvec_v[ih][jh] = make_uint2(0, 0);
+#pragma unroll
+  for (int jh = 0; jh < NH; ++jh) bias_v[jh] = make_uint2(0, 0);
+  {
+    const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
+    const uint16_t* __restrict__ bias = (const uint16_t*)p.bias;
+    const uint16_t* __restrict__ rowvec = (const uint16_t*)p.rowvec;
+    if (resid) {
+#pragma unroll
+      for (int ih = 0; ih < MH; ++ih) {
+        const int m = min(row_of(ih), p.M - 1);
+#pragma unroll
+        for (int jh = 0; jh < NH; ++jh) res_v[ih][jh] = *(const uint2*)(resid + (size_t)m * p.ldr + min(col_of(jh), p.N - 4));
+      }
+    }
+    if (bias) {
+#pragma unroll
+      for (int jh = 0; jh < NH; ++jh) bias_v[jh] = *(const uint2*)(bias + min(col_of(jh), p.N - 4));
+    }
+    if (rowvec) {
+#pragma unroll
+      for (int ih = 0; ih < MH; ++ih) {
+        const int m = min(row_of(ih), p.M - 1);
+        const size_t ro = (size_t)(m / p.rows_per_batch) * p.ld_rowvec;
+#pragma unroll
+        for (int jh = 0; jh < NH; ++jh) rowvec_v[ih][jh] = *(const uint2*)(rowvec + ro + min(col_of(jh), p.N - 4));
+      }
+    }
+  }
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row r16 of a 16-row tile, 16-byte chunk (kq + 4 ks) ^ ((r16 >> 1) & 7); k-step 1 = chunk ^ 4
+  const int fsw = (r16 >> 1) & 7;
+  const int foff0 = r16 * 128 + ((kq ^ fsw) << 4), foff1 = r16 * 128 + (((kq ^ fsw) ^ 4) << 4);
+  const int xfrag = g * SLICE + (wm * MT) * 2048, wfrag = g * SLICE + XBYTES + (wn * NT) * 2048;
+  bf16x8_t xf0[MT], wf0[NT], xf1[MT], wf1[NT];
+#define DA2_FRAG(XF, WF, SLOT, OFF)                                                                         \
+  do {                                                                                                      \
+    const unsigned char* xb_ = smem + (SLOT) * PAIR + xfrag + (OFF);                                        \
+    const unsigned char* wb_ = smem + (SLOT) * PAIR + wfrag + (OFF);                                        \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) WF[j] = *(const bf16x8_t*)(wb_ + j * 2048);              \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) XF[i] = *(const bf16x8_t*)(xb_ + i * 2048);              \
+  } while (0)
+#define DA2_MFMA(XF, WF)                                                                                    \
+  do {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                          \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                          \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j], XF[i], acc[i][j], 0, 0, 0);                \
+  } while (0)
+#define DA2_SG_DS(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define DA2_SG_MF(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define DA2_SG_VM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+
+  // ---- prologue: pairs 0 .. NSLOT-1 in flight (zeros past the end of K), pair 0 landed, its k-step-0 fragments on their way ----
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    stage_issue(s);
+    stage_advance();
+  }
+  DA2_WAIT_PAIRS(NSLOT - 1);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  DA2_FRAG(xf0, wf0, 0, foff0);
+
+  auto first_half_pins = [&]() {
+    static_for<MT + NT>([](auto rc) {                     // k-step 1's MT + NT reads spread under k-step 0's MT * NT MFMAs
+      constexpr int r = decltype(rc)::value, R = MT + NT, Q = MT * NT;
+      DA2_SG_DS(1);
+      DA2_SG_MF((Q * (r + 1)) / R - (Q * r) / R);
+    });
+  };
+  int slot = 0;                                           // ring slot of pair pr
+  for (int pr = 0; pr + 1 < nk2; ++pr) {
+    // first half: k-step 0 under the ds_reads of k-step 1
+    DA2_FRAG(xf1, wf1, slot, foff1);
+    DA2_MFMA(xf0, wf0);
+    first_half_pins();
+    __builtin_amdgcn_sched_barrier(0);
+    // rendezvous: every fragment of this pair is in registers (lgkmcnt(0)) and the next pair has landed for this wave;
+    // past the barrier this pair's ring slot is free (nobody reads it any more) and the next pair is visible to everybody
+    const int nslot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DA2_WAIT_PAIRS(NSLOT - 2);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // second half: k-step 1 under the LDS-DMA issue of pair pr + NSLOT and the next pair's k-step-0 reads
+    stage_issue(slot);
+    DA2_FRAG(xf0, wf0, nslot, foff0);
+    DA2_MFMA(xf1, wf1);
+    static_for<XI + WI + MT + NT>([](auto rc) {
+      // one memory operation per share of the MT * NT MFMAs: the LDS-DMA issues, then the fragment reads
+      constexpr int r = decltype(rc)::value, V = XI + WI, R = V + MT + NT, Q = MT * NT;
+      if constexpr (r < V) DA2_SG_VM(1);
+      else DA2_SG_DS(1);
+      DA2_SG_MF((Q * (r + 1)) / R - (Q * r) / R);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    stage_advance();
+    slot = nslot;
+  }
+  // last pair: nothing left to wait for or to fetch
+  DA2_FRAG(xf1, wf1, slot, foff1);
+  DA2_MFMA(xf0, wf0);
+  first_half_pins();
+  __builtin_amdgcn_sched_barrier(0);
+  DA2_MFMA(xf1, wf1);
+#undef DA2_FRAG
+#undef DA2_MFMA
+
+  // ---- the two K-groups meet: each sends the half it does not finish, through the (now free) ring ----
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  f32x4_t keep[MH][NH];
+  {
+    f32x4_t* xch = (f32x4_t*)smem + (size_t)wq * (MT * NT) * 64 + lane;
+#pragma unroll
+    for (int ih = 0; ih < MH; ++ih)
+#pragma unroll
+      for (int jh = 0; jh < NH; ++jh) {
+        // lower / upper half of the wave tile: acc[ih][jh] and acc[ih + MH][jh] (column halves when MT is odd)
+        const f32x4_t lo = acc[ih][jh];
+        f32x4_t hi;
+        if constexpr (SPLIT_M) hi = acc[ih + MT / 2][jh];
+        else hi = acc[ih][jh + NT / 2];
+        f32x4_t snd, kp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          snd[e] = g ? lo[e] : hi[e];
+          kp[e] = g ? hi[e] : lo[e];
+        }
+        keep[ih][jh] = kp;
+        xch[(size_t)((ih * NH + jh) + (g ? 0 : MH * NH)) * 64] = snd;   // group 0 sends the upper half, group 1 the lower
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ih = 0; ih < MH; ++ih)
+#pragma unroll
+      for (int jh = 0; jh < NH; ++jh) {
+        const f32x4_t o = xch[(size_t)((ih * NH + jh) + (g ? MH * NH : 0)) * 64];   // what the partner sent for MY half
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[ih][jh][e] += o[e];                        // (even slices) + (odd slices), commutative
+      }
+  }
+
+  // ---- epilogue: lane holds, for output row (r16 of a 16-row tile), channels 4 kq .. 4 kq + 3 of a 16-column tile ----
+  const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
+  const bool has_bias = p.bias != nullptr, has_rowvec = p.rowvec != nullptr, has_res = p.residual != nullptr;
+  if (geglu) {
+    // packed weight rows: per 64 = [32 value | 32 gate]  ->  16-column tiles (4u, 4u+1) = value, (4u+2, 4u+3) = gate
+    if constexpr (SPLIT_M && (NT % 4) == 0) {
+#pragma unroll
+      for (int ih = 0; ih < MH; ++ih) {
+        const int m = row_of(ih);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int u = 0; u < NT / 4; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const int jv = 4 * u + v, jg = jv + 2;
+            const int nv = col_of(jv);
+            if (nv >= p.N) continue;
+            const int no = (n0 >> 1) + (wn * (NT / 4) + u) * 32 + v * 16 + 4 * kq;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float hv = keep[ih][jv][e] * p.alpha, gv = keep[ih][jg][e] * p.alpha;
+              if (has_bias) {
+                const uint2 bh = bias_v[jv], bg = bias_v[jg];
+                hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
+                gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
+              }
+              hv = bf2f(f2bf(hv));   // the reference rounds the projection to bf16 before chunk / gelu / mul
+              gv = bf2f(f2bf(gv));
+              o[e] = hv * bf2f(f2bf(p.act == DA_ACT_GEGLU ? gelu_erf_f(gv) : gelu_tanh_f(gv)));
+            }
+            uint2 pk;
+            pk.x = pack_bf2(o[0], o[1]);
+            pk.y = pack_bf2(o[2], o[3]);
+            *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + no) = pk;
+          }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int ih = 0; ih < MH; ++ih) {
+    const int m = row_of(ih);
+    if (m >= p.M) continue;
+    const int bidx = (has_rowvec || p.gate != nullptr) ? (m / p.rows_per_batch) : 0;
+    const float brow = bias_rows ? bf2f(bias_rows[m]) : 0.f;
+#pragma unroll
+    for (int jh = 0; jh < NH; ++jh) {
+      const int n = col_of(jh);
+      if (n >= p.N) continue;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
+      epilogue4(p, o, m, n, bidx, brow, has_bias, bias_v[jh], has_rowvec, rowvec_v[ih][jh], has_res, res_v[ih][jh]);
+      if (p.out_f32) {
+        *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        uint2 pk;
+        pk.x = pack_bf2(o[0], o[1]);
+        pk.y = pack_bf2(o[2], o[3]);
+        *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + n) = pk;
+      }
+    }
+  }
+#undef DA2_LDS
+#undef DA2_WAIT_PAIRS
+#undef DA2_SG_DS
+#undef DA2_SG_MF
+#undef DA2_SG_VM
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---- host side ----
+inline int choose_xcd_gx2(int tiles_m, int tiles_n, int BM, int BN) {   // as da_gemm::choose_xcd_gx
+  int best = 1;
+  double best_cost = 1e300;
+  for (int gx = 1; gx <= 8; gx *= 2) {
+    const int gy = 8 / gx;
+    const int tm_per = (tiles_m + gy - 1) / gy, tn_per = (tiles_n + gx - 1) / gx;
+    const double inflation = (double)(8 * tm_per * tn_per) / ((double)tiles_m * tiles_n);
+    const double cost = ((double)tm_per * BM + (double)tn_per * BN) * inflation * inflation;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = gx;
+    }
+  }
+  return best;
+}
+
+// 31-bit offset budget of the buffer-addressed staging (as da_gemm::buffer_staging_fits, for tiles up to 256 rows)
+inline bool staging_fits(const da_gemm_params& p) {
+  const size_t lim = 0x3fffffffull;
+  if ((size_t)p.ldw * 512 >= lim || (size_t)p.K * 2 >= lim) return false;
+  if (!p.conv) return (size_t)p.lda * 512 < lim;
+  const size_t cmax = (size_t)(p.C1 > p.C2 ? p.C1 : p.C2);
+  const size_t span = (size_t)256 * p.stride * p.stride + (size_t)(6 + 2 * p.stride) * p.Win + 64;
+  return span * cmax * 2 < lim && (size_t)p.M / ((size_t)p.Hout * p.Wout) * p.Hin * p.Win < 0x7fffffffull;
+}
+
+template <int WM, int WN, int MT, int NT, int NSLOT, bool CONV>
+int launch(const da_gemm_params& p, hipStream_t s) {
+  constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int gx = choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
+  const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
+  constexpr size_t lds = (size_t)NSLOT * 2 * (BM + BN) * 128 + ((((2 * BM / 8) % 8) || ((2 * BN / 8) % 8)) ? 1024 : 0);
+  auto kern = igemm2_bf16_kernel<WM, WN, MT, NT, NSLOT, CONV>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return DA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  DA_LAUNCH(kern, dim3(grid), dim3(512), lds, s, p, gx);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// K2 tile codes -> instantiations.  staging: DA_STAGE_LDS_DIRECT = ring of 2 slice pairs, DA_STAGE_LDS_DIRECT3 = 3 (where it fits).
+template <bool CONV>
+int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
+  if (p.split_k > 1 || p.stats_out || p.ln_stats || !staging_fits(p)) return DA_ERR_UNSUPPORTED;
+  const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
+  if (geglu && tile != DA_TILE_K2_128x128) return DA_ERR_UNSUPPORTED;   // value / gate column tiles must share a wave
+  const int ns = staging == DA_STAGE_LDS_DIRECT ? 2 : staging == DA_STAGE_LDS_DIRECT3 ? 3 : 0;
+  if (ns == 0) return DA_ERR_UNSUPPORTED;
+  switch (tile) {
+    case DA_TILE_K2_128x128:
+      if (ns == 2) return launch<2, 2, 4, 4, 2, CONV>(p, s);
+      break;
+    case DA_TILE_K2_128x80:
+      return ns == 2 ? launch<4, 1, 2, 5, 2, CONV>(p, s) : launch<4, 1, 2, 5, 3, CONV>(p, s);
+    case DA_TILE_K2_128x160:
+      if (ns == 2) return launch<2, 2, 4, 5, 2, CONV>(p, s);
+      break;
+    case DA_TILE_K2_80x128:
+      if constexpr (!CONV) return ns == 2 ? launch<1, 4, 5, 2, 2, false>(p, s) : launch<1, 4, 5, 2, 3, false>(p, s);
+      break;
+    case DA_TILE_K2_128x64:
+      return ns == 2 ? launch<2, 2, 4, 2, 2, CONV>(p, s) : launch<2, 2, 4, 2, 3, CONV>(p, s);
+  }
+  return DA_ERR_UNSUPPORTED;
+}
+
+}  // namespace da_gemm2

@@ -49,6 +49,18 @@ extern "C" {
                                 DA_TILE_128x128, for problems with fewer tiles than CUs where ONE block per CU has to hide the
                                 fill latency on its own; LDS-direct, 2 / 3 / 4 ring slots; not for GEGLU epilogues */
 
+/* Second kernel family "K2" (csrc/gemm2_kernel.cuh): 8 waves = 2 K-groups x 4 waves on alternate K slices of one tile,
+ * v_mfma_f32_16x16x32_bf16, slice pairs with one mid-pair rendezvous, built for ONE workgroup per CU; tile shapes in
+ * 16-column steps.  staging: DA_STAGE_LDS_DIRECT = ring of 2 slice pairs, DA_STAGE_LDS_DIRECT3 = 3 pairs (128x80, 80x128,
+ * 128x64).  Not for split_k / LayerNorm fold / paired launches; GEGLU epilogues on DA_TILE_K2_128x128 only.  All K2
+ * tiles give bit-identical results; versus the first family the fp32 summation order differs ((even K slices) + (odd)). */
+#define DA_TILE_K2_128x128 9  /* wave tile 64 x 64 */
+#define DA_TILE_K2_128x80 10  /* wave tile 32 x 80: M 2048 x N 1280 = 256 tiles, one per CU */
+#define DA_TILE_K2_128x160 11 /* wave tile 64 x 80: M 8192 x N 640 = 256 tiles */
+#define DA_TILE_K2_80x128 12  /* wave tile 80 x 32 (nn.Linear only): the swapped V^T = W_v X^T products */
+#define DA_TILE_K2_128x64 13  /* wave tile 64 x 32 */
+#define DA_TILE_COUNT 14
+
 #define DA_STAGE_REGISTER 0   /* global_load_dwordx4 -> ds_write_b128 */
 /* LDS-DMA variants: buffer-addressed (buffer_load_dwordx4 ... offen lds: descriptor base at the tile's first operand row,
  * loop-invariant per-lane offsets, scalar K advance, range-check zero fill for conv padding) whenever the tile's operand
