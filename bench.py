@@ -13,11 +13,13 @@ same way, docs/source/en/training/distributed_inference.md:62-108).  Rank 0 prin
 
 Besides the contract keys the line carries, all measured OUTSIDE the timed region on rank 0 at N = 1:
   roofline            dominant kernel (igemm_bf16_kernel), HIP events around every launch of one eager denoising step
-  parity              PSNR of the engine's 50-step image against the reference graph run by PyTorch-ROCm in fp32 on this
-                      GPU on the same weights / latents / embeddings, with the bf16 run of the same graph as noise floor
-  torch_rocm_baseline the same reference graph, eager bf16 on PyTorch-ROCm (hipBLASLt / MIOpen / SDPA): the denominator
-                      of BASELINE.json's ">= 1.5x stock diffusers on PyTorch-ROCm"
-  cpu_baseline        the oracle U-Net forward on the host cores (bounded sample, extrapolated by FLOPs)
+  parity              PSNR of the engine's 50-step image against the REFERENCE PACKAGE itself (StableDiffusionXLPipeline over
+                      the reference's own classes, from the oracle/_ref archive) run by PyTorch-ROCm in fp32 on this GPU on
+                      the same weights / latents / embeddings, with the bf16 run of the same pipeline as noise floor
+  torch_rocm_baseline the same reference pipeline, eager bf16 on PyTorch-ROCm (hipBLASLt / MIOpen / SDPA): the denominator
+                      of BASELINE.json's ">= 1.5x stock diffusers on PyTorch-ROCm"   ("kind": "reference"; "port" = the
+                      oracle restatement, used only when the archive did not ship)
+  cpu_baseline        the reference classes on the host cores: one full-size step + one decode (image = 50 x step + decode)
 """
 from __future__ import annotations
 
@@ -69,6 +71,12 @@ def _sync() -> None:
     torch.cuda.synchronize()
 
 
+def _tuned_live() -> int:
+    """GEMM / conv shapes this rank had to tune live during warm-up (0 when the shipped table covers the workload)."""
+    from diffusers_amd import tuning
+    return int(tuning.LIVE_COUNT)
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -102,49 +110,113 @@ def synth_inputs(n_prompts, tiny, device):
     return {k: torch.stack(v).to(torch.bfloat16).to(device) for k, v in out.items()}
 
 
-def instrumented_gemm_pass(pipe, run_one_step):
-    """Roofline leg: one eager denoising step with a HIP-event pair around every igemm launch (linear + conv), on the
-    stream the kernels are launched on.  Returns (launches, total_ms, total_algorithmic_flops, total_algorithmic_bytes)."""
+HBM_PEAK_GBS = 8000.0                       # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
+
+
+def instrumented_pass(run):
+    """Roofline legs: run() eagerly with a HIP-event pair around every launch of the kernel families that carry the path, on
+    the stream the kernels are launched on.  Returns {family: [launches, ms, algorithmic flop, algorithmic bytes]}:
+      igemm      every Linear / Conv2d launch INCLUDING the paired Q|K + V^T launches (ops.linear_pair)
+      attention  flash attention forward (4 B H Sq Skv D flop)
+      groupnorm  GroupNorm (+ SiLU): read for the statistics, read + write for the apply pass = 6 B per element
+      layernorm  LayerNorm: read + write = 4 B per element"""
     from diffusers_amd import ops
     records = []
-    orig_linear, orig_conv = ops.linear, ops.conv2d_nhwc
+    names = ("linear", "linear_pair", "conv2d_nhwc", "attention", "group_norm_nhwc", "layer_norm")
+    orig = {n: getattr(ops, n) for n in names}
 
-    def timed(fn, flops_of):
+    def timed(fn, work_of, family):
         def wrapper(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(*a, **k)
             e1.record()
-            records.append((e0, e1, flops_of(a, k, out)))
+            records.append((family, e0, e1, work_of(a, k, out)))
             return out
         return wrapper
 
-    def lin_flops(a, k, out):
+    def lin_work(a, k, out):
         x, w = a[0], a[1]
         if x.shape[0] <= 8:
             return None  # skinny path: not the igemm kernel
         # (flops, algorithmic bytes = each operand and the output once)
         return 2.0 * x.shape[0] * w.shape[0] * x.shape[1], 2.0 * (x.numel() + w.numel() + out.numel())
 
-    def conv_flops(a, k, out):
+    def pair_work(a, k, out):
+        tot_f = tot_b = 0.0
+        for prob, o in zip(a, out):
+            x, w = prob["x"], prob["w"]
+            tot_f += 2.0 * x.shape[0] * w.shape[0] * x.shape[1]
+            tot_b += 2.0 * (x.numel() + w.numel() + o.numel())
+        return tot_f, tot_b
+
+    def conv_work(a, k, out):
         x, w = a[0], a[1]
         x2 = k.get("x2")
         return (2.0 * out.shape[0] * out.shape[1] * out.shape[2] * w.shape[0] * w.shape[1],
                 2.0 * (x.numel() + (x2.numel() if x2 is not None else 0) + w.numel() + out.numel()))
 
-    ops.linear, ops.conv2d_nhwc = timed(orig_linear, lin_flops), timed(orig_conv, conv_flops)
+    def attn_work(a, k, out):
+        q, kk, vt = a[0], a[1], a[2]
+        B, H, D, Sq, Skv = k["B"], k["H"], k["D"], k["Sq"], k["Skv"]
+        return 4.0 * B * H * Sq * Skv * D, 2.0 * (2 * B * H * Sq * D + 2 * B * H * Skv * D)
+
+    def gn_work(a, k, out):
+        x2 = k.get("x2")
+        n = out.numel()
+        return 0.0, 6.0 * n
+
+    def ln_work(a, k, out):
+        return 0.0, 4.0 * out.numel()
+
+    ops.linear = timed(orig["linear"], lin_work, "igemm")
+    ops.linear_pair = timed(orig["linear_pair"], pair_work, "igemm")
+    ops.conv2d_nhwc = timed(orig["conv2d_nhwc"], conv_work, "igemm")
+    ops.attention = timed(orig["attention"], attn_work, "attention")
+    ops.group_norm_nhwc = timed(orig["group_norm_nhwc"], gn_work, "groupnorm")
+    ops.layer_norm = timed(orig["layer_norm"], ln_work, "layernorm")
     try:
-        run_one_step()
+        run()
         torch.cuda.synchronize()
     finally:
-        ops.linear, ops.conv2d_nhwc = orig_linear, orig_conv
-    recs = [(e0.elapsed_time(e1), f) for e0, e1, f in records if f is not None]
-    return len(recs), sum(r[0] for r in recs), sum(r[1][0] for r in recs), sum(r[1][1] for r in recs)
+        for n in names:
+            setattr(ops, n, orig[n])
+    fam = {}
+    for family, e0, e1, work in records:
+        if work is None:
+            continue
+        f = fam.setdefault(family, [0, 0.0, 0.0, 0.0])
+        f[0] += 1
+        f[1] += e0.elapsed_time(e1)
+        f[2] += work[0]
+        f[3] += work[1]
+    return fam
+
+
+def _kernel_entry(name, kernel, bound, rec, extra=None):
+    n, ms, fl, nb = rec
+    e = {"name": name, "kernel": kernel, "bound": bound, "launches": n, "ms": ms, "avg_launch_us": 1000.0 * ms / max(n, 1)}
+    if bound == "mfma":
+        e.update({"achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"})
+    else:
+        e.update({"achieved": nb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"})
+    e["frac"] = e["achieved"] / e["peak"]
+    e["algorithmic_gflop"], e["algorithmic_mbytes"] = fl / 1e9, nb / 1e6
+    if extra:
+        e.update(extra)
+    return e
+
+
+def build_fingerprint() -> str:
+    """Identity of the kernels a measurement was taken on (the stamp diffusers_amd/build.py writes next to the library)."""
+    stamp = ROOT / "diffusers_amd" / "_C" / "build.stamp"
+    return stamp.read_text().strip()[:16] if stamp.exists() else "unknown"
 
 
 def roofline_leg(pipe, mine, world, images_per_s):
-    """Dominant kernel = igemm_bf16_kernel (all Linear + Conv2d 3x3/1x1): MFMA-bound.  The conditioning is built here
-    (not taken from the graph's static inputs), so the leg also works after --no-graph / the eager fallback."""
+    """Dominant kernel = the implicit-GEMM family (igemm_bf16_kernel + igemm2_bf16_kernel: all Linear + Conv2d 3x3 / 1x1, paired
+    launches included): MFMA-bound.  `kernels` carries the other families of the denoising step and the VAE decode.  The
+    conditioning is built here (not taken from the graph's static inputs), so the leg also works after --no-graph."""
     sch = pipe.scheduler
     dev = mine["latents"].device
     pe = torch.cat([mine["negative_prompt_embeds"], mine["prompt_embeds"]], dim=0).contiguous()
@@ -158,40 +230,121 @@ def roofline_leg(pipe, mine, world, images_per_s):
         sch.reset(0)
         pipe._step(lat, cond, GUIDANCE, True)
     one_step()  # untimed warm pass
-    n, ms, fl, nbytes = instrumented_gemm_pass(pipe, one_step)
+    fam = instrumented_pass(one_step)
+    n, ms, fl, nbytes = fam["igemm"]
     ach = fl / (ms * 1e-3) / 1e12
+    fp = build_fingerprint()
     traffic, note = None, "no committed PMC measurement (profiles/sdxl_traffic.json)"
     if TRAFFIC_FILE.exists():
         try:
             tr = json.loads(TRAFFIC_FILE.read_text())
-            traffic, note = tr["igemm_bytes_per_launch"], tr.get("source", str(TRAFFIC_FILE.name))
+            if tr.get("build_fingerprint") == fp:
+                traffic, note = tr["igemm_bytes_per_launch"], tr.get("source", str(TRAFFIC_FILE.name))
+            else:
+                note = (f"stale: {TRAFFIC_FILE.name} was measured on build {tr.get('build_fingerprint', 'unstamped (round 2)')}, "
+                        f"this library is {fp}; re-run tools/gpu_r3.sh traffic")
         except (ValueError, KeyError) as e:
             note = f"unreadable {TRAFFIC_FILE.name}: {e}"
+    kernels = [_kernel_entry("igemm", "igemm_bf16_kernel + igemm2_bf16_kernel (Linear, Conv2d, paired Q|K + V^T)", "mfma", fam["igemm"])]
+    if "attention" in fam:
+        kernels.append(_kernel_entry("attention", "attn_fwd_kernel (flash attention forward)", "mfma", fam["attention"]))
+    if "groupnorm" in fam:
+        kernels.append(_kernel_entry("groupnorm", "gn_stats_kernel + gn_apply_kernel (GroupNorm + SiLU)", "hbm", fam["groupnorm"]))
+    if "layernorm" in fam:
+        kernels.append(_kernel_entry("layernorm", "layernorm_kernel", "hbm", fam["layernorm"]))
+    # the VAE decode (once per image): wall time with events, its own implicit-GEMM share, algorithmic traffic of its norms
+    try:
+        z = (mine["latents"] / 0.13025).contiguous()
+        pipe.vae.decode(z, return_dict=False)          # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        pipe.vae.decode(z, return_dict=False)
+        e1.record()
+        e1.synchronize()
+        wall_ms = e0.elapsed_time(e1)
+        vf = instrumented_pass(lambda: pipe.vae.decode(z, return_dict=False))
+        vg = vf.get("igemm", [0, 0.0, 0.0, 0.0])
+        vn = vf.get("groupnorm", [0, 0.0, 0.0, 0.0])
+        kernels.append({"name": "vae_decode", "kernel": "AutoencoderKL.decode 128x128 -> 1024x1024 (whole call)", "bound": "mfma",
+                        "ms": wall_ms, "achieved": 10.4704 / (wall_ms * 1e-3), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": 10.4704 / (wall_ms * 1e-3) / MFMA_PEAK_TFLOPS, "algorithmic_gflop": 10470.4,
+                        "igemm_ms": vg[1], "igemm_tflops": vg[2] / max(vg[1], 1e-9) / 1e9,
+                        "groupnorm_ms": vn[1], "groupnorm_gbs": vn[3] / max(vn[1], 1e-9) / 1e6,
+                        "groupnorm_frac_of_hbm_peak": vn[3] / max(vn[1], 1e-9) / 1e6 / HBM_PEAK_GBS})
+    except Exception as e:  # a diagnostic must not cost the line
+        kernels.append({"name": "vae_decode", "error": f"{type(e).__name__}: {e}"})
     return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": note,
-            "kernel": "igemm_bf16_kernel (Linear + Conv2d implicit GEMM)",
+            "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": note, "build_fingerprint": fp,
+            "kernel": "igemm_bf16_kernel + igemm2_bf16_kernel (Linear + Conv2d implicit GEMM, paired launches included)",
             "launches_per_denoise_step": n, "avg_launch_us": 1000.0 * ms / max(n, 1),
             "algorithmic_tflop_per_denoise_step": fl / 1e12,
             "algorithmic_bytes_per_launch": nbytes / max(n, 1),
-            "end_to_end_frac": images_per_s * TFLOP_PER_IMAGE / world / MFMA_PEAK_TFLOPS}
+            "end_to_end_frac": images_per_s * TFLOP_PER_IMAGE / world / MFMA_PEAK_TFLOPS,
+            "kernels": kernels}
 
 
 # CFG-batched (B=2) SDXL U-Net forward at 32x32 latents, from the 128x128 op census of SURVEY.md 8a: conv 3.246/16,
 # linear (8.709 - 0.105)/16 + 0.105 (the cross-attention K/V projections see 154 text rows at any resolution),
 # attention 1.503/256 (self, quadratic in tokens) + 0.0646/16 (cross)
 CPU_SAMPLE_TFLOP = 3.246 / 16 + (8.709 - 0.105) / 16 + 0.105 + 1.503 / 256 + 0.0646 / 16
+VAE_TFLOP = 10.4704
 
 
-def cpu_baseline(unet_sd, cfg_full, budget_s=25.0):
-    """CPU leg (rank 0, N=1): the oracle restatement of the U-Net forward (oracle/reference_math.py, kind "port") on the
-    host cores this process may run on, on a bounded sample: CFG-batched forward of the FULL SDXL architecture at 32x32
-    latents, fp32.  images/s is EXTRAPOLATED by algorithmic FLOPs (CPU_SAMPLE_TFLOP per sample, 686.6 TFLOP per image)."""
-    from oracle import reference_math as R
+def _host_threads():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
+    return max(1, min(cores, 64))
+
+
+def cpu_baseline_reference(ref, unet_sd, vae_sd, ucfg, vcfg, budget_s=200.0):
+    """CPU leg, kind "reference": the REAL reference classes (oracle/_ref archive) in fp32 on the host cores, on the bounded
+    sample SURVEY.md 8d plans: ONE full-size denoising step (CFG-batched `UNet2DConditionModel.forward` at 128x128 latents,
+    13.52 TFLOP) and ONE `AutoencoderKL.decode` to 1024x1024 (10.47 TFLOP).  The 50 steps of an image are cost-identical, so
+    seconds per image = 50 x step + decode (the only extrapolation).  The decode is skipped (and scaled by FLOPs from the step)
+    if the step alone used most of the budget."""
+    from oracle import ref_runtime as RR
+    threads = _host_threads()
+    torch.set_num_threads(threads)
+    t_start = time.perf_counter()
+    unet = RR.build_unet(ref, ucfg, unet_sd, "cpu", torch.float32)
+    g = torch.Generator("cpu").manual_seed(7)
+    sample = torch.randn((2, 4, 128, 128), generator=g)
+    ehs = torch.randn((2, 77, 2048), generator=g)
+    added = {"text_embeds": torch.randn((2, 1280), generator=g),
+             "time_ids": torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]]).repeat(2, 1)}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        unet(sample, torch.tensor(961.0), encoder_hidden_states=ehs, added_cond_kwargs=added, return_dict=False)
+        t_step = time.perf_counter() - t0
+    log(f"cpu_baseline: reference UNet2DConditionModel.forward (B=2, 128x128 latents, fp32) took {t_step:.1f} s on {threads} threads")
+    del unet
+    t_dec, dec_note = None, ""
+    if time.perf_counter() - t_start + t_step * VAE_TFLOP / UNET_TFLOP < budget_s:
+        vae = RR.build_vae(ref, vcfg, vae_sd, "cpu", torch.float32)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            vae.decode(torch.randn((1, 4, 128, 128), generator=g), return_dict=False)
+            t_dec = time.perf_counter() - t0
+        log(f"cpu_baseline: reference AutoencoderKL.decode (1024x1024, fp32) took {t_dec:.1f} s")
+    else:
+        t_dec = t_step * VAE_TFLOP / UNET_TFLOP
+        dec_note = " (decode not run: scaled by FLOPs from the step)"
+    secs = 50 * t_step + t_dec
+    return {"value": 1.0 / secs, "unit": "images/s", "cores": threads, "kind": "reference", "extrapolated": True,
+            "seconds_per_image": secs,
+            "sample": f"1 full-size CFG-batched reference U-Net step ({t_step:.1f} s, {UNET_TFLOP} TFLOP) + 1 reference VAE decode "
+                      f"({t_dec:.1f} s{dec_note}), fp32, huggingface/diffusers 0.40.0.dev0 on torch CPU; image = 50 x step + decode",
+            "cpu_tflops": (UNET_TFLOP + (VAE_TFLOP if not dec_note else 0)) / (t_step + (t_dec if not dec_note else 0))}
+
+
+def cpu_baseline(unet_sd, cfg_full, budget_s=25.0):
+    """CPU leg fallback, kind "port" (no reference archive on this machine): the oracle restatement of the U-Net forward
+    (oracle/reference_math.py) on the host cores, on a bounded sample: CFG-batched forward of the FULL SDXL architecture at
+    32x32 latents, fp32.  images/s is EXTRAPOLATED by algorithmic FLOPs (CPU_SAMPLE_TFLOP per sample, 686.6 TFLOP per image)."""
+    from oracle import reference_math as R
+    threads = _host_threads()
     torch.set_num_threads(threads)
     sd = {k: v.detach().to("cpu", torch.float32) for k, v in unet_sd.items()}
     g = torch.Generator("cpu").manual_seed(7)
@@ -274,16 +427,58 @@ def reference_pipeline_on_device(unet_sd, vae_sd, ucfg, vcfg, inp, steps, dtype,
     return x, img, (dt if timed else None)
 
 
-def reference_legs(engine_img, engine_lat, unet_sd, vae_sd, ucfg, vcfg, inp, steps, engine_images_per_s):
-    """parity + torch_rocm_baseline objects (rank 0, N = 1, outside the timed region)."""
-    parity = {"psnr_db": None, "ref": "reference graph (oracle restatement) on PyTorch-ROCm fp32, this GPU",
-              "steps": steps, "noise_floor_db": None}
-    base = {"images_per_s": None, "kind": "port of the reference module graph, PyTorch-ROCm eager bf16 "
-                                          "(F.conv2d / F.linear / F.scaled_dot_product_attention / F.group_norm)",
-            "unit": "images/s"}
+def reference_package_on_device(ref, unet_sd, vae_sd, ucfg, vcfg, inp, steps, dtype, timed=False, hw=1024):
+    """CHECKER / BASELINE, never the product: the REAL reference -- `StableDiffusionXLPipeline.__call__`
+    (pipeline_stable_diffusion_xl.py:823-1308) over the reference's own `UNet2DConditionModel`, `AutoencoderKL` and
+    `EulerDiscreteScheduler`, imported from the oracle/_ref archive -- on THIS GPU through PyTorch-ROCm in ``dtype``, on the
+    weights / embeddings / latents the engine ran on.  "Stock diffusers on PyTorch-ROCm": the harness pattern of
+    benchmarks/benchmarking_utils.py:22-68 (warm-up calls, then timed calls bracketed by synchronize; the best of two is
+    reported).  Returns (final latents, image in [-1, 1], seconds per image or None)."""
+    from diffusers_amd import factory
+    from oracle import ref_runtime as RR
+    dev = inp["latents"].device
+    pipe = RR.build_sdxl_pipeline(ref, ucfg, vcfg, unet_sd, vae_sd, factory.SDXL_SCHEDULER, dev, dtype)
+    RR.run_sdxl(pipe, inp, 2, GUIDANCE, hw, dtype)            # warm-up: library handles, MIOpen / hipBLASLt solution search
+    torch.cuda.synchronize()
+    secs = None
+    if timed:
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            RR.run_sdxl(pipe, inp, steps, GUIDANCE, hw, dtype)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        secs = best
+    img01, lat = RR.run_sdxl(pipe, inp, steps, GUIDANCE, hw, dtype, want_latents=True)
+    torch.cuda.synchronize()
+    return lat, img01.float() * 2.0 - 1.0, secs
+
+
+def reference_legs(engine_img, engine_lat, unet_sd, vae_sd, ucfg, vcfg, ucfg_min, vcfg_min, inp, steps, engine_images_per_s):
+    """parity + torch_rocm_baseline objects (rank 0, N = 1, outside the timed region).  With the reference archive present
+    (oracle/_ref/diffusers_ref.zip, built by oracle/build_ref.py) both legs run the REAL reference package (`kind`:
+    "reference"); without it they fall back to the oracle restatement of the module graph (`kind`: "port")."""
+    from oracle import ref_runtime as RR
+    ref = None
     try:
-        log("torch_rocm_baseline leg: reference graph, eager bf16, 50 steps + decode")
-        lat_b, img_b, secs = reference_pipeline_on_device(unet_sd, vae_sd, ucfg, vcfg, inp, steps, torch.bfloat16, timed=True)
+        ref = RR.load_reference()
+    except Exception as e:  # a broken archive must not cost the measurement
+        log(f"reference archive unusable ({type(e).__name__}: {e}); falling back to the oracle port")
+    kind = "reference" if ref is not None else "port"
+    what = ("stock diffusers 0.40.0.dev0 StableDiffusionXLPipeline.__call__ over reference UNet2DConditionModel / AutoencoderKL / "
+            "EulerDiscreteScheduler (oracle/_ref archive)" if ref is not None else
+            "port of the reference module graph (oracle restatement; F.conv2d / F.linear / F.scaled_dot_product_attention / F.group_norm)")
+    parity = {"psnr_db": None, "ref": f"{what}, PyTorch-ROCm fp32, this GPU", "kind": kind, "steps": steps, "noise_floor_db": None}
+    base = {"images_per_s": None, "kind": kind, "what": f"{what}, PyTorch-ROCm eager bf16", "unit": "images/s"}
+
+    def run(dtype, timed):
+        if ref is not None:
+            return reference_package_on_device(ref, unet_sd, vae_sd, ucfg_min, vcfg_min, inp, steps, dtype, timed=timed)
+        return reference_pipeline_on_device(unet_sd, vae_sd, ucfg, vcfg, inp, steps, dtype, timed=timed)
+    try:
+        log(f"torch_rocm_baseline leg ({kind}): eager bf16, {steps} steps + decode")
+        lat_b, img_b, secs = run(torch.bfloat16, True)
         base.update({"images_per_s": 1.0 / secs, "seconds_per_image": secs})
         log(f"torch_rocm_baseline: {secs:.2f} s / image")
     except Exception as e:  # a failing baseline must not cost the measurement
@@ -291,16 +486,16 @@ def reference_legs(engine_img, engine_lat, unet_sd, vae_sd, ucfg, vcfg, inp, ste
         lat_b = img_b = None
         log(f"torch_rocm_baseline failed: {base['error']}")
     try:
-        log("parity leg: reference graph, fp32, 50 steps + decode")
-        lat_f, img_f, _ = reference_pipeline_on_device(unet_sd, vae_sd, ucfg, vcfg, inp, steps, torch.float32)
+        log(f"parity leg ({kind}): fp32, {steps} steps + decode")
+        lat_f, img_f, _ = run(torch.float32, False)
         parity["psnr_db"] = _psnr01(engine_img, img_f)
-        d = engine_lat.float() - lat_f
-        parity["latents_rel_rms"] = float(d.pow(2).mean().sqrt() / lat_f.pow(2).mean().sqrt())
+        d = engine_lat.float() - lat_f.float()
+        parity["latents_rel_rms"] = float(d.pow(2).mean().sqrt() / lat_f.float().pow(2).mean().sqrt())
         if img_b is not None:
             parity["noise_floor_db"] = _psnr01(img_b, img_f)            # reference bf16 vs reference fp32
             parity["vs_torch_bf16_db"] = _psnr01(engine_img, img_b)
-            db = lat_b.float() - lat_f
-            parity["noise_floor_latents_rel_rms"] = float(db.pow(2).mean().sqrt() / lat_f.pow(2).mean().sqrt())
+            db = lat_b.float() - lat_f.float()
+            parity["noise_floor_latents_rel_rms"] = float(db.pow(2).mean().sqrt() / lat_f.float().pow(2).mean().sqrt())
         parity["finite"] = bool(torch.isfinite(img_f).all())
         log(f"parity: engine vs fp32 {parity['psnr_db']:.1f} dB, torch-bf16 vs fp32 {parity['noise_floor_db']} dB")
     except Exception as e:
@@ -403,6 +598,7 @@ def main(argv=None):
                    "global_batch": world, "parallelism": f"dp{world} (independent prompts, replicas)",
                    "denoise_steps": args.denoise_steps, "hip_graph": state["graph"], "output_finite": finite,
                    "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+                   "tuned_live": _tuned_live(),
                    "images_per_s_per_rank": per_rank},
     }
 
@@ -421,7 +617,7 @@ def main(argv=None):
             # the engine's own image / latents for the parity check: the same call as the timed one
             eng_lat = one_image("latent").clone()
             eng_img = one_image("raw")
-            parity, base, vs = reference_legs(eng_img, eng_lat, unet_sd, vae_sd, full_u, full_v, mine,
+            parity, base, vs = reference_legs(eng_img, eng_lat, unet_sd, vae_sd, full_u, full_v, ucfg, vcfg, mine,
                                               args.denoise_steps, value)
             result["parity"], result["torch_rocm_baseline"], result["vs_torch_rocm"] = parity, base, vs
         if world == 1 and not args.no_cpu_baseline:
@@ -433,9 +629,14 @@ def main(argv=None):
             def _alarm(signum, frame):
                 raise TimeoutError("cpu_baseline exceeded its wall-clock bound")
             signal.signal(signal.SIGALRM, _alarm)
-            signal.alarm(150)
+            signal.alarm(420)
             try:
-                result["cpu_baseline"] = cpu_baseline(unet_sd, full)
+                from oracle import ref_runtime as RR
+                ref = RR.load_reference() if RR.available() else None
+                if ref is not None:
+                    result["cpu_baseline"] = cpu_baseline_reference(ref, unet_sd, vae_sd, ucfg, vcfg)
+                else:
+                    result["cpu_baseline"] = cpu_baseline(unet_sd, full)
             except TimeoutError as e:
                 result["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": None, "kind": "port",
                                           "sample": f"not measured: {e}"}

@@ -36,7 +36,8 @@ struct TileShape {
 constexpr TileShape kTiles[] = {{0, 0, 0},      {128, 128, 4}, {64, 128, 4},  {128, 64, 4}, {64, 64, 4},
                                 {256, 128, 8},  {128, 256, 8}, {256, 256, 8}, {128, 128, 8},
                                 // K2 family (gemm2_kernel.cuh)
-                                {128, 128, 8},  {128, 80, 8},  {128, 160, 8}, {80, 128, 8}, {128, 64, 8}};
+                                {128, 128, 8},  {128, 80, 8},  {128, 160, 8}, {80, 128, 8}, {128, 64, 8},
+                                {128, 320, 8},  {256, 128, 8}, {128, 256, 8}, {256, 160, 8}, {256, 256, 8}};
 static_assert(sizeof(kTiles) / sizeof(kTiles[0]) == DA_TILE_COUNT, "kTiles / DA_TILE_* mismatch");
 inline bool is_k2(int tile) { return tile >= DA_TILE_K2_128x128; }
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
@@ -100,8 +101,9 @@ bool tile_ok(const da_gemm_params& p, int tile) {
   if (tile <= 0 || tile >= kNumTiles) return false;
   if (is_k2(tile)) {
     const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
-    return !p.stats_out && !p.ln_stats && p.split_k <= 1 && (!geglu || tile == DA_TILE_K2_128x128) &&
-           !(p.conv && tile == DA_TILE_K2_80x128);
+    const bool geglu_ok = tile == DA_TILE_K2_128x128 || tile == DA_TILE_K1_256x128 || tile == DA_TILE_K1_128x256 ||
+                          tile == DA_TILE_K1_256x256;
+    return !p.stats_out && !p.ln_stats && p.split_k <= 1 && (!geglu || geglu_ok) && !(p.conv && tile == DA_TILE_K2_80x128);
   }
   // GEGLU pairs (value, gate) 32-column tiles inside one wave: the wave must own an even number of them
   if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) &&
@@ -185,9 +187,11 @@ extern "C" int da_gemm_tune(const da_gemm_params* pp, const da_gemm_params* pair
                                  DA_STAGE_LDS_DIRECT8};
   constexpr int n_stagings = sizeof(stagings) / sizeof(stagings[0]);
   const int max_split = (best_split && !pair && p.workspace && p.sync_flags) ? 4 : 1;
+  const int family = pp->tile;   // DA_TILE_AUTO: every variant; DA_TILE_FAMILY_1 / DA_TILE_FAMILY_K2: one kernel family only
   for (int split = 1; split <= max_split; ++split) {
     p.split_k = split;
     for (int tile = 1; tile < kNumTiles; ++tile) {
+      if ((family == DA_TILE_FAMILY_1 && is_k2(tile)) || (family == DA_TILE_FAMILY_K2 && !is_k2(tile))) continue;
       if (!tile_ok(p, tile) || (pair && !tile_ok(pb, tile))) continue;
       // a tile more than twice the problem in either dimension only wastes MFMA rows
       if (kTiles[tile].bm >= 2 * p.M + 64 || kTiles[tile].bn >= 2 * p.N + 64) continue;

@@ -94,29 +94,33 @@ __device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int
   }
 }
 
-// WM x WN waves per K-group (WM * WN == 4), each wave owns MT x NT tiles of 16 x 16  ->  block tile (16*MT*WM) x (16*NT*WN).
-// NSLOT = ring depth in slice PAIRS (2 or 3).
-template <int WM, int WN, int MT, int NT, int NSLOT, bool CONV>
+// KG K-groups of WM x WN waves (KG * WM * WN == 8), each wave owns MT x NT tiles of 16 x 16  ->  block tile (16*MT*WM) x (16*NT*WN).
+// KG == 2: the design described above (two groups of four waves on alternate K slices; the ring unit is a slice PAIR).
+// KG == 1: the same loop with all eight waves on every slice (ring unit = one slice, no exchange after the loop): the large
+//          tiles (128 x 320, 256 x 128) of problems with several tiles per CU, where what binds a 128 x 128 tile is the
+//          L2 -> LDS traffic per flop, (1 / BM + 1 / BN) bytes, not the latency of a lone workgroup.
+// NSLOT = ring depth in units (2 or 3).
+template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV>
 __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(WM * WN == 4, "a K-group is four waves");
+  static_assert((KG == 1 || KG == 2) && KG * WM * WN == 8, "eight waves: one or two K-groups");
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int PX = BM / 8, PW = BN / 8;                 // 1 KiB pieces (8 rows x 128 B) per slice
-  constexpr int XBYTES = BM * 128, SLICE = (BM + BN) * 128, PAIR = 2 * SLICE;
-  constexpr int XI = (2 * PX + 7) / 8, WI = (2 * PW + 7) / 8;   // LDS-DMA instructions per wave per pair (upper bound)
-  constexpr int XRAG = (2 * PX) % 8 ? 1 : 0, WRAG = (2 * PW) % 8 ? 1 : 0;   // a last row of pieces only some waves own
+  constexpr int XBYTES = BM * 128, SLICE = (BM + BN) * 128, PAIR = KG * SLICE;   // PAIR = the ring unit (KG slices)
+  constexpr int XI = (KG * PX + 7) / 8, WI = (KG * PW + 7) / 8;   // LDS-DMA instructions per wave per unit (upper bound)
+  constexpr int XRAG = (KG * PX) % 8 ? 1 : 0, WRAG = (KG * PW) % 8 ? 1 : 0;   // a last row of pieces only some waves own
   static_assert(NSLOT == 2 || NSLOT == 3, "ring of 2 or 3 slice pairs");
   constexpr int DUMP = (XRAG || WRAG) ? 1024 : 0;          // where the out-of-range pieces of ragged tiles write their zeros
   static_assert(NSLOT * PAIR + DUMP <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
   static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows are staged in 8-row pieces");
-  static_assert(!CONV || (PX % 4) == 0, "conv: the slice parity of an activation piece must be a compile-time constant");
+  static_assert(!CONV || ((KG * PX) % 8) == 0, "conv: the slice of an activation piece must be a compile-time constant");
   static_assert((NSLOT - 1) * (XI + WI) <= 63, "vmcnt is a 6-bit counter");
-  static_assert(MT * NT * 1024 * 4 <= NSLOT * PAIR, "partial-sum exchange does not fit the ring");
+  static_assert(KG == 1 || MT * NT * 1024 * 4 <= NSLOT * PAIR, "partial-sum exchange does not fit the ring");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int g = wave >> 2, wq = wave & 3;                 // K-group, position inside the group
+  const int g = KG == 2 ? wave >> 2 : 0, wq = KG == 2 ? wave & 3 : wave;   // K-group, position inside the group
   const int wm = wq / WN, wn = wq - wm * WN;
   const int r16 = lane & 15, kq = lane >> 4;
 
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   const uint16_t* __restrict__ A2 = (const uint16_t*)p.A2;
   const uint16_t* __restrict__ Wt = (const uint16_t*)p.W;
   const int nk = p.K >> 6;                                // K slices
-  const int nk2 = (nk + 1) >> 1;                          // slice pairs
+  const int nk2 = (nk + KG - 1) / KG;                     // ring units (slice pairs for KG == 2)
   const int Ctot = CONV ? (p.C1 + p.C2) : 0;
   const int Hv = CONV ? (p.Hin << p.up) : 0, Wv = CONV ? (p.Win << p.up) : 0;
 
@@ -148,16 +152,16 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   for (int i = 0; i < XI; ++i) {
     const int q = i * 8 + wave;
     // compile-time constants wherever all eight waves of a row i agree (so the unrolled issue code has no branch / select)
-    x_ok[i] = (i * 8 + 7 < 2 * PX) ? true : (q < 2 * PX);
-    x_h[i] = (i * 8 >= PX) ? 1 : (i * 8 + 7 < PX) ? 0 : (q >= PX ? 1 : 0);
+    x_ok[i] = (i * 8 + 7 < KG * PX) ? true : (q < KG * PX);
+    x_h[i] = (KG == 1) ? 0 : (i * 8 >= PX) ? 1 : (i * 8 + 7 < PX) ? 0 : (q >= PX ? 1 : 0);
     x_r[i] = q - x_h[i] * PX;
     if (!x_ok[i]) x_h[i] = 0, x_r[i] = 0;
   }
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
     const int q = i * 8 + wave;
-    w_ok[i] = (i * 8 + 7 < 2 * PW) ? true : (q < 2 * PW);
-    w_h[i] = (i * 8 >= PW) ? 1 : (i * 8 + 7 < PW) ? 0 : (q >= PW ? 1 : 0);
+    w_ok[i] = (i * 8 + 7 < KG * PW) ? true : (q < KG * PW);
+    w_h[i] = (KG == 1) ? 0 : (i * 8 >= PW) ? 1 : (i * 8 + 7 < PW) ? 0 : (q >= PW ? 1 : 0);
     w_r[i] = q - w_h[i] * PW;
     if (!w_ok[i]) w_h[i] = 0, w_r[i] = 0;
   }
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   auto tap_offsets = [&](int h) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      if ((i >= XI / 2 ? 1 : 0) != h) continue;           // CONV: PX % 4 == 0, so pieces i < XI / 2 are parity 0
+      if ((KG == 2 && i >= XI / 2 ? 1 : 0) != h) continue;   // CONV: (KG * PX) % 8 == 0, so pieces i < XI / 2 are parity 0
       const int row = x_r[i] * 8 + (lane >> 3);
       const int sc = (lane & 7) ^ ((row >> 1) & 7);
       const int iy = xr_oy[i] + c_kh[h], ix = xr_ox[i] + c_kw[h];
@@ -251,9 +255,9 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
     }
   };
   if constexpr (CONV) {
-    if (nk > 1) cursor_step(1);                           // parity 1 starts on slice 1
+    if (KG == 2 && nk > 1) cursor_step(1);                // parity 1 starts on slice 1
     tap_offsets(0);
-    tap_offsets(1);
+    if (KG == 2) tap_offsets(1);
   }
 
 #define DA2_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
@@ -296,8 +300,8 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   auto stage_advance = [&]() {
     ++st_pr;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int want = min(2 * st_pr + h, nk - 1);
+    for (int h = 0; h < KG; ++h) {
+      const int want = min(KG * st_pr + h, nk - 1);
       if constexpr (CONV) {
         const int kh0 = c_kh[h], kw0 = c_kw[h];
         while (st_s[h] < want) {
@@ -309,34 +313,37 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
         st_s[h] = want;
       }
     }
-    st_zero[0] = (2 * st_pr < nk) ? 0 : (int)0x80000000;
-    st_zero[1] = (2 * st_pr + 1 < nk) ? 0 : (int)0x80000000;
+    st_zero[0] = (KG * st_pr < nk) ? 0 : (int)0x80000000;
+    st_zero[1] = (KG * st_pr + 1 < nk) ? 0 : (int)0x80000000;
   };
   // wait until at most PAIRS later pairs of THIS wave's LDS-DMA are in flight (a compile-time immediate)
 #define DA2_WAIT_PAIRS(PAIRS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PAIRS) * my_loads) : "memory")
 
   // ---- epilogue operands of the half tile this wave will finish: fetched BEFORE the K loop (their round trip hides there) ----
   // After the loop group g keeps the row tiles [g * MH, (g + 1) * MH) (column tiles when MT is odd) and sends the rest.
-  constexpr bool SPLIT_M = (MT % 2) == 0;
+  constexpr bool SPLIT_M = KG == 1 || (MT % 2) == 0;
   static_assert(SPLIT_M || (NT % 2) == 0, "one of the wave tile's dimensions must split between the two K-groups");
-  constexpr int MH = SPLIT_M ? MT / 2 : MT, NH = SPLIT_M ? NT : NT / 2;
+  constexpr int MH = (KG == 2 && SPLIT_M) ? MT / 2 : MT, NH = (KG == 1 || SPLIT_M) ? NT : NT / 2;
   const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
   auto row_of = [&](int ih) { return m0 + (wm * MT + (SPLIT_M ? g * MH : 0) + ih) * 16 + r16; };
   auto col_of = [&](int jh) { return n0 + (wn * NT + (SPLIT_M ? 0 : g * NH) + jh) * 16 + 4 * kq; };
-  uint2 res_v[MH][NH], bias_v[NH], rowvec_v[MH][NH];
+  // (Only while the registers last: a wave that finishes more than 12 tiles -- the KG == 1 shapes -- fetches the residual and
+  // the channel vector in the epilogue instead; its launches are long enough for that round trip not to matter.)
+  constexpr bool PF = MH * NH <= 12;
+  uint2 res_v[PF ? MH : 1][PF ? NH : 1], bias_v[NH], rowvec_v[PF ? MH : 1][PF ? NH : 1];
 #pragma unroll
-  for (int ih = 0; ih < MH; ++ih)
+  for (int ih = 0; ih < (PF ? MH : 1); ++ih)
 #pragma unroll
-    for (int jh = 0; jh < NH; ++jh) res_v[ih][jh] = rowvec_v[ih][jh] = make_uint2(0, 0);
+    for (int jh = 0; jh < (PF ? NH : 1); ++jh) res_v[ih][jh] = rowvec_v[ih][jh] = make_uint2(0, 0);
 #pragma unroll
   for (int jh = 0; jh < NH; ++jh) bias_v[jh] = make_uint2(0, 0);
   {
     const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
     const uint16_t* __restrict__ bias = (const uint16_t*)p.bias;
     const uint16_t* __restrict__ rowvec = (const uint16_t*)p.rowvec;
-    if (resid) {
+    if (PF && resid) {
 #pragma unroll
-      for (int ih = 0; ih < MH; ++ih) {
+      for (int ih = 0; ih < (PF ? MH : 0); ++ih) {
         const int m = min(row_of(ih), p.M - 1);
 #pragma unroll
         for (int jh = 0; jh < NH; ++jh) res_v[ih][jh] = *(const uint2*)(resid + (size_t)m * p.ldr + min(col_of(jh), p.N - 4));
@@ -346,9 +353,9 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
 #pragma unroll
       for (int jh = 0; jh < NH; ++jh) bias_v[jh] = *(const uint2*)(bias + min(col_of(jh), p.N - 4));
     }
-    if (rowvec) {
+    if (PF && rowvec) {
 #pragma unroll
-      for (int ih = 0; ih < MH; ++ih) {
+      for (int ih = 0; ih < (PF ? MH : 0); ++ih) {
         const int m = min(row_of(ih), p.M - 1);
         const size_t ro = (size_t)(m / p.rows_per_batch) * p.ld_rowvec;
 #pragma unroll
@@ -443,11 +450,16 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
 #undef DA2_MFMA
 
   // ---- the two K-groups meet: each sends the half it does not finish, through the (now free) ring ----
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
   f32x4_t keep[MH][NH];
-  {
+  if constexpr (KG == 1) {
+#pragma unroll
+    for (int ih = 0; ih < MH; ++ih)
+#pragma unroll
+      for (int jh = 0; jh < NH; ++jh) keep[ih][jh] = acc[ih][jh];
+  } else {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     f32x4_t* xch = (f32x4_t*)smem + (size_t)wq * (MT * NT) * 64 + lane;
 #pragma unroll
     for (int ih = 0; ih < MH; ++ih)
@@ -533,7 +545,15 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
-      epilogue4(p, o, m, n, bidx, brow, has_bias, bias_v[jh], has_rowvec, rowvec_v[ih][jh], has_res, res_v[ih][jh]);
+      uint2 rvv = make_uint2(0, 0), rsv = make_uint2(0, 0);
+      if constexpr (PF) {
+        rvv = rowvec_v[ih][jh];
+        rsv = res_v[ih][jh];
+      } else {
+        if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
+        if (has_res) rsv = *(const uint2*)((const uint16_t*)p.residual + (size_t)m * p.ldr + n);
+      }
+      epilogue4(p, o, m, n, bidx, brow, has_bias, bias_v[jh], has_rowvec, rvv, has_res, rsv);
       if (p.out_f32) {
         *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
       } else {
@@ -579,14 +599,14 @@ inline bool staging_fits(const da_gemm_params& p) {
   return span * cmax * 2 < lim && (size_t)p.M / ((size_t)p.Hout * p.Wout) * p.Hin * p.Win < 0x7fffffffull;
 }
 
-template <int WM, int WN, int MT, int NT, int NSLOT, bool CONV>
+template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV>
 int launch(const da_gemm_params& p, hipStream_t s) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int gx = choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
-  constexpr size_t lds = (size_t)NSLOT * 2 * (BM + BN) * 128 + ((((2 * BM / 8) % 8) || ((2 * BN / 8) % 8)) ? 1024 : 0);
-  auto kern = igemm2_bf16_kernel<WM, WN, MT, NT, NSLOT, CONV>;
+  constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + ((((KG * BM / 8) % 8) || ((KG * BN / 8) % 8)) ? 1024 : 0);
+  auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -603,23 +623,39 @@ template <bool CONV>
 int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
   if (p.split_k > 1 || p.stats_out || p.ln_stats || !staging_fits(p)) return DA_ERR_UNSUPPORTED;
   const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
-  if (geglu && tile != DA_TILE_K2_128x128) return DA_ERR_UNSUPPORTED;   // value / gate column tiles must share a wave
+  // GEGLU: the value / gate column tiles of a 64-row group must share a wave (wave tiles whose width is a multiple of 64)
+  if (geglu && tile != DA_TILE_K2_128x128 && tile != DA_TILE_K1_256x128 && tile != DA_TILE_K1_128x256 && tile != DA_TILE_K1_256x256)
+    return DA_ERR_UNSUPPORTED;
   const int ns = staging == DA_STAGE_LDS_DIRECT ? 2 : staging == DA_STAGE_LDS_DIRECT3 ? 3 : 0;
   if (ns == 0) return DA_ERR_UNSUPPORTED;
   switch (tile) {
     case DA_TILE_K2_128x128:
-      if (ns == 2) return launch<2, 2, 4, 4, 2, CONV>(p, s);
+      if (ns == 2) return launch<2, 2, 2, 4, 4, 2, CONV>(p, s);
       break;
     case DA_TILE_K2_128x80:
-      return ns == 2 ? launch<4, 1, 2, 5, 2, CONV>(p, s) : launch<4, 1, 2, 5, 3, CONV>(p, s);
+      return ns == 2 ? launch<2, 4, 1, 2, 5, 2, CONV>(p, s) : launch<2, 4, 1, 2, 5, 3, CONV>(p, s);
     case DA_TILE_K2_128x160:
-      if (ns == 2) return launch<2, 2, 4, 5, 2, CONV>(p, s);
+      if (ns == 2) return launch<2, 2, 2, 4, 5, 2, CONV>(p, s);
       break;
     case DA_TILE_K2_80x128:
-      if constexpr (!CONV) return ns == 2 ? launch<1, 4, 5, 2, 2, false>(p, s) : launch<1, 4, 5, 2, 3, false>(p, s);
+      if constexpr (!CONV) return ns == 2 ? launch<2, 1, 4, 5, 2, 2, false>(p, s) : launch<2, 1, 4, 5, 2, 3, false>(p, s);
       break;
     case DA_TILE_K2_128x64:
-      return ns == 2 ? launch<2, 2, 4, 2, 2, CONV>(p, s) : launch<2, 2, 4, 2, 3, CONV>(p, s);
+      return ns == 2 ? launch<2, 2, 2, 4, 2, 2, CONV>(p, s) : launch<2, 2, 2, 4, 2, 3, CONV>(p, s);
+    // KG == 1: eight waves on every slice, large tiles
+    case DA_TILE_K1_128x320:                                  // 4 x 2 waves of 32 x 160
+      if (ns == 2) return launch<1, 4, 2, 2, 10, 2, CONV>(p, s);
+      break;
+    case DA_TILE_K1_256x128:                                  // 4 x 2 waves of 64 x 64
+      return ns == 2 ? launch<1, 4, 2, 4, 4, 2, CONV>(p, s) : launch<1, 4, 2, 4, 4, 3, CONV>(p, s);
+    case DA_TILE_K1_128x256:                                  // 2 x 4 waves of 64 x 64
+      return ns == 2 ? launch<1, 2, 4, 4, 4, 2, CONV>(p, s) : launch<1, 2, 4, 4, 4, 3, CONV>(p, s);
+    case DA_TILE_K1_256x160:                                  // 4 x 2 waves of 64 x 80
+      if (ns == 2) return launch<1, 4, 2, 4, 5, 2, CONV>(p, s);
+      break;
+    case DA_TILE_K1_256x256:                                  // 2 x 4 waves of 128 x 64
+      if (ns == 2) return launch<1, 2, 4, 8, 4, 2, CONV>(p, s);
+      break;
   }
   return DA_ERR_UNSUPPORTED;
 }

@@ -9,7 +9,9 @@ which times them on the caller's stream; this module owns the resulting table:
   * the table is keyed by problem shape only, is plain JSON (``tuned/gfx950.json`` ships the shapes of the BASELINE
     configs measured on an MI355X) and can be extended / saved with ``save()``.
 
-All variants produce bit-identical outputs (same K order, same MFMA), so the table affects speed only.
+Within one kernel family all variants produce bit-identical outputs (same K order, same MFMA); the two families (csrc/gemm_kernel.cuh
+and the K2 family of csrc/gemm2_kernel.cuh) differ in the fp32 summation order of K, i.e. in the last bit before an output is
+rounded to bf16 -- ``FAMILY`` restricts live tuning to one of them.
 Env: ``DIFFUSERS_AMD_TUNE=0`` disables live tuning, ``DIFFUSERS_AMD_TUNE_DB=<path>`` overrides the table location,
 ``DIFFUSERS_AMD_TUNE_SAVE=<path>`` writes the (extended) table there at interpreter exit.
 """
@@ -33,6 +35,7 @@ ITERS = 3
 FLUSH_BYTES = 320 << 20  # > 256 MiB Infinity Cache: operands are timed at HBM latency, as inside the denoising loop
 
 _table: Dict[str, Tuple[int, int, float, int]] = {}   # key -> (tile, staging, microseconds, split_k)
+LIVE_COUNT = 0     # problems tuned live in this process (bench.py reports it: a tuning pass on 8 ranks at once would cost scaling)
 _loaded = False
 _dirty = False
 _scratch = {}
@@ -88,6 +91,12 @@ def save(path: Optional[os.PathLike] = None) -> Path:
 # partial-tile hand-off costs more than the idle CUs), and a split factor changes the fp32 summation order.
 SPLIT_K = os.environ.get("DIFFUSERS_AMD_SPLITK", "0") == "1"
 
+# Which kernel families compete in live tuning: "all" (default), "1" (csrc/gemm_kernel.cuh only: every variant bit-identical to
+# every other, what rounds 1-2 shipped) or "k2" (csrc/gemm2_kernel.cuh only).  The two families differ in the fp32 summation
+# order of K ((even slices) + (odd slices) in K2), i.e. in the last bit before the bf16 rounding of an output.
+FAMILY = os.environ.get("DIFFUSERS_AMD_GEMM_FAMILY", "all")
+_FAMILY_CODE = {"all": L.TILE_AUTO, "1": -1, "k2": -2}
+
 
 def pair_key(pa: "L.GemmParams", pb: "L.GemmParams") -> str:
     return "pair:" + key_of(pa) + "|" + key_of(pb)
@@ -97,7 +106,8 @@ def tune(p: "L.GemmParams", stream: int, pair: Optional["L.GemmParams"] = None) 
     """Run da_gemm_tune for this problem (synchronises the stream) and remember the winner.  ``pair``: the two problems
     are timed as ONE launch (da_gemm_pair_bf16).  When ``p`` carries a split-K workspace the split factors 2..4 compete
     with the unsplit variants."""
-    global _dirty
+    global _dirty, LIVE_COUNT
+    LIVE_COUNT += 1
     bt, bs, bk, us = C.c_int(0), C.c_int(0), C.c_int(1), C.c_float(0.0)
     dev = torch.cuda.current_device()
     if FLUSH_BYTES and dev not in _scratch:
@@ -105,9 +115,13 @@ def tune(p: "L.GemmParams", stream: int, pair: Optional["L.GemmParams"] = None) 
     sp = _scratch[dev].data_ptr() if FLUSH_BYTES else None
     # a launch of more than ~2 TFLOP runs for milliseconds: one timed launch per variant is already stable
     iters = 1 if 2.0 * p.M * p.N * p.K > 2e12 else ITERS
-    L.check(L.load().da_gemm_tune(C.byref(p), C.byref(pair) if pair is not None else None, stream, iters, sp,
-                                  FLUSH_BYTES if sp else 0, C.byref(bt), C.byref(bs), C.byref(bk), C.byref(us)),
-            "da_gemm_tune")
+    keep_tile, p.tile = p.tile, _FAMILY_CODE[FAMILY]
+    try:
+        rc = L.load().da_gemm_tune(C.byref(p), C.byref(pair) if pair is not None else None, stream, iters, sp,
+                                   FLUSH_BYTES if sp else 0, C.byref(bt), C.byref(bs), C.byref(bk), C.byref(us))
+    finally:
+        p.tile = keep_tile
+    L.check(rc, "da_gemm_tune")
     ent = (bt.value, bs.value, us.value, bk.value)
     table()[pair_key(p, pair) if pair is not None else key_of(p)] = ent
     _dirty = True

@@ -59,7 +59,18 @@ extern "C" {
 #define DA_TILE_K2_128x160 11 /* wave tile 64 x 80: M 8192 x N 640 = 256 tiles */
 #define DA_TILE_K2_80x128 12  /* wave tile 80 x 32 (nn.Linear only): the swapped V^T = W_v X^T products */
 #define DA_TILE_K2_128x64 13  /* wave tile 64 x 32 */
-#define DA_TILE_COUNT 14
+/* the same loop with all eight waves on every K slice (no K-groups): large tiles for problems with several tiles per CU,
+ * where the L2 -> LDS traffic per flop of a 128 x 128 tile is what binds */
+#define DA_TILE_K1_128x320 14 /* 4 x 2 waves of 32 x 160: M 2048 x N 10240 = 512 tiles, two per CU */
+#define DA_TILE_K1_256x128 15 /* 4 x 2 waves of 64 x 64; 2 or 3 ring slots */
+#define DA_TILE_K1_128x256 16 /* 2 x 4 waves of 64 x 64; 2 or 3 ring slots */
+#define DA_TILE_K1_256x160 17 /* 4 x 2 waves of 64 x 80 */
+#define DA_TILE_K1_256x256 18 /* 2 x 4 waves of 128 x 64 */
+#define DA_TILE_COUNT 19
+/* da_gemm_tune only: which variants compete, given in da_gemm_params.tile (DA_TILE_AUTO = all of them).  Within one family
+ * every variant is bit-identical to every other; the two families differ in the fp32 summation order. */
+#define DA_TILE_FAMILY_1 (-1)
+#define DA_TILE_FAMILY_K2 (-2)
 
 #define DA_STAGE_REGISTER 0   /* global_load_dwordx4 -> ds_write_b128 */
 /* LDS-DMA variants: buffer-addressed (buffer_load_dwordx4 ... offen lds: descriptor base at the tile's first operand row,

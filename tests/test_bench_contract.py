@@ -30,8 +30,21 @@ def test_bench_source_emits_the_contract_keys():
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in src
     assert "json.dumps(result)" in src and "max_over_ranks" in src and "barrier()" in src
-    assert not re.search(r"^\s*(from|import)\s+oracle", src.split("def cpu_baseline")[0], re.M), \
-        "oracle may only be imported inside the cpu_baseline leg"
+    # the oracle (restatement AND the reference archive, oracle/ref_runtime.py) is test / baseline infrastructure: bench.py may
+    # import it only inside the legs that run it as the thing compared against, never at module level or in the timed path
+    allowed = {"cpu_baseline", "cpu_baseline_reference", "reference_pipeline_on_device", "reference_package_on_device",
+               "reference_legs", "main"}
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            mod = node.module if isinstance(node, ast.ImportFrom) else None
+            names = [a.name for a in node.names] if isinstance(node, ast.Import) else []
+            if (mod and mod.split(".")[0] == "oracle") or any(n.split(".")[0] == "oracle" for n in names):
+                assert fn.name in allowed, f"bench.py: {fn.name}() imports the oracle"
+    for node in tree.body:
+        assert not (isinstance(node, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(node)), "module-level oracle import"
+    # in main() the only oracle use is the cpu_baseline dispatch (after the timed region)
+    main_src = src.split("def main(")[1]
+    assert main_src.index("from oracle") > main_src.index("timed region done")
 
 
 def test_graft_entry_has_build_and_smoke():
@@ -56,3 +69,26 @@ def test_recorded_bench_line_has_the_schema():
     assert LINE_KEYS <= set(rec) and ROOFLINE_KEYS <= set(rec["roofline"]) and CPU_KEYS <= set(rec["cpu_baseline"])
     assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["n_gpus"] == 1
     assert 0 < rec["roofline"]["frac"] < 1 and rec["roofline"]["bound"] in ("mfma", "hbm")
+
+
+def test_reference_archive_recipe(tmp_path):
+    """oracle/build_ref.py packs the reference package (where /root/reference exists) into ONE importable archive under the
+    git-ignored oracle/_ref/; oracle/ref_runtime.py imports exactly that version from it."""
+    import subprocess
+    import sys
+    gi = (ROOT / ".gitignore").read_text()
+    assert "oracle/_ref/" in gi
+    gri = ROOT / ".gpurunignore"
+    assert not gri.exists() or "oracle/_ref" not in gri.read_text(), "the archive must ship to the GPU box"
+    sys.path.insert(0, str(ROOT))
+    from oracle import build_ref
+    out = build_ref.build()
+    if out is None:                      # neither the reference tree nor a shipped archive: nothing to check here
+        return
+    assert out.exists() and out.suffix == ".zip"
+    code = ("import sys; sys.path.insert(0, %r); from oracle import ref_runtime as RR; m = RR.load_reference(); "
+            "print(m.__version__, m.__file__)" % str(ROOT))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    ver, where = r.stdout.strip().splitlines()[-1].split()
+    assert ver == build_ref.EXPECT_VERSION and "diffusers_ref.zip" in where

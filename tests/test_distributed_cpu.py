@@ -122,6 +122,23 @@ def test_bench_main_world2_gloo(tmp_path):
     # whole-job rate = 2 ranks x 2 images / max-over-ranks time; it cannot exceed the sum of the per-rank rates
     assert 0 < rec["value"] <= sum(rec["config"]["images_per_s_per_rank"]) * 1.001
     assert abs(rec["ms_per_step"] * rec["value"] - 2 * 1000.0) < 1e-6 * 2000.0
+    assert rec["config"]["tuned_live"] == 0      # reported so that a tuning pass on 8 ranks at once cannot hide in a scaling run
+
+
+def test_shipped_tuning_table_covers_every_sdxl_shape():
+    """at N = 8 all ranks warm up at once; if the shipped table missed a shape every rank would time ~80
+    kernel variants for it simultaneously -- the likeliest way to miss 0.9x linear scaling.  The keys below were recorded by a
+    full-size bench run that started from an EMPTY table (tools/gpu_r3.sh retune): every one must be in the shipped table, so a
+    bench warm-up never enters da_gemm_tune (bench.py reports `config.tuned_live`, 0 then)."""
+    import json
+    keys = json.loads((ROOT / "tests" / "golden" / "sdxl_gemm_shape_keys.json").read_text())["keys"]
+    table = json.loads((ROOT / "diffusers_amd" / "tuned" / "gfx950.json").read_text())
+    missing = [k for k in keys if k not in table["entries"]]
+    assert len(keys) >= 60 and not missing, f"shapes the shipped table does not hold: {missing[:5]}"
+    from diffusers_amd import _lib as L
+    assert table["tiles"] == list(L.TILE_NAMES), "table written for another tile enumeration"
+    for k, v in table["entries"].items():
+        assert 1 <= v[0] < len(L.TILE_NAMES) and 0 <= v[1] <= 5, (k, v)
 
 
 def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):

@@ -1,5 +1,6 @@
 """Checkpoint-side set-up: ``from_pretrained`` over the reference's on-disk layout, the pack-once cache,
-LoRA adapters fused into the packed weights in place.  Packing is host arithmetic, so everything here runs on CPU."""
+LoRA adapters fused into the packed weights in place.  Packing is host arithmetic, so those tests run on CPU; the `gpu`-marked test
+at the end runs the loaded / fused / unfused model's forward on hardware against the oracle on the same (merged) weights."""
 import json
 import sys
 from pathlib import Path
@@ -207,3 +208,71 @@ def test_loads_what_the_reference_save_pretrained_writes(tmp_path):
         assert gv.config.scaling_factor == v.config.scaling_factor
     finally:
         sys.path.remove(str(REF_SRC))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# on hardware: the loaded / fused / unfused model's FORWARD against the oracle
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["peft", "legacy"])
+def test_from_pretrained_and_lora_forward_on_gpu(tmp_path, fmt):
+    """`from_pretrained` of a checkpoint directory -> forward vs the fp32 oracle on the checkpoint's weights; `fuse_lora(scale)` ->
+    forward vs the oracle on the MERGED weights W + scale (alpha / r) B A (the reference's merge, loaders/lora_base.py:544 ->
+    peft's `merge`); `unfuse_lora` -> bit-identical to the base forward; a second adapter replaces the first (adapters do not
+    stack, documented in loading.py).  Key styles covered: PEFT (`lora_A.weight` / `lora_B.weight` + `.alpha`) and the legacy
+    diffusers naming (`lora.down.weight` / `lora.up.weight`), both with the pipeline-level `unet.` prefix."""
+    from diffusers_amd.unet_2d_condition import _DEFAULTS as UD
+    from oracle import reference_math as R
+    d, cfg, sd = _tiny_unet_checkpoint(tmp_path)
+    model = UNet2DConditionModel.from_pretrained(d, device="cuda")
+    full = dict(UD)
+    full.update(cfg)
+    g = torch.Generator().manual_seed(11)
+    sample = torch.randn((2, 4, 16, 16), generator=g).to(bf16)
+    ehs = torch.randn((2, 7, 64), generator=g).to(bf16)
+    te = torch.randn((2, 64), generator=g).to(bf16)
+    ids = torch.tensor([[128., 128., 0., 0., 128., 128.]]).repeat(2, 1)
+
+    def engine():
+        return model(sample.cuda(), torch.tensor(401.0), ehs.cuda(),
+                     added_cond_kwargs={"text_embeds": te.cuda(), "time_ids": ids.cuda()}).sample.float().cpu()
+
+    def oracle(weights):
+        with torch.no_grad():
+            return R.unet_forward({k: v.float() for k, v in weights.items()}, full, sample.float(), 401.0, ehs.float(),
+                                  {"text_embeds": te.float(), "time_ids": ids})
+
+    def rel(a, b):
+        return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    base = engine()
+    want_base = oracle(sd)
+    assert rel(base, want_base) < 2.5e-2
+    targets = ["down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q",
+               "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_out.0",
+               "down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k",
+               "down_blocks.1.attentions.0.transformer_blocks.0.ff.net.0.proj",
+               "mid_block.attentions.0.proj_in", "up_blocks.0.resnets.0.conv1", "down_blocks.0.resnets.0.conv1"]
+    lora, dense = _lora_for(sd, targets, fmt=fmt, r=4, seed=5)
+    # make the adapter matter: scale the deltas up so the fused forward is measurably different from the base one
+    lora = {k: (v * 6.0 if k.endswith(("lora_B.weight", "lora.up.weight")) else v) for k, v in lora.items()}
+    dense = {k: v * 6.0 for k, v in dense.items()}
+    model.fuse_lora(lora, lora_scale=0.7)
+    merged = dict(sd)
+    for n, dl in dense.items():
+        merged[n + ".weight"] = (sd[n + ".weight"].float() + 0.7 * dl).to(sd[n + ".weight"].dtype)
+    fused = engine()
+    want_fused = oracle(merged)
+    r_f, moved = rel(fused, want_fused), rel(want_fused, want_base)
+    print(f"[parity] LoRA-fused tiny U-Net ({fmt} keys) on the GPU: rel-rms vs the oracle on merged weights {r_f:.3e} "
+          f"(the adapter moves the output by {moved:.3e})")
+    assert r_f < 2.5e-2 and moved > 4 * r_f, "the fused forward must follow the merged weights, not the base ones"
+    model.unfuse_lora()
+    assert torch.equal(engine(), base), "unfuse_lora must restore the base forward bit for bit"
+    # a second adapter replaces the first
+    lora2, dense2 = _lora_for(sd, targets[:2], fmt=fmt, r=2, seed=9)
+    model.fuse_lora(lora, lora_scale=0.7)
+    model.fuse_lora(lora2, lora_scale=1.0)
+    merged2 = dict(sd)
+    for n, dl in dense2.items():
+        merged2[n + ".weight"] = (sd[n + ".weight"].float() + dl).to(sd[n + ".weight"].dtype)
+    assert rel(engine(), oracle(merged2)) < 2.5e-2

@@ -1,0 +1,82 @@
+"""The REAL reference package on the GPU box (oracle/_ref/diffusers_ref.zip, built by oracle/build_ref.py; skipped when it did
+not ship): boundary B1 / B2 / B5 of SURVEY.md 8b on hardware.
+
+1. engine `UNet2DConditionModel` + `AutoencoderKL` + `EulerDiscreteScheduler` registered into the UNCHANGED reference
+   `StableDiffusionXLPipeline` (pipelines/pipeline_utils.py:224-252), whose own `__call__`
+   (pipelines/stable_diffusion_xl/pipeline_stable_diffusion_xl.py:823-1308) then drives the HIP kernels: cat([latents] * 2),
+   scale_model_input, unet(...), torch CFG combine, scheduler.step, vae.decode, postprocess -- PSNR >= 40 dB against the
+   all-reference fp32 run on the same weights / embeddings / latents;
+2. the engine's own pipeline against the same all-reference run (what bench.py's `parity` leg does at full size)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_runtime as RR
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not RR.available(), reason="reference archive oracle/_ref/diffusers_ref.zip did not ship")]
+bf16 = torch.bfloat16
+DEV = "cuda"
+
+
+def _psnr(a, b):
+    return 10 * np.log10(1.0 / max(float((a.float() - b.float()).pow(2).mean()), 1e-12))
+
+
+def _setup(tiny=True):
+    import diffusers_amd as da
+    from diffusers_amd import factory, init as dinit
+    ref = RR.load_reference()
+    ucfg, vcfg = (dinit.TINY_SDXL_UNET, dinit.TINY_VAE) if tiny else (dinit.SDXL_UNET, dinit.SDXL_VAE)
+    unet, usd = factory.build_unet(ucfg, seed=0, device=DEV, init_device="cpu" if tiny else DEV)
+    vae, vsd = factory.build_vae(vcfg, seed=1, device=DEV, init_device="cpu" if tiny else DEV)
+    cd, pd, lat = (64, 64, 16) if tiny else (2048, 1280, 128)
+    g = torch.Generator("cpu").manual_seed(1234)
+    inp = {"prompt_embeds": torch.randn((1, 77, cd), generator=g), "negative_prompt_embeds": torch.randn((1, 77, cd), generator=g),
+           "pooled": torch.randn((1, pd), generator=g), "negative_pooled": torch.randn((1, pd), generator=g),
+           "latents": torch.randn((1, 4, lat, lat), generator=g)}
+    inp = {k: v.to(bf16).to(DEV) for k, v in inp.items()}
+    return da, factory, ref, ucfg, vcfg, unet, usd, vae, vsd, inp
+
+
+@pytest.mark.parametrize("steps", [4])
+def test_engine_components_under_the_unchanged_reference_pipeline_on_hardware(steps):
+    da, factory, ref, ucfg, vcfg, unet, usd, vae, vsd, inp = _setup(tiny=True)
+    hw = 16 * 2 ** (len(vcfg["block_out_channels"]) - 1)
+    rpipe = RR.build_sdxl_pipeline(ref, ucfg, vcfg, usd, vsd, factory.SDXL_SCHEDULER, DEV, torch.float32)
+    want, want_lat = RR.run_sdxl(rpipe, inp, steps, 5.0, hw, torch.float32, want_latents=True)        # all-reference, fp32
+    # the reference pipeline object, engine components in its slots
+    rpipe.to(bf16)
+    rpipe.register_modules(unet=unet, vae=vae, scheduler=da.EulerDiscreteScheduler.from_config(rpipe.scheduler.config))
+    got, got_lat = RR.run_sdxl(rpipe, inp, steps, 5.0, hw, bf16, want_latents=True)
+    ps = _psnr(got, want)
+    rr = float((got_lat.float() - want_lat.float()).pow(2).mean().sqrt() / want_lat.float().pow(2).mean().sqrt())
+    print(f"[drop-in] engine under the reference SDXL __call__ on the GPU: PSNR {ps:.1f} dB, latents rel-rms {rr:.3e} vs the all-reference fp32 run")
+    assert got.shape == want.shape and ps >= 40.0
+    # the engine's own pipeline (fused CFG + Euler step, HIP graph) lands on the same image
+    epipe = factory.build_sdxl_pipeline(device=DEV, tiny=True, seed=0)
+    img = epipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+                pooled_prompt_embeds=inp["pooled"], negative_pooled_prompt_embeds=inp["negative_pooled"],
+                latents=inp["latents"].clone(), num_inference_steps=steps, guidance_scale=5.0, height=hw, width=hw,
+                output_type="pt").images
+    ps2 = _psnr(img, want)
+    print(f"[drop-in] engine pipeline vs the all-reference fp32 run: PSNR {ps2:.1f} dB; vs engine-under-reference: {_psnr(img, got):.1f} dB")
+    assert ps2 >= 40.0
+
+
+def test_reference_classes_accept_the_engine_state_dicts_at_full_size():
+    """The seeded reference-format state dicts the engine packs load into the REAL reference classes (strictly for the U-Net,
+    decoder half for the VAE), and one full-size U-Net forward agrees: engine (bf16, HIP) vs reference (fp32, PyTorch-ROCm)."""
+    da, factory, ref, ucfg, vcfg, unet, usd, vae, vsd, inp = _setup(tiny=False)
+    runet = RR.build_unet(ref, ucfg, usd, DEV, torch.float32)
+    g = torch.Generator("cpu").manual_seed(5)
+    sample = torch.randn((2, 4, 64, 64), generator=g).to(DEV)
+    ehs = torch.randn((2, 77, 2048), generator=g).to(DEV)
+    added = {"text_embeds": torch.randn((2, 1280), generator=g).to(DEV),
+             "time_ids": torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]], device=DEV).repeat(2, 1)}
+    with torch.no_grad():
+        want = runet(sample, torch.tensor(481.0, device=DEV), encoder_hidden_states=ehs, added_cond_kwargs=added, return_dict=False)[0]
+    got = unet(sample.to(bf16), torch.tensor(481.0), ehs.to(bf16),
+               added_cond_kwargs={"text_embeds": added["text_embeds"].to(bf16), "time_ids": added["time_ids"]}).sample
+    rr = float((got.float() - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+    print(f"[parity] full SDXL U-Net (64x64 latents) engine vs the REAL reference class in fp32: rel-rms {rr:.3e}")
+    assert rr < 2.5e-2

@@ -21,7 +21,7 @@ import tools.ceiling_table as CT  # noqa: E402
 
 def variants(geglu=False, conv=False):
     for t in range(L.FIRST_K2_TILE, len(L.TILE_NAMES)):
-        if geglu and t != L.TILE_K2_128x128:
+        if geglu and t not in (L.TILE_K2_128x128, L.TILE_K1_256x128, L.TILE_K1_128x256, L.TILE_K1_256x256):
             continue
         if conv and t == L.TILE_K2_80x128:
             continue
@@ -41,7 +41,8 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     lin = [("to_out 1280 +b+r", 2048, 1280, 1280, True, True, 0), ("to_q 1280", 2048, 1280, 1280, False, False, 0),
            ("qk 1280", 2048, 2560, 1280, False, False, 0), ("vT 1280", 1280, 2048, 1280, False, False, 0),
-           ("geglu 1280", 2048, 10240, 1280, True, False, L.ACT_GEGLU), ("ff_down 1280 +b+r", 2048, 1280, 5120, True, True, 0),
+           ("geglu 1280", 2048, 10240, 1280, True, False, L.ACT_GEGLU), ("geglu-shape plain 1280", 2048, 10240, 1280, True, False, 0),
+           ("ff_down 1280 +b+r", 2048, 1280, 5120, True, True, 0),
            ("to_out 640 +b+r", 8192, 640, 640, True, True, 0), ("geglu 640", 8192, 5120, 640, True, False, L.ACT_GEGLU),
            ("ff_down 640 +b+r", 8192, 640, 2560, True, True, 0), ("qk 640", 8192, 1280, 640, False, False, 0),
            ("flux qkv 3072", 4608, 3072, 3072, True, False, 0), ("flux mlp 12288", 4608, 12288, 3072, True, False, L.ACT_GELU_TANH),

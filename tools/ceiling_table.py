@@ -143,7 +143,7 @@ def main():
     for r in rows:
         lines.append(f"| {r['name']} ({r['M']}x{r['N']}x{r['K']}) | {r['gflop']} | {r['ours_cold_us']:.1f} | {r['lib_gemm_cold_us']:.1f} | "
                      f"{r['ours_warm_us']:.1f} | {r['lib_gemm_warm_us']:.1f} | {r['ours_chain_us']:.1f} | {r['lib_gemm_chain_us']:.1f} | "
-                     f"{r['lib_full_chain_us']:.1f} | {r['gflop'] / r['ours_chain_us'] * 1e-3:.0f} | {r['gflop'] / r['lib_gemm_chain_us'] * 1e-3:.0f} | "
+                     f"{r['lib_full_chain_us']:.1f} | {r['gflop'] / r['ours_chain_us']:.0f} | {r['gflop'] / r['lib_gemm_chain_us']:.0f} | "
                      f"{r['ours_chain_us'] / r['lib_gemm_chain_us']:.2f} |")
     out_md.parent.mkdir(parents=True, exist_ok=True)
     out_md.write_text("\n".join(lines) + "\n")
