@@ -49,7 +49,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed images per GPU")
     ap.add_argument("--warmup", type=int, default=1, help="untimed images per GPU")
-    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--config", default="sdxl", choices=["sdxl", "sd15", "flux", "wan", "ddpm"],
+                    help="BASELINE.json config: sdxl (3, the headline metric, default), sd15 (2), flux (4), wan (5), ddpm (1)")
+    ap.add_argument("--denoise-steps", type=int, default=None, help="sampler steps per unit (default: the config's own: 50, flux 4)")
     ap.add_argument("--tiny", action="store_true", help="tiny config (plumbing check only; not a valid bench number)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -505,11 +507,113 @@ def reference_legs(engine_img, engine_lat, unet_sd, vae_sd, ucfg, vcfg, ucfg_min
     return parity, base, vs
 
 
+# ---- the other BASELINE configs under the same driver contract ------------------------------------------
+OTHER_CONFIGS = {
+    # name: (metric, unit, workload description, default sampler steps, algorithmic TFLOP per unit at that many steps)
+    "sd15": ("images/sec @ stable-diffusion-v1-5 512x512 50-step DDIM CFG 7.5 bf16", "images/s",
+             "stable-diffusion-v1-5 U-Net (860 M params) x {n} DDIM steps, CFG 7.5 (batch 2), 64x64 latents + AutoencoderKL decode "
+             "to 512x512; 1 prompt per GPU", 50, lambda n: n * 1.6065 + 2.5145),
+    "flux": ("images/sec @ FLUX.1-schnell 1024x1024 4-step FlowMatchEuler bf16", "images/s",
+             "FLUX.1-schnell transformer (11.9 B params) x {n} FlowMatchEuler steps, no CFG, 4096 image + 512 text tokens + 16-channel "
+             "AutoencoderKL decode to 1024x1024; 1 prompt per GPU", 4, lambda n: n * 74.3846 + 10.5),
+    "wan": ("videos/sec @ Wan2.1-T2V-1.3B 832x480x81 50-step CFG 5.0 bf16", "videos/s",
+            "Wan2.1-T2V-1.3B transformer x {n} FlowMatchEuler steps, CFG 5.0 (cond + uncond as one batch-2 call), 32 760 tokens, "
+            "latents out; 1 prompt per GPU", 50, lambda n: n * 2 * 283.0018),
+    "ddpm": ("images/sec @ google/ddpm-cat-256 50-step DDPM", "images/s",
+             "UNet2DModel (114 M params) x {n} ancestral DDPM steps at 256x256, batch 1 per GPU", 50, lambda n: n * 0.4970),
+}
+
+
+def run_other_config(args, argv):
+    """`--config sd15 | flux | wan | ddpm`: the same contract (W untimed units, K timed units between barriers, max over ranks, ONE
+    JSON line from rank 0) on the other BASELINE configs; one prompt per rank, no collective in the data path.  `roofline` here is
+    the whole unit against the MFMA peak (algorithmic TFLOP of SURVEY.md 8d / wall time); the per-kernel legs exist for the
+    headline config only."""
+    from diffusers_amd import distributed as D
+    from diffusers_amd import factory
+    rank, world, local = D.init_from_env()
+    dev = _device(local)
+    metric, unit, what, default_steps, tflop_of = OTHER_CONFIGS[args.config]
+    n = args.denoise_steps or default_steps
+    bf = torch.bfloat16
+    g = torch.Generator("cpu").manual_seed(1234 + rank)
+    log(f"rank {rank}/{world}: building {args.config} on {dev}")
+    if args.config == "sd15":
+        pipe = factory.build_sd15_pipeline(device=dev, tiny=args.tiny, seed=0)
+        cd, lat = (64, 16) if args.tiny else (768, 64)
+        pe, ne = (torch.randn((1, 77, cd), generator=g).to(bf).to(dev) for _ in range(2))
+        x = torch.randn((1, 4, lat, lat), generator=g).to(bf).to(dev)
+        unit_fn = lambda: pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=x.clone(), num_inference_steps=n,  # noqa: E731
+                               guidance_scale=7.5, output_type="raw", use_graph=not args.no_graph).images
+    elif args.config == "flux":
+        pipe = factory.build_flux_pipeline(device=dev, tiny=args.tiny, seed=5)
+        if args.tiny:
+            raise SystemExit("--config flux has no --tiny form here (tests/ cover the tiny pipeline)")
+        pe = torch.randn((1, 512, 4096), generator=g).to(bf).to(dev)
+        pooled = torch.randn((1, 768), generator=g).to(bf).to(dev)
+        x = torch.randn((1, 4096, 64), generator=g).to(bf).to(dev)
+        unit_fn = lambda: pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, latents=x, num_inference_steps=n, guidance_scale=0.0,  # noqa: E731
+                               height=1024, width=1024, output_type="raw").images
+    elif args.config == "wan":
+        pipe = factory.build_wan_pipeline(device=dev, tiny=args.tiny, seed=9)
+        if args.tiny:
+            raise SystemExit("--config wan has no --tiny form here (tests/ cover the tiny pipeline)")
+        pe, ne = (torch.randn((1, 512, 4096), generator=g).to(bf).to(dev) for _ in range(2))
+        x = torch.randn((1, 16, 21, 60, 104), generator=g).to(bf).to(dev)
+        unit_fn = lambda: pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=x, num_inference_steps=n, guidance_scale=5.0,  # noqa: E731
+                               height=480, width=832, num_frames=81).images
+    else:
+        pipe = factory.build_ddpm_pipeline(device=dev, tiny=args.tiny, seed=0)
+        unit_fn = lambda: pipe(batch_size=1, generator=torch.Generator().manual_seed(rank), num_inference_steps=n,  # noqa: E731
+                               output_type="pt", use_graph=not args.no_graph).images
+    log("warm-up")
+    out = None
+    for _ in range(max(args.warmup, 1)):          # at least one: variant lookup, graph capture
+        out = unit_fn()
+    _sync()
+    if world > 1:
+        torch.distributed.barrier()
+    _sync()
+    log("timed region")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = unit_fn()
+    _sync()
+    mine_s = time.perf_counter() - t0
+    if world > 1:
+        torch.distributed.barrier()
+    _sync()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    value = world * args.steps / elapsed
+    tfl = tflop_of(n)
+    ach = value / world * tfl
+    result = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+              "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "bf16", "data": "synthetic (seeded random weights, embeddings, latents)",
+              "config": {"workload": what.format(n=n), "global_batch": world, "parallelism": f"dp{world} (independent prompts, replicas)",
+                         "denoise_steps": n, "output_finite": bool(torch.isfinite(out.float()).all()),
+                         "rank_seconds_per_unit": mine_s / args.steps, "tuned_live": _tuned_live(),
+                         "algorithmic_tflop_per_unit": tfl},
+              "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                           "traffic": None, "kernel": "whole unit (end to end): algorithmic TFLOP of SURVEY.md 8d / wall time"},
+              "cpu_baseline": {"value": None, "unit": unit, "cores": None, "kind": "reference",
+                               "sample": "not measured for this config (the headline config carries the CPU leg)"}}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return result
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, argv))
+    if args.config != "sdxl":
+        return run_other_config(args, argv)
+    args.denoise_steps = args.denoise_steps or 50
     from diffusers_amd import distributed as D
     rank, world, local = D.init_from_env()
     if world != args.gpus and rank == 0:

@@ -88,12 +88,14 @@ SIGNATURES = {
     "da_flowmatch_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _i, _vp]),
     "da_unipc_flow_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _ll, _i, _i, _vp]),
     "da_advance_step": (_i, [_vp, _vp]),
+    "da_cfg_rescale": (_i, [_vp, _vp, _vp, _i, _ll, _f, _f, _i, _vp]),
     "da_cast_f32_bf16": (_i, [_vp, _vp, _i, _ll, _vp]),
     "da_mul_scalar": (_i, [_vp, _vp, _f, _i, _ll, _i, _vp]),
     "da_bcast_add_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "da_patchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_unpatchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_transpose_bf16": (_i, [_vp, _vp, _i, _i, _ll, _ll, _vp]),
+    "da_nhwc_take_nchw_bf16": (_i, [_vp, _vp, _ll, _ll, _i, _i, _vp]),
     "da_image_postprocess": (_i, [_vp, _vp, _i, _i, _ll, _i, _i, _vp]),
     "da_permute_0213_bf16": (_i, [_vp, _vp, _ll, _i, _i, _i, _vp]),
     "da_frames_to_ncthw_bf16": (_i, [_vp, _vp, _i, _i, _ll, _i, _i, _f, _f, _i, _vp]),

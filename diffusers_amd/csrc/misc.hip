@@ -250,6 +250,23 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   }
 }
 
+// out[b][c][p] = in[b][p][c] for c < cout: the first `cout` (<= 8) channels of a channels-last tensor whose rows hold `cpad`
+// channels, as NCHW planes.  Tail of a thin-output conv run on the MFMA implicit-GEMM kernel with its output channels
+// zero-padded to 16 (conv_out of the U-Nets and of the VAE decoder, models/unets/unet_2d_condition.py:1230,
+// models/autoencoders/vae.py:309): one 16-byte read per pixel, `cout` coalesced 2-byte plane writes.
+__global__ __launch_bounds__(256) void nhwc_take_nchw_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                             long long B, long long HW, int cpad, int cout) {
+  const long long total = B * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long b = i / HW, px = i - b * HW;
+    const uint4 v = *(const uint4*)(in + (size_t)i * cpad);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < cout) out[((size_t)b * cout + c) * HW + px] = (uint16_t)((c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xffffu));
+  }
+}
+
 // dst[d0][d2][d1][:] = src[d0][d1][d2][:] in 16-byte chunks (D3 a multiple of 8 bf16).  WanResample 'upsample3d'
 // (autoencoder_kl_wan.py:297-299): time_conv produces 2C channels per position, [frame][pos][2][C] here, and the two
 // halves become consecutive frames, [frame][2][pos][C].  Pure copy: HBM-bound, chunk index = destination order.
@@ -320,6 +337,16 @@ extern "C" int da_transpose_bf16(const void* in, void* out, int R, int Cc, long 
   if (!in || !out || R <= 0 || Cc <= 0 || ldi < Cc || ldo < R) return DA_ERR_INVALID;
   DA_LAUNCH(transpose_bf16_kernel, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
             (const uint16_t*)in, (uint16_t*)out, R, Cc, ldi, ldo);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_nhwc_take_nchw_bf16(const void* in, void* out, long long B, long long HW, int cpad, int cout, void* stream) {
+  if (!in || !out || B <= 0 || HW <= 0 || cpad < 8 || (cpad & 7) || cout <= 0 || cout > 8) return DA_ERR_INVALID;
+  const long long total = B * HW;
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16);
+  DA_LAUNCH(nhwc_take_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out, B, HW,
+            cpad, cout);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

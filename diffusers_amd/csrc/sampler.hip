@@ -47,6 +47,58 @@ __device__ __forceinline__ float load_eps(const T* eps, size_t i, size_t n, floa
   return IO<T>::ld(eps, i);
 }
 
+// rescale_noise_cfg (pipelines/stable_diffusion/pipeline_stable_diffusion.py:69-92), used when guidance_rescale > 0:
+//   std_text = noise_pred_text.std(dims 1..)   std_cfg = noise_cfg.std(dims 1..)         (unbiased, per sample)
+//   noise_cfg = guidance_rescale * (noise_cfg * (std_text / std_cfg)) + (1 - guidance_rescale) * noise_cfg
+// Pass 1: one workgroup per sample sums x and x^2 of the text prediction and of the CFG combination (fp64 accumulators:
+// torch reduces a bf16 tensor in fp32 and rounds the RESULT to the tensor dtype, so what has to match is the rounded std)
+// and stores ratio = rnd(rnd(std_text) / rnd(std_cfg)).  Pass 2: the combination again (same roundings as cfg_combine), then
+// every product / sum of the formula rounded in the tensor dtype.  eps layout [2][B][n_per] = (uncond, cond).
+template <typename T>
+__global__ __launch_bounds__(1024) void cfg_rescale_stats_kernel(const T* __restrict__ eps, float* __restrict__ ratio, float g,
+                                                                 size_t n_per, int B) {
+  const int b = blockIdx.x;
+  const T* u = eps + (size_t)b * n_per;
+  const T* c = eps + ((size_t)B + b) * n_per;
+  double st = 0, st2 = 0, sc = 0, sc2 = 0;
+  for (size_t i = threadIdx.x; i < n_per; i += blockDim.x) {
+    const float tv = IO<T>::ld(c, i);
+    const float cv = cfg_combine<T>(IO<T>::ld(u, i), tv, g);
+    st += tv; st2 += (double)tv * tv;
+    sc += cv; sc2 += (double)cv * cv;
+  }
+  __shared__ double red[4][16];
+  double v[4] = {st, st2, sc, sc2};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = v[0]; red[1][wave] = v[1]; red[2][wave] = v[2]; red[3][wave] = v[3]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[4] = {0, 0, 0, 0};
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t[0] += red[0][w]; t[1] += red[1][w]; t[2] += red[2][w]; t[3] += red[3][w]; }
+    const double n = (double)n_per;
+    const double var_t = fmax((t[1] - t[0] * t[0] / n) / (n - 1.0), 0.0), var_c = fmax((t[3] - t[2] * t[2] / n) / (n - 1.0), 0.0);
+    const float std_t = IO<T>::rnd((float)sqrt(var_t)), std_c = IO<T>::rnd((float)sqrt(var_c));
+    ratio[b] = IO<T>::rnd(__fdiv_rn(std_t, std_c));
+  }
+}
+
+template <typename T>
+__global__ void cfg_rescale_apply_kernel(const T* __restrict__ eps, T* __restrict__ out, const float* __restrict__ ratio,
+                                         float g, float gr, float one_minus_gr, size_t n_per, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float cv = cfg_combine<T>(IO<T>::ld(eps, i), IO<T>::ld(eps, n + i), g);
+    const float resc = IO<T>::rnd(__fmul_rn(cv, ratio[i / n_per]));
+    const float a = IO<T>::rnd(__fmul_rn(gr, resc));
+    const float b = IO<T>::rnd(__fmul_rn(one_minus_gr, cv));
+    IO<T>::st(out, i, __fadd_rn(a, b));
+  }
+}
+
 // Euler (gamma = 0): table row = [sigma, sigma_next, dt, sqrt(sigma^2+1), c_out, sigma^2+1, -, timestep]
 // PRED: 0 epsilon, 1 v_prediction, 2 sample (scheduling_euler_discrete.py:760-775)
 template <typename T, bool CFG, int PRED>
@@ -299,6 +351,29 @@ extern "C" int da_flowmatch_step(const void* v, const void* x, void* out, const 
   else if (dtype == DA_DTYPE_BF16 && x_dtype == DA_DTYPE_F32) { if (cfg) DA_FM(float, uint16_t, true); else DA_FM(float, uint16_t, false); }
   else return DA_ERR_UNSUPPORTED;
 #undef DA_FM
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_cfg_rescale(const void* eps, void* out, float* ratio_ws, int B, long long n_per_, float guidance,
+                              float guidance_rescale, int dtype, void* stream) {
+  if (!eps || !out || !ratio_ws || B <= 0 || n_per_ <= 1) return DA_ERR_INVALID;
+  const size_t n_per = (size_t)n_per_, n = n_per * (size_t)B;
+  hipStream_t s = (hipStream_t)stream;
+  const float omg = (float)(1.0 - (double)guidance_rescale);   // the reference forms (1 - guidance_rescale) in Python doubles
+  if (dtype == DA_DTYPE_BF16) {
+    DA_LAUNCH((cfg_rescale_stats_kernel<uint16_t>), dim3(B), dim3(1024), 0, s, (const uint16_t*)eps, ratio_ws, guidance, n_per, B);
+    DA_CHECK_LAUNCH();
+    DA_LAUNCH((cfg_rescale_apply_kernel<uint16_t>), ew_grid(n), dim3(256), 0, s, (const uint16_t*)eps, (uint16_t*)out, ratio_ws,
+              guidance, guidance_rescale, omg, n_per, n);
+  } else if (dtype == DA_DTYPE_F32) {
+    DA_LAUNCH((cfg_rescale_stats_kernel<float>), dim3(B), dim3(1024), 0, s, (const float*)eps, ratio_ws, guidance, n_per, B);
+    DA_CHECK_LAUNCH();
+    DA_LAUNCH((cfg_rescale_apply_kernel<float>), ew_grid(n), dim3(256), 0, s, (const float*)eps, (float*)out, ratio_ws, guidance,
+              guidance_rescale, omg, n_per, n);
+  } else {
+    return DA_ERR_UNSUPPORTED;
+  }
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

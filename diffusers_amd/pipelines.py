@@ -67,6 +67,7 @@ class _LatentDiffusionBase:
         self._static = {}
         self._eta = 0.0            # DDIM only: eta > 0 adds pre-drawn variance noise (one row per step) in the fused step
         self._noise_table = None
+        self._guidance_rescale = 0.0   # > 0: rescale_noise_cfg after the CFG combine (pipeline_stable_diffusion.py:69-92)
 
     @property
     def device(self):
@@ -88,6 +89,12 @@ class _LatentDiffusionBase:
         # in place (same buffer every replay); without CFG (guidance_scale <= 1, pipeline_stable_diffusion_xl.py:1202,
         # :1223) the U-Net ran on the un-doubled batch and the same kernel skips the combine
         kw = {"eta": self._eta, "noise_table": self._noise_table} if self._eta > 0 else {}
+        if do_cfg and self._guidance_rescale > 0.0:
+            # pipeline_stable_diffusion_xl.py:1227-1229 / pipeline_stable_diffusion.py:1057-1059: combine, then rescale_noise_cfg
+            # (per-sample std of the text and of the guided prediction: two small launches), then the step without its combine
+            eps = ops.cfg_rescale(eps, guidance_scale, self._guidance_rescale)
+            sch.step_cfg(eps, latents, guidance_scale, out=latents, cfg=False, **kw)
+            return latents
         sch.step_cfg(eps, latents, guidance_scale, out=latents, cfg=do_cfg, **kw)
         return latents
 
@@ -101,7 +108,8 @@ class _LatentDiffusionBase:
             sch._ensure(self._eta, sch.timesteps[0])
         return (tuple(latents.shape), float(guidance_scale), bool(do_cfg), cond["kvs"][0][0].skv if cond["kvs"] else 0,
                 sch.device_table.data_ptr(), sch.device_step.data_ptr(),
-                self._noise_table.data_ptr() if self._noise_table is not None else 0, float(self._eta))
+                self._noise_table.data_ptr() if self._noise_table is not None else 0, float(self._eta),
+                float(self._guidance_rescale))
 
     def _denoise(self, latents, cond, num_steps, guidance_scale, do_cfg, use_graph):
         sch = self.scheduler

@@ -318,6 +318,12 @@ int da_flowmatch_step(const void* v, const void* x, void* out, const float* tabl
 int da_unipc_flow_step(const void* v, void* x, void* last, void* m1, void* m2, const float* coef, const int* step_idx,
                        int cfg, float guidance, long long n, int x_dtype, int v_dtype, void* stream);
 int da_advance_step(int* step_idx, void* stream);
+/* rescale_noise_cfg (pipelines/stable_diffusion/pipeline_stable_diffusion.py:69-92; SDXL :1227-1229, SD :1057-1059): eps
+ * [2][B][n_per] = (uncond, cond) -> out [B][n_per] = guidance_rescale * (cfg * std(text) / std(cfg)) + (1 - guidance_rescale) * cfg
+ * with cfg = uncond + guidance * (cond - uncond), every torch op rounded in the tensor dtype; ratio_ws: B floats of scratch.
+ * The step kernels then run with cfg = 0 on `out`. */
+int da_cfg_rescale(const void* eps, void* out, float* ratio_ws, int B, long long n_per, float guidance, float guidance_rescale,
+                   int dtype, void* stream);
 /* out[r][:] = bf16(x) for r < rep: latents.to(transformer_dtype) (pipeline_wan.py:600) + CFG batch doubling */
 int da_cast_f32_bf16(const float* x, void* out, int rep, long long n, void* stream);
 /* out[r][:] = x * s in the tensor dtype for r < rep: latents * scheduler.init_noise_sigma
@@ -349,6 +355,10 @@ int da_unpatchify3d_bf16(const void* tokens, void* x, int B, int C, int F, int H
 /* out[c][r] = in[r][c]: turns a token-major value tensor into the V^T operand of da_attention_bf16 (attention backends
  * that receive (B, S, H, D) tensors, attention_dispatch.py:494-515) */
 int da_transpose_bf16(const void* in, void* out, int R, int C, long long ldi, long long ldo, void* stream);
+/* out[b][c][p] = in[b][p][c], c < cout <= 8, rows of `cpad` channels (cpad % 8 == 0): the NCHW planes of a thin-output conv
+ * (conv_out 320 -> 4 of the U-Net, unet_2d_condition.py:1230; 128 -> 3 of the VAE decoder, vae.py:309) that ran on the
+ * implicit-GEMM kernel with its output channels zero-padded to 16 */
+int da_nhwc_take_nchw_bf16(const void* in, void* out, long long B, long long HW, int cpad, int cout, void* stream);
 /* dst[D0][D2][D1][D3] = src[D0][D1][D2][D3] (bf16, D3 % 8 == 0): the channel-halves -> frame pairs interleave of
  * WanResample 'upsample3d' (autoencoder_kl_wan.py:297-299) on channels-last frames. */
 int da_permute_0213_bf16(const void* src, void* dst, long long D0, int D1, int D2, int D3, void* stream);

@@ -125,6 +125,31 @@ def test_bench_main_world2_gloo(tmp_path):
     assert rec["config"]["tuned_live"] == 0      # reported so that a tuning pass on 8 ranks at once cannot hide in a scaling run
 
 
+@pytest.mark.parametrize("config,unit", [("sd15", "images/s"), ("ddpm", "images/s")])
+def test_bench_other_configs_world2_gloo(tmp_path, config, unit):
+    """`bench.py --config sd15 | ddpm` (the other BASELINE configs under the driver contract), world size 2
+    on CPU stand-ins: one JSON line with the contract keys, the config's own metric and n_gpus = 2."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "tests" / "bench_cpu_worker.py"), "--gpus", "2", "--steps", "1", "--warmup",
+           "1", "--tiny", "--no-graph", "--denoise-steps", "2", "--config", config]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 2 and rec["unit"] == unit and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["denoise_steps"] == 2 and rec["config"]["output_finite"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rec["roofline"])
+
+
 def test_shipped_tuning_table_covers_every_sdxl_shape():
     """at N = 8 all ranks warm up at once; if the shipped table missed a shape every rank would time ~80
     kernel variants for it simultaneously -- the likeliest way to miss 0.9x linear scaling.  The keys below were recorded by a

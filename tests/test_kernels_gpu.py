@@ -905,6 +905,17 @@ def test_conv_thin_in_out():
         ref = F.conv2d(xh.float().permute(0, 3, 1, 2), wo.float(), bo.float(), padding=1)
         assert y.shape == ref.shape
         assert_close_bf16(y, ref, f"conv_thin_out Cout={co}", rtol=8e-3, atol_rms=4e-3)
+    # enough pixels and whole K slices (Cin % 64 == 0): the same call runs on the MFMA implicit-GEMM kernel with the output
+    # channels zero-padded to 16, then nhwc_take_nchw lays out the planes (U-Net conv_out 320 -> 4, VAE conv_out 128 -> 3)
+    for (Bb, Hh, Ww, ci, co) in [(2, 72, 64, 320, 4), (1, 96, 80, 128, 3), (1, 64, 64, 64, 1)]:
+        xb = rnd((Bb, Hh, Ww, ci), 71)
+        wo, bo = rnd((co, ci, 3, 3), 72, scale=(9 * ci) ** -0.5), rnd((co,), 73, scale=0.1)
+        wpk = ops.pack_conv_weight(wo)
+        y = ops.conv_thin_out(xb, wpk, bo)
+        ref = F.conv2d(xb.float().permute(0, 3, 1, 2), wo.float(), bo.float(), padding=1)
+        assert y.shape == ref.shape and y.is_contiguous()
+        assert_close_bf16(y, ref, f"conv_thin_out via igemm {ci}->{co}", rtol=8e-3, atol_rms=4e-3)
+        assert torch.equal(y, ops.conv_thin_out(xb, wpk, bo))          # padded weights come from the cache the second time
 
 
 # ----------------------------------------------------------------------------------------------------------------------

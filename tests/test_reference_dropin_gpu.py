@@ -47,6 +47,13 @@ def test_engine_components_under_the_unchanged_reference_pipeline_on_hardware(st
     # the reference pipeline object, engine components in its slots
     rpipe.to(bf16)
     rpipe.register_modules(unet=unet, vae=vae, scheduler=da.EulerDiscreteScheduler.from_config(rpipe.scheduler.config))
+    # DiffusionPipeline._execution_device is the device of the pipeline's nn.Module components (pipeline_utils.py:1152): in
+    # real use the text encoders; here (prompt embeddings are passed) a tiny CLIP pair that is never called
+    from test_text_encoding import _clip, _tokenizer
+    tok, nv = _tokenizer()
+    rpipe.register_modules(tokenizer=tok, tokenizer_2=tok, text_encoder=_clip(nv, 32, seed=1).to(DEV, bf16),
+                           text_encoder_2=_clip(nv, 32, proj=64, seed=2).to(DEV, bf16))
+    assert str(rpipe._execution_device).startswith("cuda")
     got, got_lat = RR.run_sdxl(rpipe, inp, steps, 5.0, hw, bf16, want_latents=True)
     ps = _psnr(got, want)
     rr = float((got_lat.float() - want_lat.float()).pow(2).mean().sqrt() / want_lat.float().pow(2).mean().sqrt())
