@@ -430,7 +430,10 @@ extern "C" int da_conv_thin_in_bf16(const void* x, const void* w, const void* bi
   const size_t lds = (size_t)coc * kk * sizeof(float);
   size_t total = (size_t)B * H * W * (coc / 8);
   size_t blocks = (total + 255) / 256;
-  const size_t cap = 4096 / nchunk > 0 ? 4096 / nchunk : 1;
+  // every block first stages its chunk's weights into LDS (up to 64 KiB, transposed, one integer division per element): with
+  // thousands of blocks that staging, not the convolution, was the kernel (U-Net conv_in 4 -> 320 at 128 x 128: 140 us for 21 MB
+  // of output).  Three blocks per CU (what 46-64 KiB of LDS each admits), grid-stride over the pixels.
+  const size_t cap = 768 / nchunk > 0 ? 768 / nchunk : 1;
   if (blocks > cap) blocks = cap;
   DA_LAUNCH(conv_thin_in_kernel, dim3((unsigned)blocks, (unsigned)nchunk), dim3(256), lds, (hipStream_t)stream,
             (const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)y, B, H, W, Cin, Cout, ksize,

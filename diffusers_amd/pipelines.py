@@ -208,8 +208,9 @@ class StableDiffusionXLPipeline(_LatentDiffusionBase):
                  original_size: Optional[Tuple[int, int]] = None, crops_coords_top_left: Tuple[int, int] = (0, 0),
                  target_size: Optional[Tuple[int, int]] = None, generator=None, use_graph: bool = True,
                  prompt_2=None, negative_prompt=None, negative_prompt_2=None, num_images_per_prompt: int = 1,
-                 clip_skip=None):
+                 clip_skip=None, guidance_rescale: float = 0.0):
         do_cfg = guidance_scale > 1.0
+        self._guidance_rescale = float(guidance_rescale)    # pipeline_stable_diffusion_xl.py:849, :1227-1229
         if prompt is not None:
             if prompt_embeds is not None:
                 raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one "
@@ -277,7 +278,8 @@ class StableDiffusionPipeline(_LatentDiffusionBase):
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, eta: float = 0.0,
                  latents: Optional[torch.Tensor] = None, prompt_embeds=None, negative_prompt_embeds=None,
                  output_type: str = "pt", return_dict: bool = True, generator=None, use_graph: bool = True,
-                 negative_prompt=None, num_images_per_prompt: int = 1, clip_skip=None):
+                 negative_prompt=None, num_images_per_prompt: int = 1, clip_skip=None, guidance_rescale: float = 0.0):
+        self._guidance_rescale = float(guidance_rescale)    # pipeline_stable_diffusion.py:1057-1059
         if eta < 0.0 or eta > 1.0:
             raise ValueError("eta (DDIM) must be in [0, 1]")
         do_cfg = guidance_scale > 1.0

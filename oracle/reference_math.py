@@ -259,6 +259,20 @@ def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.T
     return (x.float() * c + rot.float() * s).to(x.dtype)
 
 
+def _sdpa(q, k, v):
+    """F.scaled_dot_product_attention on (B, H, S, D) tensors.  Same arithmetic; on a GPU in fp32 at video sequence lengths
+    (Wan: 32 760 tokens, where PyTorch-ROCm's fp32 path would materialise 12 x 32 760^2 scores) the queries are processed in
+    blocks -- each block still sees every key, so every output row is the exact softmax(q k^T / sqrt D) v."""
+    Sq, Skv = q.shape[-2], k.shape[-2]
+    if not (q.is_cuda and q.dtype == torch.float32 and Sq * Skv > (1 << 26)):
+        return F.scaled_dot_product_attention(q, k, v)
+    out = torch.empty_like(q)
+    step = max(256, (1 << 26) // Skv)
+    for s0 in range(0, Sq, step):
+        out[..., s0:s0 + step, :] = F.scaled_dot_product_attention(q[..., s0:s0 + step, :], k, v)
+    return out
+
+
 def _rms(x, w, eps):
     """torch.nn.RMSNorm(head_dim, eps) (transformer_flux.py:316-317)."""
     return F.rms_norm(x, (x.shape[-1],), w, eps)
@@ -266,7 +280,7 @@ def _rms(x, w, eps):
 
 def _flux_attention(q, k, v, heads):
     """dispatch_attention_fn native backend on (B, S, H, D) tensors (attention_dispatch.py:3709)."""
-    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+    o = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
     return o.transpose(1, 2).flatten(2, 3)
 
 
@@ -417,7 +431,7 @@ def wan_attention(sd, p, x, ctx, heads, cos=None, sin=None, eps=1e-6):
     q, k, v = (t.unflatten(2, (heads, -1)) for t in (q, k, v))
     if cos is not None:
         q, k = wan_apply_rope(q, cos, sin), wan_apply_rope(k, cos, sin)
-    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+    o = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
     o = o.flatten(2, 3).type_as(q)
     return F.linear(o, sd[f"{p}.to_out.0.weight"], sd[f"{p}.to_out.0.bias"])
 

@@ -63,6 +63,16 @@ def cfg_combine(uncond: torch.Tensor, cond: torch.Tensor, g: float) -> torch.Ten
     return uncond + g * (cond - uncond)
 
 
+def rescale_noise_cfg(noise_cfg: torch.Tensor, noise_pred_text: torch.Tensor, guidance_rescale: float = 0.0) -> torch.Tensor:
+    """pipelines/stable_diffusion/pipeline_stable_diffusion.py:69-92 (pipeline_stable_diffusion_xl.py:84-107): match the
+    per-sample std of the guided prediction to that of the text prediction, then mix by ``guidance_rescale``."""
+    dims = list(range(1, noise_pred_text.ndim))
+    std_text = noise_pred_text.std(dim=dims, keepdim=True)
+    std_cfg = noise_cfg.std(dim=dims, keepdim=True)
+    rescaled = noise_cfg * (std_text / std_cfg)
+    return guidance_rescale * rescaled + (1 - guidance_rescale) * noise_cfg
+
+
 class EulerOracle:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  timestep_spacing="linspace", steps_offset=0, prediction_type="epsilon", device_scalars=False):

@@ -424,11 +424,24 @@ def cast_f32_bf16(x, rep=1):
     return torch.cat([x.to(bf16)] * rep, 0)
 
 
+def cfg_rescale(eps2b, guidance, guidance_rescale, out=None):
+    """da_cfg_rescale: the reference's op chain on the tensor dtype (pipeline_stable_diffusion.py:69-92, :1054-1059)."""
+    u, c = eps2b.chunk(2)
+    cfg = u + guidance * (c - u)
+    dims = list(range(1, c.ndim))
+    resc = cfg * (c.std(dim=dims, keepdim=True) / cfg.std(dim=dims, keepdim=True))
+    y = guidance_rescale * resc + (1 - guidance_rescale) * cfg
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def install(monkeypatch, ops_module):
     """Replace the kernels behind ``ops_module`` with the stand-ins above (pack_* helpers are pure torch and stay)."""
     for name in ("conv2d_nhwc", "linear", "linear_pair", "linear_small_m", "rms_norm", "attention", "softmax_rows", "group_norm_nhwc", "layer_norm",
                  "rmsnorm_rope_", "rmsnorm_channels", "timestep_embedding", "permute_0213", "frames_to_ncthw",
                  "conv_thin_in", "conv_thin_out", "bcast_add_f32", "patchify3d", "unpatchify3d", "transpose",
-                 "mul_scalar", "cast_f32_bf16", "require_hip", "euler_scale_model_input", "euler_step", "x0_linear_step",
+                 "mul_scalar", "cast_f32_bf16", "cfg_rescale", "require_hip", "euler_scale_model_input", "euler_step", "x0_linear_step",
                  "flowmatch_step", "unipc_flow_step_", "advance_step", "image_postprocess"):
         monkeypatch.setattr(ops_module, name, globals()[name])

@@ -326,6 +326,26 @@ def test_ddim_eta_survives_the_graph_key_of_a_second_call():
     assert keys[0] == keys[1] and keys[0] != keys[2]
 
 
+def test_sdxl_pipeline_guidance_rescale_vs_reference_golden(golden):
+    """`guidance_rescale=0.7` (pipeline_stable_diffusion_xl.py:1227-1229): the engine pipeline's host path (combine + rescale as
+    its own launches, then the step without its combine) on the stand-ins against the LIVE reference pipeline's fp32 run
+    (tests/golden/guidance_rescale.npz)."""
+    from diffusers_amd import factory
+    g = golden("guidance_rescale")
+    pipe = factory.build_sdxl_pipeline(device="cpu", tiny=True, seed=0)
+    kw = dict(prompt_embeds=_t(g, "pipe_prompt_embeds"), negative_prompt_embeds=_t(g, "pipe_negative_prompt_embeds"),
+              pooled_prompt_embeds=_t(g, "pipe_pooled_prompt_embeds"), negative_pooled_prompt_embeds=_t(g, "pipe_negative_pooled_prompt_embeds"),
+              num_inference_steps=4, guidance_scale=5.0, guidance_rescale=0.7, height=128, width=128, use_graph=False)
+    lat = pipe(latents=_t(g, "pipe_latents").clone(), output_type="latent", **kw).images
+    img = pipe(latents=_t(g, "pipe_latents").clone(), output_type="pt", **kw).images
+    plain = pipe(latents=_t(g, "pipe_latents").clone(), output_type="latent", **dict(kw, guidance_rescale=0.0)).images
+    rr = _rel(lat, torch.from_numpy(g["pipe_final_latents"]))
+    ps = _psnr01(img, torch.from_numpy(g["pipe_image01"]))
+    moved = _rel(plain, torch.from_numpy(g["pipe_final_latents"]))
+    print(f"[host] tiny SDXL pipeline, guidance_rescale 0.7: latents rel rms {rr:.3e} (without the rescale: {moved:.3e}), PSNR {ps:.1f} dB")
+    assert rr < 4e-2 and ps >= 40.0 and moved > 1.3 * rr     # the rescale is visible above the bf16 noise
+
+
 def test_sdxl_pipeline_without_cfg():
     """SDXL with guidance_scale = 1: no negative embeddings needed, batch of one through the U-Net, the fused Euler step
     without the combine (pipeline_stable_diffusion_xl.py:1202, :1223)."""

@@ -1372,3 +1372,26 @@ def test_text_encoder_epilogues_and_rmsnorm():
         xf = xr.float()
         want = gm.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(bf16).float()
         assert torch.equal(got, want.to(bf16)) or float((got.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+
+
+def test_cfg_rescale_matches_the_reference_bit_for_bit(golden):
+    """da_cfg_rescale (CFG combine + rescale_noise_cfg, pipeline_stable_diffusion.py:69-92, :1054-1059) against the live
+    reference's outputs: bf16 bit-exact (every torch op's rounding reproduced; the per-sample std is reduced in fp64 and
+    rounded to bf16 as torch rounds its fp32 reduction), fp32 to reduction-order accuracy."""
+    ops, L = _ops()
+    g = golden("guidance_rescale")
+    for case in "abc":
+        for dt_name, dt in (("bf16", bf16), ("f32", torch.float32)):
+            u = torch.from_numpy(g[f"{case}_{dt_name}_uncond"]).to(dt).to(DEV)
+            c = torch.from_numpy(g[f"{case}_{dt_name}_cond"]).to(dt).to(DEV)
+            want = torch.from_numpy(g[f"{case}_{dt_name}_out"])
+            gs, gr = (float(v) for v in g[f"{case}_{dt_name}_params"])
+            y = ops.cfg_rescale(torch.cat([u, c]).contiguous(), gs, gr)
+            assert y.shape == u.shape and y.dtype == dt
+            if dt == bf16:
+                bad = int((y.float().cpu() != want).sum())
+                assert bad == 0, f"case {case}: {bad} of {want.numel()} bf16 outputs differ from the reference"
+            else:
+                assert torch.allclose(y.cpu(), want, rtol=2e-5, atol=2e-6), f"case {case} fp32"
+    with pytest.raises(ValueError):
+        ops.cfg_rescale(torch.zeros((3, 4, 8, 8), device=DEV, dtype=bf16), 5.0, 0.5)     # odd batch: not (uncond, cond)

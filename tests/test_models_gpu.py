@@ -441,3 +441,23 @@ def test_sd15_ddim_eta_graph_replay_keeps_the_variance_noise():
     for eta, seed in [(0.4, 1), (0.4, 2), (0.0, 1), (0.4, 1)]:     # capture, replay, re-key for eta = 0, back to eta > 0
         got = run(eta, seed, True)
         assert torch.equal(got, want[(eta, seed)]), f"graphed DDIM call eta={eta} seed={seed} differs from the eager loop"
+
+
+def test_tiny_sdxl_pipeline_guidance_rescale_vs_reference(golden):
+    """guidance_rescale = 0.7 on the GPU (eager and as a replayed HIP graph) against the live reference pipeline's fp32 run."""
+    from diffusers_amd import factory
+    g = golden("guidance_rescale")
+    pipe = factory.build_sdxl_pipeline(device=DEV, tiny=True, seed=0)
+    kw = dict(prompt_embeds=t(g, "pipe_prompt_embeds"), negative_prompt_embeds=t(g, "pipe_negative_prompt_embeds"),
+              pooled_prompt_embeds=t(g, "pipe_pooled_prompt_embeds"), negative_pooled_prompt_embeds=t(g, "pipe_negative_pooled_prompt_embeds"),
+              num_inference_steps=4, guidance_scale=5.0, height=128, width=128)
+    lat_e = pipe(latents=t(g, "pipe_latents").clone(), output_type="latent", use_graph=False, guidance_rescale=0.7, **kw).images.clone()
+    lat_g = pipe(latents=t(g, "pipe_latents").clone(), output_type="latent", use_graph=True, guidance_rescale=0.7, **kw).images.clone()
+    plain = pipe(latents=t(g, "pipe_latents").clone(), output_type="latent", use_graph=True, guidance_rescale=0.0, **kw).images.clone()
+    lat_g2 = pipe(latents=t(g, "pipe_latents").clone(), output_type="latent", use_graph=True, guidance_rescale=0.7, **kw).images.clone()
+    assert torch.equal(lat_e, lat_g) and torch.equal(lat_g, lat_g2) and not torch.equal(lat_g, plain)
+    rr = rel_rms(lat_e, torch.from_numpy(g["pipe_final_latents"]))
+    img = pipe(latents=t(g, "pipe_latents").clone(), output_type="pt", guidance_rescale=0.7, **kw).images
+    ps = 10 * np.log10(1.0 / float((img.float().cpu() - torch.from_numpy(g["pipe_image01"])).pow(2).mean()))
+    print(f"[parity] tiny SDXL pipeline, guidance_rescale 0.7, on the GPU: latents rel_rms {rr:.3e}, PSNR {ps:.1f} dB vs the reference")
+    assert rr < 4e-2 and ps >= 40.0

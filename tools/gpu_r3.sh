@@ -43,3 +43,24 @@ if [[ $WHAT == *prof* ]]; then
   cd $R
   python tools/prof_summary.py $(find $O/prof -name '*kernel_stats.csv' | head -1) "r03 sdxl bench (--steps 1 --warmup 1)" > $O/prof_summary.md 2>> $O/prof.log; head -40 $O/prof_summary.md
 fi
+if [[ $WHAT == *ksweep* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/ksweep; mkdir -p $O/ksweep
+  DIFFUSERS_AMD_TUNE=0 timeout 500 rocprofv3 --kernel-trace -f csv -d $O/ksweep -o ks -- python $R/tools/ksweep.py $O/ksweep/manifest.json > $O/ksweep/run.log 2>&1; echo "ksweep rc=$?"
+  cd $R
+  python tools/ksweep_report.py $O/ksweep/manifest.json $(find $O/ksweep -name '*kernel_trace.csv' | head -1) > $O/ksweep_report.md 2>> $O/ksweep/run.log
+  find $O/ksweep -name '*kernel_trace*' -delete
+  grep -A40 "K sweep" $O/ksweep_report.md; tail -3 $O/ksweep/run.log
+fi
+if [[ $WHAT == *fullsize* ]]; then
+  timeout 1500 python -m pytest tests/test_full_size_gpu.py -m gpu -q -s --timeout 900 > $O/pytest_fullsize.log 2>&1; echo "pytest fullsize rc=$?" | tee -a $O/pytest_fullsize.log
+  grep -E "passed|failed|FAILED|Error|\[parity\]" $O/pytest_fullsize.log | tail -30
+fi
+if [[ $WHAT == *others* ]]; then
+  # the other BASELINE configs under the driver contract; unseen GEMM / conv shapes are tuned live (both kernel families) and saved
+  for cfg in sd15 flux ddpm wan; do
+    ST=2; [[ $cfg == wan ]] && ST=1
+    DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_$cfg.json timeout 1200 python bench.py --config $cfg --steps $ST --warmup 1 > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "$cfg rc=$?"
+    cut -c1-700 $O/bench_$cfg.json; tail -2 $O/bench_$cfg.err
+  done
+fi

@@ -23,7 +23,10 @@ def rnd(shape, scale=1.0):
 def main():
     manifest = []
     flush = torch.empty(320 << 20, dtype=torch.uint8, device="cuda")
-    variants = [(L.TILE_64x64, 1), (L.TILE_128x64, 2), (L.TILE_128x128, 1), (L.TILE_128x128_W8, 2), (L.TILE_256x128, 2)]
+    variants = [(L.TILE_128x64, 2), (L.TILE_128x128_W8, 2), (L.TILE_K2_128x80, 1), (L.TILE_K2_128x80, 2), (L.TILE_K2_128x160, 1),
+                (L.TILE_K2_128x128, 1), (L.TILE_K1_256x128, 2), (L.TILE_K1_128x320, 1)]
+    if len(sys.argv) > 2 and sys.argv[2] == "r2":       # the round-2 variant set
+        variants = [(L.TILE_64x64, 1), (L.TILE_128x64, 2), (L.TILE_128x128, 1), (L.TILE_128x128_W8, 2), (L.TILE_256x128, 2)]
     cases = [(2048, 1280, k) for k in (64, 320, 1280, 2560, 5120)]
     cases += [(m, 1280, 1280) for m in (256, 1024, 4096, 8192)]
     cases += [(2048, n, 1280) for n in (320, 640, 2560, 5120)]

@@ -12,7 +12,7 @@ def main():
     rows = []
     with open(sys.argv[2]) as f:
         for r in csv.DictReader(f):
-            if "igemm_bf16_kernel" in r["Kernel_Name"]:
+            if "igemm_bf16_kernel" in r["Kernel_Name"] or "igemm2_bf16_kernel" in r["Kernel_Name"]:
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows.sort()
     need = sum(m["reps"] for m in manifest)
