@@ -242,7 +242,7 @@ def rope_tables(ids: torch.Tensor, axes_dim, theta: float = 10000.0):
     pos = ids.float()
     cos_out, sin_out = [], []
     for i, dim in enumerate(axes_dim):
-        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64) / dim))
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64, device=ids.device) / dim))
         f = torch.outer(pos[:, i], freqs)          # float32 pos x float64 freqs -> float64
         cos_out.append(f.cos().repeat_interleave(2, dim=1).float())
         sin_out.append(f.sin().repeat_interleave(2, dim=1).float())
@@ -459,7 +459,7 @@ def wan_forward(sd: Dict[str, torch.Tensor], cfg: dict, hidden_states, timestep,
     B, C, Fr, H, W = hidden_states.shape
     pt, ph, pw = cfg["patch_size"]
     f, h, w = Fr // pt, H // ph, W // pw
-    cos, sin = wan_rope_tables(D, f, h, w, cfg["rope_max_seq_len"])
+    cos, sin = (t.to(hidden_states.device) for t in wan_rope_tables(D, f, h, w, cfg["rope_max_seq_len"]))
     x = F.conv3d(hidden_states, sd["patch_embedding.weight"], sd["patch_embedding.bias"], stride=(pt, ph, pw))
     x = x.flatten(2).transpose(1, 2).contiguous()
     # WanTimeTextImageEmbedding (transformer_wan.py:308-351)

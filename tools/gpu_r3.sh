@@ -64,3 +64,12 @@ if [[ $WHAT == *others* ]]; then
     cut -c1-700 $O/bench_$cfg.json; tail -2 $O/bench_$cfg.err
   done
 fi
+if [[ $WHAT == *pmc* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc_k2; mkdir -p $O/pmc_k2
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -f csv -d $O/pmc_k2/sq -o k2 -- python $R/tools/pmc_k2.py $O/pmc_k2/manifest.json > $O/pmc_k2/sq.log 2>&1; echo "pmc sq rc=$?"
+  cd $R
+  python tools/pmc_k2_report.py $O/pmc_k2/manifest.json $(find $O/pmc_k2/sq -name '*counter_collection.csv' | head -1) > $O/pmc_k2_report.md 2>> $O/pmc_k2/sq.log
+  find $O/pmc_k2 -name '*kernel_trace*' -delete; find $O/pmc_k2 -name '*counter_collection.csv' -size +8M -delete
+  cat $O/pmc_k2_report.md; tail -3 $O/pmc_k2/sq.log
+fi
