@@ -22,6 +22,7 @@ TILE_NAMES = ("auto", "128x128", "64x128", "128x64", "64x64", "256x128", "128x25
               "k1:128x320", "k1:256x128", "k1:128x256", "k1:256x160", "k1:256x256")
 FIRST_K2_TILE = TILE_K2_128x128   # tiles >= this run csrc/gemm2_kernel.cuh (2 K-groups x 4 waves, 16x16x32 MFMA)
 STAGE_REGISTER, STAGE_LDS_DIRECT, STAGE_LDS_DIRECT3, STAGE_LDS_DIRECT4, STAGE_LDS_DIRECT6, STAGE_LDS_DIRECT8 = range(6)
+STAGE_PINGPONG, STAGE_PINGPONG3 = 6, 7   # K2 tiles: 2- / 3-pair ring with the two K-groups half an iteration apart
 RING_SLOTS = (2, 2, 3, 4, 6, 8)  # LDS ring depth per staging code
 DTYPE_BF16, DTYPE_F32 = 0, 1
 SPLITK_FLAGS = 4096          # DA_SPLITK_FLAGS
@@ -96,6 +97,7 @@ SIGNATURES = {
     "da_unpatchify3d_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_transpose_bf16": (_i, [_vp, _vp, _i, _i, _ll, _ll, _vp]),
     "da_nhwc_take_nchw_bf16": (_i, [_vp, _vp, _ll, _ll, _i, _i, _vp]),
+    "da_nhwc_take_postprocess": (_i, [_vp, _vp, _ll, _ll, _i, _i, _i, _vp]),
     "da_image_postprocess": (_i, [_vp, _vp, _i, _i, _ll, _i, _i, _vp]),
     "da_permute_0213_bf16": (_i, [_vp, _vp, _ll, _i, _i, _i, _vp]),
     "da_frames_to_ncthw_bf16": (_i, [_vp, _vp, _i, _i, _ll, _i, _i, _f, _f, _i, _vp]),

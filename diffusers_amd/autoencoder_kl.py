@@ -7,7 +7,7 @@ path is on the BASELINE hot path; ``encode`` raises.  Input latents NCHW bf16, o
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
@@ -175,10 +175,12 @@ class AutoencoderKL(PretrainedMixin):
         raise NotImplementedError("diffusers_amd.AutoencoderKL implements the decode hot path only")
 
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None, *, latents_div: float = 1.0,
-               latents_add: float = 0.0):
+               latents_add: float = 0.0, postprocess: Optional[str] = None):
         """autoencoder_kl.py:214-240.  ``latents_div`` / ``latents_add`` fuse the pipeline's
         ``latents / scaling_factor (+ shift_factor)`` (pipeline_stable_diffusion_xl.py:1283, pipeline_flux.py:960) into
-        the first conv's input read."""
+        the first conv's input read.  ``postprocess`` ("pt" / "np" / "uint8") fuses the pipeline's
+        ``image_processor.postprocess`` (image_processor.py:738-786) into the last pass of ``conv_out``: the sample is then the
+        finished image ([0, 1] fp32 NCHW / NHWC, or NHWC bytes) instead of the bf16 decoder output in [-1, 1]."""
         if not self._built:
             raise RuntimeError("AutoencoderKL: call load_state_dict() first")
         ops.require_hip(z, "z")
@@ -199,7 +201,7 @@ class AutoencoderKL(PretrainedMixin):
             if st["up"] is not None:
                 x = st["up"](x)
         x = self.conv_norm_out(x, silu=True)
-        img = ops.conv_thin_out(x, self.conv_out_w, self.conv_out_b)
+        img = ops.conv_thin_out(x, self.conv_out_w, self.conv_out_b, postprocess=postprocess)
         if not return_dict:
             return (img,)
         return DecoderOutput(sample=img)

@@ -184,7 +184,7 @@ extern "C" int da_gemm_tune(const da_gemm_params* pp, const da_gemm_params* pair
   float best = 3.0e38f;
   int bt = 0, bs = 0, bk = 1;
   static const int stagings[] = {DA_STAGE_LDS_DIRECT, DA_STAGE_LDS_DIRECT3, DA_STAGE_LDS_DIRECT4, DA_STAGE_LDS_DIRECT6,
-                                 DA_STAGE_LDS_DIRECT8};
+                                 DA_STAGE_LDS_DIRECT8, DA_STAGE_PINGPONG, DA_STAGE_PINGPONG3};
   constexpr int n_stagings = sizeof(stagings) / sizeof(stagings[0]);
   const int max_split = (best_split && !pair && p.workspace && p.sync_flags) ? 4 : 1;
   const int family = pp->tile;   // DA_TILE_AUTO: every variant; DA_TILE_FAMILY_1 / DA_TILE_FAMILY_K2: one kernel family only

@@ -100,20 +100,28 @@ __device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int
 //          tiles (128 x 320, 256 x 128) of problems with several tiles per CU, where what binds a 128 x 128 tile is the
 //          L2 -> LDS traffic per flop, (1 / BM + 1 / BN) bytes, not the latency of a lone workgroup.
 // NSLOT = ring depth in units (2 or 3).
-template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV>
+// PP (KG == 2 only) = the two K-groups run half an iteration APART ("ping-pong"): each group stages only its own slice parity
+//          (four waves x (PX + PW) / 4 pieces), every iteration has two block barriers, and group 1 entered the loop one barrier
+//          late -- so the LDS-DMA issue of one group (what binds the in-phase loop: all eight waves queue their loads on the CU's
+//          one texture-address path right behind the rendezvous, profiles/r03d_pmc_sq_counters.md) always runs under the
+//          other group's MFMA-only half.
+template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false>
 __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert((KG == 1 || KG == 2) && KG * WM * WN == 8, "eight waves: one or two K-groups");
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int PX = BM / 8, PW = BN / 8;                 // 1 KiB pieces (8 rows x 128 B) per slice
   constexpr int XBYTES = BM * 128, SLICE = (BM + BN) * 128, PAIR = KG * SLICE;   // PAIR = the ring unit (KG slices)
-  constexpr int XI = (KG * PX + 7) / 8, WI = (KG * PW + 7) / 8;   // LDS-DMA instructions per wave per unit (upper bound)
-  constexpr int XRAG = (KG * PX) % 8 ? 1 : 0, WRAG = (KG * PW) % 8 ? 1 : 0;   // a last row of pieces only some waves own
+  static_assert(!PP || KG == 2, "ping-pong is a property of the two K-groups");
+  constexpr int SW = PP ? 4 : 8;                          // waves that share the staging of one unit (PP: one slice, own group)
+  constexpr int UX = PP ? PX : KG * PX, UW = PP ? PW : KG * PW;   // pieces of that unit
+  constexpr int XI = (UX + SW - 1) / SW, WI = (UW + SW - 1) / SW;   // LDS-DMA instructions per wave per unit (upper bound)
+  constexpr int XRAG = UX % SW ? 1 : 0, WRAG = UW % SW ? 1 : 0;   // a last row of pieces only some waves own
   static_assert(NSLOT == 2 || NSLOT == 3, "ring of 2 or 3 slice pairs");
   constexpr int DUMP = (XRAG || WRAG) ? 1024 : 0;          // where the out-of-range pieces of ragged tiles write their zeros
   static_assert(NSLOT * PAIR + DUMP <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
   static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows are staged in 8-row pieces");
-  static_assert(!CONV || ((KG * PX) % 8) == 0, "conv: the slice of an activation piece must be a compile-time constant");
+  static_assert(!CONV || (UX % SW) == 0, "conv: the slice of an activation piece must be a compile-time constant");
   static_assert((NSLOT - 1) * (XI + WI) <= 63, "vmcnt is a 6-bit counter");
   static_assert(KG == 1 || MT * NT * 1024 * 4 <= NSLOT * PAIR, "partial-sum exchange does not fit the ring");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -150,21 +158,23 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   bool x_ok[XI], w_ok[WI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int q = i * 8 + wave;
-    // compile-time constants wherever all eight waves of a row i agree (so the unrolled issue code has no branch / select)
-    x_ok[i] = (i * 8 + 7 < KG * PX) ? true : (q < KG * PX);
-    x_h[i] = (KG == 1) ? 0 : (i * 8 >= PX) ? 1 : (i * 8 + 7 < PX) ? 0 : (q >= PX ? 1 : 0);
+    const int q = i * SW + (PP ? wq : wave);
+    // compile-time constants wherever all staging waves of a row i agree (so the unrolled issue code has no branch / select)
+    x_ok[i] = (i * SW + SW - 1 < UX) ? true : (q < UX);
+    x_h[i] = (KG == 1 || PP) ? 0 : (i * 8 >= PX) ? 1 : (i * 8 + 7 < PX) ? 0 : (q >= PX ? 1 : 0);
     x_r[i] = q - x_h[i] * PX;
     if (!x_ok[i]) x_h[i] = 0, x_r[i] = 0;
   }
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    const int q = i * 8 + wave;
-    w_ok[i] = (i * 8 + 7 < KG * PW) ? true : (q < KG * PW);
-    w_h[i] = (KG == 1) ? 0 : (i * 8 >= PW) ? 1 : (i * 8 + 7 < PW) ? 0 : (q >= PW ? 1 : 0);
+    const int q = i * SW + (PP ? wq : wave);
+    w_ok[i] = (i * SW + SW - 1 < UW) ? true : (q < UW);
+    w_h[i] = (KG == 1 || PP) ? 0 : (i * 8 >= PW) ? 1 : (i * 8 + 7 < PW) ? 0 : (q >= PW ? 1 : 0);
     w_r[i] = q - w_h[i] * PW;
     if (!w_ok[i]) w_h[i] = 0, w_r[i] = 0;
   }
+  // PP: this wave's staging state [0] describes its OWN group's slice parity; the LDS half it fills is its group's
+  const int own_half = PP ? g * SLICE : 0;
   constexpr int my_loads = XI + WI;                       // LDS-DMA instructions per wave per pair (ragged pieces included)
 
   // conv: per staged activation row, the output pixel it belongs to
@@ -228,13 +238,13 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   // arithmetic of pair n + 1 runs under the MFMAs that follow the issue of pair n and the issue itself is straight-line.
   int c_kh[2] = {0, 0}, c_kw[2] = {0, 0}, c_c0[2] = {0, 0};
   int st_pr = 0;                                          // next pair to stage
-  int st_s[2] = {0, nk > 1 ? 1 : 0};                      // slice (clamped to nk - 1) each parity stages next
+  int st_s[2] = {PP ? min(g, nk - 1) : 0, nk > 1 ? 1 : 0};   // slice (clamped to nk - 1) each parity stages next
   // a slice of the next pair that lies past K is staged as zeros (bit 31 of the per-lane offset: beyond num_records)
-  int st_zero[2] = {0, (nk > 1) ? 0 : (int)0x80000000};
+  int st_zero[2] = {(!PP || g < nk) ? 0 : (int)0x80000000, (nk > 1) ? 0 : (int)0x80000000};
   auto tap_offsets = [&](int h) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      if ((KG == 2 && i >= XI / 2 ? 1 : 0) != h) continue;   // CONV: (KG * PX) % 8 == 0, so pieces i < XI / 2 are parity 0
+      if ((KG == 2 && !PP && i >= XI / 2 ? 1 : 0) != h) continue;   // CONV, in phase: pieces i < XI / 2 are parity 0
       const int row = x_r[i] * 8 + (lane >> 3);
       const int sc = (lane & 7) ^ ((row >> 1) & 7);
       const int iy = xr_oy[i] + c_kh[h], ix = xr_ox[i] + c_kw[h];
@@ -255,9 +265,13 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
     }
   };
   if constexpr (CONV) {
-    if (KG == 2 && nk > 1) cursor_step(1);                // parity 1 starts on slice 1
+    if (PP) {
+      if (g == 1 && nk > 1) cursor_step(0);               // group 1 starts on slice 1
+    } else if (KG == 2 && nk > 1) {
+      cursor_step(1);                                     // parity 1 starts on slice 1
+    }
     tap_offsets(0);
-    if (KG == 2) tap_offsets(1);
+    if (KG == 2 && !PP) tap_offsets(1);
   }
 
 #define DA2_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       // is issued all the same, out of range (zeros, no memory traffic) into the dump KiB behind the ring: every wave issues
       // the same loads, the loop body stays ONE basic block and the compiler's lgkmcnt / vmcnt bookkeeping stays exact.
       const int z = x_ok[i] ? (h ? st_zero[1] : st_zero[0]) : (int)0x80000000;
-      unsigned char* dst = x_ok[i] ? base + h * SLICE + x_r[i] * 1024 : smem + NSLOT * PAIR;
+      unsigned char* dst = x_ok[i] ? base + own_half + h * SLICE + x_r[i] * 1024 : smem + NSLOT * PAIR;
       if constexpr (CONV) {
         const int c0 = h ? c_c0[1] : c_c0[0];
         if (p.C2 > 0 && c0 >= p.C1)
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       constexpr int i = decltype(ic)::value;
       const int h = w_h[i];
       const int z = w_ok[i] ? (h ? st_zero[1] : st_zero[0]) : (int)0x80000000;
-      unsigned char* dst = w_ok[i] ? base + h * SLICE + XBYTES + w_r[i] * 1024 : smem + NSLOT * PAIR;
+      unsigned char* dst = w_ok[i] ? base + own_half + h * SLICE + XBYTES + w_r[i] * 1024 : smem + NSLOT * PAIR;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DA2_LDS(dst), 16, vo_w[i] | z, (h ? st_s[1] : st_s[0]) * 128, 0, 0);
     };
     static_for<XI>(issue_x);
@@ -300,8 +314,8 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   auto stage_advance = [&]() {
     ++st_pr;
 #pragma unroll
-    for (int h = 0; h < KG; ++h) {
-      const int want = min(KG * st_pr + h, nk - 1);
+    for (int h = 0; h < (PP ? 1 : KG); ++h) {
+      const int want = min(KG * st_pr + (PP ? g : h), nk - 1);
       if constexpr (CONV) {
         const int kh0 = c_kh[h], kw0 = c_kw[h];
         while (st_s[h] < want) {
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
         st_s[h] = want;
       }
     }
-    st_zero[0] = (KG * st_pr < nk) ? 0 : (int)0x80000000;
+    st_zero[0] = (KG * st_pr + (PP ? g : 0) < nk) ? 0 : (int)0x80000000;
     st_zero[1] = (KG * st_pr + 1 < nk) ? 0 : (int)0x80000000;
   };
   // wait until at most PAIRS later pairs of THIS wave's LDS-DMA are in flight (a compile-time immediate)
@@ -410,6 +424,14 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       DA2_SG_MF((Q * (r + 1)) / R - (Q * r) / R);
     });
   };
+  // PP: group 1 enters the loop one barrier late (it pairs with group 0's first rendezvous) and stays half an iteration behind:
+  // group 0's rendezvous is group 1's separator and vice versa; group 0 pays the barrier back after its last pair.
+  if constexpr (PP) {
+    if (g == 1) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
   int slot = 0;                                           // ring slot of pair pr
   for (int pr = 0; pr + 1 < nk2; ++pr) {
     // first half: k-step 0 under the ds_reads of k-step 1
@@ -437,6 +459,11 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       DA2_SG_MF((Q * (r + 1)) / R - (Q * r) / R);
     });
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PP) {                                   // separator: the other group's rendezvous
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
     stage_advance();
     slot = nslot;
   }
@@ -446,6 +473,13 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   first_half_pins();
   __builtin_amdgcn_sched_barrier(0);
   DA2_MFMA(xf1, wf1);
+  if constexpr (PP) {
+    if (g == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                       // pairs with group 1's last separator
+      asm volatile("" ::: "memory");
+    }
+  }
 #undef DA2_FRAG
 #undef DA2_MFMA
 
@@ -599,14 +633,15 @@ inline bool staging_fits(const da_gemm_params& p) {
   return span * cmax * 2 < lim && (size_t)p.M / ((size_t)p.Hout * p.Wout) * p.Hin * p.Win < 0x7fffffffull;
 }
 
-template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV>
+template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false>
 int launch(const da_gemm_params& p, hipStream_t s) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int gx = choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
-  constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + ((((KG * BM / 8) % 8) || ((KG * BN / 8) % 8)) ? 1024 : 0);
-  auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV>;
+  constexpr int SW = PP ? 4 : 8, UX = (PP ? 1 : KG) * BM / 8, UW = (PP ? 1 : KG) * BN / 8;   // as in the kernel
+  constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + (((UX % SW) || (UW % SW)) ? 1024 : 0);
+  auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -618,7 +653,8 @@ int launch(const da_gemm_params& p, hipStream_t s) {
   return DA_OK;
 }
 
-// K2 tile codes -> instantiations.  staging: DA_STAGE_LDS_DIRECT = ring of 2 slice pairs, DA_STAGE_LDS_DIRECT3 = 3 (where it fits).
+// K2 tile codes -> instantiations.  staging: DA_STAGE_LDS_DIRECT = ring of 2 slice pairs, DA_STAGE_LDS_DIRECT3 = 3 (where it fits);
+// DA_STAGE_PINGPONG / DA_STAGE_PINGPONG3 = the same rings with the two K-groups half an iteration apart (KG == 2 tiles only).
 template <bool CONV>
 int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
   if (p.split_k > 1 || p.stats_out || p.ln_stats || !staging_fits(p)) return DA_ERR_UNSUPPORTED;
@@ -626,8 +662,27 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
   // GEGLU: the value / gate column tiles of a 64-row group must share a wave (wave tiles whose width is a multiple of 64)
   if (geglu && tile != DA_TILE_K2_128x128 && tile != DA_TILE_K1_256x128 && tile != DA_TILE_K1_128x256 && tile != DA_TILE_K1_256x256)
     return DA_ERR_UNSUPPORTED;
-  const int ns = staging == DA_STAGE_LDS_DIRECT ? 2 : staging == DA_STAGE_LDS_DIRECT3 ? 3 : 0;
+  const int ns = (staging == DA_STAGE_LDS_DIRECT || staging == DA_STAGE_PINGPONG) ? 2
+                 : (staging == DA_STAGE_LDS_DIRECT3 || staging == DA_STAGE_PINGPONG3) ? 3 : 0;
   if (ns == 0) return DA_ERR_UNSUPPORTED;
+  if (staging == DA_STAGE_PINGPONG || staging == DA_STAGE_PINGPONG3) {   // the K-groups half an iteration apart (KG == 2 tiles)
+    switch (tile) {
+      case DA_TILE_K2_128x128:
+        if (ns == 2) return launch<2, 2, 2, 4, 4, 2, CONV, true>(p, s);
+        break;
+      case DA_TILE_K2_128x80:
+        return ns == 2 ? launch<2, 4, 1, 2, 5, 2, CONV, true>(p, s) : launch<2, 4, 1, 2, 5, 3, CONV, true>(p, s);
+      case DA_TILE_K2_128x160:
+        if (ns == 2) return launch<2, 2, 2, 4, 5, 2, CONV, true>(p, s);
+        break;
+      case DA_TILE_K2_80x128:
+        if constexpr (!CONV) return ns == 2 ? launch<2, 1, 4, 5, 2, 2, false, true>(p, s) : launch<2, 1, 4, 5, 2, 3, false, true>(p, s);
+        break;
+      case DA_TILE_K2_128x64:
+        return ns == 2 ? launch<2, 2, 2, 4, 2, 2, CONV, true>(p, s) : launch<2, 2, 2, 4, 2, 3, CONV, true>(p, s);
+    }
+    return DA_ERR_UNSUPPORTED;
+  }
   switch (tile) {
     case DA_TILE_K2_128x128:
       if (ns == 2) return launch<2, 2, 2, 4, 4, 2, CONV>(p, s);

@@ -1084,7 +1084,8 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s, cons
       return DA_ERR_UNSUPPORTED;
   }
 #undef DA_V
-  return DA_ERR_INVALID;
+  // the ping-pong stagings are codes of the K2 family (gemm2_kernel.cuh): known, not built here
+  return (staging == DA_STAGE_PINGPONG || staging == DA_STAGE_PINGPONG3) ? DA_ERR_UNSUPPORTED : DA_ERR_INVALID;
 }
 
 }  // namespace da_gemm

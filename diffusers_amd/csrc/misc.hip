@@ -254,7 +254,11 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
 // channels, as NCHW planes.  Tail of a thin-output conv run on the MFMA implicit-GEMM kernel with its output channels
 // zero-padded to 16 (conv_out of the U-Nets and of the VAE decoder, models/unets/unet_2d_condition.py:1230,
 // models/autoencoders/vae.py:309): one 16-byte read per pixel, `cout` coalesced 2-byte plane writes.
-__global__ __launch_bounds__(256) void nhwc_take_nchw_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+// MODE >= 0 fuses VaeImageProcessor.postprocess (image_processor.py:738-786; the modes and the arithmetic of
+// image_postprocess_kernel below, applied to the same bf16-rounded conv output) into this pass, so the decoded image is
+// written once, in the layout and type the caller asked for: 0 = NCHW fp32 in [0, 1], 1 = NHWC fp32, 2 = NHWC uint8.
+template <int MODE>
+__global__ __launch_bounds__(256) void nhwc_take_nchw_kernel(const uint16_t* __restrict__ in, void* __restrict__ outv,
                                                              long long B, long long HW, int cpad, int cout) {
   const long long total = B * HW;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -262,8 +266,18 @@ __global__ __launch_bounds__(256) void nhwc_take_nchw_kernel(const uint16_t* __r
     const uint4 v = *(const uint4*)(in + (size_t)i * cpad);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (c < cout) out[((size_t)b * cout + c) * HW + px] = (uint16_t)((c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xffffu));
+    for (int c = 0; c < 8; ++c) {
+      if (c >= cout) break;
+      const uint16_t h = (uint16_t)((c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xffffu));
+      if (MODE < 0) {
+        ((uint16_t*)outv)[((size_t)b * cout + c) * HW + px] = h;
+      } else {
+        const float y = fminf(fmaxf(bf2f(h) * 0.5f + 0.5f, 0.f), 1.f);
+        if (MODE == 0) ((float*)outv)[((size_t)b * cout + c) * HW + px] = y;
+        else if (MODE == 1) ((float*)outv)[(size_t)i * cout + c] = y;
+        else ((uint8_t*)outv)[(size_t)i * cout + c] = (uint8_t)rintf(y * 255.f);
+      }
+    }
   }
 }
 
@@ -341,14 +355,27 @@ extern "C" int da_transpose_bf16(const void* in, void* out, int R, int Cc, long 
   return DA_OK;
 }
 
-extern "C" int da_nhwc_take_nchw_bf16(const void* in, void* out, long long B, long long HW, int cpad, int cout, void* stream) {
-  if (!in || !out || B <= 0 || HW <= 0 || cpad < 8 || (cpad & 7) || cout <= 0 || cout > 8) return DA_ERR_INVALID;
+static int take_launch(const void* in, void* out, long long B, long long HW, int cpad, int cout, int mode, void* stream) {
   const long long total = B * HW;
   const unsigned blocks = (unsigned)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16);
-  DA_LAUNCH(nhwc_take_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out, B, HW,
-            cpad, cout);
+  hipStream_t s = (hipStream_t)stream;
+#define DA_TAKE(M_) DA_LAUNCH(nhwc_take_nchw_kernel<M_>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)in, out, B, HW, cpad, cout)
+  if (mode < 0) DA_TAKE(-1); else if (mode == 0) DA_TAKE(0); else if (mode == 1) DA_TAKE(1); else DA_TAKE(2);
+#undef DA_TAKE
   DA_CHECK_LAUNCH();
   return DA_OK;
+}
+
+extern "C" int da_nhwc_take_nchw_bf16(const void* in, void* out, long long B, long long HW, int cpad, int cout, void* stream) {
+  if (!in || !out || B <= 0 || HW <= 0 || cpad < 8 || (cpad & 7) || cout <= 0 || cout > 8) return DA_ERR_INVALID;
+  return take_launch(in, out, B, HW, cpad, cout, -1, stream);
+}
+
+extern "C" int da_nhwc_take_postprocess(const void* in, void* out, long long B, long long HW, int cpad, int cout, int mode,
+                                        void* stream) {
+  if (!in || !out || B <= 0 || HW <= 0 || cpad < 8 || (cpad & 7) || cout <= 0 || cout > 4 || mode < 0 || mode > 2)
+    return DA_ERR_INVALID;
+  return take_launch(in, out, B, HW, cpad, cout, mode, stream);
 }
 
 extern "C" int da_bcast_add_f32(const float* a, const void* m, float* out, int B, int n, void* stream) {

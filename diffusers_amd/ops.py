@@ -717,6 +717,9 @@ def frames_to_ncthw(x: torch.Tensor, *, batch: int, channels: int, lo: float = -
     return out
 
 
+_PP_MODES = {"pt": 0, "np": 1, "uint8": 2}
+
+
 def image_postprocess(img: torch.Tensor, output_type: str) -> torch.Tensor:
     """VaeImageProcessor.postprocess on a decoded image [B][C][H][W] or video [B][C][T][H][W] (bf16 / fp32):
     "pt" -> same layout, fp32 in [0, 1]; "np" -> channels last fp32; "uint8" -> channels last bytes (what numpy_to_pil
@@ -725,7 +728,7 @@ def image_postprocess(img: torch.Tensor, output_type: str) -> torch.Tensor:
         raise TypeError("image_postprocess: bf16 / fp32 HIP tensor required")
     if not img.is_contiguous() or img.dim() not in (4, 5) or img.shape[1] > 4:
         raise ValueError("image_postprocess: contiguous [B][C<=4][...] tensor required")
-    mode = {"pt": 0, "np": 1, "uint8": 2}.get(output_type)
+    mode = _PP_MODES.get(output_type)
     if mode is None:
         raise ValueError(f"image_postprocess: output_type {output_type!r} (use 'pt', 'np' or 'uint8')")
     B, Cc = img.shape[:2]
@@ -816,7 +819,8 @@ def pad_thin_out(w: torch.Tensor, bias: Optional[torch.Tensor]):
     return ent[0], ent[1]
 
 
-def conv_thin_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, out_f32: bool = False) -> torch.Tensor:
+def conv_thin_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, out_f32: bool = False,
+                  postprocess: Optional[str] = None) -> torch.Tensor:
     """Conv2d 3x3 with small Cout.  x: NHWC; w: [Cout][9*Cin]; returns NCHW [B][Cout][H][W].
 
     Where the input has whole K slices (Cin % 64 == 0) and enough pixels to fill the chip, the conv runs on the MFMA
@@ -827,14 +831,24 @@ def conv_thin_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
     _req(x, "x"), _req(w, "w")
     B, H, W_, Cin = x.shape
     Cout = w.shape[0]
+    if postprocess is not None and (out_f32 or postprocess not in _PP_MODES):
+        raise ValueError(f"conv_thin_out: postprocess={postprocess!r} (use 'pt', 'np' or 'uint8' on the bf16 result)")
     if not out_f32 and Cin % 64 == 0 and Cout <= 8 and B * H * W_ >= 4096 and w.shape[1] == 9 * Cin:
         wp, bp = pad_thin_out(w, bias)
         y16 = conv2d_nhwc(x, wp, bp, ksize=3)
+        if postprocess is not None and Cout <= 4:
+            # VaeImageProcessor.postprocess as the epilogue of the layout pass: the decoded image is written once
+            mode = _PP_MODES[postprocess]
+            shape = (B, Cout, H, W_) if mode == 0 else (B, H, W_, Cout)
+            y = torch.empty(shape, device=x.device, dtype=torch.uint8 if mode == 2 else torch.float32)
+            L.check(L.load().da_nhwc_take_postprocess(y16.data_ptr(), y.data_ptr(), B, H * W_, THIN_OUT_PAD, Cout, mode, _stream()),
+                    "da_nhwc_take_postprocess")
+            return y
         y = torch.empty((B, Cout, H, W_), device=x.device, dtype=bf16)
         L.check(L.load().da_nhwc_take_nchw_bf16(y16.data_ptr(), y.data_ptr(), B, H * W_, THIN_OUT_PAD, Cout, _stream()),
                 "da_nhwc_take_nchw_bf16")
-        return y
+        return y if postprocess is None else image_postprocess(y, postprocess)
     y = torch.empty((B, Cout, H, W_), device=x.device, dtype=torch.float32 if out_f32 else bf16)
     L.check(L.load().da_conv_thin_out_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, H, W_, Cin, Cout,
                                            int(out_f32), _stream()), "da_conv_thin_out_bf16")
-    return y
+    return y if postprocess is None else image_postprocess(y, postprocess)

@@ -53,6 +53,22 @@ def postprocess_images(img: torch.Tensor, output_type: str):
     raise ValueError(f"output_type={output_type!r}: use 'pil', 'np', 'pt', 'raw' or 'latent'")
 
 
+def decode_postprocessed(vae, latents: torch.Tensor, output_type: str, **decode_kw):
+    """``vae.decode(latents / scaling_factor).sample`` followed by ``image_processor.postprocess(..., output_type)``
+    (pipeline_stable_diffusion_xl.py:1283-1299) with the postprocess fused into the decoder's last pass."""
+    mode = {"pt": "pt", "np": "np", "pil": "uint8"}.get(output_type)
+    if mode is None:
+        return postprocess_images(vae.decode(latents, return_dict=False, **decode_kw)[0], output_type)
+    out = vae.decode(latents, return_dict=False, postprocess=mode, **decode_kw)[0]
+    if output_type == "pt":
+        return out
+    arr = out.cpu().numpy()
+    if output_type == "np":
+        return arr
+    from PIL import Image
+    return [Image.fromarray(a.squeeze(-1), mode="L") if a.shape[-1] == 1 else Image.fromarray(a) for a in arr]
+
+
 @dataclass
 class PipelineOutput:
     images: torch.Tensor
@@ -161,8 +177,7 @@ class _LatentDiffusionBase:
             # decode entry takes one scalar divisor, so a VAE that ships them is refused rather than decoded wrongly
             raise NotImplementedError("AutoencoderKL configs with latents_mean / latents_std are not supported by the "
                                       "engine pipelines (decode the returned output_type='latent' tensor yourself)")
-        img = self.vae.decode(latents, return_dict=False, latents_div=float(vc.scaling_factor))[0]
-        return postprocess_images(img, output_type)
+        return decode_postprocessed(self.vae, latents, output_type, latents_div=float(vc.scaling_factor))
 
 
 class StableDiffusionXLPipeline(_LatentDiffusionBase):
@@ -489,9 +504,8 @@ class FluxPipeline:
         else:
             unp = self._unpack_latents(latents, height, width, self.vae_scale_factor).contiguous()
             vc = self.vae.config
-            img = self.vae.decode(unp, return_dict=False, latents_div=float(vc.scaling_factor),
-                                  latents_add=float(vc.shift_factor or 0.0))[0]
-            images = postprocess_images(img, output_type)
+            images = decode_postprocessed(self.vae, unp, output_type, latents_div=float(vc.scaling_factor),
+                                          latents_add=float(vc.shift_factor or 0.0))
         if not return_dict:
             return (images,)
         return PipelineOutput(images=images)

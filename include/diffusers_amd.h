@@ -82,6 +82,8 @@ extern "C" {
 #define DA_STAGE_LDS_DIRECT4 3 /* LDS-DMA, 4-slot ring (tiles up to 128x128) */
 #define DA_STAGE_LDS_DIRECT6 4 /* LDS-DMA, 6-slot ring (64x128, 128x64, 64x64) */
 #define DA_STAGE_LDS_DIRECT8 5 /* LDS-DMA, 8-slot ring (64x64): 112 KiB in flight per CU */
+#define DA_STAGE_PINGPONG 6    /* K2 tiles: 2-pair ring, the two K-groups half an iteration apart (each stages its own slices) */
+#define DA_STAGE_PINGPONG3 7   /* K2 tiles: 3-pair ring, ditto */
 
 int da_version(void);
 /* name of the HIP runtime error behind this thread's most recent DA_ERR_LAUNCH (diagnostics only) */
@@ -359,6 +361,11 @@ int da_transpose_bf16(const void* in, void* out, int R, int C, long long ldi, lo
  * (conv_out 320 -> 4 of the U-Net, unet_2d_condition.py:1230; 128 -> 3 of the VAE decoder, vae.py:309) that ran on the
  * implicit-GEMM kernel with its output channels zero-padded to 16 */
 int da_nhwc_take_nchw_bf16(const void* in, void* out, long long B, long long HW, int cpad, int cout, void* stream);
+/* The same pass with VaeImageProcessor.postprocess (image_processor.py:738-786) as its epilogue: the decoder's conv_out result
+ * (bf16, padded rows) is denormalised ((x * 0.5 + 0.5).clamp(0, 1)) and written ONCE in the caller's layout -- mode 0: NCHW
+ * fp32 ("pt"), 1: NHWC fp32 ("np"), 2: NHWC uint8 (the bytes numpy_to_pil hands to PIL).  cout <= 4.  Same values as
+ * da_nhwc_take_nchw_bf16 followed by da_image_postprocess. */
+int da_nhwc_take_postprocess(const void* in, void* out, long long B, long long HW, int cpad, int cout, int mode, void* stream);
 /* dst[D0][D2][D1][D3] = src[D0][D1][D2][D3] (bf16, D3 % 8 == 0): the channel-halves -> frame pairs interleave of
  * WanResample 'upsample3d' (autoencoder_kl_wan.py:297-299) on channels-last frames. */
 int da_permute_0213_bf16(const void* src, void* dst, long long D0, int D1, int D2, int D3, void* stream);

@@ -387,7 +387,7 @@ def test_tuning_keys_bucket_giant_row_counts_only():
     table = json.loads((Path(tuning.__file__).parent / "tuned" / "gfx950.json").read_text())
     assert table["arch"] == "gfx950" and len(table["entries"]) >= 250
     for key, (tile, staging, us) in table["entries"].items():
-        assert 1 <= tile < len(L.TILE_NAMES) and 0 <= staging <= 5 and us > 0, key
+        assert 1 <= tile < len(L.TILE_NAMES) and 0 <= staging <= 7 and us > 0, key
 
 
 def test_torch_library_ops_are_registered_with_fake_kernels():

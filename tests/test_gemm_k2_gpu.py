@@ -35,7 +35,7 @@ def k2_variants(L, conv=False, geglu=False):
             continue
         if geglu and t not in (L.TILE_K2_128x128, L.TILE_K1_256x128, L.TILE_K1_128x256, L.TILE_K1_256x256):
             continue
-        for st in (L.STAGE_LDS_DIRECT, L.STAGE_LDS_DIRECT3):
+        for st in (L.STAGE_LDS_DIRECT, L.STAGE_LDS_DIRECT3, L.STAGE_PINGPONG, L.STAGE_PINGPONG3):
             out.append((t, st))
     return out
 

@@ -1249,6 +1249,25 @@ def test_image_postprocess_matches_reference_chain(dtype):
         ops.image_postprocess(x, "jpeg")
 
 
+def test_conv_out_postprocess_epilogue_equals_the_separate_pass():
+    """`conv_thin_out(..., postprocess=)` (the VAE decoder's conv_out with VaeImageProcessor.postprocess fused into its layout
+    pass, image_processor.py:738-786) == conv_thin_out followed by image_postprocess, bit for bit, on the implicit-GEMM route
+    (128 -> 3 at 96 x 80) and on the small-image fallback (32 -> 3 at 16 x 16)."""
+    ops, L = _ops()
+    for (ci, h, w_, seed) in ((128, 96, 80, 81), (32, 16, 16, 83)):
+        x = rnd((2, h, w_, ci), seed, scale=2.0)
+        wpk = ops.pack_conv_weight(rnd((3, ci, 3, 3), seed + 1, scale=(9 * ci) ** -0.5))
+        b = rnd((3,), seed + 2)
+        base = ops.conv_thin_out(x, wpk, b)
+        assert base.dtype == bf16 and float(base.abs().max()) > 1.0          # some values clamp
+        for mode in ("pt", "np", "uint8"):
+            got = ops.conv_thin_out(x, wpk, b, postprocess=mode)
+            want = ops.image_postprocess(base, mode)
+            assert got.dtype == want.dtype and got.shape == want.shape and torch.equal(got, want), (ci, mode)
+    with pytest.raises(ValueError):
+        ops.conv_thin_out(x, wpk, b, postprocess="pil")
+
+
 def test_torch_library_ops_run_the_kernels_and_trace():
     """torch.ops.mi355x.* == the ctypes entry points bit for bit, and a function written over them is traceable by
     torch.compile (aot_eager: the tracer needs only the fake kernels; no inductor / Triton code generation involved)."""

@@ -99,6 +99,14 @@ def test_tiny_sdxl_pipeline_vs_reference(golden):
     print(f"[parity] tiny SDXL pipeline: latents rel_rms={rr:.3e}  image PSNR vs reference fp32 = {ps:.1f} dB")
     assert rr < 4e-2
     assert ps >= 40.0  # BASELINE.json target (measured 51-52 dB; the bf16 reference itself sits at the same floor)
+    # output_type "pt" / "np" / "pil": image_processor.postprocess (fused into the decoder's last pass where the conv_out runs
+    # on the implicit-GEMM kernel) == the same arithmetic on the raw decoder output
+    want = (img.float() * 0.5 + 0.5).clamp(0, 1)
+    assert torch.equal(pipe(latents=t(g, "latents").clone(), output_type="pt", **kw).images, want)
+    nhwc = want.permute(0, 2, 3, 1).cpu().numpy()
+    assert np.array_equal(pipe(latents=t(g, "latents").clone(), output_type="np", **kw).images, nhwc)
+    pil = pipe(latents=t(g, "latents").clone(), output_type="pil", **kw).images
+    assert len(pil) == nhwc.shape[0] and np.array_equal(np.asarray(pil[0]), (nhwc[0] * 255).round().astype("uint8"))
 
 
 def test_sdxl_architecture_small_latents_vs_oracle():

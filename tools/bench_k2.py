@@ -25,7 +25,7 @@ def variants(geglu=False, conv=False):
             continue
         if conv and t == L.TILE_K2_80x128:
             continue
-        for st in (L.STAGE_LDS_DIRECT, L.STAGE_LDS_DIRECT3):
+        for st in (L.STAGE_LDS_DIRECT, L.STAGE_LDS_DIRECT3, L.STAGE_PINGPONG, L.STAGE_PINGPONG3):
             yield t, st
 
 

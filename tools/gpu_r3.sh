@@ -73,3 +73,17 @@ if [[ $WHAT == *pmc* ]]; then
   find $O/pmc_k2 -name '*kernel_trace*' -delete; find $O/pmc_k2 -name '*counter_collection.csv' -size +8M -delete
   cat $O/pmc_k2_report.md; tail -3 $O/pmc_k2/sq.log
 fi
+if [[ $WHAT == *traffic* ]]; then
+  # per-launch HBM-side traffic of the denoising-step kernels (2 eager steps): FETCH and WRITE in separate --pmc passes, stamped
+  # with the build fingerprint bench.py compares before it reports roofline.traffic
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc_traffic; mkdir -p $O/pmc_traffic
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_traffic/fetch -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/fetch.log 2>&1; echo "pmc fetch rc=$?"
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_traffic/write -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/write.log 2>&1; echo "pmc write rc=$?"
+  cd $R
+  ALGO=$(python -c "import json;print(json.load(open('$O/bench.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null)
+  python tools/pmc_traffic.py $O/pmc_traffic/fetch $O/pmc_traffic/write $O/r03_sdxl_traffic.md $O/sdxl_traffic.json $ALGO
+  find $O/pmc_traffic -name '*kernel_trace*' -delete
+  find $O/pmc_traffic -name '*counter_collection.csv' -size +8M -delete
+  tail -4 $O/pmc_traffic/fetch.log | cut -c1-200
+fi

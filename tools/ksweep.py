@@ -23,7 +23,8 @@ def rnd(shape, scale=1.0):
 def main():
     manifest = []
     flush = torch.empty(320 << 20, dtype=torch.uint8, device="cuda")
-    variants = [(L.TILE_128x64, 2), (L.TILE_128x128_W8, 2), (L.TILE_K2_128x80, 1), (L.TILE_K2_128x80, 2), (L.TILE_K2_128x160, 1),
+    variants = [(L.TILE_128x64, 2), (L.TILE_128x128_W8, 2), (L.TILE_K2_128x80, 1), (L.TILE_K2_128x80, 2), (L.TILE_K2_128x80, 6), (L.TILE_K2_128x80, 7), (L.TILE_K2_128x160, 1),
+                (L.TILE_K2_128x160, 6), (L.TILE_K2_128x128, 6),
                 (L.TILE_K2_128x128, 1), (L.TILE_K1_256x128, 2), (L.TILE_K1_128x320, 1)]
     if len(sys.argv) > 2 and sys.argv[2] == "r2":       # the round-2 variant set
         variants = [(L.TILE_64x64, 1), (L.TILE_128x64, 2), (L.TILE_128x128, 1), (L.TILE_128x128_W8, 2), (L.TILE_256x128, 2)]

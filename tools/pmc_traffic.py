@@ -17,6 +17,8 @@ from pathlib import Path
 
 def family(name: str) -> str:
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    if "igemm2_bf16_kernel" in name:          # the K2 / K1 family counts with the implicit-GEMM family (one roofline entry)
+        return "igemm_bf16_kernel"
     for key in ("igemm_bf16_kernel", "attn_fwd_kernel", "layernorm_kernel", "gn_apply_kernel", "gn_stats_kernel",
                 "linear_small_m_kernel", "conv_thin_in_kernel", "conv_thin_out_kernel", "softmax_rows_kernel",
                 "euler_step_kernel", "euler_scale_input_kernel"):
@@ -46,7 +48,7 @@ def main():
     algo = float(sys.argv[5]) if len(sys.argv) > 5 else None
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     fams = sorted(set(fe) | set(wr), key=lambda k: -(2 * fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1]))
-    lines = ["# HBM-side traffic per launch, SDXL bench (eager launches, rocprofv3 --pmc; FETCH and WRITE in separate passes)",
+    lines = ["# HBM-side traffic per launch, SDXL denoising step (eager launches, rocprofv3 --pmc; FETCH and WRITE in separate passes)",
              "",
              "fetched = 2 x FETCH_SIZE KiB (gfx950 wide-stream correction, MI355X_MICROARCH.md HBM section); written = "
              "WRITE_SIZE KiB as reported (uncalibrated).  Per launch = counter sum / dispatches of the family.", "",
@@ -66,9 +68,12 @@ def main():
             continue
         lines.append(f"| `{k}` | {n} | {fb / 1e6:.3f} | {wb / 1e6:.3f} | {(fb + wb) / 1e6:.3f} | {(fb * nf + wb * nw) / 1e9:.2f} |")
     ig = rec.get("igemm_bf16_kernel")
-    out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 2x FETCH_SIZE correction) on the SDXL "
+    stamp = Path(__file__).resolve().parent.parent / "diffusers_amd" / "_C" / "build.stamp"
+    out = {"build_fingerprint": stamp.read_text().strip()[:16] if stamp.exists() else "unknown",   # as bench.build_fingerprint()
+           "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 2x FETCH_SIZE correction) on the SDXL "
                      f"denoising-step kernels launched eagerly (tools/pmc_one_step.py); profiles/{out_md.name}",
            "unit": "bytes", "families": rec}
+    out["source"] = out["source"].replace("igemm_bf16_kernel", "igemm")
     if ig:
         tot = ig["fetched_bytes_per_launch"] + ig["written_bytes_per_launch"]
         out["igemm_bytes_per_launch"] = tot
