@@ -41,6 +41,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base,
 }
 #endif
 
+// Stage timestamps (tools/trace_gemm2.hip builds this header with -DDA_GEMM2_TRACE; the library never does): s_memtime at the
+// marks below, kept in SGPRs and written by lane 0 of every wave after its last output store.
+#if defined(DA_GEMM2_TRACE)
+__device__ unsigned long long* g_da2_trace;
+#define DA2_TRACE(i) tr_[i] = __builtin_readcyclecounter()
+#else
+#define DA2_TRACE(i) ((void)0)
+#endif
+
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (N > 0) {
@@ -126,6 +135,10 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   static_assert(KG == 1 || MT * NT * 1024 * 4 <= NSLOT * PAIR, "partial-sum exchange does not fit the ring");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+#if defined(DA_GEMM2_TRACE)
+  unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  DA2_TRACE(0);                                           // kernel entry
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g = KG == 2 ? wave >> 2 : 0, wq = KG == 2 ? wave & 3 : wave;   // K-group, position inside the group
@@ -407,14 +420,17 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
 #define DA2_SG_VM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
 
   // ---- prologue: pairs 0 .. NSLOT-1 in flight (zeros past the end of K), pair 0 landed, its k-step-0 fragments on their way ----
+  DA2_TRACE(1);                                           // set-up done, first LDS-DMA about to issue
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
     stage_issue(s);
     stage_advance();
   }
+  DA2_TRACE(2);                                           // ring issued
   DA2_WAIT_PAIRS(NSLOT - 1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  DA2_TRACE(3);                                           // first pair landed for everybody
   DA2_FRAG(xf0, wf0, 0, foff0);
 
   auto first_half_pins = [&]() {
@@ -483,6 +499,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
 #undef DA2_FRAG
 #undef DA2_MFMA
 
+  DA2_TRACE(4);                                           // K loop done
   // ---- the two K-groups meet: each sends the half it does not finish, through the (now free) ring ----
   f32x4_t keep[MH][NH];
   if constexpr (KG == 1) {
@@ -526,6 +543,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       }
   }
 
+  DA2_TRACE(5);                                           // partial sums exchanged
   // ---- epilogue: lane holds, for output row (r16 of a 16-row tile), channels 4 kq .. 4 kq + 3 of a 16-column tile ----
   const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
   const bool has_bias = p.bias != nullptr, has_rowvec = p.rowvec != nullptr, has_res = p.residual != nullptr;
@@ -598,6 +616,15 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       }
     }
   }
+#if defined(DA_GEMM2_TRACE)
+  DA2_TRACE(6);                                           // output stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DA2_TRACE(7);                                           // ... and acknowledged
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_da2_trace[((size_t)blockIdx.x * 8 + wave) * 8 + i] = tr_[i];
+  }
+#endif
 #undef DA2_LDS
 #undef DA2_WAIT_PAIRS
 #undef DA2_SG_DS
