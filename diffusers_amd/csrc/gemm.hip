@@ -103,7 +103,8 @@ bool tile_ok(const da_gemm_params& p, int tile) {
     const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
     const bool geglu_ok = tile == DA_TILE_K2_128x128 || tile == DA_TILE_K1_256x128 || tile == DA_TILE_K1_128x256 ||
                           tile == DA_TILE_K1_256x256;
-    return !p.stats_out && !p.ln_stats && p.split_k <= 1 && (!geglu || geglu_ok) && !(p.conv && tile == DA_TILE_K2_80x128);
+    return !p.stats_out && !p.ln_stats && p.split_k <= 1 && (!geglu || geglu_ok) &&
+           !(p.conv && (tile == DA_TILE_K2_80x128 || tile == DA_TILE_K1_256x256));
   }
   // GEGLU pairs (value, gate) 32-column tiles inside one wave: the wave must own an even number of them
   if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) &&

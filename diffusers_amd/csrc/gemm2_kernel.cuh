@@ -60,24 +60,30 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // One 4-channel group of one output row: the fused epilogue of gemm_kernel.cuh (bias, per-row bias, per-batch channel
 // vector, activation, gate, residual, output scale) with the same rounding points.  o[] in, o[] out (fp32).
-__device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int m, int n, int bidx, float brow, bool has_bias,
-                                          uint2 bv, bool has_rowvec, uint2 rv, bool has_res, uint2 resv) {
-  if (has_bias) { o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y); }
-  if (p.bias_rows) {
+// ACT / GATE are compile-time (ACT = -1: decided at run time, the gated launches): the epilogue of a launch is ONE straight
+// line of code per output tile -- with the activation switch inside the unrolled tile loop every tile jumped through its own
+// copy of a 4 KB switch and the epilogue, 650-820 cycles per tile, was bound by instruction fetch
+// (profiles/r03e_gemm_stage_trace.md).  Absent operands are ZERO vectors (adding a bf16 zero / multiplying by 1.0f is exact),
+// so there is no per-tile branch on them either.  FINISH = false stops in front of the residual: the row-contiguous store
+// path adds it (and the output scale) after the values went through LDS -- the same fp32 operations in the same order.
+// GATE: 0 none, 1 bf16 [B][ld_gate], 2 fp32.
+template <int ACT, int GATE, bool FINISH>
+__device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int n, int bidx, float brow, uint2 bv, uint2 rv, uint2 resv) {
+  o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] += brow;
-  }
-  if (has_rowvec) { o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y); }
-  if (p.act == DA_ACT_GELU_TANH) {
+  for (int e = 0; e < 4; ++e) o[e] += brow;
+  o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
+  const int act = ACT >= 0 ? ACT : p.act;
+  if (act == DA_ACT_GELU_TANH) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = gelu_tanh_f(bf2f(f2bf(o[e])));
-  } else if (p.act == DA_ACT_SILU) {
+  } else if (act == DA_ACT_SILU) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = silu_f(bf2f(f2bf(o[e])));
-  } else if (p.act == DA_ACT_GELU_ERF) {
+  } else if (act == DA_ACT_GELU_ERF) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(bf2f(f2bf(o[e])));
-  } else if (p.act == DA_ACT_QUICK_GELU) {
+  } else if (act == DA_ACT_QUICK_GELU) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float xv = bf2f(f2bf(o[e]));
@@ -85,19 +91,19 @@ __device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int
       o[e] = xv * bf2f(f2bf(1.0f / (1.0f + __expf(-tv))));
     }
   }
-  if (p.gate && p.gate_f32) {
+  if constexpr (GATE == 2) {
     const float4 gv = *(const float4*)((const float*)p.gate + (size_t)bidx * p.ld_gate + n);
     o[0] = bf2f(f2bf(o[0])) * gv.x; o[1] = bf2f(f2bf(o[1])) * gv.y;
     o[2] = bf2f(f2bf(o[2])) * gv.z; o[3] = bf2f(f2bf(o[3])) * gv.w;
-  } else if (p.gate) {
+  } else if constexpr (GATE == 1) {
     const uint2 gv = *(const uint2*)((const uint16_t*)p.gate + (size_t)bidx * p.ld_gate + n);
     o[0] = bf2f(f2bf(bf2f(f2bf(o[0])) * bf_lo(gv.x)));
     o[1] = bf2f(f2bf(bf2f(f2bf(o[1])) * bf_hi(gv.x)));
     o[2] = bf2f(f2bf(bf2f(f2bf(o[2])) * bf_lo(gv.y)));
     o[3] = bf2f(f2bf(bf2f(f2bf(o[3])) * bf_hi(gv.y)));
   }
-  if (has_res) { o[0] += bf_lo(resv.x); o[1] += bf_hi(resv.x); o[2] += bf_lo(resv.y); o[3] += bf_hi(resv.y); }
-  if (p.out_scale != 1.0f) {
+  if constexpr (FINISH) {
+    o[0] += bf_lo(resv.x); o[1] += bf_hi(resv.x); o[2] += bf_lo(resv.y); o[3] += bf_hi(resv.y);
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] *= p.out_scale;
   }
@@ -356,24 +362,64 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   auto col_of = [&](int jh) { return n0 + (wn * NT + (SPLIT_M ? 0 : g * NH) + jh) * 16 + 4 * kq; };
   // (Only while the registers last: a wave that finishes more than 12 tiles -- the KG == 1 shapes -- fetches the residual and
   // the channel vector in the epilogue instead; its launches are long enough for that round trip not to matter.)
-  constexpr bool PF = MH * NH <= 12;
-  uint2 res_v[PF ? MH : 1][PF ? NH : 1], bias_v[NH], rowvec_v[PF ? MH : 1][PF ? NH : 1];
+  constexpr bool PF = MH * NH <= (CONV ? 8 : 12);         // (conv carries its pixel cursors: fewer registers to spare)
+  // Row-contiguous output (STG): a wave's 16 x (16 NH) band of finished values goes through LDS once so that every lane stores
+  // (and, for the residual, loads) 16 contiguous bytes of ONE row -- NH * 32 contiguous bytes per row instead of NH separate
+  // 32-byte segments per row.  The store path is bound by line requests, not bytes (profiles/r03e_gemm_stage_trace.md: the
+  // 8-byte-per-lane epilogue cost 650-820 cycles per 16 x 16 tile, 13-27 % of a launch).  Piece q = lane + 64 t of a band:
+  // row q / PPR, 16-byte (8-channel) slot q % PPR.  Needs 16-byte aligned rows; anything else keeps the 8-byte path.
+  constexpr bool STG = NH >= 2;
+  constexpr int PPR = 2 * NH, NPIECE = 16 * PPR, TT = (NPIECE + 63) / 64, ROWB = NH * 64 + 16;
+  static_assert(!STG || (KG == 2 ? 4 * MT * NT * 1024 : 0) + 8 * 16 * ROWB <= NSLOT * PAIR, "output staging does not fit the ring");
+  const bool wide = STG && !geglu && !p.out_f32 && !(p.ldc & 7) && !((size_t)p.C & 15) && !(p.N & 7) &&
+                    (!p.residual || (!(p.ldr & 7) && !((size_t)p.residual & 15)));
+  const int band_col0 = n0 + (wn * NT + (SPLIT_M ? 0 : g * NH)) * 16;
+  auto band_row0 = [&](int ih) { return m0 + (wm * MT + (SPLIT_M ? g * MH : 0) + ih) * 16; };
+  constexpr bool PFN = PF && !STG;                        // the 8-byte layout prefetches its residual only where it is the only path
+  uint2 res_v[PFN ? MH : 1][PFN ? NH : 1], bias_v[NH], rowvec_v[PF ? MH : 1][PF ? NH : 1];
+  uint4 resw[(PF && STG) ? MH : 1][(PF && STG) ? TT : 1];
 #pragma unroll
   for (int ih = 0; ih < (PF ? MH : 1); ++ih)
 #pragma unroll
-    for (int jh = 0; jh < (PF ? NH : 1); ++jh) res_v[ih][jh] = rowvec_v[ih][jh] = make_uint2(0, 0);
+    for (int jh = 0; jh < (PF ? NH : 1); ++jh) rowvec_v[ih][jh] = make_uint2(0, 0);
+#pragma unroll
+  for (int ih = 0; ih < (PFN ? MH : 1); ++ih)
+#pragma unroll
+    for (int jh = 0; jh < (PFN ? NH : 1); ++jh) res_v[ih][jh] = make_uint2(0, 0);
+#pragma unroll
+  for (int ih = 0; ih < ((PF && STG) ? MH : 1); ++ih)
+#pragma unroll
+    for (int t = 0; t < ((PF && STG) ? TT : 1); ++t) resw[ih][t] = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int jh = 0; jh < NH; ++jh) bias_v[jh] = make_uint2(0, 0);
-  {
+  // Issued right behind the FIRST pair's LDS-DMA (the matrix stream starts first; these loads are older than pairs 1 .. and
+  // therefore covered by every counted wait that covers pair 0).
+  auto prefetch_epilogue_operands = [&]() {
     const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
     const uint16_t* __restrict__ bias = (const uint16_t*)p.bias;
     const uint16_t* __restrict__ rowvec = (const uint16_t*)p.rowvec;
-    if (PF && resid) {
+    if constexpr (PFN) {
+      if (resid) {
 #pragma unroll
-      for (int ih = 0; ih < (PF ? MH : 0); ++ih) {
-        const int m = min(row_of(ih), p.M - 1);
+        for (int ih = 0; ih < MH; ++ih) {
+          const int m = min(row_of(ih), p.M - 1);
 #pragma unroll
-        for (int jh = 0; jh < NH; ++jh) res_v[ih][jh] = *(const uint2*)(resid + (size_t)m * p.ldr + min(col_of(jh), p.N - 4));
+          for (int jh = 0; jh < NH; ++jh) res_v[ih][jh] = *(const uint2*)(resid + (size_t)m * p.ldr + min(col_of(jh), p.N - 4));
+        }
+      }
+    }
+    if constexpr (PF && STG) {
+      if (resid && wide) {
+#pragma unroll
+        for (int ih = 0; ih < MH; ++ih)
+#pragma unroll
+          for (int t = 0; t < TT; ++t) {
+            const int q = lane + 64 * t;
+            if (NPIECE % 64 == 0 || q < NPIECE) {
+              const int m = min(band_row0(ih) + q / PPR, p.M - 1), n = min(band_col0 + (q % PPR) * 8, p.N - 8);
+              resw[ih][t] = *(const uint4*)(resid + (size_t)m * p.ldr + n);
+            }
+          }
       }
     }
     if (bias) {
@@ -389,7 +435,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
         for (int jh = 0; jh < NH; ++jh) rowvec_v[ih][jh] = *(const uint2*)(rowvec + ro + min(col_of(jh), p.N - 4));
       }
     }
-  }
+  };
 
   f32x4_t acc[MT][NT];
 #pragma unroll
@@ -425,6 +471,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   for (int s = 0; s < NSLOT; ++s) {
     stage_issue(s);
     stage_advance();
+    if (s == 0) prefetch_epilogue_operands();
   }
   DA2_TRACE(2);                                           // ring issued
   DA2_WAIT_PAIRS(NSLOT - 1);
@@ -546,85 +593,172 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   DA2_TRACE(5);                                           // partial sums exchanged
   // ---- epilogue: lane holds, for output row (r16 of a 16-row tile), channels 4 kq .. 4 kq + 3 of a 16-column tile ----
   const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
-  const bool has_bias = p.bias != nullptr, has_rowvec = p.rowvec != nullptr, has_res = p.residual != nullptr;
+  const bool has_rowvec = p.rowvec != nullptr, has_res = p.residual != nullptr;
+#if defined(DA_GEMM2_TRACE)
+#define DA2_TRACE_END()                                                                                     \
+  do {                                                                                                      \
+    DA2_TRACE(6);                                         /* output stores issued */                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+    DA2_TRACE(7);                                         /* ... and acknowledged */                        \
+    if (lane == 0) {                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) g_da2_trace[((size_t)blockIdx.x * 8 + wave) * 8 + i] = tr_[i]; \
+    }                                                                                                       \
+  } while (0)
+#else
+#define DA2_TRACE_END() ((void)0)
+#endif
   if (geglu) {
     // packed weight rows: per 64 = [32 value | 32 gate]  ->  16-column tiles (4u, 4u+1) = value, (4u+2, 4u+3) = gate
     if constexpr (SPLIT_M && (NT % 4) == 0) {
+      auto body = [&](auto tanh_c) __attribute__((always_inline)) {
+        constexpr bool TANH = decltype(tanh_c)::value;
 #pragma unroll
-      for (int ih = 0; ih < MH; ++ih) {
-        const int m = row_of(ih);
-        if (m >= p.M) continue;
+        for (int ih = 0; ih < MH; ++ih) {
+          const int m = row_of(ih);
+          if (m >= p.M) continue;
 #pragma unroll
-        for (int u = 0; u < NT / 4; ++u)
+          for (int u = 0; u < NT / 4; ++u)
 #pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            const int jv = 4 * u + v, jg = jv + 2;
-            const int nv = col_of(jv);
-            if (nv >= p.N) continue;
-            const int no = (n0 >> 1) + (wn * (NT / 4) + u) * 32 + v * 16 + 4 * kq;
-            float o[4];
+            for (int v = 0; v < 2; ++v) {
+              const int jv = 4 * u + v, jg = jv + 2;
+              const int nv = col_of(jv);
+              if (nv >= p.N) continue;
+              const int no = (n0 >> 1) + (wn * (NT / 4) + u) * 32 + v * 16 + 4 * kq;
+              const uint2 bh = bias_v[jv], bg = bias_v[jg];          // zeros without a bias
+              float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float hv = keep[ih][jv][e] * p.alpha, gv = keep[ih][jg][e] * p.alpha;
-              if (has_bias) {
-                const uint2 bh = bias_v[jv], bg = bias_v[jg];
+              for (int e = 0; e < 4; ++e) {
+                float hv = keep[ih][jv][e] * p.alpha, gv = keep[ih][jg][e] * p.alpha;
                 hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
                 gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
+                hv = bf2f(f2bf(hv));   // the reference rounds the projection to bf16 before chunk / gelu / mul
+                gv = bf2f(f2bf(gv));
+                o[e] = hv * bf2f(f2bf(TANH ? gelu_tanh_f(gv) : gelu_erf_f(gv)));
               }
-              hv = bf2f(f2bf(hv));   // the reference rounds the projection to bf16 before chunk / gelu / mul
-              gv = bf2f(f2bf(gv));
-              o[e] = hv * bf2f(f2bf(p.act == DA_ACT_GEGLU ? gelu_erf_f(gv) : gelu_tanh_f(gv)));
+              uint2 pk;
+              pk.x = pack_bf2(o[0], o[1]);
+              pk.y = pack_bf2(o[2], o[3]);
+              *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + no) = pk;
             }
-            uint2 pk;
-            pk.x = pack_bf2(o[0], o[1]);
-            pk.y = pack_bf2(o[2], o[3]);
-            *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + no) = pk;
-          }
-      }
+        }
+      };
+      if (p.act == DA_ACT_GEGLU) body(std::false_type{});
+      else body(std::true_type{});
     }
     return;
   }
-#pragma unroll
-  for (int ih = 0; ih < MH; ++ih) {
-    const int m = row_of(ih);
-    if (m >= p.M) continue;
-    const int bidx = (has_rowvec || p.gate != nullptr) ? (m / p.rows_per_batch) : 0;
-    const float brow = bias_rows ? bf2f(bias_rows[m]) : 0.f;
-#pragma unroll
-    for (int jh = 0; jh < NH; ++jh) {
-      const int n = col_of(jh);
-      if (n >= p.N) continue;
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
-      uint2 rvv = make_uint2(0, 0), rsv = make_uint2(0, 0);
-      if constexpr (PF) {
-        rvv = rowvec_v[ih][jh];
-        rsv = res_v[ih][jh];
-      } else {
-        if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
-        if (has_res) rsv = *(const uint2*)((const uint16_t*)p.residual + (size_t)m * p.ldr + n);
+  // Everything else: one straight-line instantiation per (activation, gate kind), chosen ONCE per launch.
+  auto wide_body = [&](auto act_c, auto gate_c) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_c)::value, GATE = decltype(gate_c)::value;
+    if constexpr (STG) {
+      if constexpr (KG == 1) {                          // (KG == 2: the exchange barriers already emptied the ring of readers)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
       }
-      epilogue4(p, o, m, n, bidx, brow, has_bias, bias_v[jh], has_rowvec, rvv, has_res, rsv);
-      if (p.out_f32) {
-        *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-      } else {
-        uint2 pk;
-        pk.x = pack_bf2(o[0], o[1]);
-        pk.y = pack_bf2(o[2], o[3]);
-        *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + n) = pk;
+      unsigned char* stg = smem + (KG == 2 ? 4 * MT * NT * 1024 : 0) + wave * (16 * ROWB);
+      unsigned char* stg_w = stg + r16 * ROWB + kq * 16;      // this lane's slot in the MFMA layout
+      const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
+#pragma unroll
+      for (int ih = 0; ih < MH; ++ih) {
+        // finished-but-for-the-residual values of the band, fp32, in the MFMA layout -> LDS
+        const int mc = min(row_of(ih), p.M - 1);
+        const int bidx = (GATE != 0 || (!PF && has_rowvec)) ? (mc / p.rows_per_batch) : 0;
+        const float brow = bias_rows ? bf2f(bias_rows[mc]) : 0.f;
+#pragma unroll
+        for (int jh = 0; jh < NH; ++jh) {
+          const int n = min(col_of(jh), p.N - 4);
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
+          uint2 rvv = make_uint2(0, 0);
+          if constexpr (PF) rvv = rowvec_v[ih][jh];
+          else if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
+          epilogue4<ACT, GATE, false>(p, o, n, bidx, brow, bias_v[jh], rvv, make_uint2(0, 0));
+          *(float4*)(stg_w + jh * 64) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        // ... and back, 8 consecutive channels of one row per lane: + residual, * out_scale, one 16-byte store
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          const int q = lane + 64 * t;
+          if (NPIECE % 64 != 0 && q >= NPIECE) continue;
+          const int row = q / PPR, c8 = q % PPR;
+          const float4 lo = *(const float4*)(stg + row * ROWB + c8 * 32), hi = *(const float4*)(stg + row * ROWB + c8 * 32 + 16);
+          float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          const int mo = band_row0(ih) + row, no = band_col0 + c8 * 8;
+          if (mo >= p.M || no >= p.N) continue;
+          uint4 rw = make_uint4(0, 0, 0, 0);
+          if constexpr (PF) rw = resw[ih][t];
+          else if (has_res) rw = *(const uint4*)(resid + (size_t)mo * p.ldr + no);
+          o[0] += bf_lo(rw.x); o[1] += bf_hi(rw.x); o[2] += bf_lo(rw.y); o[3] += bf_hi(rw.y);
+          o[4] += bf_lo(rw.z); o[5] += bf_hi(rw.z); o[6] += bf_lo(rw.w); o[7] += bf_hi(rw.w);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] *= p.out_scale;
+          uint4 pk;
+          pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]); pk.z = pack_bf2(o[4], o[5]); pk.w = pack_bf2(o[6], o[7]);
+          *(uint4*)((uint16_t*)p.C + (size_t)mo * p.ldc + no) = pk;
+        }
       }
     }
-  }
-#if defined(DA_GEMM2_TRACE)
-  DA2_TRACE(6);                                           // output stores issued
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  DA2_TRACE(7);                                           // ... and acknowledged
-  if (lane == 0) {
+  };
+  auto narrow_body = [&](auto act_c, auto gate_c) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_c)::value, GATE = decltype(gate_c)::value;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) g_da2_trace[((size_t)blockIdx.x * 8 + wave) * 8 + i] = tr_[i];
+    for (int ih = 0; ih < MH; ++ih) {
+      const int m = row_of(ih);
+      if (m >= p.M) continue;
+      const int bidx = (GATE != 0 || (!PF && has_rowvec)) ? (m / p.rows_per_batch) : 0;
+      const float brow = bias_rows ? bf2f(bias_rows[m]) : 0.f;
+#pragma unroll
+      for (int jh = 0; jh < NH; ++jh) {
+        const int n = col_of(jh);
+        if (n >= p.N) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
+        uint2 rvv = make_uint2(0, 0), rsv = make_uint2(0, 0);
+        if constexpr (PF) rvv = rowvec_v[ih][jh];
+        else if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
+        if constexpr (PFN) rsv = res_v[ih][jh];
+        else if (has_res) rsv = *(const uint2*)((const uint16_t*)p.residual + (size_t)m * p.ldr + n);
+        epilogue4<ACT, GATE, true>(p, o, n, bidx, brow, bias_v[jh], rvv, rsv);
+        if (p.out_f32) {
+          *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          uint2 pk;
+          pk.x = pack_bf2(o[0], o[1]);
+          pk.y = pack_bf2(o[2], o[3]);
+          *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + n) = pk;
+        }
+      }
+    }
+  };
+  {
+    using std::integral_constant;
+    auto by_act = [&](auto&& f, auto gate_c) __attribute__((always_inline)) {
+      if (p.act == DA_ACT_NONE) f(integral_constant<int, DA_ACT_NONE>{}, gate_c);
+      else if (p.act == DA_ACT_GELU_TANH) f(integral_constant<int, DA_ACT_GELU_TANH>{}, gate_c);
+      else if (p.act == DA_ACT_SILU) f(integral_constant<int, DA_ACT_SILU>{}, gate_c);
+      else if (p.act == DA_ACT_GELU_ERF) f(integral_constant<int, DA_ACT_GELU_ERF>{}, gate_c);
+      else f(integral_constant<int, DA_ACT_QUICK_GELU>{}, gate_c);
+    };
+    // gated launches (adaLN gates of the DiT blocks: activation NONE in practice) keep the run-time activation switch; where
+    // the row-contiguous path exists the 8-byte path is only the unaligned-rows fallback and gets ONE run-time-switched copy
+    constexpr integral_constant<int, -1> RT{};
+    constexpr integral_constant<int, 0> G0{};
+    if (STG && wide) {
+      if (p.gate && p.gate_f32) wide_body(RT, integral_constant<int, 2>{});
+      else if (p.gate) wide_body(RT, integral_constant<int, 1>{});
+      else by_act(wide_body, G0);
+    } else {
+      if (p.gate && p.gate_f32) narrow_body(RT, integral_constant<int, 2>{});
+      else if (p.gate) narrow_body(RT, integral_constant<int, 1>{});
+      else if constexpr (STG) narrow_body(RT, G0);
+      else by_act(narrow_body, G0);
+    }
   }
-#endif
+  DA2_TRACE_END();
+#undef DA2_TRACE_END
 #undef DA2_LDS
 #undef DA2_WAIT_PAIRS
 #undef DA2_SG_DS
@@ -736,7 +870,9 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
       if (ns == 2) return launch<1, 4, 2, 4, 5, 2, CONV>(p, s);
       break;
     case DA_TILE_K1_256x256:                                  // 2 x 4 waves of 128 x 64
-      if (ns == 2) return launch<1, 2, 4, 8, 4, 2, CONV>(p, s);
+      if constexpr (!CONV) {                                  // (the conv build of this tile needs 19 registers it does not have)
+        if (ns == 2) return launch<1, 2, 4, 8, 4, 2, false>(p, s);
+      }
       break;
   }
   return DA_ERR_UNSUPPORTED;

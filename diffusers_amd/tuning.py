@@ -39,6 +39,7 @@ LIVE_COUNT = 0     # problems tuned live in this process (bench.py reports it: a
 _loaded = False
 _dirty = False
 _scratch = {}
+_session_tuned = set()   # unpaired problems timed by THIS process
 
 
 def _m_key(m: int) -> int:
@@ -123,6 +124,8 @@ def tune(p: "L.GemmParams", stream: int, pair: Optional["L.GemmParams"] = None) 
         p.tile = keep_tile
     L.check(rc, "da_gemm_tune")
     ent = (bt.value, bs.value, us.value, bk.value)
+    if pair is None:
+        _session_tuned.add(key_of(p))
     table()[pair_key(p, pair) if pair is not None else key_of(p)] = ent
     _dirty = True
     return ent
@@ -158,6 +161,11 @@ def lookup_pair(pa: "L.GemmParams", pb: "L.GemmParams", stream: int) -> Optional
         if not (LIVE and not torch.cuda.is_current_stream_capturing()):
             return None
         ent = tune(pa, stream, pair=pb)
+        # the caller compares the pair with the two separate launches: measure those in the SAME session (an entry from an
+        # older table was timed on older kernels)
+        for q in (pa, pb):
+            if key_of(q) not in _session_tuned:
+                tune(q, stream)
     return ent[0], ent[1], ent[2]
 
 

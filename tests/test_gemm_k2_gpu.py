@@ -31,7 +31,7 @@ def rnd(shape, seed, scale=1.0, dtype=bf16):
 def k2_variants(L, conv=False, geglu=False):
     out = []
     for t in range(L.FIRST_K2_TILE, len(L.TILE_NAMES)):
-        if conv and t == L.TILE_K2_80x128:
+        if conv and t in (L.TILE_K2_80x128, L.TILE_K1_256x256):
             continue
         if geglu and t not in (L.TILE_K2_128x128, L.TILE_K1_256x128, L.TILE_K1_128x256, L.TILE_K1_256x256):
             continue

@@ -1,16 +1,12 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-T=tools/_trace_gemm2
-{
-$T 2048 1280 1280 10 2 1
-$T 2048 1280 64 10 2 1
-$T 2048 1280 5120 10 2 1
-$T 2048 1280 1280 10 7 1
-$T 8192 640 640 10 2 1
-$T 2048 10240 1280 16 2 0
-$T 2048 10240 1280 9 6 0
-$T 2048 2560 1280 11 6 0
-} > $O/trace_gemm2.md 2>&1
-cat $O/trace_gemm2.md | head -150
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_models_gpu.py -m gpu -q -x --timeout 600 -k "postprocess or thin_out or sdxl_pipeline or tiny_sdxl or flux_pipeline" 2>&1 | tail -5
-bash tools/gpu_r3.sh "benchfast traffic"
+timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline > $O/bench_A.json 2> $O/bench_A.err; echo "bench A (shipped table) rc=$?"; cut -c1-160 $O/bench_A.json
+bash tools/gpu_r3.sh "retune benchfast"
+cp $O/bench.json $O/bench_B.json
+python - <<'PY'
+import json
+for n in ("A","B"):
+    d=json.load(open(f"gpurun_out/bench_{n}.json"))
+    k={x["name"]:x for x in d["roofline"]["kernels"]}
+    print(n, d["value"], "igemm ms", round(k["igemm"]["ms"],2), "frac", round(k["igemm"]["frac"],4), "attn ms", round(k["attention"]["ms"],2), "vae ms", round(k["vae_decode"]["ms"],2), "tuned_live", d["config"].get("tuned_live"))
+PY

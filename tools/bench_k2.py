@@ -23,7 +23,7 @@ def variants(geglu=False, conv=False):
     for t in range(L.FIRST_K2_TILE, len(L.TILE_NAMES)):
         if geglu and t not in (L.TILE_K2_128x128, L.TILE_K1_256x128, L.TILE_K1_128x256, L.TILE_K1_256x256):
             continue
-        if conv and t == L.TILE_K2_80x128:
+        if conv and t in (L.TILE_K2_80x128, L.TILE_K1_256x256):
             continue
         for st in (L.STAGE_LDS_DIRECT, L.STAGE_LDS_DIRECT3, L.STAGE_PINGPONG, L.STAGE_PINGPONG3):
             yield t, st
