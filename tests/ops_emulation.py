@@ -237,12 +237,13 @@ def timestep_embedding(t, dim, *, batch, flip_sin_to_cos, shift, scale=1.0, max_
     return emb if out_f32 else emb.to(bf16)
 
 
-def conv_thin_out(x, w, bias, *, out_f32=False):
+def conv_thin_out(x, w, bias, *, out_f32=False, postprocess=None):
     B, H, W_, C = x.shape
     co = w.shape[0]
     y = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, C).permute(0, 3, 1, 2),
                  None if bias is None else bias.float(), padding=1)
-    return y.contiguous() if out_f32 else y.to(bf16).contiguous()
+    y = y.contiguous() if out_f32 else y.to(bf16).contiguous()
+    return y if postprocess is None else image_postprocess(y, postprocess)
 
 
 def bcast_add_f32(a, m):

@@ -163,7 +163,7 @@ def test_shipped_tuning_table_covers_every_sdxl_shape():
     from diffusers_amd import _lib as L
     assert table["tiles"] == list(L.TILE_NAMES), "table written for another tile enumeration"
     for k, v in table["entries"].items():
-        assert 1 <= v[0] < len(L.TILE_NAMES) and 0 <= v[1] <= 5, (k, v)
+        assert 1 <= v[0] < len(L.TILE_NAMES) and 0 <= v[1] <= L.STAGE_PINGPONG3, (k, v)
 
 
 def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
