@@ -37,7 +37,7 @@ constexpr TileShape kTiles[] = {{0, 0, 0},      {128, 128, 4}, {64, 128, 4},  {1
                                 {256, 128, 8},  {128, 256, 8}, {256, 256, 8}, {128, 128, 8},
                                 // K2 family (gemm2_kernel.cuh)
                                 {128, 128, 8},  {128, 80, 8},  {128, 160, 8}, {80, 128, 8}, {128, 64, 8},
-                                {128, 320, 8},  {256, 128, 8}, {128, 256, 8}, {256, 160, 8}, {256, 256, 8}};
+                                {128, 320, 8},  {256, 128, 8}, {128, 256, 8}, {256, 160, 8}, {256, 256, 8}, {256, 320, 8}};
 static_assert(sizeof(kTiles) / sizeof(kTiles[0]) == DA_TILE_COUNT, "kTiles / DA_TILE_* mismatch");
 inline bool is_k2(int tile) { return tile >= DA_TILE_K2_128x128; }
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
@@ -102,9 +102,9 @@ bool tile_ok(const da_gemm_params& p, int tile) {
   if (is_k2(tile)) {
     const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
     const bool geglu_ok = tile == DA_TILE_K2_128x128 || tile == DA_TILE_K1_256x128 || tile == DA_TILE_K1_128x256 ||
-                          tile == DA_TILE_K1_256x256;
+                          tile == DA_TILE_K1_256x256 || tile == DA_TILE_K1_256x320 || (tile == DA_TILE_K1_128x320 && !p.conv);
     return !p.stats_out && !p.ln_stats && p.split_k <= 1 && (!geglu || geglu_ok) &&
-           !(p.conv && (tile == DA_TILE_K2_80x128 || tile == DA_TILE_K1_256x256));
+           !(p.conv && (tile == DA_TILE_K2_80x128 || tile == DA_TILE_K1_256x256 || tile == DA_TILE_K1_256x320));
   }
   // GEGLU pairs (value, gate) 32-column tiles inside one wave: the wave must own an even number of them
   if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) &&

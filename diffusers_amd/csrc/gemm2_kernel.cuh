@@ -120,7 +120,15 @@ __device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int
 //          late -- so the LDS-DMA issue of one group (what binds the in-phase loop: all eight waves queue their loads on the CU's
 //          one texture-address path right behind the rendezvous, profiles/r03d_pmc_sq_counters.md) always runs under the
 //          other group's MFMA-only half.
-template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false>
+// STREAMW (KG == 1, 2-slice ring) = "streaming W": a wave tile too large to hold both k-steps' fragments next to its accumulators
+//          (64 x 160: 160 accumulator registers) keeps the slice's X fragments and streams the W fragments through a short
+//          register queue, each feeding MT MFMAs; one rendezvous per slice, the next-but-one slice's LDS-DMA spread under
+//          the slice's MFMAs.  The 256 x 320 tile this enables covers M 2048 x N 10240 (SDXL's GEGLU projection) in exactly
+//          one round of 256 workgroups at 1 / 256 + 1 / 320 staged bytes per flop.
+// GIL (KG == 1, two wave columns) = GEGLU-interleaved column ownership: of each 64-column [32 value | 32 gate] group of the packed weight a
+//          wave owns the 16-column tiles {wn, wn + 2} (one value tile and ITS gate tile), so a wave tile whose width (160)
+//          is not a multiple of 64 can still finish GEGLU on its own accumulators.
+template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false>
 __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert((KG == 1 || KG == 2) && KG * WM * WN == 8, "eight waves: one or two K-groups");
@@ -128,6 +136,8 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   constexpr int PX = BM / 8, PW = BN / 8;                 // 1 KiB pieces (8 rows x 128 B) per slice
   constexpr int XBYTES = BM * 128, SLICE = (BM + BN) * 128, PAIR = KG * SLICE;   // PAIR = the ring unit (KG slices)
   static_assert(!PP || KG == 2, "ping-pong is a property of the two K-groups");
+  static_assert(!STREAMW || (KG == 1 && NSLOT == 2 && !CONV), "streaming-W loop: one K-group, two-slice ring, nn.Linear");
+  static_assert(!GIL || (KG == 1 && !CONV && WN == 2 && (NT % 2) == 0), "GEGLU-interleaved ownership: two wave columns, value / gate tile pairs");
   constexpr int SW = PP ? 4 : 8;                          // waves that share the staging of one unit (PP: one slice, own group)
   constexpr int UX = PP ? PX : KG * PX, UW = PP ? PW : KG * PW;   // pieces of that unit
   constexpr int XI = (UX + SW - 1) / SW, WI = (UW + SW - 1) / SW;   // LDS-DMA instructions per wave per unit (upper bound)
@@ -299,8 +309,8 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   // num_records, the range check writes zeros to LDS without touching memory), so an odd slice count makes group 1 multiply
   // zeros once, every rendezvous issues the same number of loads (one vmcnt immediate) and the loop body has no branch.
   // Pieces only some waves own (ragged tiles) go first: their wave-uniform branch then sits in front of the straight-line part.
-  auto stage_issue = [&](int slot) {
-    unsigned char* base = smem + slot * PAIR;
+  auto stage_issue_base = [&](unsigned char* base, auto which_c) {
+    constexpr int WHICH = decltype(which_c)::value;      // -1: every piece of the unit; k >= 0: the k-th piece only (streaming-W loop)
     auto issue_x = [&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const int h = x_h[i];
@@ -326,9 +336,16 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       unsigned char* dst = w_ok[i] ? base + own_half + h * SLICE + XBYTES + w_r[i] * 1024 : smem + NSLOT * PAIR;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DA2_LDS(dst), 16, vo_w[i] | z, (h ? st_s[1] : st_s[0]) * 128, 0, 0);
     };
-    static_for<XI>(issue_x);
-    static_for<WI>(issue_w);
+    if constexpr (WHICH >= 0) {                           // weights (the HBM-cold operand) first
+      if constexpr (WHICH < WI) issue_w(std::integral_constant<int, WHICH < WI ? WHICH : 0>{});
+      else issue_x(std::integral_constant<int, WHICH >= WI ? WHICH - WI : 0>{});
+    } else {
+      static_for<XI>(issue_x);
+      static_for<WI>(issue_w);
+    }
   };
+  auto stage_issue = [&](int slot) { stage_issue_base(smem + slot * PAIR, std::integral_constant<int, -1>{}); };
+  auto stage_issue_one = [&](unsigned char* base, auto k_c) { stage_issue_base(base, k_c); };
   // Move the staging state to the following pair (scalar arithmetic; conv: a tap change recomputes that parity's offsets).
   auto stage_advance = [&]() {
     ++st_pr;
@@ -359,7 +376,9 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   constexpr int MH = (KG == 2 && SPLIT_M) ? MT / 2 : MT, NH = (KG == 1 || SPLIT_M) ? NT : NT / 2;
   const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
   auto row_of = [&](int ih) { return m0 + (wm * MT + (SPLIT_M ? g * MH : 0) + ih) * 16 + r16; };
-  auto col_of = [&](int jh) { return n0 + (wn * NT + (SPLIT_M ? 0 : g * NH) + jh) * 16 + 4 * kq; };
+  // 16-column tile `jh` of this wave inside the block tile (GIL: tiles {wn, wn + 2} of every group of four)
+  auto col_tile = [&](int jh) { return GIL ? 4 * (jh >> 1) + 2 * (jh & 1) + wn : wn * NT + (SPLIT_M ? 0 : g * NH) + jh; };
+  auto col_of = [&](int jh) { return n0 + col_tile(jh) * 16 + 4 * kq; };
   // (Only while the registers last: a wave that finishes more than 12 tiles -- the KG == 1 shapes -- fetches the residual and
   // the channel vector in the epilogue instead; its launches are long enough for that round trip not to matter.)
   constexpr bool PF = MH * NH <= (CONV ? 8 : 12);         // (conv carries its pixel cursors: fewer registers to spare)
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   constexpr bool STG = NH >= 2;
   constexpr int PPR = 2 * NH, NPIECE = 16 * PPR, TT = (NPIECE + 63) / 64, ROWB = NH * 64 + 16;
   static_assert(!STG || (KG == 2 ? 4 * MT * NT * 1024 : 0) + 8 * 16 * ROWB <= NSLOT * PAIR, "output staging does not fit the ring");
-  const bool wide = STG && !geglu && !p.out_f32 && !(p.ldc & 7) && !((size_t)p.C & 15) && !(p.N & 7) &&
+  const bool wide = STG && !GIL && !geglu && !p.out_f32 && !(p.ldc & 7) && !((size_t)p.C & 15) && !(p.N & 7) &&
                     (!p.residual || (!(p.ldr & 7) && !((size_t)p.residual & 15)));
   const int band_col0 = n0 + (wn * NT + (SPLIT_M ? 0 : g * NH)) * 16;
   auto band_row0 = [&](int ih) { return m0 + (wm * MT + (SPLIT_M ? g * MH : 0) + ih) * 16; };
@@ -422,7 +441,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
           }
       }
     }
-    if (bias) {
+    if (!STREAMW && bias) {
 #pragma unroll
       for (int jh = 0; jh < NH; ++jh) bias_v[jh] = *(const uint2*)(bias + min(col_of(jh), p.N - 4));
     }
@@ -446,13 +465,14 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   // fragment addresses: row r16 of a 16-row tile, 16-byte chunk (kq + 4 ks) ^ ((r16 >> 1) & 7); k-step 1 = chunk ^ 4
   const int fsw = (r16 >> 1) & 7;
   const int foff0 = r16 * 128 + ((kq ^ fsw) << 4), foff1 = r16 * 128 + (((kq ^ fsw) ^ 4) << 4);
-  const int xfrag = g * SLICE + (wm * MT) * 2048, wfrag = g * SLICE + XBYTES + (wn * NT) * 2048;
+  const int xfrag = g * SLICE + (wm * MT) * 2048, wfrag = g * SLICE + XBYTES + (GIL ? wn : wn * NT) * 2048;
+  auto wtile_off = [](int j) { return (GIL ? 4 * (j >> 1) + 2 * (j & 1) : j) * 2048; };   // LDS offset of the wave's j-th W tile
   bf16x8_t xf0[MT], wf0[NT], xf1[MT], wf1[NT];
 #define DA2_FRAG(XF, WF, SLOT, OFF)                                                                         \
   do {                                                                                                      \
     const unsigned char* xb_ = smem + (SLOT) * PAIR + xfrag + (OFF);                                        \
     const unsigned char* wb_ = smem + (SLOT) * PAIR + wfrag + (OFF);                                        \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j) WF[j] = *(const bf16x8_t*)(wb_ + j * 2048);              \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) WF[j] = *(const bf16x8_t*)(wb_ + wtile_off(j));          \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) XF[i] = *(const bf16x8_t*)(xb_ + i * 2048);              \
   } while (0)
 #define DA2_MFMA(XF, WF)                                                                                    \
@@ -467,17 +487,80 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
 
   // ---- prologue: pairs 0 .. NSLOT-1 in flight (zeros past the end of K), pair 0 landed, its k-step-0 fragments on their way ----
   DA2_TRACE(1);                                           // set-up done, first LDS-DMA about to issue
+  // (streaming-W loop: slice 0 only -- every iteration of that loop, the first included, sends the following slice)
 #pragma unroll
-  for (int s = 0; s < NSLOT; ++s) {
+  for (int s = 0; s < (STREAMW ? 1 : NSLOT); ++s) {
     stage_issue(s);
     stage_advance();
     if (s == 0) prefetch_epilogue_operands();
   }
   DA2_TRACE(2);                                           // ring issued
-  DA2_WAIT_PAIRS(NSLOT - 1);
+  DA2_WAIT_PAIRS(STREAMW ? 0 : NSLOT - 1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   DA2_TRACE(3);                                           // first pair landed for everybody
+  if constexpr (STREAMW) {
+    // ---- streaming-W loop: per slice 2 k-steps x NT W fragments, each read once and used by MT MFMAs ----
+    constexpr int QD = 2;                                 // W fragments in flight ahead of the MFMAs that use them
+    constexpr int NG = 2 * NT;                            // (k-step, W tile) groups per slice
+    static_assert(XI + WI <= NG, "one LDS-DMA per MFMA group at most");
+    const unsigned char* xbase_ = smem + xfrag, * wbase_ = smem + wfrag;
+    auto wfrag_at = [&](const unsigned char* wb, int gi) {   // group gi = ks * NT + j
+      return *(const bf16x8_t*)(wb + wtile_off(gi % NT) + (gi < NT ? foff0 : foff1));
+    };
+    // The two waves that share a SIMD (w and w + 4) run this body with their LDS-DMA issue in DIFFERENT thirds of the slice
+    // (DOFF): an LDS-DMA instruction holds its wave's issue slot for ~100 cycles, and with both waves of a SIMD stalled at the
+    // same time the matrix pipe idled for a third of every slice (4.06 k cycles per slice against 2.56 k of MFMA work).
+    auto slice_body = [&](auto doff_c, int slot) __attribute__((always_inline)) {
+      constexpr int DOFF = decltype(doff_c)::value;
+      static_assert(DOFF + XI + WI <= NG, "LDS-DMA window past the end of the slice");
+      const unsigned char* xb = xbase_ + slot * PAIR;
+      const unsigned char* wb = wbase_ + slot * PAIR;
+      bf16x8_t xs[2][MT], wq[QD + 1];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xs[0][i] = *(const bf16x8_t*)(xb + i * 2048 + foff0);
+#pragma unroll
+      for (int q = 0; q < QD; ++q) wq[q] = wfrag_at(wb, q);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xs[1][i] = *(const bf16x8_t*)(xb + i * 2048 + foff1);
+      // Source order IS the schedule: a sched_barrier after every group.  (Group pins only fix the instruction KINDS: the
+      // scheduler then filled each "one ds_read" slot with the read needed soonest and the queue depth collapsed to zero.)
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned char* nbase = smem + (slot ^ 1) * PAIR;    // slice sl + 1 (zeros past the end of K)
+      static_for<NG>([&](auto gc) {
+        constexpr int gi = decltype(gc)::value, ks = gi / NT, j = gi % NT;
+        if constexpr (gi + QD < NG) wq[(gi + QD) % (QD + 1)] = wfrag_at(wb, gi + QD);
+        if constexpr (gi >= DOFF && gi < DOFF + XI + WI) stage_issue_one(nbase, std::integral_constant<int, gi - DOFF>{});
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[gi % (QD + 1)], xs[ks][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    // One complete loop per wave group (the group is fixed for the life of the wave: one branch, not one per slice).
+    auto slice_loop = [&](auto doff_c) __attribute__((always_inline)) {
+      int slot = 0;
+      for (int sl = 0; sl < nk2; ++sl) {
+        // slice sl has landed and is visible (prologue / the rendezvous at the end of the previous iteration); the other ring
+        // slot is free: every wave has retired its reads of slice sl - 1.  Slice sl + 1 goes out now, one LDS-DMA per MFMA
+        // group inside this wave's window, weights (the HBM-cold operand) first.
+        slice_body(doff_c, slot);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_advance();
+        if (sl + 1 < nk2) {
+          // rendezvous: my reads of this slice retired, my share of slice sl + 1 landed (the only LDS-DMA in flight): past the
+          // barrier slice sl + 1 is visible and this slice's slot may be overwritten
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          DA2_WAIT_PAIRS(0);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        slot ^= 1;
+      }
+    };
+    if (wave < 4) slice_loop(std::integral_constant<int, 0>{});
+    else slice_loop(std::integral_constant<int, NG - (XI + WI) - 3>{});
+  } else {
   DA2_FRAG(xf0, wf0, 0, foff0);
 
   auto first_half_pins = [&]() {
@@ -543,6 +626,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       asm volatile("" ::: "memory");
     }
   }
+  }
 #undef DA2_FRAG
 #undef DA2_MFMA
 
@@ -590,6 +674,12 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       }
   }
 
+  if constexpr (STREAMW) {                                // (no registers to carry the bias through this loop: fetched here)
+    if (p.bias) {
+#pragma unroll
+      for (int jh = 0; jh < NH; ++jh) bias_v[jh] = *(const uint2*)((const uint16_t*)p.bias + min(col_of(jh), p.N - 4));
+    }
+  }
   DA2_TRACE(5);                                           // partial sums exchanged
   // ---- epilogue: lane holds, for output row (r16 of a 16-row tile), channels 4 kq .. 4 kq + 3 of a 16-column tile ----
   const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
@@ -608,8 +698,58 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
 #define DA2_TRACE_END() ((void)0)
 #endif
   if (geglu) {
+    if constexpr (GIL) {
+      // wave tiles (2u, 2u + 1) = block tiles (4u + wn, 4u + wn + 2) = a value tile and its gate tile.  The finished bf16 values
+      // of the whole block tile (BM x BN / 2) meet in LDS and leave as whole rows, 16 bytes per lane.
+      constexpr int OROW = BN + 16;                       // bytes per staged output row (BN / 2 bf16 + pad)
+      static_assert(BM * OROW <= NSLOT * PAIR, "output tile does not fit the ring");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // every wave is out of the ring
+      asm volatile("" ::: "memory");
+      auto body = [&](auto tanh_c) __attribute__((always_inline)) {
+        constexpr bool TANH = decltype(tanh_c)::value;
+#pragma unroll
+        for (int ih = 0; ih < MH; ++ih) {
+          unsigned char* orow = smem + ((wm * MT + ih) * 16 + r16) * OROW + (wn * 16 + 4 * kq) * 2;
+#pragma unroll
+          for (int u = 0; u < NT / 2; ++u) {
+            const uint2 bh = bias_v[2 * u], bg = bias_v[2 * u + 1];      // zeros without a bias
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float hv = keep[ih][2 * u][e] * p.alpha, gv = keep[ih][2 * u + 1][e] * p.alpha;
+              hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
+              gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
+              hv = bf2f(f2bf(hv));   // the reference rounds the projection to bf16 before chunk / gelu / mul
+              gv = bf2f(f2bf(gv));
+              o[e] = hv * bf2f(f2bf(TANH ? gelu_tanh_f(gv) : gelu_erf_f(gv)));
+            }
+            uint2 pk;
+            pk.x = pack_bf2(o[0], o[1]);
+            pk.y = pack_bf2(o[2], o[3]);
+            *(uint2*)(orow + u * 64) = pk;
+          }
+        }
+      };
+      if (p.act == DA_ACT_GEGLU) body(std::false_type{});
+      else body(std::true_type{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      constexpr int OPR = BN / 16, NOP = BM * OPR;        // 16-byte pieces per output row / per tile
+      const int no0 = n0 >> 1, Nout = p.N >> 1;
+#pragma unroll
+      for (int k = 0; k < (NOP + 511) / 512; ++k) {
+        const int q = t + 512 * k;
+        if (NOP % 512 != 0 && q >= NOP) continue;
+        const int row = q / OPR, c = q % OPR;
+        if (m0 + row >= p.M || no0 + c * 8 >= Nout) continue;
+        *(uint4*)((uint16_t*)p.C + (size_t)(m0 + row) * p.ldc + no0 + c * 8) = *(const uint4*)(smem + row * OROW + c * 16);
+      }
+      return;
+    }
     // packed weight rows: per 64 = [32 value | 32 gate]  ->  16-column tiles (4u, 4u+1) = value, (4u+2, 4u+3) = gate
-    if constexpr (SPLIT_M && (NT % 4) == 0) {
+    if constexpr (!GIL && SPLIT_M && (NT % 4) == 0) {
       auto body = [&](auto tanh_c) __attribute__((always_inline)) {
         constexpr bool TANH = decltype(tanh_c)::value;
 #pragma unroll
@@ -794,7 +934,7 @@ inline bool staging_fits(const da_gemm_params& p) {
   return span * cmax * 2 < lim && (size_t)p.M / ((size_t)p.Hout * p.Wout) * p.Hin * p.Win < 0x7fffffffull;
 }
 
-template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false>
+template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false>
 int launch(const da_gemm_params& p, hipStream_t s) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -802,7 +942,7 @@ int launch(const da_gemm_params& p, hipStream_t s) {
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
   constexpr int SW = PP ? 4 : 8, UX = (PP ? 1 : KG) * BM / 8, UW = (PP ? 1 : KG) * BN / 8;   // as in the kernel
   constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + (((UX % SW) || (UW % SW)) ? 1024 : 0);
-  auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP>;
+  auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP, STREAMW, GIL>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -821,7 +961,8 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
   if (p.split_k > 1 || p.stats_out || p.ln_stats || !staging_fits(p)) return DA_ERR_UNSUPPORTED;
   const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
   // GEGLU: the value / gate column tiles of a 64-row group must share a wave (wave tiles whose width is a multiple of 64)
-  if (geglu && tile != DA_TILE_K2_128x128 && tile != DA_TILE_K1_256x128 && tile != DA_TILE_K1_128x256 && tile != DA_TILE_K1_256x256)
+  if (geglu && tile != DA_TILE_K2_128x128 && tile != DA_TILE_K1_256x128 && tile != DA_TILE_K1_128x256 && tile != DA_TILE_K1_256x256 &&
+      tile != DA_TILE_K1_256x320 && tile != DA_TILE_K1_128x320)
     return DA_ERR_UNSUPPORTED;
   const int ns = (staging == DA_STAGE_LDS_DIRECT || staging == DA_STAGE_PINGPONG) ? 2
                  : (staging == DA_STAGE_LDS_DIRECT3 || staging == DA_STAGE_PINGPONG3) ? 3 : 0;
@@ -860,7 +1001,14 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
       return ns == 2 ? launch<2, 2, 2, 4, 2, 2, CONV>(p, s) : launch<2, 2, 2, 4, 2, 3, CONV>(p, s);
     // KG == 1: eight waves on every slice, large tiles
     case DA_TILE_K1_128x320:                                  // 4 x 2 waves of 32 x 160
-      if (ns == 2) return launch<1, 4, 2, 2, 10, 2, CONV>(p, s);
+      if (ns != 2) break;
+      if (!geglu) return launch<1, 4, 2, 2, 10, 2, CONV>(p, s);
+      // GEGLU: interleaved column ownership (a 160-column wave tile is not a whole number of [32 | 32] groups), whole output
+      // rows from LDS (16-byte aligned output rows).  M 2048 x N 10240 = 512 tiles: two exact rounds of 256 workgroups.
+      if constexpr (!CONV) {
+        if ((p.ldc & 7) || ((size_t)p.C & 15) || (p.N & 15)) break;
+        return launch<1, 4, 2, 2, 10, 2, false, false, false, true>(p, s);
+      }
       break;
     case DA_TILE_K1_256x128:                                  // 4 x 2 waves of 64 x 64
       return ns == 2 ? launch<1, 4, 2, 4, 4, 2, CONV>(p, s) : launch<1, 4, 2, 4, 4, 3, CONV>(p, s);
@@ -868,6 +1016,15 @@ int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
       return ns == 2 ? launch<1, 2, 4, 4, 4, 2, CONV>(p, s) : launch<1, 2, 4, 4, 4, 3, CONV>(p, s);
     case DA_TILE_K1_256x160:                                  // 4 x 2 waves of 64 x 80
       if (ns == 2) return launch<1, 4, 2, 4, 5, 2, CONV>(p, s);
+      break;
+    case DA_TILE_K1_256x320:                                  // 4 x 2 waves of 64 x 160, streaming-W loop (nn.Linear only)
+      if constexpr (!CONV) {
+        if (ns != 2) break;
+        if (!geglu) return launch<1, 4, 2, 4, 10, 2, false, false, true, false>(p, s);
+        // GEGLU: interleaved column ownership, whole output rows from LDS (16-byte aligned output rows)
+        if ((p.ldc & 7) || ((size_t)p.C & 15) || (p.N & 15)) break;
+        return launch<1, 4, 2, 4, 10, 2, false, false, true, true>(p, s);
+      }
       break;
     case DA_TILE_K1_256x256:                                  // 2 x 4 waves of 128 x 64
       if constexpr (!CONV) {                                  // (the conv build of this tile needs 19 registers it does not have)

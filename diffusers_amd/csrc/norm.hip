@@ -180,6 +180,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
   const int nchunks = C >> 3;
   float v[NCH][8];
   const uint16_t* xr = x + (size_t)row * ldx;
+  // the affine parameters are fetched WITH the row (they do not depend on it): their round trip runs under the two wave
+  // reductions instead of behind them -- the kernel is latency-bound (10 MB through a 6 us launch)
+  uint4 gq[NCH], bq[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = min(lane + 64 * i, nchunks - 1);
+    gq[i] = gamma ? *(const uint4*)(gamma + ch * 8) : make_uint4(0, 0, 0, 0);
+    bq[i] = beta ? *(const uint4*)(beta + ch * 8) : make_uint4(0, 0, 0, 0);
+  }
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -220,13 +229,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
       for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd;
       if (gamma) {
         float g[8];
-        unpack8(*(const uint4*)(gamma + ch * 8), g);
+        unpack8(gq[i], g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] *= g[e];
       }
       if (beta) {
         float bb[8];
-        unpack8(*(const uint4*)(beta + ch * 8), bb);
+        unpack8(bq[i], bb);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += bb[e];
       }

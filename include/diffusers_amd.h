@@ -66,7 +66,8 @@ extern "C" {
 #define DA_TILE_K1_128x256 16 /* 2 x 4 waves of 64 x 64; 2 or 3 ring slots */
 #define DA_TILE_K1_256x160 17 /* 4 x 2 waves of 64 x 80 */
 #define DA_TILE_K1_256x256 18 /* 2 x 4 waves of 128 x 64 */
-#define DA_TILE_COUNT 19
+#define DA_TILE_K1_256x320 19 /* 4 x 2 waves of 64 x 160, W fragments streamed (nn.Linear; GEGLU with interleaved tile ownership) */
+#define DA_TILE_COUNT 20
 /* da_gemm_tune only: which variants compete, given in da_gemm_params.tile (DA_TILE_AUTO = all of them).  Within one family
  * every variant is bit-identical to every other; the two families differ in the fp32 summation order. */
 #define DA_TILE_FAMILY_1 (-1)

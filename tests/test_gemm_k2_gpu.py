@@ -31,9 +31,9 @@ def rnd(shape, seed, scale=1.0, dtype=bf16):
 def k2_variants(L, conv=False, geglu=False):
     out = []
     for t in range(L.FIRST_K2_TILE, len(L.TILE_NAMES)):
-        if conv and t in (L.TILE_K2_80x128, L.TILE_K1_256x256):
+        if conv and t in (L.TILE_K2_80x128, L.TILE_K1_256x256, L.TILE_K1_256x320):
             continue
-        if geglu and t not in (L.TILE_K2_128x128, L.TILE_K1_256x128, L.TILE_K1_128x256, L.TILE_K1_256x256):
+        if geglu and t not in (L.TILE_K2_128x128, L.TILE_K1_256x128, L.TILE_K1_128x256, L.TILE_K1_256x256, L.TILE_K1_256x320, L.TILE_K1_128x320):
             continue
         for st in (L.STAGE_LDS_DIRECT, L.STAGE_LDS_DIRECT3, L.STAGE_PINGPONG, L.STAGE_PINGPONG3):
             out.append((t, st))
