@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   // 8-byte-per-lane epilogue cost 650-820 cycles per 16 x 16 tile, 13-27 % of a launch).  Piece q = lane + 64 t of a band:
   // row q / PPR, 16-byte (8-channel) slot q % PPR.  Needs 16-byte aligned rows; anything else keeps the 8-byte path.
   constexpr bool STG = NH >= 2;
-  constexpr int PPR = 2 * NH, NPIECE = 16 * PPR, TT = (NPIECE + 63) / 64, ROWB = NH * 64 + 16;
+  constexpr int PPR = 2 * NH, NPIECE = 16 * PPR, TT = (NPIECE + 63) / 64, ROWB = NH * 64 + 32;   // (ROWB / 2: the packed rows)
   static_assert(!STG || (KG == 2 ? 4 * MT * NT * 1024 : 0) + 8 * 16 * ROWB <= NSLOT * PAIR, "output staging does not fit the ring");
   const bool wide = STG && !GIL && !geglu && !p.out_f32 && !(p.ldc & 7) && !((size_t)p.C & 15) && !(p.N & 7) &&
                     (!p.residual || (!(p.ldr & 7) && !((size_t)p.residual & 15)));
@@ -788,8 +788,11 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
     return;
   }
   // Everything else: one straight-line instantiation per (activation, gate kind), chosen ONCE per launch.
-  auto wide_body = [&](auto act_c, auto gate_c) __attribute__((always_inline)) {
+  // PACKED = nothing happens behind the activation (no residual, out_scale == 1): the band goes through LDS already rounded to
+  // bf16 and the way back is one 16-byte read + one 16-byte store per lane.
+  auto wide_body = [&](auto act_c, auto gate_c, auto packed_c) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_c)::value, GATE = decltype(gate_c)::value;
+    constexpr bool PACKED = decltype(packed_c)::value;
     if constexpr (STG) {
       if constexpr (KG == 1) {                          // (KG == 2: the exchange barriers already emptied the ring of readers)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -815,7 +818,14 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
           if constexpr (PF) rvv = rowvec_v[ih][jh];
           else if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
           epilogue4<ACT, GATE, false>(p, o, n, bidx, brow, bias_v[jh], rvv, make_uint2(0, 0));
-          *(float4*)(stg_w + jh * 64) = make_float4(o[0], o[1], o[2], o[3]);
+          if constexpr (PACKED) {
+            uint2 pk;
+            pk.x = pack_bf2(o[0], o[1]);
+            pk.y = pack_bf2(o[2], o[3]);
+            *(uint2*)(stg + r16 * (ROWB / 2) + kq * 8 + jh * 32) = pk;
+          } else {
+            *(float4*)(stg_w + jh * 64) = make_float4(o[0], o[1], o[2], o[3]);
+          }
         }
         // ... and back, 8 consecutive channels of one row per lane: + residual, * out_scale, one 16-byte store
 #pragma unroll
@@ -823,9 +833,14 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
           const int q = lane + 64 * t;
           if (NPIECE % 64 != 0 && q >= NPIECE) continue;
           const int row = q / PPR, c8 = q % PPR;
+          const int mo = band_row0(ih) + row, no = band_col0 + c8 * 8;
+          if constexpr (PACKED) {
+            const uint4 pk = *(const uint4*)(stg + row * (ROWB / 2) + c8 * 16);
+            if (mo < p.M && no < p.N) *(uint4*)((uint16_t*)p.C + (size_t)mo * p.ldc + no) = pk;
+            continue;
+          }
           const float4 lo = *(const float4*)(stg + row * ROWB + c8 * 32), hi = *(const float4*)(stg + row * ROWB + c8 * 32 + 16);
           float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          const int mo = band_row0(ih) + row, no = band_col0 + c8 * 8;
           if (mo >= p.M || no >= p.N) continue;
           uint4 rw = make_uint4(0, 0, 0, 0);
           if constexpr (PF) rw = resw[ih][t];
@@ -875,21 +890,23 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   };
   {
     using std::integral_constant;
-    auto by_act = [&](auto&& f, auto gate_c) __attribute__((always_inline)) {
-      if (p.act == DA_ACT_NONE) f(integral_constant<int, DA_ACT_NONE>{}, gate_c);
-      else if (p.act == DA_ACT_GELU_TANH) f(integral_constant<int, DA_ACT_GELU_TANH>{}, gate_c);
-      else if (p.act == DA_ACT_SILU) f(integral_constant<int, DA_ACT_SILU>{}, gate_c);
-      else if (p.act == DA_ACT_GELU_ERF) f(integral_constant<int, DA_ACT_GELU_ERF>{}, gate_c);
-      else f(integral_constant<int, DA_ACT_QUICK_GELU>{}, gate_c);
+    auto by_act = [&](auto&& f, auto... tail) __attribute__((always_inline)) {
+      if (p.act == DA_ACT_NONE) f(integral_constant<int, DA_ACT_NONE>{}, tail...);
+      else if (p.act == DA_ACT_GELU_TANH) f(integral_constant<int, DA_ACT_GELU_TANH>{}, tail...);
+      else if (p.act == DA_ACT_SILU) f(integral_constant<int, DA_ACT_SILU>{}, tail...);
+      else if (p.act == DA_ACT_GELU_ERF) f(integral_constant<int, DA_ACT_GELU_ERF>{}, tail...);
+      else f(integral_constant<int, DA_ACT_QUICK_GELU>{}, tail...);
     };
     // gated launches (adaLN gates of the DiT blocks: activation NONE in practice) keep the run-time activation switch; where
     // the row-contiguous path exists the 8-byte path is only the unaligned-rows fallback and gets ONE run-time-switched copy
     constexpr integral_constant<int, -1> RT{};
     constexpr integral_constant<int, 0> G0{};
     if (STG && wide) {
-      if (p.gate && p.gate_f32) wide_body(RT, integral_constant<int, 2>{});
-      else if (p.gate) wide_body(RT, integral_constant<int, 1>{});
-      else by_act(wide_body, G0);
+      const bool packed = !has_res && p.out_scale == 1.0f;
+      if (p.gate && p.gate_f32) wide_body(RT, integral_constant<int, 2>{}, std::false_type{});
+      else if (p.gate) wide_body(RT, integral_constant<int, 1>{}, std::false_type{});
+      else if (packed) by_act(wide_body, G0, std::true_type{});
+      else by_act(wide_body, G0, std::false_type{});
     } else {
       if (p.gate && p.gate_f32) narrow_body(RT, integral_constant<int, 2>{});
       else if (p.gate) narrow_body(RT, integral_constant<int, 1>{});

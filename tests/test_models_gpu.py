@@ -43,19 +43,22 @@ def test_tiny_unet_vs_reference(golden, name, added, fold, monkeypatch):
 
 
 def test_unet_staging_paths_agree(golden):
-    """LDS-direct and register staging run the same MFMA sequence: outputs must be bit-identical."""
+    """LDS-direct and register staging of the first kernel family (csrc/gemm_kernel.cuh) run the same MFMA sequence: outputs
+    must be bit-identical.  Per-shape tuning is off for the comparison: the tuner may give a shape to the K2 / K1 family, whose
+    fp32 summation order differs in the last bit (tests/test_gemm_k2_gpu.py bounds that difference)."""
     from diffusers_amd import _lib as L, factory, init as dinit, ops
     g = golden("tiny_unet_sdxl")
     unet, _ = factory.build_unet(dinit.TINY_SDXL_UNET, seed=0, device=DEV)
     kw = {"added_cond_kwargs": {"text_embeds": t(g, "text_embeds"), "time_ids": t(g, "time_ids", torch.float32)}}
     outs = []
-    old = ops.DEFAULT_STAGING
+    old, old_tuning = ops.DEFAULT_STAGING, ops.TUNING
     try:
+        ops.TUNING = False
         for st in (L.STAGE_REGISTER, L.STAGE_LDS_DIRECT):
             ops.DEFAULT_STAGING = st
             outs.append(unet(t(g, "sample"), torch.tensor(801.0), t(g, "ehs"), **kw).sample)
     finally:
-        ops.DEFAULT_STAGING = old
+        ops.DEFAULT_STAGING, ops.TUNING = old, old_tuning
     assert torch.equal(outs[0], outs[1])
 
 
