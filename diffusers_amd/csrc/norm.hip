@@ -60,11 +60,18 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* 
   if (t < G) {
     const int cpg = C / G;
     float ts = 0.f, tq = 0.f;
+    // eight LDS reads in flight, added in index order (the sequential sum, bit for bit; a slot past the group adds + 0.0f)
     for (int r = 0; r < krows; ++r) {
-      const float* row = sm + ((size_t)r * C + t * cpg) * 2;
-      for (int c = 0; c < cpg; ++c) {
-        ts += row[2 * c];
-        tq += row[2 * c + 1];
+      const float2* row = (const float2*)(sm + ((size_t)r * C + t * cpg) * 2);
+      for (int c0 = 0; c0 < cpg; c0 += 8) {
+        float2 pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = (c0 + u < cpg) ? row[c0 + u] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          ts += pv[u].x;
+          tq += pv[u].y;
+        }
       }
     }
     float* o = ws + (((size_t)b * gridDim.x + blk) * G + t) * 2;
@@ -94,10 +101,20 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
     const int g = t % G, sl = t / G;
     double ts = 0.0, tq = 0.0;
     const float* w = ws + ((size_t)b * nblk_stats * G + g) * 2;
-    for (int i = sl; i < nblk_stats; i += SL) {
-      const float2 pq = *(const float2*)(w + (size_t)i * G * 2);
-      ts += (double)pq.x;
-      tq += (double)pq.y;
+    // 16 partials in flight per thread, added in index order (the sequential sum, bit for bit): with one load per iteration
+    // the fold was a chain of 26-49 dependent L2 round trips in front of every block's first pixel
+    for (int i = sl; i < nblk_stats; i += 16 * SL) {
+      float2 pq[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int idx = i + u * SL;                       // past the end: + 0.0, which changes nothing
+        pq[u] = (idx < nblk_stats) ? *(const float2*)(w + (size_t)idx * G * 2) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        ts += (double)pq[u].x;
+        tq += (double)pq[u].y;
+      }
     }
     s_part[sl][g][0] = ts;
     s_part[sl][g][1] = tq;
