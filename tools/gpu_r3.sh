@@ -87,3 +87,28 @@ if [[ $WHAT == *traffic* ]]; then
   find $O/pmc_traffic -name '*counter_collection.csv' -size +8M -delete
   tail -4 $O/pmc_traffic/fetch.log | cut -c1-200
 fi
+if [[ $WHAT == *reothers* ]]; then
+  # re-measure the variant choice of every shape of the other BASELINE configs with the current kernels (empty table), merge
+  # the results over the shipped table, then run each config's driver-contract line on the merged table
+  python - <<PYEOF
+import json, shutil
+shutil.copy("$R/diffusers_amd/tuned/gfx950.json", "$O/tuned_all.json")
+PYEOF
+  for cfg in sd15 flux ddpm wan; do
+    rm -f $O/tuned_$cfg.json
+    DIFFUSERS_AMD_TUNE_DB=$O/none.json DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_$cfg.json timeout 1500 python bench.py --config $cfg --steps 1 --warmup 1 > $O/retune_$cfg.json 2> $O/retune_$cfg.err; echo "retune $cfg rc=$?"
+    python - <<PYEOF
+import json
+a = json.load(open("$O/tuned_all.json"))
+b = json.load(open("$O/tuned_$cfg.json"))
+a["entries"].update(b["entries"]); a["format"], a["tiles"] = b["format"], b["tiles"]
+json.dump(a, open("$O/tuned_all.json", "w"), indent=0)
+print("$cfg:", len(b["entries"]), "shapes tuned; table now", len(a["entries"]))
+PYEOF
+  done
+  for cfg in sd15 flux ddpm wan; do
+    ST=2; [[ $cfg == wan ]] && ST=1
+    DIFFUSERS_AMD_TUNE_DB=$O/tuned_all.json timeout 1200 python bench.py --config $cfg --steps $ST --warmup 1 > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "$cfg rc=$?"
+    cut -c1-330 $O/bench_$cfg.json
+  done
+fi
