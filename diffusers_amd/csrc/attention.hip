@@ -59,9 +59,14 @@ __device__ __forceinline__ int k_swz(int row) {
 // under tile j's softmax arithmetic instead of behind it (one more P fragment set and one more ring slot -- tile j - 1's V^T
 // stays resident while tile j + 1 lands).  Same operations on the same values in the same order per accumulator:
 // bit-identical to the unpipelined kernel.
-template <int D, int NS, bool MASKED = false, int NW = 4, bool PIPE = false>
+// PIPE == 2 (unmasked, NS = 4): additionally the Q.K^T product of tile j + 1 is issued inside tile j's softmax slices, next to
+// tile j - 1's P.V: per slice one (D = 128: two) MFMA of each, so NEITHER matrix product has a phase of its own and the
+// iteration is as long as its VALU work (one more score-tile register set, one more ring slot: tile j - 1's V^T, tile j's V^T
+// and tile j + 1's K resident while tile j + 2 lands).  Same operations on the same values in the same order per accumulator.
+template <int D, int NS, bool MASKED = false, int NW = 4, int PIPE = 0>
 __global__ __launch_bounds__(64 * NW, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const da_attention_params p) {
-  static_assert(!PIPE || (NS == 3 && !MASKED), "the pipelined loop is the unmasked 3-slot variant");
+  static_assert(PIPE != 1 || (NS == 3 && !MASKED), "the pipelined loop is the unmasked 3-slot variant");
+  static_assert(PIPE != 2 || (NS == 4 && !MASKED && NW == 4), "the doubly pipelined loop is the unmasked 4-slot variant");
   using C = AttnCfg<D, NW>;
   constexpr int QT = 32 * NW;                // queries per block
   constexpr int PD = NS - 1;                 // prefetch distance (tiles in flight ahead of the one being consumed)
@@ -157,7 +162,166 @@ __global__ __launch_bounds__(64 * NW, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(co
   const int ksw = k_swz<D>(l31);           // K fragment swizzle of this lane's row
   const int vsw = (l31 >> 1) & 7;          // V^T 16-byte chunk swizzle of this lane's row ((32*dt + l31) >> 1) & 7
 
-  if constexpr (PIPE) {
+  if constexpr (PIPE == 2) {
+    bf16x8_t pf[4];            // P^T fragments of the previous tile, consumed one iteration late
+    auto vfrag = [&](const unsigned char* vb, int k) {           // V^T fragment of P.V MFMA k = u * DT + dt
+      constexpr int DT = D / 32;
+      const int u = k / DT, dt = k % DT;
+      const unsigned char* vrow = vb + (32 * dt + l31) * 128;
+      const uint2 a0 = *(const uint2*)(vrow + (((2 * u) ^ vsw) << 4) + 8 * hi);
+      const uint2 a1 = *(const uint2*)(vrow + (((2 * u + 1) ^ vsw) << 4) + 8 * hi);
+      return __builtin_bit_cast(bf16x8_t, make_uint4(a0.x, a0.y, a1.x, a1.y));
+    };
+    auto kfrag = [&](const unsigned char* kb, int k) {           // K fragment of Q.K^T MFMA k = 2 * ks + st
+      const int ks = k >> 1, st = k & 1;
+      return *(const bf16x8_t*)(kb + (32 * st + l31) * (2 * D) + (((2 * ks + hi) ^ ksw) << 4));
+    };
+    constexpr int DT = D / 32, NPV = 4 * DT, NQK = 2 * (D / 16), PERV = NPV / 8, PERK = NQK / 8;
+    static_assert(NPV % 8 == 0 && NQK % 8 == 0, "eight softmax slices per tile");
+    issue(0, 0);
+    if (ntiles > 1) {
+      issue(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x16_t s[2], sn[2];    // scores of the tile in its softmax / partial scores of the next tile
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NQK; ++k) s[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(smem, k), qf[k >> 1], s[k & 1], 0, 0, 0);
+    // One iteration = softmax of tile j over the score registers `s` (complete since the previous iteration), with tile j - 1's
+    // P.V (HAS_PREV) and tile j + 1's Q.K^T into `sn` (HAS_NEXT) riding in its eight slices; RAGGED: tile j may reach past Skv.
+    // The LAST Q.K^T MFMA of each score tile writes its result into `s` (D != C): tile st's registers are dead once slice 6 + st
+    // has packed them, so the final product of tile 0 goes out at the head of slice 7 and that of tile 1 right behind slice 7 --
+    // no copy and ONE loop body.
+    auto iter = [&](int j, auto has_prev_c, auto has_next_c, auto ragged_c) __attribute__((always_inline)) {
+      constexpr bool HAS_PREV = decltype(has_prev_c)::value, HAS_NEXT = decltype(has_next_c)::value, RAGGED = decltype(ragged_c)::value;
+      // in flight: tile j + 1 only (sent one iteration ago); past the rendezvous every wave has finished iteration j - 1, i.e.
+      // its reads of tile j - 2's V^T -- the slot tile j + 2 now goes to
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (j + 2 < ntiles) issue(j + 2, (j + 2) & 3);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* kbn = smem + ((j + 1) & 3) * C::STAGE;
+      const unsigned char* vbp = smem + ((j + 3) & 3) * C::STAGE + C::KBYTES;
+      const int kv0 = j * 64;
+      if constexpr (RAGGED) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = kv0 + 32 * st + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            s[st][r] = (kv >= p.Skv) ? -1e30f : s[st][r];
+          }
+      }
+      float mx = -1e30f, m_new = 0.f, alpha = 1.f, psum = 0.f;
+      // (P^T of tile j is packed straight into `pf`: fragment u of tile j - 1 was consumed by the P.V MFMAs of slices 2u, 2u + 1,
+      // all issued before slice 6 / 7 overwrite it -- sixteen registers the 256-register budget of two waves per SIMD needs)
+      auto slice = [&](int sl) {
+        if (sl == 1) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][r]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          m_new = fmaxf(m_run, mx * sl2);
+          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+        } else if (sl >= 2 && sl <= 5) {
+          const int st = (sl - 2) >> 1, r0 = 8 * ((sl - 2) & 1);
+#pragma unroll
+          for (int r = r0; r < r0 + 8; ++r) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sl2, -m_new));
+            s[st][r] = e;
+            psum += e;
+          }
+        } else if (sl >= 6) {
+          if (sl == 6) l_run = l_run * alpha + psum;
+#pragma unroll
+          for (int u = 2 * (sl - 6); u < 2 * (sl - 6) + 2; ++u) {
+            const int b8 = 8 * (u & 1);
+            const uint4 pk = make_uint4(pack_bf2(s[u >> 1][b8 + 0], s[u >> 1][b8 + 1]), pack_bf2(s[u >> 1][b8 + 2], s[u >> 1][b8 + 3]),
+                                        pack_bf2(s[u >> 1][b8 + 4], s[u >> 1][b8 + 5]), pack_bf2(s[u >> 1][b8 + 6], s[u >> 1][b8 + 7]));
+            pf[u] = __builtin_bit_cast(bf16x8_t, pk);
+          }
+        }
+      };
+      // fragments of slice sl + 1 are read during slice sl (statically indexed: no copies, short live ranges)
+      bf16x8_t avs[8][PERV], kfs[8][PERK];
+      if constexpr (HAS_PREV) {
+#pragma unroll
+        for (int q = 0; q < PERV; ++q) avs[0][q] = vfrag(vbp, q);
+      }
+      if constexpr (HAS_NEXT) {
+#pragma unroll
+        for (int q = 0; q < PERK; ++q) kfs[0][q] = kfrag(kbn, q);
+      }
+      const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) {
+        if (sl < 7) {
+          if constexpr (HAS_PREV) {
+#pragma unroll
+            for (int q = 0; q < PERV; ++q) avs[sl + 1][q] = vfrag(vbp, (sl + 1) * PERV + q);
+          }
+          if constexpr (HAS_NEXT) {
+#pragma unroll
+            for (int q = 0; q < PERK; ++q) kfs[sl + 1][q] = kfrag(kbn, (sl + 1) * PERK + q);
+          }
+        }
+        if constexpr (HAS_PREV) {
+#pragma unroll
+          for (int q = 0; q < PERV; ++q) {
+            const int k = sl * PERV + q;
+            o[k % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avs[sl][q], pf[k / DT], o[k % DT], 0, 0, 0);
+          }
+        }
+        if constexpr (HAS_NEXT) {
+#pragma unroll
+          for (int q = 0; q < PERK; ++q) {
+            const int k = sl * PERK + q;                          // k < 2: the first product of score tile k (C operand = 0)
+            if (k < NQK - 2) sn[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfs[sl][q], qf[k >> 1], k < 2 ? zero16 : sn[k & 1], 0, 0, 0);
+          }
+          if (sl == 7) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfs[(NQK - 2) / PERK][(NQK - 2) % PERK], qf[(NQK - 2) >> 1], sn[0], 0, 0, 0);
+        }
+        slice(sl);
+        if constexpr (HAS_NEXT) {
+          if (sl == 7) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfs[(NQK - 1) / PERK][(NQK - 1) % PERK], qf[(NQK - 1) >> 1], sn[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(pf[u]));
+      __builtin_amdgcn_sched_barrier(0);
+      // rescale AFTER tile j - 1's product has been added: O_j-1 complete, then * alpha_j, then (next iteration) + P_j V_j
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (ntiles == 1) {
+      iter(0, F_{}, F_{}, T_{});
+    } else {
+      iter(0, F_{}, T_{}, F_{});
+      for (int j = 1; j < ntiles - 1; ++j) iter(j, T_{}, T_{}, F_{});
+      iter(ntiles - 1, T_{}, F_{}, T_{});
+    }
+    {                                                             // the last tile's product
+      const unsigned char* vb = smem + ((ntiles - 1) & 3) * C::STAGE + C::KBYTES;
+#pragma unroll
+      for (int k = 0; k < NPV; ++k) o[k % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(vb, k), pf[k / DT], o[k % DT], 0, 0, 0);
+    }
+  } else if constexpr (PIPE == 1) {
     bf16x8_t pf[4];            // P^T fragments of the previous tile, consumed one iteration late
     auto pv = [&](const unsigned char* vb) {
 #pragma unroll
@@ -469,7 +633,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 64 ? 2 : 1)) void attn_fwd_kernel(co
   }
 }
 
-template <int D, int NS, bool MASKED = false, int NW = 4, bool PIPE = false>
+template <int D, int NS, bool MASKED = false, int NW = 4, int PIPE = 0>
 int launch_attn(const da_attention_params& p, hipStream_t s) {
   using C = AttnCfg<D, NW>;
   const size_t lds = (size_t)NS * C::STAGE;
@@ -514,9 +678,12 @@ int launch_attn_ring(const da_attention_params& p, hipStream_t s) {
   }
   // PV-delayed loop: on request, for the head sizes it is built for; by default where it measured faster (see above)
   if constexpr (D == 64 || D == 128) {
-    const bool delay = p.pv_delay ? p.pv_delay > 0 : (D == 64 && p.Skv >= 512);
+    const bool delay = p.pv_delay ? p.pv_delay == 1 : (D == 64 && p.Skv >= 512);
+    if (p.pv_delay == 2 && p.Skv > 64 && (p.ring_slots == 0 || p.ring_slots == 4) && p.q_block != 64) {
+      if constexpr (4 * C::STAGE <= 160 * 1024) return launch_attn<D, 4, false, 4, 2>(p, s);
+    }
     if (delay && p.Skv > 64 && (p.ring_slots == 0 || p.ring_slots == 3) && p.q_block != 64)
-      return launch_attn<D, 3, false, 4, true>(p, s);
+      return launch_attn<D, 3, false, 4, 1>(p, s);
   }
   switch (ns) {
     case 2: return launch_attn<D, 2>(p, s);
@@ -536,7 +703,7 @@ extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
   if (p.Skv_alloc < p.Skv || (p.Skv_alloc & 7)) return DA_ERR_INVALID;
   if (p.ring_slots != 0 && (p.ring_slots < 2 || p.ring_slots > 4)) return DA_ERR_INVALID;
   if (p.q_block != 0 && p.q_block != 64 && p.q_block != 128) return DA_ERR_INVALID;
-  if (p.pv_delay < -1 || p.pv_delay > 1) return DA_ERR_INVALID;
+  if (p.pv_delay < -1 || p.pv_delay > 2) return DA_ERR_INVALID;
   if (p.bias && ((p.bias_row_stride != 0 && p.bias_row_stride < ((p.Skv + 63) & ~63)) || (p.bias_row_stride & 3) || (p.bias_batch_stride & 3) ||
                  (p.bias_head_stride & 3) || p.scale == 0.0f))
     return DA_ERR_INVALID;

@@ -115,6 +115,16 @@ bool tile_ok(const da_gemm_params& p, int tile) {
   return true;
 }
 
+// Reads n 16-byte chunks (grid-stride) and keeps nothing: brings a tensor back into the memory-side cache for da_gemm_tune.
+__global__ __launch_bounds__(256) void touch_kernel(const uint4* __restrict__ src, size_t n, unsigned* __restrict__ sink) {
+  unsigned acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint4 v = src[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9e3779b9u) sink[0] = acc;   // (never in practice: keeps the loads alive)
+}
+
 int run(const da_gemm_params& p, int tile, int staging, hipStream_t s, const da_gemm_params* pb = nullptr) {
   if (is_k2(tile)) {
     if (pb) return DA_ERR_UNSUPPORTED;
@@ -210,7 +220,21 @@ extern "C" int da_gemm_tune(const da_gemm_params* pp, const da_gemm_params* pair
         for (int it = 0; it < iters; ++it) {
           // evict the operands from L2 / Infinity Cache: in the denoising loop the weights of a layer were last touched
           // one whole step (5 GB of other weights) ago, so the variant must be chosen for HBM-latency operands
-          if (scratch && scratch_bytes) (void)hipMemsetAsync(scratch, 0, scratch_bytes, s);
+          if (scratch && scratch_bytes) {
+            (void)hipMemsetAsync(scratch, 0, scratch_bytes, s);
+            // ... but the ACTIVATIONS were written by the kernel in front of this one: they sit in the memory-side cache when
+            // the launch starts.  Re-reading them (touch_kernel) restores that state; timing with
+            // everything cold picked variants that lost in the loop (FF-down: 42 us in situ against 36 for the runner-up).
+            const da_gemm_params* both[2] = {&p, pair ? &pb : nullptr};
+            for (int w = 0; w < 2; ++w) {
+              if (!both[w]) continue;
+              const da_gemm_params& q = *both[w];
+              const size_t na = q.conv ? (size_t)(q.M / ((size_t)q.Hout * q.Wout)) * q.Hin * q.Win * q.C1 * 2
+                                       : ((size_t)(q.M - 1) * q.lda + q.K) * 2;
+              if (na <= ((size_t)192 << 20))
+                DA_LAUNCH(touch_kernel, dim3(1024), dim3(256), 0, s, (const uint4*)q.A, na / 16, (unsigned*)scratch);
+            }
+          }
           (void)hipEventRecord(e0, s);
           rc = run(p, tile, st, s, pair ? &pb : nullptr);
           (void)hipEventRecord(e1, s);

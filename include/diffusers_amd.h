@@ -234,7 +234,9 @@ typedef struct da_attention_params {
                   the same order either way -> bit-identical outputs */
   int pv_delay; /* 0 = default for the head size, 1 = on, -1 = off.  On (D = 64 / 128, unmasked, 3 ring slots): the P.V
                    product of K / V tile j - 1 is issued after the Q.K^T product of tile j so that it runs under tile j's
-                   softmax arithmetic.  Speed only: the same operations in the same order per accumulator. */
+                   softmax arithmetic.  2 (4 ring slots): tile j + 1's Q.K^T product rides in those softmax slices as well
+                   (measured: no faster -- the loop is bound by its instruction issue, not by latency; kept as a variant).
+                   Speed only: the same operations in the same order per accumulator. */
 } da_attention_params;
 
 int da_attention_bf16(const da_attention_params* p, void* stream);

@@ -512,8 +512,9 @@ def test_flash_attention_query_block_sizes_are_bit_identical(B, H, Sq, Skv):
 @pytest.mark.parametrize("B,H,D,Sq,Skv", [(2, 3, 64, 256, 256), (1, 2, 64, 200, 333), (1, 5, 64, 1024, 1024), (2, 2, 64, 130, 77),
                                          (1, 2, 64, 96, 64), (1, 2, 128, 192, 320), (1, 2, 128, 520, 1030), (2, 1, 128, 64, 129)])
 def test_flash_attention_pv_delay_is_bit_identical(B, H, D, Sq, Skv):
-    """da_attention_params.pv_delay: the loop that issues tile j - 1's P.V product under tile j's softmax performs the same
-    operations in the same order per accumulator -- not one bit may differ from the plain loop (and it must be right)."""
+    """da_attention_params.pv_delay: the loops that issue tile j - 1's P.V product (1) and also tile j + 1's Q.K^T product (2) under
+    tile j's softmax perform the same operations in the same order per accumulator -- not one bit may differ from the plain loop
+    (and it must be right)."""
     ops, L = _ops()
     C = H * D
     q, k, v = rnd((B, Sq, C), 36), rnd((B, Skv, C), 37), rnd((B, Skv, C), 38)
@@ -529,6 +530,9 @@ def test_flash_attention_pv_delay_is_bit_identical(B, H, D, Sq, Skv):
                              vt_ld=B * sa, vt_batch_stride=sa, pv_delay=pd)
     plain, delayed, auto = run(-1), run(1), run(0)
     assert torch.equal(plain, delayed) and torch.equal(auto, plain)
+    # pv_delay = 2: the next tile's Q.K^T rides in the softmax slices as well (4-slot ring, the last MFMA of a score tile writes
+    # the registers the softmax reads next) -- same operations, same order, same bits
+    assert torch.equal(run(2), plain)
     assert_close_bf16(delayed, _attn_ref(q, k, v, H).view(B * Sq, C), f"flash attn pv_delay B{B} H{H} D{D} Sq{Sq} Skv{Skv}",
                       rtol=1.6e-2, atol_rms=1.6e-2)
 

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-bash tools/gpu_r3.sh "reothers"
+timeout 300 python tools/bench_attn_r3.py 2>&1 | tail -5 | cut -c1-500

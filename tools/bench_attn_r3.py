@@ -29,7 +29,7 @@ def main():
         ref = run(ring_slots=2, pv_delay=-1)
         rec = {"op": "attn", "name": name, "tflop": round(4.0 * B * H * S * Skv * D / 1e12, 4)}
         variants = {"default": {}, "ring2": dict(ring_slots=2, pv_delay=-1), "ring3": dict(ring_slots=3, pv_delay=-1),
-                    "ring4": dict(ring_slots=4, pv_delay=-1), "pipe": dict(pv_delay=1)}
+                    "ring4": dict(ring_slots=4, pv_delay=-1), "pipe": dict(pv_delay=1), "pipe2": dict(pv_delay=2)}
         if D == 64:
             variants["q64"] = dict(q_block=64, ring_slots=2, pv_delay=-1)
         for vn, kw in variants.items():
