@@ -19,12 +19,12 @@
 // through a per-tile descriptor, or global_load_lds_dwordx4 with per-lane pointers; swizzle applied on the per-lane SOURCE
 // offset, LDS image lane-linear) -- see the staging-mode notes in gemm_kernel.cuh.
 #include "gemm_kernel.cuh"
-#include "gemm2_kernel.cuh"
 
 namespace da_gemm {
 int dispatch_conv(const da_gemm_params& p, int tile, int staging, hipStream_t s);  // gemm_conv.hip
 }
-namespace da_gemm2 {
+namespace da_gemm2 {   // the K2 / K1 family (gemm2_kernel.cuh) compiles in its own two translation units
+int dispatch_lin(const da_gemm_params& p, int tile, int staging, hipStream_t s);   // gemm2_lin.hip
 int dispatch_conv(const da_gemm_params& p, int tile, int staging, hipStream_t s);  // gemm2_conv.hip
 }
 
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void touch_kernel(const uint4* __restrict__ sr
 int run(const da_gemm_params& p, int tile, int staging, hipStream_t s, const da_gemm_params* pb = nullptr) {
   if (is_k2(tile)) {
     if (pb) return DA_ERR_UNSUPPORTED;
-    return p.conv ? da_gemm2::dispatch_conv(p, tile, staging, s) : da_gemm2::dispatch<false>(p, tile, staging, s);
+    return p.conv ? da_gemm2::dispatch_conv(p, tile, staging, s) : da_gemm2::dispatch_lin(p, tile, staging, s);
   }
   if (p.conv) return pb ? DA_ERR_UNSUPPORTED : da_gemm::dispatch_conv(p, tile, staging, s);
   return da_gemm::dispatch<false>(p, tile, staging, s, pb);
