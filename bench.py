@@ -228,9 +228,13 @@ def roofline_leg(pipe, mine, world, images_per_s):
     sch.set_timesteps(50, device=dev)
     lat = mine["latents"].clone()
 
+    from diffusers_amd import ops as _ops
+    pf = getattr(pipe, "_weight_prefetch", None)      # the trace the timed runs recorded: the leg measures the same launches
+
     def one_step():
         sch.reset(0)
-        pipe._step(lat, cond, GUIDANCE, True)
+        with _ops.weight_prefetch(pf, "apply"):
+            pipe._step(lat, cond, GUIDANCE, True)
     one_step()  # untimed warm pass
     fam = instrumented_pass(one_step)
     n, ms, fl, nbytes = fam["igemm"]

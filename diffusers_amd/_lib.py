@@ -48,6 +48,7 @@ class GemmParams(C.Structure):
         ("split_k", C.c_int), ("workspace", C.c_void_p), ("sync_flags", C.c_void_p), ("workspace_bytes", C.c_longlong),
         ("stats_out", C.c_void_p), ("stats_ld", C.c_int), ("ln_stats", C.c_void_p), ("ln_stats_ld", C.c_int),
         ("ln_parts", C.c_int), ("ln_s", C.c_void_p), ("ln_c", C.c_void_p), ("ln_eps", C.c_float), ("k_valid", C.c_int),
+        ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_longlong),
     ]
 
 

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   constexpr int XI = (UX + SW - 1) / SW, WI = (UW + SW - 1) / SW;   // LDS-DMA instructions per wave per unit (upper bound)
   constexpr int XRAG = UX % SW ? 1 : 0, WRAG = UW % SW ? 1 : 0;   // a last row of pieces only some waves own
   static_assert(NSLOT == 2 || NSLOT == 3, "ring of 2 or 3 slice pairs");
-  constexpr int DUMP = (XRAG || WRAG) ? 1024 : 0;          // where the out-of-range pieces of ragged tiles write their zeros
+  constexpr int DUMP = 1024;                               // where the out-of-range pieces of ragged tiles and the prefetch land
   static_assert(NSLOT * PAIR + DUMP <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
   static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows are staged in 8-row pieces");
   static_assert(!CONV || (UX % SW) == 0, "conv: the slice of an activation piece must be a compile-time constant");
@@ -680,6 +680,20 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       for (int jh = 0; jh < NH; ++jh) bias_v[jh] = *(const uint2*)((const uint16_t*)p.bias + min(col_of(jh), p.N - 4));
     }
   }
+  // ---- optional: pull a later launch's weight towards the memory-side cache (da_gemm_params.prefetch).  Each wave sends up to
+  // eight 1 KiB LDS-DMA reads of this workgroup's share into the scratch KiB; nothing waits for them (a kernel that loads its
+  // residual in the epilogue would queue behind them: it skips the prefetch) ----
+  if (p.prefetch && (PF || !p.residual)) {
+    const int nchunk = (int)min((long long)0x7fffffff >> 10, p.prefetch_bytes >> 10);
+    __amdgpu_buffer_rsrc_t rs_pf = uniform_rsrc(p.prefetch, (size_t)nchunk << 10);
+    const int stride = (int)gridDim.x * 8;
+    int c = bid * 8 + wave;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (c < nchunk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pf, DA2_LDS(smem + NSLOT * PAIR), 16, lane * 16, c << 10, 0, 0);
+      c += stride;
+    }
+  }
   DA2_TRACE(5);                                           // partial sums exchanged
   // ---- epilogue: lane holds, for output row (r16 of a 16-row tile), channels 4 kq .. 4 kq + 3 of a 16-column tile ----
   const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
@@ -957,8 +971,7 @@ int launch(const da_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int gx = choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
-  constexpr int SW = PP ? 4 : 8, UX = (PP ? 1 : KG) * BM / 8, UW = (PP ? 1 : KG) * BN / 8;   // as in the kernel
-  constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + (((UX % SW) || (UW % SW)) ? 1024 : 0);
+  constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + 1024;   // ring + the scratch KiB (ragged pieces, prefetch)
   auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP, STREAMW, GIL>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {

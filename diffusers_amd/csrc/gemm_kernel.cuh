@@ -669,6 +669,25 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
     }
   }
 
+  // ---- optional: pull a later launch's weight towards the memory-side cache (da_gemm_params.prefetch; see gemm2_kernel.cuh).
+  // Buffer-addressed builds only (they own the scratch KiB behind the ring); every epilogue operand of those builds was fetched
+  // before the K loop, so nothing queues behind these reads ----
+  if constexpr (SM == 2 && !SPLITK && !LNFOLD) {
+    if (p.prefetch) {
+      const int nchunk = (int)min((long long)0x7fffffff >> 10, p.prefetch_bytes >> 10);
+      __amdgpu_buffer_rsrc_t rs_pf = uniform_rsrc(p.prefetch, (size_t)nchunk << 10);
+      const int stride = (int)gridDim.x * (WM * WN);
+      int c = (int)blockIdx.x * (WM * WN) + wave;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (c < nchunk)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pf, (__attribute__((address_space(3))) void*)(smem + (BM + BN) * 128 * STAGES), 16,
+                                                   lane * 16, c << 10, 0, 0);
+        c += stride;
+      }
+    }
+  }
+
   // ---- epilogue: lane holds, for output row m (= lane&31 within the 32-tile), channels 8*(r>>2)+4*hi+(r&3) ----
   const uint16_t* __restrict__ bias = (const uint16_t*)p.bias;
   const uint16_t* __restrict__ rowvec = (const uint16_t*)p.rowvec;
@@ -910,7 +929,7 @@ int launch(const da_gemm_params& p, const da_gemm_params* pb, hipStream_t s) {
   int gx_a = 1, gx_b = 1;
   const int grid_a = problem_grid<BM, BN>(p, &gx_a);
   const int grid_b = pb ? problem_grid<BM, BN>(*pb, &gx_b) : 0;
-  const size_t lds = (size_t)(BM + BN) * 128 * STAGES;
+  const size_t lds = (size_t)(BM + BN) * 128 * STAGES + (SM == 2 ? 1024 : 0);   // ring (+ the prefetch scratch KiB)
   if (!SPLITK && p.split_k > 1) return DA_ERR_UNSUPPORTED;
   if (p.split_k > 1) {
     // the reducer block of a tile spins on its producers: every block of the launch must be co-resident (LDS and the

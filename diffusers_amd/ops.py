@@ -21,6 +21,85 @@ DEFAULT_STAGING = L.STAGE_LDS_DIRECT
 DEFAULT_TILE = L.TILE_AUTO
 TUNING = True  # per-shape (tile, staging) from diffusers_amd.tuning when the caller does not pin them
 
+# ---- weight prefetch hints (da_gemm_params.prefetch) -------------------------------------------------------------------------
+# Inside a denoising step every weight is met cold: a step streams 5 GB of weights through a 256 MB memory-side cache.  A GEMM
+# launch can read the NEXT launch's weight behind its own K loop (the second kernel family does; measured 7-16 % per launch on
+# SDXL's projections, tools/bench_prefetch.py).  The ops layer does not know what comes next, so the pipelines run ONE step
+# under `weight_prefetch(pf, "record")` -- every implicit-GEMM launch notes its weight tensor, in issue order -- and every later
+# step (the one captured into the HIP graph included) under `weight_prefetch(pf, "apply")`: launch i is handed the weight of
+# launch i + 1, the last one that of launch 0 (the next step).  The weight of a launch is whichever operand the MODEL owns.  A sequence that does not reproduce the recorded one switches the
+# hints off for the rest of that step (they are a speed hint: results never depend on them).
+PREFETCH = os.environ.get("DIFFUSERS_AMD_PREFETCH", "1") != "0"
+_prefetch_state = None
+
+
+class WeightPrefetch:
+    def __init__(self, models=()):
+        self.models = tuple(m for m in models if m is not None)   # whose tensors count as weights (never an activation address:
+        self.ptrs = set()                                          # a hint captured into a HIP graph must stay valid for ever)
+        self.seq = []          # per implicit-GEMM launch of one step, in issue order: (ptr, bytes) of its weight, or None
+        self.mode = None
+        self.idx = 0
+        self.ok = True
+        self.applied = 0       # hints handed out by the last "apply" pass (diagnostics)
+
+    def refresh(self):
+        from .packed_cache import packed_tensors
+        self.ptrs = {t.data_ptr() for m in self.models for t in packed_tensors(m).values() if t.is_cuda}
+
+
+class weight_prefetch:
+    """Context manager around ONE step: `mode` = "record" or "apply" (see above)."""
+
+    def __init__(self, pf: Optional[WeightPrefetch], mode: str):
+        self.pf, self.mode = pf, mode
+
+    def __enter__(self):
+        global _prefetch_state
+        self.prev = _prefetch_state
+        if self.pf is not None and PREFETCH:
+            pf = self.pf
+            pf.mode, pf.idx, pf.applied = self.mode, 0, 0
+            if self.mode == "record":
+                pf.seq, pf.ok = [], True
+                pf.refresh()
+            _prefetch_state = pf
+        return self.pf
+
+    def __exit__(self, *exc):
+        global _prefetch_state
+        pf = self.pf
+        if pf is not None and PREFETCH and _prefetch_state is pf and pf.mode == "apply" and pf.idx != len(pf.seq):
+            pf.ok = False                                          # not the step that was recorded
+        _prefetch_state = self.prev
+        return False
+
+
+def _nbytes16(t: torch.Tensor) -> int:
+    return (t.numel() * t.element_size()) & ~15
+
+
+def _prefetch_hook(p: "L.GemmParams", x: torch.Tensor, w: torch.Tensor) -> None:
+    pf = _prefetch_state
+    if pf is None:
+        return
+    # the weight is whichever operand the model owns (the swapped V^T projections pass it as `x`)
+    mine = (w.data_ptr(), _nbytes16(w)) if w.data_ptr() in pf.ptrs else (x.data_ptr(), _nbytes16(x)) if x.data_ptr() in pf.ptrs else None
+    if pf.mode == "record":
+        pf.seq.append(mine)
+        return
+    i = pf.idx
+    pf.idx += 1
+    if not pf.ok or i >= len(pf.seq) or pf.seq[i] != mine:
+        if pf.ok and os.environ.get("DIFFUSERS_AMD_PREFETCH_DEBUG"):
+            print(f"[prefetch] launch {i}: operands {tuple(x.shape)} / {tuple(w.shape)} are not the recorded step's", flush=True)
+        pf.ok = False                                              # not the step that was recorded: no more hints this step
+        return
+    nxt = pf.seq[(i + 1) % len(pf.seq)]
+    if nxt is not None:
+        p.prefetch, p.prefetch_bytes = nxt
+        pf.applied += 1
+
 
 SPLITK_WS_BYTES = 64 << 20    # split-K workspace per (device, stream): 256 fp32 partial tiles of 256x256
 _splitk_ws = {}
@@ -138,7 +217,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            alpha: float = 1.0, out_scale: float = 1.0, out: Optional[torch.Tensor] = None, out_f32: bool = False,
            bias_rows: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
            tile: Optional[int] = None, staging: Optional[int] = None, split_k: Optional[int] = None,
-           stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None, k_valid: int = 0) -> torch.Tensor:
+           stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None, k_valid: int = 0,
+           prefetch: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M][N] = epilogue(alpha * x[M][K] @ w[N][K]^T).  For act == GEGLU, w/bias are in the packed layout of
     :func:`pack_geglu` and the output has N/2 columns.  ``k_valid`` > 0: columns k >= k_valid of BOTH operands are
     zero padding (da_gemm_params.k_valid): the kernel skips the MFMA steps that would multiply them.
@@ -148,7 +228,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     wrote (``w`` pre-scaled by :func:`fold_layernorm`)."""
     p, st = _linear_params(x, w, bias, act=act, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch,
                            alpha=alpha, out_scale=out_scale, out=out, out_f32=out_f32, bias_rows=bias_rows, gate=gate,
-                           tile=tile, staging=staging, split_k=split_k, stats_out=stats_out, ln=ln, k_valid=k_valid)
+                           tile=tile, staging=staging, split_k=split_k, stats_out=stats_out, ln=ln, k_valid=k_valid,
+                           prefetch=prefetch)
     if p is None:
         return st     # the skinny-M path ran
     L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(linear)")
@@ -189,7 +270,7 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
                    out: Optional[torch.Tensor] = None, out_f32: bool = False, bias_rows: Optional[torch.Tensor] = None,
                    gate: Optional[torch.Tensor] = None, tile: Optional[int] = None, staging: Optional[int] = None,
                    split_k: Optional[int] = None, stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None,
-                   k_valid: int = 0):
+                   k_valid: int = 0, prefetch: Optional[torch.Tensor] = None):
     """Checks + da_gemm_params of one nn.Linear problem; returns (params, stream), or (None, result) when the skinny-M
     kernel handled it."""
     _req(x, "x"), _req(w, "w")
@@ -212,6 +293,10 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     p.ld_rowvec = _rows2d(rowvec, "rowvec") if rowvec is not None else 0
     p.bias_rows, p.gate = _ptr(bias_rows), _ptr(gate)
     p.ld_gate = _rows2d(gate, "gate") if gate is not None else 0
+    if prefetch is not None:      # a later launch's weight: read towards the memory-side cache behind this launch's K loop
+        p.prefetch, p.prefetch_bytes = prefetch.data_ptr(), (prefetch.numel() * prefetch.element_size()) & ~15
+    else:
+        _prefetch_hook(p, x, w)
     if gate is not None:
         if gate.dtype not in (bf16, torch.float32):
             raise TypeError("linear: gate must be bf16 (Flux rounding) or float32 (Wan rounding)")
@@ -318,6 +403,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     if not 0 <= k_valid <= C1 or (k_valid and C2):
         raise ValueError(f"conv2d_nhwc: k_valid {k_valid} outside [0, C1 = {C1}] (or given with a second source)")
     p.k_valid = 0 if k_valid == C1 else k_valid
+    _prefetch_hook(p, x, w)
     st = _stream()
     _select_variant(p, tile, staging, st, inplace=inplace, split_k=split_k, device=x.device)
     L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(conv)")

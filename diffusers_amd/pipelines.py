@@ -69,6 +69,14 @@ def decode_postprocessed(vae, latents: torch.Tensor, output_type: str, **decode_
     return [Image.fromarray(a.squeeze(-1), mode="L") if a.shape[-1] == 1 else Image.fromarray(a) for a in arr]
 
 
+def _pf(pipe) -> "ops.WeightPrefetch":
+    """The pipeline's weight-prefetch trace (ops.weight_prefetch): recorded by one eager step, applied to every later one."""
+    pf = getattr(pipe, "_weight_prefetch", None)
+    if pf is None:
+        pf = pipe._weight_prefetch = ops.WeightPrefetch([getattr(pipe, n, None) for n in ("unet", "transformer")])
+    return pf
+
+
 @dataclass
 class PipelineOutput:
     images: torch.Tensor
@@ -131,8 +139,9 @@ class _LatentDiffusionBase:
         sch = self.scheduler
         sch.reset(0)
         if not use_graph:
-            for _ in range(num_steps):
-                self._step(latents, cond, guidance_scale, do_cfg)
+            for i in range(num_steps):
+                with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
+                    self._step(latents, cond, guidance_scale, do_cfg)
             return latents
         key = self._make_graph_key(latents, cond, guidance_scale, do_cfg)
         if self._graph is None or self._graph_key != key:
@@ -141,12 +150,13 @@ class _LatentDiffusionBase:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self._step(latents, cond, guidance_scale, do_cfg)
+                with ops.weight_prefetch(_pf(self), "record"):
+                    self._step(latents, cond, guidance_scale, do_cfg)
             torch.cuda.current_stream().wait_stream(s)
             latents.copy_(saved)
             sch.reset(0)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE):
+            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(self), "apply"):
                 self._step(latents, cond, guidance_scale, do_cfg)
             self._graph, self._graph_key = g, key
             self._static = {"latents": latents, "cond": cond, "noise_table": self._noise_table}
@@ -411,8 +421,9 @@ class FluxPipeline:
         sch = self.scheduler
         sch.reset(0)
         if not use_graph:
-            for _ in range(num_steps):
-                self._step(latents, pe, cond)
+            for i in range(num_steps):
+                with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
+                    self._step(latents, pe, cond)
             return latents
         key = (tuple(latents.shape), tuple(pe.shape), sch.device_table.data_ptr(), sch.device_step.data_ptr())
         if self._graph is None or self._graph_key != key:
@@ -420,12 +431,13 @@ class FluxPipeline:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self._step(latents, pe, cond)      # warm-up: variant tuning + lazy one-time driver calls
+                with ops.weight_prefetch(_pf(self), "record"):
+                    self._step(latents, pe, cond)      # warm-up: variant tuning + lazy one-time driver calls
             torch.cuda.current_stream().wait_stream(s)
             latents.copy_(saved)
             sch.reset(0)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE):
+            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(self), "apply"):
                 self._step(latents, pe, cond)
             self._graph, self._graph_key = g, key
             self._static = {"latents": latents, "pe": pe, "cond": cond}
@@ -557,8 +569,9 @@ class WanPipeline:
         sch = self.scheduler
         sch.reset(0)
         if not use_graph:
-            for _ in range(num_steps):
-                self._step(latents, cond, guidance_scale, do_cfg)
+            for i in range(num_steps):
+                with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
+                    self._step(latents, cond, guidance_scale, do_cfg)
             return latents
         key = (tuple(latents.shape), float(guidance_scale), do_cfg, cond["St"], sch.device_table.data_ptr())
         if self._graph is None or self._graph_key != key:
@@ -566,12 +579,13 @@ class WanPipeline:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self._step(latents, cond, guidance_scale, do_cfg)
+                with ops.weight_prefetch(_pf(self), "record"):
+                    self._step(latents, cond, guidance_scale, do_cfg)
             torch.cuda.current_stream().wait_stream(s)
             latents.copy_(saved)
             sch.reset(0)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE):
+            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(self), "apply"):
                 self._step(latents, cond, guidance_scale, do_cfg)
             self._graph, self._graph_key = g, key
             self._static = {"latents": latents, "cond": cond}
@@ -689,8 +703,9 @@ class DDPMPipeline:
         noise_table = torch.stack(draws).to(device=dev, dtype=bf16).contiguous()
         sch.reset(0)
         if not use_graph:
-            for _ in ts:
-                self._step(image, noise_table)
+            for i, _ in enumerate(ts):
+                with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
+                    self._step(image, noise_table)
         else:
             key = (tuple(shape), len(ts), sch.device_table.data_ptr())
             if getattr(self, "_graph_key", None) != key:
@@ -698,12 +713,13 @@ class DDPMPipeline:
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
-                    self._step(image, noise_table)          # warm-up: variant tuning, lazy driver calls
+                    with ops.weight_prefetch(_pf(self), "record"):
+                        self._step(image, noise_table)          # warm-up: variant tuning, lazy driver calls
                 torch.cuda.current_stream().wait_stream(s)
                 image.copy_(saved)
                 sch.reset(0)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE):
+                with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(self), "apply"):
                     self._step(image, noise_table)
                 self._graph, self._graph_key = g, key
                 self._static = {"image": image, "noise": noise_table}

@@ -164,6 +164,12 @@ typedef struct da_gemm_params {
                   128).  The operand values past k_valid MUST be zeros in both operands' layouts (activation channels and
                   weight columns); the kernel then runs half the MFMA steps on a slice that is half padding and none on a
                   slice that is all padding.  Results equal k_valid = 0 (adding products of zeros changes nothing). */
+  const void* prefetch;     /* optional (second kernel family): a tensor a LATER launch will stream from HBM -- the next layer's
+                               weight.  Every workgroup reads its share of the first prefetch_bytes behind its K loop (LDS-DMA into a
+                               scratch KiB, nothing waits for it), so the lines sit in the memory-side cache when that launch starts:
+                               inside a denoising step every weight is otherwise met cold (5 GB of weights per step against a 256 MB
+                               cache).  Speed only; the bytes are never interpreted. */
+  long long prefetch_bytes; /* multiple of 16 */
 } da_gemm_params;
 
 /* number of stats partials per row the launch *p (tile resolved as da_gemm_bf16 resolves it) writes to stats_out */
