@@ -398,3 +398,49 @@ def test_flux_rope_cache_distinguishes_portrait_from_landscape():
         assert torch.equal(got, want)
     again = tr.precompute_conditioning(pooled, b_ids, txt)
     assert again["cos"] is cb["cos"], "an identical grid must hit the cache"
+
+
+def test_weight_prefetch_record_apply_state_machine():
+    """ops.weight_prefetch (da_gemm_params.prefetch hints): a recorded step hands launch i the weight of launch i + 1 (cyclically),
+    the weight is whichever operand the MODEL owns (the swapped V^T projections pass it as `x`), an activation address never
+    becomes a hint, and a step that does not reproduce the recorded sequence gets no further hints."""
+    from diffusers_amd import _lib as L, ops
+    w = [torch.zeros(64, 32, dtype=torch.bfloat16) for _ in range(3)]      # "weights"
+    act = [torch.zeros(16, 32, dtype=torch.bfloat16) for _ in range(3)]    # "activations"
+    pf = ops.WeightPrefetch()
+    pf.refresh = lambda: None                                              # (CPU tensors: the owner set is given directly)
+    pf.ptrs = {t.data_ptr() for t in w}
+    launches = [(act[0], w[0]), (w[1], act[1]), (act[2], w[2])]            # the second one is a swapped product
+
+    def step(seq):
+        out = []
+        for x, ww in seq:
+            p = L.GemmParams()
+            ops._prefetch_hook(p, x, ww)
+            out.append((p.prefetch, p.prefetch_bytes))
+        return out
+    with ops.weight_prefetch(pf, "record"):
+        assert step(launches) == [(None, 0)] * 3                            # recording hands out nothing
+    assert [e[0] for e in pf.seq] == [t.data_ptr() for t in w]
+    with ops.weight_prefetch(pf, "apply"):
+        got = step(launches)
+    nb = w[0].numel() * 2
+    assert got == [(w[1].data_ptr(), nb), (w[2].data_ptr(), nb), (w[0].data_ptr(), nb)] and pf.ok and pf.applied == 3
+    # a launch with other operands: that launch and every later one of the step go without a hint
+    with ops.weight_prefetch(pf, "apply"):
+        got = step([launches[0], (act[1], w[2]), launches[2]])
+    assert got[0] == (w[1].data_ptr(), nb) and got[1] == (None, 0) and got[2] == (None, 0) and not pf.ok
+    # a shorter step is noticed when the context closes; outside any context the hook is inert
+    with ops.weight_prefetch(pf, "record"):
+        step(launches)
+    with ops.weight_prefetch(pf, "apply"):
+        step(launches[:2])
+    assert not pf.ok
+    assert step(launches) == [(None, 0)] * 3
+    # an operand nobody owns is never offered as a hint
+    pf.ptrs = {w[0].data_ptr(), w[2].data_ptr()}
+    with ops.weight_prefetch(pf, "record"):
+        step(launches)
+    with ops.weight_prefetch(pf, "apply"):
+        got = step(launches)
+    assert got == [(None, 0), (w[2].data_ptr(), nb), (w[0].data_ptr(), nb)]
