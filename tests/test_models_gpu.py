@@ -112,6 +112,28 @@ def test_tiny_sdxl_pipeline_vs_reference(golden):
     assert len(pil) == nhwc.shape[0] and np.array_equal(np.asarray(pil[0]), (nhwc[0] * 255).round().astype("uint8"))
 
 
+def test_weight_prefetch_hints_change_no_bit(golden, monkeypatch):
+    """da_gemm_params.prefetch (ops.weight_prefetch): every implicit-GEMM launch of a step reads the NEXT launch's weight behind its
+    K loop -- a speed hint whose bytes are never interpreted.  The tiny SDXL loop with the hints (eager and as a replayed HIP graph)
+    must equal the loop without them, and the hints must actually have been handed out."""
+    from diffusers_amd import factory, ops
+    g = golden("tiny_sdxl_pipeline")
+    kw = dict(prompt_embeds=t(g, "prompt_embeds"), negative_prompt_embeds=t(g, "negative_prompt_embeds"),
+              pooled_prompt_embeds=t(g, "pooled"), negative_pooled_prompt_embeds=t(g, "negative_pooled"),
+              num_inference_steps=4, guidance_scale=5.0, height=128, width=128, output_type="latent")
+    pipe = factory.build_sdxl_pipeline(device=DEV, tiny=True, seed=0)
+    monkeypatch.setattr(ops, "PREFETCH", False)
+    plain = pipe(latents=t(g, "latents").clone(), use_graph=False, **kw).images.clone()
+    assert getattr(pipe, "_weight_prefetch", None) is None or pipe._weight_prefetch.applied == 0
+    monkeypatch.setattr(ops, "PREFETCH", True)
+    eager = pipe(latents=t(g, "latents").clone(), use_graph=False, **kw).images.clone()
+    pf = pipe._weight_prefetch
+    assert pf.ok and len(pf.seq) > 20 and pf.applied >= len(pf.seq) - 2, (pf.ok, len(pf.seq), pf.applied)
+    graph = pipe(latents=t(g, "latents").clone(), use_graph=True, **kw).images.clone()
+    assert pf.ok and pf.applied >= len(pf.seq) - 2
+    assert torch.equal(plain, eager) and torch.equal(plain, graph)
+
+
 def test_sdxl_architecture_small_latents_vs_oracle():
     """Full SDXL-base U-Net architecture (2.57 B parameters, every one of the 70 transformer blocks) at 32x32 latents,
     against the fp32 CPU oracle on the same seeded weights."""
