@@ -62,6 +62,7 @@ class AttentionParams(C.Structure):
         ("scale", C.c_float), ("ring_slots", C.c_int),
         ("bias", C.c_void_p), ("bias_batch_stride", C.c_longlong), ("bias_head_stride", C.c_longlong),
         ("bias_row_stride", C.c_int), ("bias_f32", C.c_int), ("causal", C.c_int), ("q_block", C.c_int), ("pv_delay", C.c_int),
+        ("algo", C.c_int),
     ]
 
 

@@ -26,6 +26,8 @@
 
 #include "common.cuh"
 
+int da_attn2_dispatch(const da_attention_params& p, hipStream_t s);   // attention2.hip
+
 namespace {
 
 __device__ uint4 g_zero_chunk[1];  // 16 B of zeros: the source of every K / V^T chunk past the end of the sequence
@@ -702,7 +704,8 @@ extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
   if (p.B <= 0 || p.H <= 0 || p.Sq <= 0 || p.Skv <= 0) return DA_ERR_INVALID;
   if (p.Skv_alloc < p.Skv || (p.Skv_alloc & 7)) return DA_ERR_INVALID;
   if (p.ring_slots != 0 && (p.ring_slots < 2 || p.ring_slots > 4)) return DA_ERR_INVALID;
-  if (p.q_block != 0 && p.q_block != 64 && p.q_block != 128) return DA_ERR_INVALID;
+  if (p.q_block != 0 && p.q_block != 64 && p.q_block != 128 && p.q_block != 256) return DA_ERR_INVALID;
+  if (p.algo < 0 || p.algo > 3) return DA_ERR_INVALID;
   if (p.pv_delay < -1 || p.pv_delay > 2) return DA_ERR_INVALID;
   if (p.bias && ((p.bias_row_stride != 0 && p.bias_row_stride < ((p.Skv + 63) & ~63)) || (p.bias_row_stride & 3) || (p.bias_batch_stride & 3) ||
                  (p.bias_head_stride & 3) || p.scale == 0.0f))
@@ -711,6 +714,13 @@ extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
     return DA_ERR_UNSUPPORTED;
   if ((p.q_batch_stride & 7) || (p.k_batch_stride & 7) || (p.o_batch_stride & 3)) return DA_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  // second generation (attention2.hip) unless the caller pinned the first one or one of its variants
+  const bool pinned_v1 = p.algo == 1 || (p.algo == 0 && (p.ring_slots == 2 || p.q_block == 64 || p.pv_delay != 0));
+  if (!pinned_v1 && (p.o_row_stride & 3) == 0) {
+    const int rc = da_attn2_dispatch(p, s);
+    if (rc != DA_ERR_UNSUPPORTED || p.algo >= 2) return rc;
+  }
+  if (p.q_block == 256) return DA_ERR_UNSUPPORTED;
   switch (p.D) {
     case 64: return launch_attn_ring<64>(p, s);
     case 96: return launch_attn_ring<96>(p, s);

@@ -1,0 +1,454 @@
+// Flash attention forward, second kernel generation ("v2") for gfx950: unmasked, D = 64 / 128, bf16 in / bf16 out.
+//
+// Same call sites as attention.hip (F.scaled_dot_product_attention at diffusers models/attention_processor.py:2767 and
+// models/attention_dispatch.py:3709) and the same swapped products
+//
+//   S^T[kv][q] = K[kv][:] . Q[q][:]^T      A = K tile (LDS), B = Q (registers)         v_mfma_f32_32x32x16_bf16
+//   O^T[d][q]  = V^T[d][kv] . P^T[kv][q]   A = V^T tile (LDS), B = P^T (registers, straight from the S^T accumulators)
+//
+// so that a lane owns ONE query.  What changed against the round-1..3 kernel (profiles/r03d_pmc_sq_counters.md: 49 % of the
+// wave cycles parked, LDS conflicts 0.35 of LDS-active, ~250 issued instructions around 16 MFMAs per 64-key tile):
+//
+//  * K rows are fed to the Q.K^T product PERMUTED (A-row i takes key pi(i), pi = swap of bits 2 and 3): the C/D layout of the
+//    32 x 32 MFMA then leaves every lane with eight CONSECUTIVE keys per register octet, the P^T B-fragment of the P.V product
+//    is in natural key order, and a V^T A-fragment is ONE conflict-free ds_read_b128 (it was two 2-way-conflicting
+//    ds_read_b64 plus register shuffles).
+//  * K / V^T tiles arrive by BUFFER-addressed LDS-DMA: per-lane byte offsets are loop constants, the tile advance is one
+//    scalar offset, chunks past the end of the sequence set bit 31 of the offset (the range check writes zeros): ~12
+//    instructions per tile where the pointer-select form issued ~50.
+//  * Deferred maximum: the O / l rescale runs only when some row's score exceeds the running shift by more than 2^THR
+//    (wave vote); otherwise P = exp2(s * c - m) with the OLD shift, bounded by 2^THR.  The first tile always takes the
+//    branch (m starts at -1e30).  The decision is taken before tile j's exponentials and the O rescale is applied after
+//    tile j - 1's P.V product has been added (the order of the previous kernel).
+//  * The row sum is kept in four partial accumulators inside the softmax slices (the compiler used to sink all 32 adds
+//    into one dependent chain behind the last MFMA); the cross-half exchanges are v_permlane32_swap, not LDS permutes.
+//  * O leaves through LDS as whole rows, 16 bytes per lane (the 8-byte-per-lane MFMA layout touched 32 lines per store).
+//  * NW = 4 or 8 waves per workgroup (128 / 256 queries share one K / V^T stream): D = 128 gets two waves per SIMD.
+//
+// Numerics: fp32 scores, fp32 softmax statistics, P rounded to bf16 for the second product, fp32 O accumulation -- as before;
+// results differ from the previous kernel in the last bits (different shift m, different summation order of l).
+#include <type_traits>
+
+#include "common.cuh"
+
+namespace da_attn2 {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, size_t bytes) {
+  const uint64_t v = (uint64_t)base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+#endif
+
+constexpr float kDeferLog2 = 8.0f;   // THR: P stays <= 2^8 between rescales
+
+template <int D>
+struct Cfg {
+  static constexpr int CPR = D / 8;              // 16-byte chunks per K row
+  static constexpr int KBYTES = 64 * D * 2;      // K tile  [64][D]
+  static constexpr int VBYTES = D * 128;         // V^T tile [D][64]
+  static constexpr int STAGE = KBYTES + VBYTES;
+};
+
+// 16-byte-slot XOR of K row `row` (source side): conflict-free ds_read_b128 for the permuted rows of every lane group
+template <int D>
+__device__ __forceinline__ int k_swz(int row) {
+  return D == 64 ? (row >> 1) & 7 : row & 15;
+}
+
+// AUG: the shift -m of the online softmax rides in the Q.K^T product as one extra k-step (A = a ones column, B = -m in bf16),
+// with Q pre-multiplied by scale * log2(e): the scores leave the MFMA as s * c - m and the 32 v_fma_f32 per tile in front of the
+// exponentials disappear (two more MFMAs per tile instead).  m is kept bf16-exact; the softmax is invariant to the shift, so
+// its rounding is harmless; the pre-multiplied Q is rounded to bf16 once more than the reference's (scores within bf16 noise).
+template <int D, int NW, int NS, bool AUG>
+// min waves per SIMD: D = 64 / four waves: three workgroups per CU (<= 168 registers); eight waves: one workgroup = two per SIMD
+__global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 1)) void attn2_fwd_kernel(const da_attention_params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using C = Cfg<D>;
+  static_assert(D == 64 || D == 128, "head sizes of the v2 kernel");
+  static_assert(NW == 4 || NW == 8, "four or eight waves");
+  static_assert(NS == 3 || NS == 4, "ring of 3 or 4 tiles (tile j - 1's V^T stays resident while tile j is consumed)");
+  constexpr int QT = 32 * NW;                    // queries per workgroup
+  constexpr int PD = NS - 2;                     // tiles in flight ahead of the one being consumed
+  constexpr int KCH = C::CPR / NW;               // K pieces (1 KiB) per wave per tile
+  constexpr int VCH = (D / 8) / NW;              // V^T pieces per wave per tile
+  static_assert(KCH >= 1 && VCH >= 1 && KCH * NW == C::CPR && VCH * NW == D / 8, "pieces divide among the waves");
+  constexpr int LOADS = KCH + VCH;
+  constexpr int DT = D / 32, NPV = 4 * DT, NQK = 2 * (D / 16), PER = NPV / 8;
+  constexpr int RING = NS * C::STAGE;
+  static_assert(RING <= 160 * 1024, "K / V^T ring exceeds the LDS of a CU");
+  static_assert(NW * 32 * (2 * D + 16) <= RING, "output staging does not fit the ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // XCD-aware mapping (speed only): all query tiles of one (batch, head) pair go to ONE XCD (attention.hip)
+  const int qtiles = (p.Sq + QT - 1) / QT;
+  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+  const int pair = (slot_id / qtiles) * 8 + xcd;
+  if (pair >= p.B * p.H) return;
+  const int b = pair / p.H, h = pair - b * p.H;
+  const int q0 = (slot_id % qtiles) * QT + wave * 32;
+
+  const uint16_t* __restrict__ Q = (const uint16_t*)p.q + (size_t)b * p.q_batch_stride + (size_t)h * D;
+  const uint16_t* __restrict__ K = (const uint16_t*)p.k + (size_t)b * p.k_batch_stride + (size_t)h * D;
+  const uint16_t* __restrict__ VT = (const uint16_t*)p.vt + (size_t)h * D * p.vt_ld + (size_t)b * p.vt_batch_stride;
+  uint16_t* __restrict__ O = (uint16_t*)p.out + (size_t)b * p.o_batch_stride + (size_t)h * D;
+  const float sl2 = p.scale * 1.4426950408889634f;
+  const int ntiles = (p.Skv + 63) >> 6;
+
+  // ---- staging: buffer-addressed LDS-DMA, one 1 KiB piece (64 lanes x 16 B) per wave instruction ----
+  // piece pi = i * NW + wave; K: chunk pch = 64 pi + lane -> (row = pch / CPR, slot = pch % CPR), source chunk slot ^ k_swz(row);
+  // V^T: (d = pch / 8, slot = pch % 8), source chunk slot ^ ((d >> 1) & 7).  Offsets are bytes from the (batch, head) base;
+  // the tile advance is the scalar offset.  Only the LAST tile can reach past Skv_alloc: its offsets (vl_*) carry bit 31 on
+  // the chunks that do (beyond num_records: the range check writes zeros to LDS without touching memory).
+  const __amdgpu_buffer_rsrc_t rs_k = uniform_rsrc(K, 0x7fffffff);
+  const __amdgpu_buffer_rsrc_t rs_v = uniform_rsrc(VT, 0x7fffffff);
+  int vo_k[KCH], vl_k[KCH], vo_v[VCH], vl_v[VCH];
+  {
+    const int rem_last = p.Skv_alloc - (ntiles - 1) * 64;      // keys of the last tile that exist
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int pch = (i * NW + wave) * 64 + lane;
+      const int row = pch / C::CPR, slot = pch % C::CPR;
+      vo_k[i] = (row * p.k_row_stride + ((slot ^ k_swz<D>(row)) << 3)) * 2;
+      vl_k[i] = vo_k[i] | (row >= rem_last ? (int)0x80000000 : 0);
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+      const int pch = (i * NW + wave) * 64 + lane;
+      const int d = pch >> 3, slot = pch & 7;
+      const int c = slot ^ ((d >> 1) & 7);
+      vo_v[i] = (d * p.vt_ld + c * 8) * 2;
+      vl_v[i] = vo_v[i] | (c * 8 >= rem_last ? (int)0x80000000 : 0);   // Skv_alloc % 8 == 0: a chunk is all in or all out
+    }
+  }
+#define DA_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
+  auto issue = [&](int tile, int buf_off) {
+    unsigned char* kb = smem + buf_off;
+    unsigned char* vb = kb + C::KBYTES;
+    const int so_k = tile * 64 * p.k_row_stride * 2, so_v = tile * 128;
+    if (tile == ntiles - 1) {                                   // wave-uniform
+#pragma unroll
+      for (int i = 0; i < KCH; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, DA_LDS(kb + (i * NW + wave) * 1024), 16, vl_k[i], so_k, 0, 0);
+#pragma unroll
+      for (int i = 0; i < VCH; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, DA_LDS(vb + (i * NW + wave) * 1024), 16, vl_v[i], so_v, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < KCH; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, DA_LDS(kb + (i * NW + wave) * 1024), 16, vo_k[i], so_k, 0, 0);
+#pragma unroll
+      for (int i = 0; i < VCH; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, DA_LDS(vb + (i * NW + wave) * 1024), 16, vo_v[i], so_v, 0, 0);
+    }
+  };
+#undef DA_LDS
+  // ---- prologue: tiles 0 .. PD - 1 in flight before anything else ----
+#pragma unroll
+  for (int t0 = 0; t0 < PD; ++t0)
+    if (t0 < ntiles) issue(t0, t0 * C::STAGE);
+
+  // ---- Q fragments (MFMA B operand): lane (q = l31, hi) holds Q[q][16 ks + 8 hi + 0..7] ----
+  bf16x8_t qf[D / 16];
+  {
+    const int q = q0 + l31;
+    const bool ok = q < p.Sq;
+    const uint16_t* qp = Q + (size_t)(ok ? q : 0) * p.q_row_stride + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      uint4 v = *(const uint4*)(qp + 16 * ks);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      if constexpr (AUG) {
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= sl2;
+        v = pack8(f);
+      }
+      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  // AUG: the extra k-step.  A = K side: 1.0 at k = 0 for every key row; B = Q side: -m of the lane's query at k = 0.
+  const bf16x8_t kx = __builtin_bit_cast(bf16x8_t, make_uint4(hi == 0 ? 0x3F80u : 0u, 0u, 0u, 0u));
+  bf16x8_t qx = __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u));
+
+  f32x16_t o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = AUG ? 0.f : -1e30f, l_run = 0.f;
+
+  // fragment addresses (bytes inside a ring slot): 4 K and 4 V^T lane-constant offsets, the rest are immediates
+  const int pi_row = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // key row this lane feeds as A-row l31
+  const int ksw = k_swz<D>(pi_row);
+  const int kbase = pi_row * (2 * D);
+  const int vsw = (l31 >> 1) & 7;
+  const int vbase = C::KBYTES + l31 * 128;
+  auto kfrag = [&](const unsigned char* sb, int k) {            // Q.K^T MFMA k = 2 ks + st
+    const int ks = k >> 1, st = k & 1;
+    return *(const bf16x8_t*)(sb + kbase + st * (32 * 2 * D) + (((2 * ks + hi) ^ ksw) << 4));
+  };
+  auto vfrag = [&](const unsigned char* sb, int k) {            // P.V MFMA k = u * DT + dt: keys 16 u + 8 hi + 0..7 of row 32 dt + l31
+    const int u = k / DT, dt = k % DT;
+    return *(const bf16x8_t*)(sb + vbase + dt * 4096 + (((2 * u + hi) ^ vsw) << 4));
+  };
+  auto xhalf_max = [](float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  };
+
+  bf16x8_t pf[4];            // P^T fragments of the previous tile, consumed one iteration late
+  int cur = 0, prv = (NS - 1) * C::STAGE, nxt = PD * C::STAGE;   // ring offsets of tile j, tile j - 1, tile j + PD
+  // One iteration: [rendezvous, DMA of tile j + PD, Q.K^T(j), softmax(j) in eight slices with P.V(j - 1) riding in them].
+  auto iter = [&](int j, auto has_prev_c) __attribute__((always_inline)) {
+    constexpr bool HAS_PREV = decltype(has_prev_c)::value;
+    // issued so far: tiles 0 .. min(ntiles, j + PD) - 1; tile j must have landed, the later ones may stay in flight
+    if (PD >= 2 && j + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // past the rendezvous every wave has finished iteration j - 1, i.e. its reads of tile j - 2's V^T: that slot is free
+    const unsigned char* sb = smem + cur;
+    const unsigned char* sbp = smem + prv;
+    f32x16_t s[2];
+    {
+      bf16x8_t kf[NQK];
+#pragma unroll
+      for (int k = 0; k < NQK; ++k) kf[k] = kfrag(sb, k);      // the reads the first MFMAs wait for go out first
+      if (j + PD < ntiles) issue(j + PD, nxt);
+      const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if constexpr (AUG) {
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx, qx, zero16, 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx, qx, zero16, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < NQK; ++k)
+        s[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k], qf[k >> 1], (!AUG && k < 2) ? zero16 : s[k & 1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ragged last tile: keys past Skv never win the maximum and exponentiate to exactly 0 (wave-uniform branch)
+    const int kv0 = j * 64;
+    if (kv0 + 64 > p.Skv) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + 32 * st + 16 * (r >> 3) + 8 * hi + (r & 7);
+          s[st][r] = (kv >= p.Skv) ? -1e30f : s[st][r];
+        }
+    }
+    float alpha = 1.f;
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    bf16x8_t pn[4];
+    auto slice = [&](int sl) {
+      if (sl == 0) {
+        float mx0 = fmaxf(s[0][0], s[0][1]), mx1 = fmaxf(s[1][0], s[1][1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) {
+          mx0 = fmaxf(fmaxf(mx0, s[0][r]), s[0][r + 1]);
+          mx1 = fmaxf(fmaxf(mx1, s[1][r]), s[1][r + 1]);
+        }
+        const float mxr = xhalf_max(fmaxf(mx0, mx1));            // row maximum of this tile
+        if constexpr (AUG) {
+          // scores are already s * c - m.  Deferred maximum: keep the shift while no row of the wave outgrows it by 2^THR;
+          // the first tile always sets it (m = 0 so far: the scores may sit far below as well as above).
+          if (__builtin_amdgcn_ballot_w64(!HAS_PREV || mxr > kDeferLog2) != 0) {
+            const float delta = HAS_PREV ? fmaxf(mxr, 0.f) : mxr;
+            const float m_new = bf2f(f2bf(m_run + delta));       // bf16-exact: it rides in the next tiles' MFMA
+            const float d_eff = m_new - m_run;
+            alpha = __builtin_amdgcn_exp2f(-d_eff);
+            m_run = m_new;
+            qx = __builtin_bit_cast(bf16x8_t, make_uint4(hi == 0 ? (uint32_t)f2bf(-m_new) : 0u, 0u, 0u, 0u));
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s[st][r] -= d_eff;
+          }
+        } else {
+          const float mx = mxr * sl2;                            // scaled (sl2 > 0)
+          // deferred maximum: keep the old shift while no row of the wave outgrows it by more than 2^THR (m starts at -1e30:
+          // the first tile always takes the branch)
+          if (__builtin_amdgcn_ballot_w64(mx - m_run > kDeferLog2) != 0) {
+            const float m_new = fmaxf(m_run, mx);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+          }
+        }
+      } else if (sl >= 1 && sl <= 4) {
+        const int st = (sl - 1) >> 1, r0 = 8 * ((sl - 1) & 1);
+#pragma unroll
+        for (int r = r0; r < r0 + 8; ++r) {
+          const float e = AUG ? __builtin_amdgcn_exp2f(s[st][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sl2, -m_run));
+          s[st][r] = e;
+          ps[r & 3] += e;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(ps[u]));   // the adds stay in this slice
+      } else if (sl >= 5 && sl <= 6) {
+#pragma unroll
+        for (int u = 2 * (sl - 5); u < 2 * (sl - 5) + 2; ++u) {
+          const int b8 = 8 * (u & 1);
+          const uint4 pk = make_uint4(pack_bf2(s[u >> 1][b8 + 0], s[u >> 1][b8 + 1]), pack_bf2(s[u >> 1][b8 + 2], s[u >> 1][b8 + 3]),
+                                      pack_bf2(s[u >> 1][b8 + 4], s[u >> 1][b8 + 5]), pack_bf2(s[u >> 1][b8 + 6], s[u >> 1][b8 + 7]));
+          pn[u] = __builtin_bit_cast(bf16x8_t, pk);
+        }
+      } else if (sl == 7) {
+        l_run = l_run * alpha + ((ps[0] + ps[1]) + (ps[2] + ps[3]));
+      }
+    };
+    if constexpr (HAS_PREV) {
+      bf16x8_t av[PER], an[PER];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) av[q] = vfrag(sbp, q);
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if (sl < 7) an[q] = vfrag(sbp, (sl + 1) * PER + q);     // next slice's V^T fragments fly under this slice
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          const int k = sl * PER + q;
+          o[k % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q], pf[k / DT], o[k % DT], 0, 0, 0);
+        }
+        slice(sl);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) av[q] = an[q];
+      }
+    } else {
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) {
+        slice(sl);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(pn[u]));
+    __builtin_amdgcn_sched_barrier(0);
+    // rescale AFTER tile j - 1's product has been added: O_j-1 complete, then * alpha_j, then (next iteration) + P_j V_j.
+    // alpha is exactly 1.0f unless the deferred-maximum branch ran (x * 1.0f is exact: same bits either way).
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pf[u] = pn[u];
+    prv = cur;
+    cur = (cur + C::STAGE == RING) ? 0 : cur + C::STAGE;
+    nxt = (nxt + C::STAGE == RING) ? 0 : nxt + C::STAGE;
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  iter(0, F_{});
+  for (int j = 1; j < ntiles; ++j) iter(j, T_{});
+  {                                                               // the last tile's product (its slot was not refilled)
+    const unsigned char* sbl = smem + prv;
+#pragma unroll
+    for (int k = 0; k < NPV; ++k) o[k % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(sbl, k), pf[k / DT], o[k % DT], 0, 0, 0);
+  }
+
+  // ---- epilogue: O^T registers -> LDS (per wave) -> whole rows, 16 bytes per lane ----
+  float l_tot;
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_tot = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  const float inv = 1.0f / l_tot;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                   // every wave is out of the ring
+  asm volatile("" ::: "memory");
+  constexpr int OROW = 2 * D + 16;                                // bytes per staged row (pad: the 8-byte writes spread over the banks)
+  unsigned char* stg = smem + wave * (32 * OROW);
+  if ((p.o_row_stride & 7) == 0 && ((size_t)p.out & 15) == 0 && (p.o_batch_stride & 7) == 0) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        pk.y = pack_bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(uint2*)(stg + l31 * OROW + (32 * dt + 8 * g + 4 * hi) * 2) = pk;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // wave-private region: no barrier
+    constexpr int CPRO = D / 8;                                   // 16-byte pieces per output row
+#pragma unroll
+    for (int i = 0; i < (32 * CPRO) / 64; ++i) {
+      const int pc = i * 64 + lane;
+      const int row = pc / CPRO, c = pc % CPRO;
+      const uint4 v = *(const uint4*)(stg + row * OROW + c * 16);
+      if (q0 + row < p.Sq) *(uint4*)(O + (size_t)(q0 + row) * p.o_row_stride + c * 8) = v;
+    }
+  } else {
+    const int q = q0 + l31;
+    if (q < p.Sq) {
+      uint16_t* op = O + (size_t)q * p.o_row_stride;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 pk;
+          pk.x = pack_bf2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+          pk.y = pack_bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          *(uint2*)(op + 32 * dt + 8 * g + 4 * hi) = pk;
+        }
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int D, int NW, int NS, bool AUG>
+int launch(const da_attention_params& p, hipStream_t s) {
+  using C = Cfg<D>;
+  const size_t lds = (size_t)NS * C::STAGE;
+  auto kern = attn2_fwd_kernel<D, NW, NS, AUG>;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int qtiles = (p.Sq + 32 * NW - 1) / (32 * NW), rounds = (p.B * p.H + 7) / 8;
+  DA_LAUNCH(kern, dim3(8 * rounds * qtiles), dim3(64 * NW), lds, s, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+}  // namespace da_attn2
+
+// Entry used by da_attention_bf16 (attention.hip).  Returns DA_ERR_UNSUPPORTED for anything this generation does not cover
+// (masked / biased attention, D = 96 / 160, 32-bit offset overflow): the caller then runs the first-generation kernel.
+int da_attn2_dispatch(const da_attention_params& p, hipStream_t s) {
+  if (p.bias || p.causal) return DA_ERR_UNSUPPORTED;
+  if (p.D != 64 && p.D != 128) return DA_ERR_UNSUPPORTED;
+  if (p.ring_slots != 0 && p.ring_slots != 3 && p.ring_slots != 4) return DA_ERR_UNSUPPORTED;
+  if (p.q_block != 0 && p.q_block != 128 && p.q_block != 256) return DA_ERR_UNSUPPORTED;
+  // 31-bit byte offsets of the buffer-addressed staging
+  if ((size_t)p.Skv_alloc * (size_t)p.k_row_stride * 2 + 64ull * p.k_row_stride * 2 >= 0x7fffffffull) return DA_ERR_UNSUPPORTED;
+  if ((size_t)p.D * (size_t)p.vt_ld * 2 + (size_t)p.Skv_alloc * 2 >= 0x7fffffffull) return DA_ERR_UNSUPPORTED;
+  const int ns = p.ring_slots ? p.ring_slots : 3;
+  // queries per workgroup: eight waves halve the K / V^T traffic per flop and give D = 128 (one workgroup per CU) two waves per
+  // SIMD; four waves keep more, smaller workgroups for short sequences (load balance over 256 CUs)
+  int qb = p.q_block;
+  if (qb == 0) {
+    const long long blocks256 = (long long)p.B * p.H * ((p.Sq + 255) / 256);
+    qb = (p.D == 128) ? (blocks256 >= 192 ? 256 : 128) : (blocks256 >= 512 ? 256 : 128);
+  }
+  const bool aug = p.algo == 3;
+#define DA_A2(D_, NW_)                                                                                               \
+  return ns == 3 ? (aug ? da_attn2::launch<D_, NW_, 3, true>(p, s) : da_attn2::launch<D_, NW_, 3, false>(p, s))     \
+                 : (aug ? da_attn2::launch<D_, NW_, 4, true>(p, s) : da_attn2::launch<D_, NW_, 4, false>(p, s))
+  if (p.D == 64) {
+    if (qb == 256) DA_A2(64, 8);
+    DA_A2(64, 4);
+  }
+  if (qb == 256) DA_A2(128, 8);
+  DA_A2(128, 4);
+#undef DA_A2
+}

@@ -454,7 +454,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: 
               Skv_alloc: int, q_row_stride: int, k_row_stride: int, q_batch_stride: int, k_batch_stride: int,
               vt_ld: int, vt_batch_stride: int, scale: Optional[float] = None,
               out: Optional[torch.Tensor] = None, ring_slots: int = 0, causal: bool = False,
-              bias: Optional[torch.Tensor] = None, q_block: int = 0, pv_delay: int = 0) -> torch.Tensor:
+              bias: Optional[torch.Tensor] = None, q_block: int = 0, pv_delay: int = 0, algo: int = 0) -> torch.Tensor:
     """Flash attention over strided views; returns out [B*Sq][H*D].  ``causal`` / ``bias`` (D = 64 only): the masked
     variant for the text encoders -- ``bias`` is [B or 1][H or 1][Sq][>= ceil64(Skv)] (bf16 or fp32), added to
     scale * q.k^T; entries <= -1e29 mask a key."""
@@ -472,6 +472,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: 
     p.ring_slots = ring_slots
     p.q_block = q_block
     p.pv_delay = pv_delay
+    p.algo = algo
     p.causal = int(causal)
     if bias is not None:
         _req(bias, "bias", None)

@@ -235,14 +235,23 @@ typedef struct da_attention_params {
   const void* bias;
   long long bias_batch_stride, bias_head_stride; /* elements; 0 = shared across batches / heads */
   int bias_row_stride, bias_f32, causal;
-  int q_block; /* queries per workgroup: 0 / 128 = four waves (default), 64 = two waves (D = 64, unmasked, ring depth 2
-                  only; other cases run 128).  Speed only: each wave owns 32 queries and walks the same K / V^T tiles in
+  int q_block; /* queries per workgroup: 0 = default, 128 = four waves, 64 = two waves (first generation: D = 64, unmasked,
+                  ring depth 2 only; other cases run 128), 256 = eight waves (second generation, see algo).  Speed only: each wave owns 32 queries and walks the same K / V^T tiles in
                   the same order either way -> bit-identical outputs */
   int pv_delay; /* 0 = default for the head size, 1 = on, -1 = off.  On (D = 64 / 128, unmasked, 3 ring slots): the P.V
                    product of K / V tile j - 1 is issued after the Q.K^T product of tile j so that it runs under tile j's
                    softmax arithmetic.  2 (4 ring slots): tile j + 1's Q.K^T product rides in those softmax slices as well
                    (measured: no faster -- the loop is bound by its instruction issue, not by latency; kept as a variant).
                    Speed only: the same operations in the same order per accumulator. */
+  int algo; /* kernel generation.  0 = default: the second-generation kernel (attention2.hip: permuted-key Q.K^T so that V^T
+               fragments are single 16-byte reads, buffer-addressed staging, deferred running maximum, whole-row output stores,
+               128- or 256-query workgroups) wherever it exists -- unmasked, D = 64 / 128, no first-generation variant pinned
+               through ring_slots = 2 / q_block = 64 / pv_delay != 0 -- else the first-generation kernel;
+               1 = first generation (attention.hip) always; 2 = second generation or DA_ERR_UNSUPPORTED;
+               3 = second generation with the softmax shift folded into the Q.K^T product ("AUG": Q pre-multiplied by
+               scale * log2 e and rounded to bf16 once more, -m as one extra k-step).
+               The generations agree to bf16 rounding of the output, not bit for bit (different shift, different order of
+               the row sum); within the second generation q_block 128 / 256 and ring_slots 3 / 4 are bit-identical. */
 } da_attention_params;
 
 int da_attention_bf16(const da_attention_params* p, void* stream);

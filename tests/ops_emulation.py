@@ -139,7 +139,7 @@ def linear_small_m(x, w, bias=None, *, act_in=0, act_out=0, residual=None, out=N
 
 
 def attention(q, k, vt, *, B, H, D, Sq, Skv, Skv_alloc, q_row_stride, k_row_stride, q_batch_stride, k_batch_stride,
-              vt_ld, vt_batch_stride, scale=None, out=None, ring_slots=0, causal=False, bias=None, q_block=0, pv_delay=0):
+              vt_ld, vt_batch_stride, scale=None, out=None, ring_slots=0, causal=False, bias=None, q_block=0, pv_delay=0, algo=0):
     assert D in (64, 96, 128, 160) and Skv_alloc % 8 == 0 and Skv_alloc >= Skv
     for s_ in (q_row_stride, k_row_stride, q_batch_stride, k_batch_stride, vt_ld, vt_batch_stride):
         assert s_ % 8 == 0, "C ABI: attention strides % 8"

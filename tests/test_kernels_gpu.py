@@ -497,16 +497,29 @@ def test_flash_attention_query_block_sizes_are_bit_identical(B, H, Sq, Skv):
     kp[:, :Skv] = k
     vt = torch.zeros((C, B * sa), device=DEV, dtype=bf16)
     vt.view(C, B, sa)[:, :, :Skv] = v.permute(2, 0, 1)
-    def run(qb):
+    def run(qb, **kw):
         return ops.attention(q.view(B * Sq, C), kp.view(B * sa, C), vt, B=B, H=H, D=D, Sq=Sq, Skv=Skv, Skv_alloc=sa,
                              q_row_stride=C, k_row_stride=C, q_batch_stride=Sq * C, k_batch_stride=sa * C,
-                             vt_ld=B * sa, vt_batch_stride=sa, q_block=qb)
-    o128, o64, oauto = run(128), run(64), run(0)
+                             vt_ld=B * sa, vt_batch_stride=sa, q_block=qb, **kw)
+    # first generation (algo = 1; q_block = 64 exists only there and pins it)
+    o128, o64, oauto = run(128, algo=1), run(64), run(0, algo=1)
     assert torch.equal(o128, o64) and torch.equal(oauto, o128)
-    assert_close_bf16(o64, _attn_ref(q, k, v, H).view(B * Sq, C), f"flash attn q_block=64 B{B} H{H} Sq{Sq} Skv{Skv}",
-                      rtol=1.6e-2, atol_rms=1.6e-2)
+    ref = _attn_ref(q, k, v, H).view(B * Sq, C)
+    assert_close_bf16(o64, ref, f"flash attn q_block=64 B{B} H{H} Sq{Sq} Skv{Skv}", rtol=1.6e-2, atol_rms=1.6e-2)
+    # second generation (the default): 128- and 256-query workgroups, 3- and 4-tile rings -- every wave walks the same tiles in the
+    # same order with the same arithmetic
+    n128, n256, nauto = run(128, algo=2), run(256, algo=2), run(0)
+    assert torch.equal(n128, n256) and torch.equal(nauto, n128)
+    assert torch.equal(run(128, algo=2, ring_slots=4), n128) and torch.equal(run(256, algo=2, ring_slots=4), n128)
+    assert_close_bf16(n256, ref, f"flash attn v2 q_block=256 B{B} H{H} Sq{Sq} Skv{Skv}", rtol=1.6e-2, atol_rms=1.6e-2)
+    # ... and with the softmax shift folded into the first product (algo = 3: Q pre-scaled, one more bf16 rounding)
+    a128, a256 = run(128, algo=3), run(256, algo=3)
+    assert torch.equal(a128, a256)
+    assert_close_bf16(a128, ref, f"flash attn v2 aug B{B} H{H} Sq{Sq} Skv{Skv}", rtol=1.6e-2, atol_rms=1.6e-2)
     with pytest.raises(RuntimeError):
         run(32)
+    with pytest.raises(RuntimeError):
+        run(256, algo=1)
 
 
 @pytest.mark.parametrize("B,H,D,Sq,Skv", [(2, 3, 64, 256, 256), (1, 2, 64, 200, 333), (1, 5, 64, 1024, 1024), (2, 2, 64, 130, 77),
@@ -528,8 +541,8 @@ def test_flash_attention_pv_delay_is_bit_identical(B, H, D, Sq, Skv):
         return ops.attention(q.view(B * Sq, C), kp.view(B * sa, C), vt, B=B, H=H, D=D, Sq=Sq, Skv=Skv, Skv_alloc=sa,
                              q_row_stride=C, k_row_stride=C, q_batch_stride=Sq * C, k_batch_stride=sa * C,
                              vt_ld=B * sa, vt_batch_stride=sa, pv_delay=pd)
-    plain, delayed, auto = run(-1), run(1), run(0)
-    assert torch.equal(plain, delayed) and torch.equal(auto, plain)
+    plain, delayed = run(-1), run(1)                            # (a pinned pv_delay selects the first-generation kernel)
+    assert torch.equal(plain, delayed)
     # pv_delay = 2: the next tile's Q.K^T rides in the softmax slices as well (4-slot ring, the last MFMA of a score tile writes
     # the registers the softmax reads next) -- same operations, same order, same bits
     assert torch.equal(run(2), plain)
@@ -545,9 +558,44 @@ def test_flash_attention_rescale_branch():
     k[0, 400] = q[0, 17] * 4.0
     k[0, 3] = q[0, 100] * 3.0
     vt = v.permute(2, 0, 1).reshape(D, B * S).contiguous()
-    o = ops.attention(q.view(S, D), k.view(S, D), vt, B=B, H=H, D=D, Sq=S, Skv=S, Skv_alloc=S, q_row_stride=D,
-                      k_row_stride=D, q_batch_stride=S * D, k_batch_stride=S * D, vt_ld=S, vt_batch_stride=S)
-    assert_close_bf16(o, _attn_ref(q, k, v, H).view(S, D), "flash attn spiked keys", rtol=1.6e-2, atol_rms=1.6e-2)
+    ref = _attn_ref(q, k, v, H).view(S, D)
+    for algo in (0, 1, 2, 3):      # default, first generation, second generation (deferred maximum), shift folded into Q.K^T
+        o = ops.attention(q.view(S, D), k.view(S, D), vt, B=B, H=H, D=D, Sq=S, Skv=S, Skv_alloc=S, q_row_stride=D,
+                          k_row_stride=D, q_batch_stride=S * D, k_batch_stride=S * D, vt_ld=S, vt_batch_stride=S, algo=algo)
+        assert_close_bf16(o, ref, f"flash attn spiked keys algo {algo}", rtol=1.6e-2, atol_rms=1.6e-2)
+
+
+@pytest.mark.parametrize("D,S,Skv,lo", [(64, 300, 1000, -40.0), (128, 200, 700, -60.0), (64, 128, 77, 25.0), (128, 96, 320, 0.0)])
+def test_flash_attention_v2_deferred_maximum(D, S, Skv, lo):
+    """Second-generation kernel: the running shift is only raised when a row outgrows it by more than 2^8.  Scores with a large
+    common offset (very negative: the first tile must LOWER the initial shift of the AUG variant; very positive: it must raise
+    it at once), a slow upward drift (many small raises that stay under the threshold until they add up) and late spikes."""
+    ops, L = _ops()
+    B, H = 1, 2
+    C = H * D
+    q, k, v = rnd((B, S, C), 51), rnd((B, Skv, C), 52), rnd((B, Skv, C), 53)
+    k = k.float()
+    qn = q.float() / q.float().norm(dim=-1, keepdim=True)
+    # every score of query i gets the offset lo * (1 + drift): add a multiple of q_0's direction ... simpler: a shared direction u
+    u = torch.nn.functional.normalize(torch.randn(C, device=DEV), dim=0)
+    qf = q.float() + 6.0 * u                                      # all queries share a strong component along u
+    drift = torch.linspace(0.0, 1.0, Skv, device=DEV)[None, :, None]
+    k = k + (lo / 6.0 + 4.0 * drift) * u * (D ** 0.5) / H        # keys walk along u: scores = lo + slow upward drift
+    k[0, Skv - 5] += qn[0, 7] * 30.0                              # late spikes
+    k[0, Skv // 3] += qn[0, S - 1] * 20.0
+    q, k = qf.to(bf16), k.to(bf16)
+    sa = ((Skv + 15) // 16) * 16
+    kp = torch.zeros((B, sa, C), device=DEV, dtype=bf16)
+    kp[:, :Skv] = k
+    vt = torch.zeros((C, B * sa), device=DEV, dtype=bf16)
+    vt.view(C, B, sa)[:, :, :Skv] = v.permute(2, 0, 1)
+    ref = _attn_ref(q, k, v, H).view(B * S, C)
+    for algo in (2, 3):
+        o = ops.attention(q.view(B * S, C), kp.view(B * sa, C), vt, B=B, H=H, D=D, Sq=S, Skv=Skv, Skv_alloc=sa,
+                          q_row_stride=C, k_row_stride=C, q_batch_stride=S * C, k_batch_stride=sa * C, vt_ld=B * sa,
+                          vt_batch_stride=sa, algo=algo)
+        assert torch.isfinite(o.float()).all()
+        assert_close_bf16(o, ref, f"flash attn v2 deferred max D{D} S{S} Skv{Skv} offset {lo} algo {algo}", rtol=2e-2, atol_rms=2e-2)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
