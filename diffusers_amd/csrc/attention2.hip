@@ -433,12 +433,14 @@ int da_attn2_dispatch(const da_attention_params& p, hipStream_t s) {
   if ((size_t)p.Skv_alloc * (size_t)p.k_row_stride * 2 + 64ull * p.k_row_stride * 2 >= 0x7fffffffull) return DA_ERR_UNSUPPORTED;
   if ((size_t)p.D * (size_t)p.vt_ld * 2 + (size_t)p.Skv_alloc * 2 >= 0x7fffffffull) return DA_ERR_UNSUPPORTED;
   const int ns = p.ring_slots ? p.ring_slots : 3;
-  // queries per workgroup: eight waves halve the K / V^T traffic per flop and give D = 128 (one workgroup per CU) two waves per
-  // SIMD; four waves keep more, smaller workgroups for short sequences (load balance over 256 CUs)
+  // Queries per workgroup, measured (profiles/r04a_attention_v2.md).  D = 128 (one workgroup per CU either way): eight waves put two
+  // waves on every SIMD and halve the K / V^T stream per flop -- 1.35x over four (Flux 332 -> 245 us, Wan 9.3 -> 7.8 ms) whenever
+  // there are enough 256-query workgroups to cover the chip.  D = 64: three 128-query workgroups per CU (three waves per SIMD, by
+  // registers) beat one 256-query workgroup (two per SIMD) as soon as the launch has more than two workgroups per CU, and tie below.
   int qb = p.q_block;
   if (qb == 0) {
     const long long blocks256 = (long long)p.B * p.H * ((p.Sq + 255) / 256);
-    qb = (p.D == 128) ? (blocks256 >= 192 ? 256 : 128) : (blocks256 >= 512 ? 256 : 128);
+    qb = (p.D == 128 && blocks256 >= 192) ? 256 : 128;
   }
   const bool aug = p.algo == 3;
 #define DA_A2(D_, NW_)                                                                                               \

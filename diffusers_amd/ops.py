@@ -170,6 +170,7 @@ def _select_variant(p: "L.GemmParams", tile: Optional[int], staging: Optional[in
     if want_ws and not inplace:
         ws, flags = splitk_workspace(device, stream)
         p.workspace, p.sync_flags, p.workspace_bytes = ws.data_ptr(), flags.data_ptr(), ws.numel()
+    p._auto = auto
     if auto:
         p.tile, p.staging, sk = tuning.lookup(p, stream, inplace=inplace)
         p.split_k = sk if p.workspace else 1
@@ -181,6 +182,21 @@ def _select_variant(p: "L.GemmParams", tile: Optional[int], staging: Optional[in
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+DA_ERR_UNSUPPORTED = 3
+
+
+def _launch_gemm(p: "L.GemmParams", st: int, what: str) -> None:
+    """da_gemm_bf16 with the selected variant.  The per-shape table is keyed by shape only, but the second kernel family
+    (tiles >= FIRST_K2_TILE) also looks at operand alignment / strides and the 31-bit offset budget of its staging: when a
+    TABLE-selected variant is refused for such a property the launch is retried with the library's own choice from the first
+    family (TILE_AUTO), which serves every operand layout.  A variant the CALLER pinned is never replaced."""
+    rc = L.load().da_gemm_bf16(C.byref(p), st)
+    if rc == DA_ERR_UNSUPPORTED and getattr(p, "_auto", False) and p.tile != L.TILE_AUTO:
+        p.tile, p.staging, p.split_k = L.TILE_AUTO, L.STAGE_LDS_DIRECT, 1
+        rc = L.load().da_gemm_bf16(C.byref(p), st)
+    L.check(rc, what)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -232,13 +248,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                            prefetch=prefetch)
     if p is None:
         return st     # the skinny-M path ran
-    L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(linear)")
+    _launch_gemm(p, st, "da_gemm_bf16(linear)")
     return p._out
 
 
 def linear_pair(a: dict, b: dict):
     """Two independent nn.Linear problems in ONE launch (da_gemm_pair_bf16): ``a`` / ``b`` are keyword dicts of
-    :func:`linear` (x, w, bias, ...).  Bit-identical to two :func:`linear` calls; used where neither problem fills the
+    :func:`linear` (x, w, bias, ...).  The paired launch runs the first kernel family (csrc/gemm_kernel.cuh): bit-identical to
+    two :func:`linear` calls pinned to a first-family tile, and within one bf16 ulp of the rounded GEMM term of launches the
+    table sends to the second family (a different fp32 summation order of K).  Used where neither problem fills the
     256 CUs on its own (the Q|K and V^T projections of a self-attention layer).  Falls back to two launches when the
     paired variant is unknown and cannot be tuned now, or is not faster than the two separate launches."""
     if a["x"].shape[0] <= 8 or b["x"].shape[0] <= 8:
@@ -256,8 +274,8 @@ def linear_pair(a: dict, b: dict):
         if all(sep) and pair[2] >= sep[0][2] + sep[1][2]:
             pair = None
     if pair is None:
-        L.check(lib.da_gemm_bf16(C.byref(pa), st), "da_gemm_bf16(linear)")
-        L.check(lib.da_gemm_bf16(C.byref(pb), st), "da_gemm_bf16(linear)")
+        _launch_gemm(pa, st, "da_gemm_bf16(linear)")
+        _launch_gemm(pb, st, "da_gemm_bf16(linear)")
     else:
         pa.tile, pa.staging, pa.split_k, pb.split_k = pair[0], pair[1], 1, 1
         L.check(lib.da_gemm_pair_bf16(C.byref(pa), C.byref(pb), st), "da_gemm_pair_bf16")
@@ -406,7 +424,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     _prefetch_hook(p, x, w)
     st = _stream()
     _select_variant(p, tile, staging, st, inplace=inplace, split_k=split_k, device=x.device)
-    L.check(L.load().da_gemm_bf16(C.byref(p), st), "da_gemm_bf16(conv)")
+    _launch_gemm(p, st, "da_gemm_bf16(conv)")
     return out
 
 
@@ -891,7 +909,8 @@ _thin_out_cache = {}
 def pad_thin_out(w: torch.Tensor, bias: Optional[torch.Tensor]):
     """[Cout][K] (+ bias) zero-padded to THIN_OUT_PAD output channels, cached on the packed weight's identity (models pack once;
     the padded copy must exist before a HIP-graph capture, which the pipelines' warm-up pass guarantees)."""
-    key = (w.data_ptr(), w._version if not w.is_inference() else -1, tuple(w.shape), bias.data_ptr() if bias is not None else 0)
+    key = (w.data_ptr(), w._version if not w.is_inference() else -1, tuple(w.shape), bias.data_ptr() if bias is not None else 0,
+           (bias._version if not bias.is_inference() else -1) if bias is not None else 0)
     ent = _thin_out_cache.get(key)
     if ent is None:
         wp = torch.zeros((THIN_OUT_PAD, w.shape[1]), device=w.device, dtype=w.dtype)
@@ -900,9 +919,9 @@ def pad_thin_out(w: torch.Tensor, bias: Optional[torch.Tensor]):
         if bias is not None:
             bp = torch.zeros((THIN_OUT_PAD,), device=w.device, dtype=bias.dtype)
             bp[: w.shape[0]] = bias
-        if len(_thin_out_cache) > 64:
-            _thin_out_cache.clear()
-        ent = _thin_out_cache[key] = (wp, bp, w)      # keeps `w` alive: its address is the key
+        # Entries are never evicted: a captured HIP graph references the padded copies by raw pointer only (a few KiB per
+        # thin-output conv, one or two per model).  An in-place edit of the weight / bias (LoRA fuse) makes a new entry.
+        ent = _thin_out_cache[key] = (wp, bp, w, bias)      # keeps `w` / `bias` alive: their addresses are the key
     return ent[0], ent[1]
 
 
