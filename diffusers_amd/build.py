@@ -40,6 +40,28 @@ def _fingerprint() -> str:
     return h.hexdigest()
 
 
+def _unit_fingerprint(src: Path, flags) -> str:
+    import re
+    seen, todo = {}, [src]
+    while todo:
+        f = todo.pop()
+        if f in seen or not f.exists():
+            continue
+        text = f.read_bytes()
+        seen[f] = text
+        for name in re.findall(rb'#include\s+"([^"]+)"', text):
+            for base in (f.parent, CSRC, ROOT / "include"):
+                cand = base / name.decode()
+                if cand.exists():
+                    todo.append(cand)
+                    break
+    h = hashlib.sha256(" ".join(flags).encode())
+    for f in sorted(seen):
+        h.update(f.name.encode())
+        h.update(seen[f])
+    return h.hexdigest()
+
+
 def build_extension(force: bool = False, verbose: bool = False) -> Path:
     """Compile every ``csrc/*.hip`` for gfx950 and link ``libdiffusers_amd.so``; returns the library path."""
     OUT_DIR.mkdir(exist_ok=True)
@@ -55,13 +77,20 @@ def build_extension(force: bool = False, verbose: bool = False) -> Path:
     objs = []
 
     def compile_one(src: Path) -> Path:
+        # per-object stamp: the source, the headers it includes (transitively) and the flags -- an unchanged translation unit is
+        # not recompiled (the two GEMM families take minutes)
         obj = OUT_DIR / (src.stem + ".o")
+        ostamp = OUT_DIR / (src.stem + ".o.stamp")
+        ofp = _unit_fingerprint(src, flags)
+        if not force and obj.exists() and ostamp.exists() and ostamp.read_text().strip() == ofp:
+            return obj
         cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
+        ostamp.write_text(ofp)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:

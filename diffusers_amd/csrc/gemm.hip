@@ -93,7 +93,11 @@ int validate(da_gemm_params& p) {
   return DA_OK;
 }
 
-int stats_parts(const da_gemm_params& p, int tile) {   // one partial per column tile
+int stats_parts(const da_gemm_params& p, int tile) {   // one partial per column tile (K2 family: per 80-column wave band)
+  if (is_k2(tile)) {
+    const int band = (tile == DA_TILE_K2_128x80 || tile == DA_TILE_K2_128x160) ? 80 : 0;
+    return band ? (p.N + band - 1) / band : 0;
+  }
   return (p.N + kTiles[tile].bn - 1) / kTiles[tile].bn;
 }
 
@@ -103,7 +107,13 @@ bool tile_ok(const da_gemm_params& p, int tile) {
     const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
     const bool geglu_ok = tile == DA_TILE_K2_128x128 || tile == DA_TILE_K1_256x128 || tile == DA_TILE_K1_128x256 ||
                           tile == DA_TILE_K1_256x256 || tile == DA_TILE_K1_256x320 || (tile == DA_TILE_K1_128x320 && !p.conv);
-    return !p.stats_out && !p.ln_stats && p.split_k <= 1 && (!geglu || geglu_ok) &&
+    // LayerNorm fold (round 4): nn.Linear, the tiles of the SDXL transformer blocks (gemm2_kernel.cuh dispatch_lnf)
+    if (p.stats_out || p.ln_stats) {
+      if (p.conv || p.split_k > 1) return false;
+      if (p.stats_out && (geglu || (tile != DA_TILE_K2_128x80 && tile != DA_TILE_K2_128x160))) return false;
+      return geglu ? tile == DA_TILE_K1_128x320 : (tile == DA_TILE_K2_128x80 || tile == DA_TILE_K2_128x160);
+    }
+    return p.split_k <= 1 && (!geglu || geglu_ok) &&
            !(p.conv && (tile == DA_TILE_K2_80x128 || tile == DA_TILE_K1_256x256 || tile == DA_TILE_K1_256x320));
   }
   // GEGLU pairs (value, gate) 32-column tiles inside one wave: the wave must own an even number of them
@@ -144,7 +154,7 @@ extern "C" int da_gemm_bf16(const da_gemm_params* pp, void* stream) {
   int tile = p.tile;
   if (tile == DA_TILE_AUTO) tile = pick_tile(p);
   if (!tile_ok(p, tile)) return DA_ERR_UNSUPPORTED;
-  if (p.stats_out && p.stats_ld < 2 * stats_parts(p, tile)) return DA_ERR_INVALID;
+  if (p.stats_out && (stats_parts(p, tile) <= 0 || p.stats_ld < 2 * stats_parts(p, tile))) return DA_ERR_INVALID;
   return run(p, tile, p.staging, (hipStream_t)stream);
 }
 

@@ -128,7 +128,16 @@ __device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int
 // GIL (KG == 1, two wave columns) = GEGLU-interleaved column ownership: of each 64-column [32 value | 32 gate] group of the packed weight a
 //          wave owns the 16-column tiles {wn, wn + 2} (one value tile and ITS gate tile), so a wave tile whose width (160)
 //          is not a multiple of 64 can still finish GEGLU on its own accumulators.
-template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false>
+// LNF = LayerNorm fold (da_gemm_params.stats_out / ln_*), nn.Linear only, in its OWN instantiations: carried by every kernel the
+//          fold's registers cost the register-heaviest tiles 5-9 % (profiles/r02d_layernorm_fold.md).
+//          Producer (stats_out): the row-contiguous store path also sums the bf16-ROUNDED values it stores (what a LayerNorm
+//          kernel would read): every lane's 8 channels -> LDS -> 16 lanes add the PPR pieces of their row in piece order
+//          (deterministic) and write ONE (sum, sum of squares) pair per (row, 16 NH-column band).
+//          Consumer (ln_stats): mean / rstd of the rows a lane finishes, formed from the producer's partials (loaded with the
+//          other epilogue operands, behind the first LDS-DMA), and rstd * (acc - mean * s[n]) + c[n] applied to every
+//          accumulator group in front of the bias.
+template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false,
+          bool LNF = false>
 __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert((KG == 1 || KG == 2) && KG * WM * WN == 8, "eight waves: one or two K-groups");
@@ -138,6 +147,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   static_assert(!PP || KG == 2, "ping-pong is a property of the two K-groups");
   static_assert(!STREAMW || (KG == 1 && NSLOT == 2 && !CONV), "streaming-W loop: one K-group, two-slice ring, nn.Linear");
   static_assert(!GIL || (KG == 1 && !CONV && WN == 2 && (NT % 2) == 0), "GEGLU-interleaved ownership: two wave columns, value / gate tile pairs");
+  static_assert(!LNF || (!CONV && !STREAMW), "LayerNorm fold: nn.Linear instantiations of the ring loops");
   constexpr int SW = PP ? 4 : 8;                          // waves that share the staging of one unit (PP: one slice, own group)
   constexpr int UX = PP ? PX : KG * PX, UW = PP ? PW : KG * PW;   // pieces of that unit
   constexpr int XI = (UX + SW - 1) / SW, WI = (UW + SW - 1) / SW;   // LDS-DMA instructions per wave per unit (upper bound)
@@ -390,6 +400,8 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   constexpr bool STG = NH >= 2;
   constexpr int PPR = 2 * NH, NPIECE = 16 * PPR, TT = (NPIECE + 63) / 64, ROWB = NH * 64 + 32;   // (ROWB / 2: the packed rows)
   static_assert(!STG || (KG == 2 ? 4 * MT * NT * 1024 : 0) + 8 * 16 * ROWB <= NSLOT * PAIR, "output staging does not fit the ring");
+  constexpr int STATS_OFF = (KG == 2 ? 4 * MT * NT * 1024 : 0) + 8 * 16 * ROWB;   // LNF producer: 8 waves x TT * 64 float2 slots
+  static_assert(!(LNF && STG) || STATS_OFF + 8 * TT * 64 * 8 <= NSLOT * PAIR, "statistics scratch does not fit the ring");
   const bool wide = STG && !GIL && !geglu && !p.out_f32 && !(p.ldc & 7) && !((size_t)p.C & 15) && !(p.N & 7) &&
                     (!p.residual || (!(p.ldr & 7) && !((size_t)p.residual & 15)));
   const int band_col0 = n0 + (wn * NT + (SPLIT_M ? 0 : g * NH)) * 16;
@@ -411,9 +423,29 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
     for (int t = 0; t < ((PF && STG) ? TT : 1); ++t) resw[ih][t] = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int jh = 0; jh < NH; ++jh) bias_v[jh] = make_uint2(0, 0);
+  // LayerNorm fold, consumer side: the 24 (sum, sum of squares) slots of a row this lane finishes are read by its four kq lanes,
+  // six slots (three 16-byte loads) each; rows hold DA_LN_MAX_PARTS slots, the ones past ln_parts are masked when summed.
+  constexpr bool LN_PF = LNF && MH == 1;                  // (more rows per lane: no registers to carry them through the K loop -- loaded behind it)
+  float4 lnq[LN_PF ? MH : 1][3];
+#pragma unroll
+  for (int ih = 0; ih < (LN_PF ? MH : 1); ++ih)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) lnq[ih][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto ln_load = [&](int ih, float4* dst) {
+    const int m = min(row_of(ih), p.M - 1);
+    const float* sp = p.ln_stats + (size_t)m * p.ln_stats_ld + 12 * kq;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) dst[u] = *(const float4*)(sp + 4 * u);
+  };
   // Issued right behind the FIRST pair's LDS-DMA (the matrix stream starts first; these loads are older than pairs 1 .. and
   // therefore covered by every counted wait that covers pair 0).
   auto prefetch_epilogue_operands = [&]() {
+    if constexpr (LN_PF) {
+      if (p.ln_stats) {
+#pragma unroll
+        for (int ih = 0; ih < MH; ++ih) ln_load(ih, lnq[ih]);
+      }
+    }
     const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
     const uint16_t* __restrict__ bias = (const uint16_t*)p.bias;
     const uint16_t* __restrict__ rowvec = (const uint16_t*)p.rowvec;
@@ -695,6 +727,53 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
     }
   }
   DA2_TRACE(5);                                           // partial sums exchanged
+  // LayerNorm fold, consumer side: mean / rstd of the MH rows this lane finishes.  Each kq lane adds its six slots in slot order,
+  // the four lanes of a row combine as (a + b) + (c + d): the same bits in all four.
+  float ln_mu[MH], ln_rs[MH];
+#pragma unroll
+  for (int ih = 0; ih < MH; ++ih) ln_mu[ih] = 0.f, ln_rs[ih] = 1.f;
+  const bool ln_on = LNF && p.ln_stats != nullptr;
+  if constexpr (LNF) {
+    if (ln_on) {
+      const float inv_c = 1.0f / (float)p.K;              // the normalised dimension is this GEMM's K
+#pragma unroll
+      for (int ih = 0; ih < MH; ++ih) {
+        float4 v[3];
+        if constexpr (LN_PF) {
+#pragma unroll
+          for (int u = 0; u < 3; ++u) v[u] = lnq[ih][u];
+        } else {
+          ln_load(ih, v);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int q = 6 * kq + 2 * u;
+          s1 += (q < p.ln_parts ? v[u].x : 0.f) + (q + 1 < p.ln_parts ? v[u].z : 0.f);
+          s2 += (q < p.ln_parts ? v[u].y : 0.f) + (q + 1 < p.ln_parts ? v[u].w : 0.f);
+        }
+        s1 += __shfl_xor(s1, 16, 64);
+        s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float mean = s1 * inv_c;
+        ln_mu[ih] = mean;
+        ln_rs[ih] = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + p.ln_eps);
+      }
+    }
+  }
+  // o[0..3] = alpha * acc of row tile ih, columns n .. n + 3  ->  LayerNorm-folded value (identity without ln_stats)
+  auto ln_apply4 = [&](float* o, int ih, int n) __attribute__((always_inline)) {
+    if constexpr (LNF) {
+      if (ln_on) {
+        const float4 sv = *(const float4*)(p.ln_s + n), cv = *(const float4*)(p.ln_c + n);
+        o[0] = ln_rs[ih] * (o[0] - ln_mu[ih] * sv.x) + cv.x;
+        o[1] = ln_rs[ih] * (o[1] - ln_mu[ih] * sv.y) + cv.y;
+        o[2] = ln_rs[ih] * (o[2] - ln_mu[ih] * sv.z) + cv.z;
+        o[3] = ln_rs[ih] * (o[3] - ln_mu[ih] * sv.w) + cv.w;
+      }
+    }
+  };
   // ---- epilogue: lane holds, for output row (r16 of a 16-row tile), channels 4 kq .. 4 kq + 3 of a 16-column tile ----
   const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
   const bool has_rowvec = p.rowvec != nullptr, has_res = p.residual != nullptr;
@@ -728,10 +807,14 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
 #pragma unroll
           for (int u = 0; u < NT / 2; ++u) {
             const uint2 bh = bias_v[2 * u], bg = bias_v[2 * u + 1];      // zeros without a bias
-            float o[4];
+            float o[4], hq[4], gq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hq[e] = keep[ih][2 * u][e] * p.alpha, gq[e] = keep[ih][2 * u + 1][e] * p.alpha;
+            ln_apply4(hq, ih, min(col_of(2 * u), p.N - 4));
+            ln_apply4(gq, ih, min(col_of(2 * u + 1), p.N - 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float hv = keep[ih][2 * u][e] * p.alpha, gv = keep[ih][2 * u + 1][e] * p.alpha;
+              float hv = hq[e], gv = gq[e];
               hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
               gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
               hv = bf2f(f2bf(hv));   // the reference rounds the projection to bf16 before chunk / gelu / mul
@@ -779,10 +862,14 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
               if (nv >= p.N) continue;
               const int no = (n0 >> 1) + (wn * (NT / 4) + u) * 32 + v * 16 + 4 * kq;
               const uint2 bh = bias_v[jv], bg = bias_v[jg];          // zeros without a bias
-              float o[4];
+              float o[4], hq[4], gq[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) hq[e] = keep[ih][jv][e] * p.alpha, gq[e] = keep[ih][jg][e] * p.alpha;
+              ln_apply4(hq, ih, nv);
+              ln_apply4(gq, ih, col_of(jg));
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                float hv = keep[ih][jv][e] * p.alpha, gv = keep[ih][jg][e] * p.alpha;
+                float hv = hq[e], gv = gq[e];
                 hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
                 gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
                 hv = bf2f(f2bf(hv));   // the reference rounds the projection to bf16 before chunk / gelu / mul
@@ -828,6 +915,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
+          ln_apply4(o, ih, n);
           uint2 rvv = make_uint2(0, 0);
           if constexpr (PF) rvv = rowvec_v[ih][jh];
           else if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
@@ -842,30 +930,59 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
           }
         }
         // ... and back, 8 consecutive channels of one row per lane: + residual, * out_scale, one 16-byte store
+        // (LNF producer: the lane's share of its row's statistics, from the ROUNDED values, goes to the wave's scratch slots)
+        float2* part = (float2*)(smem + STATS_OFF) + wave * (TT * 64);
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
           const int q = lane + 64 * t;
           if (NPIECE % 64 != 0 && q >= NPIECE) continue;
           const int row = q / PPR, c8 = q % PPR;
           const int mo = band_row0(ih) + row, no = band_col0 + c8 * 8;
-          if constexpr (PACKED) {
-            const uint4 pk = *(const uint4*)(stg + row * (ROWB / 2) + c8 * 16);
-            if (mo < p.M && no < p.N) *(uint4*)((uint16_t*)p.C + (size_t)mo * p.ldc + no) = pk;
-            continue;
-          }
-          const float4 lo = *(const float4*)(stg + row * ROWB + c8 * 32), hi = *(const float4*)(stg + row * ROWB + c8 * 32 + 16);
-          float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          if (mo >= p.M || no >= p.N) continue;
-          uint4 rw = make_uint4(0, 0, 0, 0);
-          if constexpr (PF) rw = resw[ih][t];
-          else if (has_res) rw = *(const uint4*)(resid + (size_t)mo * p.ldr + no);
-          o[0] += bf_lo(rw.x); o[1] += bf_hi(rw.x); o[2] += bf_lo(rw.y); o[3] += bf_hi(rw.y);
-          o[4] += bf_lo(rw.z); o[5] += bf_hi(rw.z); o[6] += bf_lo(rw.w); o[7] += bf_hi(rw.w);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] *= p.out_scale;
+          const bool inside = mo < p.M && no < p.N;
           uint4 pk;
-          pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]); pk.z = pack_bf2(o[4], o[5]); pk.w = pack_bf2(o[6], o[7]);
-          *(uint4*)((uint16_t*)p.C + (size_t)mo * p.ldc + no) = pk;
+          if constexpr (PACKED) {
+            pk = *(const uint4*)(stg + row * (ROWB / 2) + c8 * 16);
+          } else {
+            const float4 lo = *(const float4*)(stg + row * ROWB + c8 * 32), hi = *(const float4*)(stg + row * ROWB + c8 * 32 + 16);
+            float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            uint4 rw = make_uint4(0, 0, 0, 0);
+            if constexpr (PF) rw = resw[ih][t];
+            else if (has_res && inside) rw = *(const uint4*)(resid + (size_t)mo * p.ldr + no);
+            o[0] += bf_lo(rw.x); o[1] += bf_hi(rw.x); o[2] += bf_lo(rw.y); o[3] += bf_hi(rw.y);
+            o[4] += bf_lo(rw.z); o[5] += bf_hi(rw.z); o[6] += bf_lo(rw.w); o[7] += bf_hi(rw.w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= p.out_scale;
+            pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]); pk.z = pack_bf2(o[4], o[5]); pk.w = pack_bf2(o[6], o[7]);
+          }
+          if (inside) *(uint4*)((uint16_t*)p.C + (size_t)mo * p.ldc + no) = pk;
+          if constexpr (LNF) {
+            if (p.stats_out) {
+              float r[8];
+              unpack8(pk, r);
+              const float s1 = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+              const float s2 = ((r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3])) +
+                               ((r[4] * r[4] + r[5] * r[5]) + (r[6] * r[6] + r[7] * r[7]));
+              part[q] = inside ? make_float2(s1, s2) : make_float2(0.f, 0.f);
+            }
+          }
+        }
+        if constexpr (LNF) {
+          if (p.stats_out) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private slots: no barrier
+            if (lane < 16) {
+              float a = 0.f, b = 0.f;
+#pragma unroll
+              for (int c = 0; c < PPR; ++c) {                       // piece order: a fixed summation order
+                const float2 v = part[lane * PPR + c];
+                a += v.x;
+                b += v.y;
+              }
+              const int mo = band_row0(ih) + lane;
+              if (mo < p.M && band_col0 < p.N)
+                *(float2*)(p.stats_out + (size_t)mo * p.stats_ld + 2 * (band_col0 / (16 * NH))) = make_float2(a, b);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the slots are rewritten by the next row tile
+          }
         }
       }
     }
@@ -885,6 +1002,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
+        ln_apply4(o, ih, n);
         uint2 rvv = make_uint2(0, 0), rsv = make_uint2(0, 0);
         if constexpr (PF) rvv = rowvec_v[ih][jh];
         else if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
@@ -965,14 +1083,15 @@ inline bool staging_fits(const da_gemm_params& p) {
   return span * cmax * 2 < lim && (size_t)p.M / ((size_t)p.Hout * p.Wout) * p.Hin * p.Win < 0x7fffffffull;
 }
 
-template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false>
+template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false,
+          bool LNF = false>
 int launch(const da_gemm_params& p, hipStream_t s) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int gx = choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
   constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + 1024;   // ring + the scratch KiB (ragged pieces, prefetch)
-  auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP, STREAMW, GIL>;
+  auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP, STREAMW, GIL, LNF>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -986,9 +1105,48 @@ int launch(const da_gemm_params& p, hipStream_t s) {
 
 // K2 tile codes -> instantiations.  staging: DA_STAGE_LDS_DIRECT = ring of 2 slice pairs, DA_STAGE_LDS_DIRECT3 = 3 (where it fits);
 // DA_STAGE_PINGPONG / DA_STAGE_PINGPONG3 = the same rings with the two K-groups half an iteration apart (KG == 2 tiles only).
+// Column band of one statistics partial of a K2 tile that can PRODUCE them (0: it cannot): 16 * NH columns.
+inline int stats_band_cols(int tile) { return (tile == DA_TILE_K2_128x80 || tile == DA_TILE_K2_128x160) ? 80 : 0; }
+
+// LayerNorm-fold instantiations (nn.Linear): the tiles the SDXL transformer blocks use -- 128 x 80 / 128 x 160 as producer
+// (to_out, + residual) and consumer (to_q), the interleaved-ownership GEGLU tile (128 x 320) as consumer.
+inline int dispatch_lnf(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
+  const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
+  const int ns = (staging == DA_STAGE_LDS_DIRECT || staging == DA_STAGE_PINGPONG) ? 2
+                 : (staging == DA_STAGE_LDS_DIRECT3 || staging == DA_STAGE_PINGPONG3) ? 3 : 0;
+  const bool pp = staging == DA_STAGE_PINGPONG || staging == DA_STAGE_PINGPONG3;
+  if (ns == 0) return DA_ERR_UNSUPPORTED;
+  if (p.stats_out) {
+    // statistics come out of the row-contiguous store path only: 16-byte aligned bf16 rows (and residual rows)
+    if (geglu || p.out_f32 || (p.ldc & 7) || ((size_t)p.C & 15) || (p.N & 7) || p.gate ||
+        (p.residual && ((p.ldr & 7) || ((size_t)p.residual & 15))) || stats_band_cols(tile) == 0)
+      return DA_ERR_UNSUPPORTED;
+  }
+  switch (tile) {
+    case DA_TILE_K2_128x80:
+      if (geglu) break;
+      if (pp) return ns == 2 ? launch<2, 4, 1, 2, 5, 2, false, true, false, false, true>(p, s)
+                             : launch<2, 4, 1, 2, 5, 3, false, true, false, false, true>(p, s);
+      return ns == 2 ? launch<2, 4, 1, 2, 5, 2, false, false, false, false, true>(p, s)
+                     : launch<2, 4, 1, 2, 5, 3, false, false, false, false, true>(p, s);
+    case DA_TILE_K2_128x160:
+      if (geglu || ns != 2) break;
+      return pp ? launch<2, 2, 2, 4, 5, 2, false, true, false, false, true>(p, s)
+                : launch<2, 2, 2, 4, 5, 2, false, false, false, false, true>(p, s);
+    case DA_TILE_K1_128x320:
+      if (!geglu || p.stats_out || ns != 2 || pp || (p.ldc & 7) || ((size_t)p.C & 15) || (p.N & 15)) break;
+      return launch<1, 4, 2, 2, 10, 2, false, false, false, true, true>(p, s);
+  }
+  return DA_ERR_UNSUPPORTED;
+}
+
 template <bool CONV>
 int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
-  if (p.split_k > 1 || p.stats_out || p.ln_stats || !staging_fits(p)) return DA_ERR_UNSUPPORTED;
+  if (p.split_k > 1 || !staging_fits(p)) return DA_ERR_UNSUPPORTED;
+  if (p.stats_out || p.ln_stats) {
+    if constexpr (CONV) return DA_ERR_UNSUPPORTED;
+    else return dispatch_lnf(p, tile, staging, s);
+  }
   const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
   // GEGLU: the value / gate column tiles of a 64-row group must share a wave (wave tiles whose width is a multiple of 64)
   if (geglu && tile != DA_TILE_K2_128x128 && tile != DA_TILE_K1_256x128 && tile != DA_TILE_K1_128x256 && tile != DA_TILE_K1_256x256 &&

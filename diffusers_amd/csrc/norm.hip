@@ -7,6 +7,8 @@
 //                        models/unets/unet_2d_condition.py:1228  models/autoencoders/vae.py:305
 //                        models/attention_processor.py:2740 ; followed by SiLU at resnet.py:327,:362 etc.
 //   nn.LayerNorm(C)      models/attention.py:986,:1030,:1056 (BasicTransformerBlock norm1/2/3)
+#include <cstdlib>
+
 #include "common.cuh"
 
 namespace {
@@ -475,18 +477,25 @@ int launch_rms_channels(const void* x, const void* gamma, void* y, long long row
 struct GnPlan {
   int threads, krows, nblk, pix_per_blk;
 };
+// Plan knobs (experiments only: DA_GN_THREADS / DA_GN_MINPIX / DA_GN_MAXBLK override the defaults below; read once)
+int gn_knob(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 GnPlan gn_plan(int B, int HW, int C) {
+  static const int k_threads = gn_knob("DA_GN_THREADS", 256), k_minpix = gn_knob("DA_GN_MINPIX", 8),
+                   k_maxblk = gn_knob("DA_GN_MAXBLK", 512), k_cap = gn_knob("DA_GN_CAP", 2048);
   GnPlan g;
   const int cpr = C / 8;
-  int k = 256 / cpr;
+  int k = k_threads / cpr;
   if (k < 1) k = 1;
   while (k > 1 && cpr * k > 512) --k;
   g.krows = k;
   g.threads = cpr * k;
-  int nblk = (HW + 8 * k - 1) / (8 * k);  // at least 8 pixels per thread row (two rounds of 4 loads in flight)
-  const int cap = 2048 / (B > 0 ? B : 1);
+  int nblk = (HW + k_minpix * k - 1) / (k_minpix * k);  // at least 8 pixels per thread row (two rounds of 4 loads in flight)
+  const int cap = k_cap / (B > 0 ? B : 1);
   if (nblk > cap) nblk = cap;
-  if (nblk > 512) nblk = 512;
+  if (nblk > k_maxblk) nblk = k_maxblk;
   if (nblk < 1) nblk = 1;
   int ppb = (HW + nblk - 1) / nblk;
   ppb = ((ppb + k - 1) / k) * k;

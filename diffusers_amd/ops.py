@@ -128,6 +128,7 @@ def splitk_error(device=None) -> bool:
 # default: measured on an MI355X (profiles/r02d_layernorm_fold.md) the folded consumers cost +4.5 us (to_q) and +15 us (GEGLU
 # projection) against the 8.6 us LayerNorm launch + ~1.5 us boundary they remove -- a wash for norm2, a loss for norm3.
 LN_FOLD = os.environ.get("DIFFUSERS_AMD_LN_FOLD", "0") == "1"
+LN_FOLD_K2 = os.environ.get("DIFFUSERS_AMD_LN_FOLD_K2", "1") == "1"   # folded launches may use the second kernel family (round 4)
 STATS_MAX_PARTS = 64          # DA_LN_MAX_PARTS: slots per row of a statistics buffer
 STATS_MAX_CONSUMED = 24       # 4 * DA_LN_PAIR_LOADS: partials per row a consumer launch reads
 
@@ -338,10 +339,23 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         p.ln_s, p.ln_c, p.ln_eps = fold.s.data_ptr(), fold.c.data_ptr(), fold.eps
     tile_given = tile is not None
     if (stats_out is not None or ln is not None) and tile is None:
-        # the LayerNorm fold lives in its own kernel instantiations (a subset of the variants; the per-shape table knows
-        # nothing about them): fixed choices that measured best on the SDXL shapes (profiles/r02d_layernorm_fold.md)
-        tile, staging, split_k = ((L.TILE_128x128, L.STAGE_LDS_DIRECT) if act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH)
-                                  else (L.TILE_128x64, L.STAGE_LDS_DIRECT3)) + (1,)
+        # The LayerNorm fold lives in its own kernel instantiations (a subset of the variants).  Round 4: the second kernel family
+        # carries it on the tiles the SDXL transformer blocks use -- when the per-shape table sends the SAME problem without the
+        # fold to one of them (and the operands have the 16-byte aligned rows its row-contiguous store path needs), the folded
+        # launch takes that (tile, staging); otherwise the first family's fixed choices (profiles/r02d_layernorm_fold.md).
+        geglu_ = act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH)
+        ent = tuning.table().get(tuning.key_of(p)) if TUNING else None
+        if geglu_ and ent is not None and ent[0] in (L.TILE_K1_256x256, L.TILE_K1_128x256, L.TILE_K1_256x128, L.TILE_K1_256x320):
+            ent = (L.TILE_K1_128x320, L.STAGE_LDS_DIRECT) + tuple(ent[2:])     # the GEGLU tile of that family that carries the fold
+        k2_ok = (ent is not None and ent[0] in ((L.TILE_K1_128x320,) if geglu_ else (L.TILE_K2_128x80, L.TILE_K2_128x160))
+                 and not out_f32 and p.ldc % 8 == 0 and out.data_ptr() % 16 == 0 and N % 16 == 0 and gate is None
+                 and (residual is None or (p.ldr % 8 == 0 and residual.data_ptr() % 16 == 0))
+                 and not (ent[0] == L.TILE_K2_128x160 and ent[1] in (L.STAGE_LDS_DIRECT3, L.STAGE_PINGPONG3))
+                 and not (geglu_ and ent[1] != L.STAGE_LDS_DIRECT))
+        if k2_ok and LN_FOLD_K2:
+            tile, staging, split_k = ent[0], ent[1], 1
+        else:
+            tile, staging, split_k = ((L.TILE_128x128, L.STAGE_LDS_DIRECT) if geglu_ else (L.TILE_128x64, L.STAGE_LDS_DIRECT3)) + (1,)
     _select_variant(p, tile, staging, st, inplace=inplace, split_k=split_k, device=x.device)
     if stats_out is not None:
         if act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH) or out_f32 or stats_out.buf.shape[0] != M:

@@ -228,3 +228,85 @@ def test_k2_refuses_what_it_does_not_implement():
         ops.linear(x, w, tile=L.TILE_K2_128x80, staging=L.STAGE_REGISTER)
     with pytest.raises(RuntimeError, match="UNSUPPORTED"):
         ops.linear(x, w, tile=L.TILE_K2_128x80, staging=L.STAGE_LDS_DIRECT, split_k=2)
+
+
+@pytest.mark.parametrize("M,C,N", [(2048, 1280, 1280), (520, 320, 400), (8192, 640, 640)])
+def test_k2_layernorm_fold_producer_and_consumers(M, C, N):
+    """LayerNorm fold on the second kernel family (round 4: da_gemm_params.stats_out / ln_* in gemm2_kernel.cuh, LNF instantiations).
+      * PRODUCER (k2:128x80 / k2:128x160, every ring): one (sum, sum of squares) pair per row and 80-column band of the bf16 output;
+        their sum equals the row statistics of the stored tensor, the output is bit-identical to the launch without statistics,
+        da_gemm_stats_parts() = ceil(N / 80) pairs are written and nothing beyond them;
+      * CONSUMER: linear(x, W', ln=...) == linear(layer_norm(x), W) within the bf16 tolerance of one GEMM, plain epilogue
+        (k2:128x80 / k2:128x160, + bias) and GEGLU epilogue (k1:128x320, interleaved ownership); rows with a large
+        mean (|mu| = 8 sigma) and ragged M / N edges included;
+      * statistics from the first family's producers feed the second family's consumers and vice versa."""
+    ops, L = _ops()
+    a, wprod, res = rnd((M, 192), 61), rnd((C, 192), 62, 192 ** -0.5), rnd((M, C), 63)
+    res = res + 8.0 * (torch.arange(M, device=DEV) % 3 == 0).to(bf16)[:, None]
+    gamma, beta = rnd((C,), 64) * 0.3 + 1.0, rnd((C,), 65) * 0.2
+    w, b = rnd((N, C), 66, C ** -0.5), rnd((N,), 67)
+    w1 = rnd((2 * max(N // 128, 1) * 128, C), 68, C ** -0.5)
+    b1 = rnd((w1.shape[0],), 69)
+    wl, fold = ops.fold_layernorm(w, gamma, beta, 1e-5)
+    w1l, fold1 = ops.fold_layernorm(w1, gamma, beta, 1e-5)
+    w1p, b1p = ops.pack_geglu(w1l, b1)
+    n2 = w1.shape[0] // 2
+    idx = torch.arange(n2, device=DEV).view(n2 // 32, 32)
+    order = torch.cat([idx, idx + n2], dim=1).reshape(-1)
+    fold1p = ops.LNFold(fold1.s[order].contiguous(), fold1.c[order].contiguous(), fold1.eps)
+    ref_x = None
+    prods = [(L.TILE_K2_128x80, s) for s in (L.STAGE_LDS_DIRECT, L.STAGE_LDS_DIRECT3, L.STAGE_PINGPONG, L.STAGE_PINGPONG3)] + \
+            [(L.TILE_K2_128x160, s) for s in (L.STAGE_LDS_DIRECT, L.STAGE_PINGPONG)]
+    cons = prods
+    gcons = [(L.TILE_K1_128x320, L.STAGE_LDS_DIRECT)]
+    stats = []
+    for tile, stg in prods:
+        x_plain = ops.linear(a, wprod, residual=res, tile=tile, staging=stg)
+        st = ops.RowStats(M, DEV)
+        st.buf.fill_(float("nan"))
+        x = ops.linear(a, wprod, residual=res, tile=tile, staging=stg, stats_out=st)
+        what = f"K2 LN fold producer {L.TILE_NAMES[tile]}/{stg} M{M} C{C}"
+        assert torch.equal(x, x_plain), f"{what}: statistics changed the output"
+        assert st.parts == (C + 79) // 80, f"{what}: {st.parts} partials"
+        xf = x.float()
+        tot = st.buf[:, :st.parts].sum(dim=1)
+        assert torch.isfinite(tot).all() and torch.isnan(st.buf[:, st.parts:]).all(), f"{what}: wrong number of partials"
+        assert torch.allclose(tot[:, 0], xf.sum(dim=1), rtol=1e-5, atol=1e-2), what
+        assert torch.allclose(tot[:, 1], (xf * xf).sum(dim=1), rtol=1e-5, atol=1e-2), what
+        if ref_x is None:
+            ref_x = x
+        assert torch.equal(x, ref_x)                      # every K2 variant: the same bits
+        stats.append(st)
+    xf = ref_x.float()
+    ln_ref = F.layer_norm(xf, (C,), gamma.float(), beta.float(), 1e-5)
+    ref = ln_ref @ w.float().t() + b.float()
+    g = ln_ref @ w1.float().t() + b1.float()
+    h_, g_ = g.chunk(2, dim=-1)
+    ref_geglu = h_ * F.gelu(g_)
+    # a first-family producer's statistics of the same tensor (its output differs from the K2 one in last bits only: use the
+    # K2 tensor with K2 statistics, and the first-family tensor with its own)
+    st1 = ops.RowStats(M, DEV)
+    x1 = ops.linear(a, wprod, residual=res, tile=L.TILE_128x128, staging=1, stats_out=st1)
+    base = None
+    for ctile, cstg in cons:
+        for st in (stats[0], stats[-1]):
+            y = ops.linear(ref_x, wl, b, tile=ctile, staging=cstg, ln=(st, fold))
+            assert_close_bf16(y, ref, f"K2 LN fold consumer {L.TILE_NAMES[ctile]}/{cstg} M{M} C{C} N{N} parts {st.parts}", rel_rms_max=6e-3)
+            if base is None:
+                base = y
+            assert torch.equal(y, base), "K2 consumers: every (tile, ring, statistics source) must give the same bits"
+    y1 = ops.linear(x1, wl, b, tile=cons[0][0], staging=cons[0][1], ln=(st1, fold))       # first-family statistics -> K2 consumer
+    ref1 = F.layer_norm(x1.float(), (C,), gamma.float(), beta.float(), 1e-5) @ w.float().t() + b.float()
+    assert_close_bf16(y1, ref1, "first-family statistics -> K2 consumer", rel_rms_max=6e-3)
+    y2 = ops.linear(ref_x, wl, b, tile=L.TILE_128x64, staging=L.STAGE_LDS_DIRECT3, ln=(stats[0], fold))   # K2 statistics -> first family
+    assert_close_bf16(y2, ref, "K2 statistics -> first-family consumer", rel_rms_max=6e-3)
+    for ctile, cstg in gcons:
+        yg = ops.linear(ref_x, w1p, b1p, act=L.ACT_GEGLU, tile=ctile, staging=cstg, ln=(stats[0], fold1p))
+        assert_close_bf16(yg, ref_geglu, f"K2 LN fold + GEGLU consumer {L.TILE_NAMES[ctile]} M{M} C{C}", rtol=2.5e-2, atol_rms=2.5e-2,
+                          rel_rms_max=8e-3)
+    # the automatic choice (tile=None) follows the per-shape table onto the K2 tiles where it lists them
+    st = ops.RowStats(M, DEV)
+    xa = ops.linear(a, wprod, residual=res, stats_out=st)
+    ya = ops.linear(xa, wl, b, ln=(st, fold))
+    refa = F.layer_norm(xa.float(), (C,), gamma.float(), beta.float(), 1e-5) @ w.float().t() + b.float()
+    assert_close_bf16(ya, refa, "LN fold, automatic variant choice", rel_rms_max=6e-3)

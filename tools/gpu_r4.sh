@@ -19,3 +19,25 @@ if [[ $WHAT == *benchfast* ]]; then
   timeout 900 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
   cut -c1-1200 $O/bench.json; grep "^\[bench" $O/bench.err | tail -20
 fi
+if [[ $WHAT == *others* ]]; then
+  for cfg in flux wan sd15; do
+    ST=2; [[ $cfg == wan ]] && ST=1
+    timeout 900 python bench.py --config $cfg --steps $ST --warmup 1 > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "$cfg rc=$?"
+    cut -c1-400 $O/bench_$cfg.json; tail -2 $O/bench_$cfg.err | cut -c1-300
+  done
+fi
+if [[ $WHAT == *lnfold* ]]; then
+  timeout 600 python -m pytest tests/test_gemm_k2_gpu.py tests/test_kernels_gpu.py -m gpu -q -s --timeout 300 -k "layernorm_fold" > $O/pytest_lnfold.log 2>&1; echo "pytest lnfold rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert" $O/pytest_lnfold.log | tail -20
+  rm -f $O/lnfold_r4.jsonl
+  timeout 300 python tools/bench_lnfold_r4.py $O/lnfold_r4.jsonl > $O/lnfold_r4.log 2>&1; echo "lnfold bench rc=$?"
+  cat $O/lnfold_r4.jsonl | cut -c1-600
+fi
+if [[ $WHAT == *norms* ]]; then
+  rm -f $O/norms_r4.jsonl
+  timeout 120 python tools/bench_norms_r4.py $O/norms_r4.jsonl > $O/norms_r4.log 2>&1; echo "norms default rc=$?"
+  for kn in "DA_GN_THREADS=512" "DA_GN_MINPIX=16" "DA_GN_MINPIX=4" "DA_GN_MAXBLK=1024 DA_GN_CAP=4096" "DA_GN_THREADS=512 DA_GN_MINPIX=16" "DA_GN_MAXBLK=256"; do
+    env $kn timeout 120 python tools/bench_norms_r4.py $O/norms_r4.jsonl >> $O/norms_r4.log 2>&1
+  done
+  grep "sum over\|layernorm" $O/norms_r4.jsonl | cut -c1-200
+fi
