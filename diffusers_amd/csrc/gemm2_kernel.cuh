@@ -154,7 +154,8 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   constexpr int XRAG = UX % SW ? 1 : 0, WRAG = UW % SW ? 1 : 0;   // a last row of pieces only some waves own
   static_assert(NSLOT == 2 || NSLOT == 3, "ring of 2 or 3 slice pairs");
   constexpr int DUMP = 1024;                               // where the out-of-range pieces of ragged tiles and the prefetch land
-  static_assert(NSLOT * PAIR + DUMP <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
+  constexpr int LNSC = LNF ? 2 * BN * 4 : 0;               // LNF consumer: the block's s[n] / c[n] (fp32), behind the dump KiB
+  static_assert(NSLOT * PAIR + DUMP + LNSC <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
   static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows are staged in 8-row pieces");
   static_assert(!CONV || (UX % SW) == 0, "conv: the slice of an activation piece must be a compile-time constant");
   static_assert((NSLOT - 1) * (XI + WI) <= 63, "vmcnt is a 6-bit counter");
@@ -440,6 +441,20 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   // Issued right behind the FIRST pair's LDS-DMA (the matrix stream starts first; these loads are older than pairs 1 .. and
   // therefore covered by every counted wait that covers pair 0).
   auto prefetch_epilogue_operands = [&]() {
+    if constexpr (LNF) {
+      if (p.ln_stats) {
+        // the block's BN columns of s and c go to LDS once (every lane of the epilogue reads 2 x 16 bytes per 4-column group:
+        // from global memory that was a chain of L2 round trips, + 10 us on the GEGLU projection); visible after the first
+        // rendezvous of the K loop, read after the last
+        float* lnsc = (float*)(smem + NSLOT * PAIR + DUMP);
+        if (t < BN / 2) {
+          const int j = t < BN / 4 ? t : t - BN / 4;        // 16-byte group of s (first BN / 4 threads) or c
+          const int n = min(n0 + 4 * j, p.N - 4);
+          const float4 v = *(const float4*)((t < BN / 4 ? p.ln_s : p.ln_c) + n);
+          *(float4*)(lnsc + (t < BN / 4 ? 0 : BN) + 4 * j) = v;
+        }
+      }
+    }
     if constexpr (LN_PF) {
       if (p.ln_stats) {
 #pragma unroll
@@ -766,7 +781,9 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   auto ln_apply4 = [&](float* o, int ih, int n) __attribute__((always_inline)) {
     if constexpr (LNF) {
       if (ln_on) {
-        const float4 sv = *(const float4*)(p.ln_s + n), cv = *(const float4*)(p.ln_c + n);
+        const float* lnsc = (const float*)(smem + NSLOT * PAIR + DUMP);
+        const int j = min(n - n0, BN - 4);                 // (n is clamped to N - 4 by the callers: stay inside the block's slice)
+        const float4 sv = *(const float4*)(lnsc + j), cv = *(const float4*)(lnsc + BN + j);
         o[0] = ln_rs[ih] * (o[0] - ln_mu[ih] * sv.x) + cv.x;
         o[1] = ln_rs[ih] * (o[1] - ln_mu[ih] * sv.y) + cv.y;
         o[2] = ln_rs[ih] * (o[2] - ln_mu[ih] * sv.z) + cv.z;
@@ -1090,7 +1107,7 @@ int launch(const da_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int gx = choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
-  constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + 1024;   // ring + the scratch KiB (ragged pieces, prefetch)
+  constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + 1024 + (LNF ? 2 * BN * 4 : 0);   // ring + the scratch KiB (ragged pieces, prefetch) + s / c
   auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP, STREAMW, GIL, LNF>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {

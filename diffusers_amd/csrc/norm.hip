@@ -483,8 +483,15 @@ int gn_knob(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 GnPlan gn_plan(int B, int HW, int C) {
-  static const int k_threads = gn_knob("DA_GN_THREADS", 256), k_minpix = gn_knob("DA_GN_MINPIX", 8),
+  static const int e_threads = gn_knob("DA_GN_THREADS", 0), e_minpix = gn_knob("DA_GN_MINPIX", 0),
                    k_maxblk = gn_knob("DA_GN_MAXBLK", 512), k_cap = gn_knob("DA_GN_CAP", 2048);
+  // Measured on the 14 GroupNorm shapes of an SDXL denoising step (profiles/r04c_norms.jsonl; 454 -> 369 us over the 14): from
+  // ~4 M elements up 512-thread blocks (wide tensors had ONE pixel row per block: C = 1280 -> 160 threads), from ~10 M up 16
+  // pixels per thread row; the small tensors (two ~8 us latency-bound launches) and the VAE's very large ones keep the old plan.
+  const long long elems = (long long)B * HW * C;
+  const bool mid = elems >= (4ll << 20) && elems <= (48ll << 20);
+  const int k_threads = e_threads ? e_threads : (mid ? 512 : 256);
+  const int k_minpix = e_minpix ? e_minpix : (mid && elems >= (10ll << 20) ? 16 : 8);
   GnPlan g;
   const int cpr = C / 8;
   int k = k_threads / cpr;

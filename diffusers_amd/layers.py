@@ -318,18 +318,26 @@ class BasicTransformerBlock:
         self.norm3 = LayerNorm(w, prefix + ".norm3")
         # the folded copies (a second GEGLU up-projection, a second to_q, fp32 s / c vectors: ~1.7 GB for SDXL) exist only
         # when the opt-in fold was on at LOAD time; it is part of the packed-cache fingerprint (loading.py)
-        self.folded = bool(ops.LN_FOLD)
-        self.ff = FeedForwardGEGLU(w, prefix + ".ff", norm=self.norm3 if self.folded else None)
+        self.folded = int(ops.LN_FOLD)          # 0 off, 1 norm2 + norm3, 2 norm2 only (ops.LN_FOLD)
+        self.ff = FeedForwardGEGLU(w, prefix + ".ff", norm=self.norm3 if self.folded == 1 else None)
         if self.folded:
             self.attn2.fold_norm(self.norm2)
 
     def __call__(self, x, batch, seq, kv: CrossKV):
-        if ops.LN_FOLD and not self.folded:
+        mode = int(ops.LN_FOLD)
+        if mode and (not self.folded or (mode == 1 and self.folded != 1)):
             raise RuntimeError("ops.LN_FOLD was switched on after this model was loaded: the folded weights are built at "
-                               "load_state_dict() time (set DIFFUSERS_AMD_LN_FOLD=1 / ops.LN_FOLD before loading)")
-        if not ops.LN_FOLD:
+                               "load_state_dict() time (set DIFFUSERS_AMD_LN_FOLD / ops.LN_FOLD before loading)")
+        if not mode:
             x = self.attn1(self.norm1(x), batch, seq, residual=x)
             x = self.attn2(self.norm2(x), batch, seq, residual=x, kv=kv)
+            return self.ff(self.norm3(x), residual=x)
+        if mode == 2:
+            # norm2 never runs as a kernel: attn1.to_out also writes the row statistics of the residual stream it produces and
+            # attn2.to_q applies the normalisation in its epilogue
+            st1 = ops.RowStats(x.shape[0], x.device)
+            x = self.attn1(self.norm1(x), batch, seq, residual=x, stats_out=st1)
+            x = self.attn2(x, batch, seq, residual=x, kv=kv, stats=st1)
             return self.ff(self.norm3(x), residual=x)
         # norm2 and norm3 never run as kernels: attn1.to_out / attn2.to_out also write the row statistics of the
         # residual stream they produce, and attn2.to_q / the GEGLU projection apply the normalisation in their epilogue

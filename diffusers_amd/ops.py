@@ -127,7 +127,10 @@ def splitk_error(device=None) -> bool:
 # BasicTransformerBlock can fold norm2 / norm3 into the GEMMs either side of them (linear(stats_out=) / linear(ln=)).  OFF by
 # default: measured on an MI355X (profiles/r02d_layernorm_fold.md) the folded consumers cost +4.5 us (to_q) and +15 us (GEGLU
 # projection) against the 8.6 us LayerNorm launch + ~1.5 us boundary they remove -- a wash for norm2, a loss for norm3.
-LN_FOLD = os.environ.get("DIFFUSERS_AMD_LN_FOLD", "0") == "1"
+# Round 4: the second kernel family carries the fold.  Modes: 0 = off; 2 = norm2 only (attn1.to_out writes the statistics, attn2.to_q
+# applies them; measured: to_out > LayerNorm > to_q 42.7 -> 32.5 us per chain at the 1280 level, 40.7 -> 32.7 at 640,
+# profiles/r04b_layernorm_fold_k2.jsonl); 1 (or True) = norm2 and norm3 (the GEGLU projection as the second consumer).
+LN_FOLD = int(os.environ.get("DIFFUSERS_AMD_LN_FOLD", "2"))
 LN_FOLD_K2 = os.environ.get("DIFFUSERS_AMD_LN_FOLD_K2", "1") == "1"   # folded launches may use the second kernel family (round 4)
 STATS_MAX_PARTS = 64          # DA_LN_MAX_PARTS: slots per row of a statistics buffer
 STATS_MAX_CONSUMED = 24       # 4 * DA_LN_PAIR_LOADS: partials per row a consumer launch reads

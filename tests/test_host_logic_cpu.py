@@ -28,10 +28,10 @@ def _emulated_kernels(monkeypatch):
     monkeypatch.setattr(ops, "TUNING", False)
 
 
-@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("fold", [0, 1, 2])
 @pytest.mark.parametrize("name,added", [("tiny_unet_sdxl", True), ("tiny_unet_sd15", False)])
 def test_unet2d_condition(golden, name, added, fold, monkeypatch):
-    """``fold``: the opt-in LayerNorm fold (ops.LN_FOLD: norm2 / norm3 applied inside the GEMMs either side of them)."""
+    """``fold``: the LayerNorm fold (ops.LN_FOLD: 0 off, 1 norm2 + norm3, 2 norm2 only -- applied inside the GEMMs either side of them)."""
     from diffusers_amd.unet_2d_condition import UNet2DConditionModel
     monkeypatch.setattr(ops, "LN_FOLD", fold)
     cfg = dinit.TINY_SDXL_UNET if added else dinit.TINY_SD15_UNET

@@ -41,3 +41,13 @@ if [[ $WHAT == *norms* ]]; then
   done
   grep "sum over\|layernorm" $O/norms_r4.jsonl | cut -c1-200
 fi
+if [[ $WHAT == *foldab* ]]; then
+  for mode in 0 2 1 0 2; do
+    DIFFUSERS_AMD_LN_FOLD=$mode timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline > $O/bench_fold$mode.json 2> $O/bench_fold$mode.err; echo "fold mode $mode rc=$? $(cut -c1-140 $O/bench_fold$mode.json | grep -o '"value": [0-9.]*')"
+  done
+fi
+if [[ $WHAT == *normsdef* ]]; then
+  rm -f $O/norms_r4b.jsonl
+  timeout 120 python tools/bench_norms_r4.py $O/norms_r4b.jsonl > $O/norms_r4b.log 2>&1; echo "norms rc=$?"
+  grep "sum over\|layernorm" $O/norms_r4b.jsonl | cut -c1-200
+fi
