@@ -20,6 +20,10 @@ Besides the contract keys the line carries, all measured OUTSIDE the timed regio
                       of BASELINE.json's ">= 1.5x stock diffusers on PyTorch-ROCm"   ("kind": "reference"; "port" = the
                       oracle restatement, used only when the archive did not ship)
   cpu_baseline        the reference classes on the host cores: one full-size step + one decode (image = 50 x step + decode)
+  dropin              the reference StableDiffusionXLPipeline.__call__ itself over ENGINE unet / vae / scheduler components, full
+                      size: images/s, ratio to the graphed engine pipeline, PSNR vs the all-reference fp32 run
+  other_configs       BASELINE configs 2, 4, 1, 5 (sd15, flux, ddpm, wan): three timed units each under the same timing rule
+                      (Wan: 3 sampler steps scaled to 50, flagged), each with per-family roofline.kernels and a cpu_baseline
 """
 from __future__ import annotations
 
@@ -56,7 +60,8 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-reference", action="store_true", help="skip the parity / torch_rocm_baseline legs")
+    ap.add_argument("--no-reference", action="store_true", help="skip the parity / torch_rocm_baseline / dropin legs")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs leg (sd15, flux, ddpm, wan) of the default run")
     ap.add_argument("--save-tuning", default=None, help="write the GEMM variant table measured during warm-up here")
     return ap.parse_args(argv)
 
@@ -493,6 +498,7 @@ def reference_legs(engine_img, engine_lat, unet_sd, vae_sd, ucfg, vcfg, ucfg_min
         log(f"torch_rocm_baseline failed: {base['error']}")
     try:
         log(f"parity leg ({kind}): fp32, {steps} steps + decode")
+        img_f = None
         lat_f, img_f, _ = run(torch.float32, False)
         parity["psnr_db"] = _psnr01(engine_img, img_f)
         d = engine_lat.float() - lat_f.float()
@@ -508,7 +514,7 @@ def reference_legs(engine_img, engine_lat, unet_sd, vae_sd, ucfg, vcfg, ucfg_min
         parity["error"] = f"{type(e).__name__}: {e}"
         log(f"parity leg failed: {parity['error']}")
     vs = engine_images_per_s / base["images_per_s"] if base.get("images_per_s") else None
-    return parity, base, vs
+    return parity, base, vs, (img_f if parity.get("psnr_db") is not None else None)
 
 
 # ---- the other BASELINE configs under the same driver contract ------------------------------------------
@@ -528,86 +534,216 @@ OTHER_CONFIGS = {
 }
 
 
-def run_other_config(args, argv):
-    """`--config sd15 | flux | wan | ddpm`: the same contract (W untimed units, K timed units between barriers, max over ranks, ONE
-    JSON line from rank 0) on the other BASELINE configs; one prompt per rank, no collective in the data path.  `roofline` here is
-    the whole unit against the MFMA peak (algorithmic TFLOP of SURVEY.md 8d / wall time); the per-kernel legs exist for the
-    headline config only."""
-    from diffusers_amd import distributed as D
+def _build_other(config, dev, rank, tiny, no_graph):
+    """(pipeline, unit(n) -> callable running one unit with n sampler steps, eager(n) -> the same without HIP-graph replay)."""
     from diffusers_amd import factory
-    rank, world, local = D.init_from_env()
-    dev = _device(local)
-    metric, unit, what, default_steps, tflop_of = OTHER_CONFIGS[args.config]
-    n = args.denoise_steps or default_steps
     bf = torch.bfloat16
     g = torch.Generator("cpu").manual_seed(1234 + rank)
-    log(f"rank {rank}/{world}: building {args.config} on {dev}")
-    if args.config == "sd15":
-        pipe = factory.build_sd15_pipeline(device=dev, tiny=args.tiny, seed=0)
-        cd, lat = (64, 16) if args.tiny else (768, 64)
+    if config == "sd15":
+        pipe = factory.build_sd15_pipeline(device=dev, tiny=tiny, seed=0)
+        cd, lat = (64, 16) if tiny else (768, 64)
         pe, ne = (torch.randn((1, 77, cd), generator=g).to(bf).to(dev) for _ in range(2))
         x = torch.randn((1, 4, lat, lat), generator=g).to(bf).to(dev)
-        unit_fn = lambda: pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=x.clone(), num_inference_steps=n,  # noqa: E731
-                               guidance_scale=7.5, output_type="raw", use_graph=not args.no_graph).images
-    elif args.config == "flux":
-        pipe = factory.build_flux_pipeline(device=dev, tiny=args.tiny, seed=5)
-        if args.tiny:
+
+        def unit(n, graph=not no_graph):
+            return lambda: pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=x.clone(), num_inference_steps=n,
+                                guidance_scale=7.5, output_type="raw", use_graph=graph).images
+    elif config == "flux":
+        if tiny:
             raise SystemExit("--config flux has no --tiny form here (tests/ cover the tiny pipeline)")
+        pipe = factory.build_flux_pipeline(device=dev, tiny=False, seed=5)
         pe = torch.randn((1, 512, 4096), generator=g).to(bf).to(dev)
         pooled = torch.randn((1, 768), generator=g).to(bf).to(dev)
         x = torch.randn((1, 4096, 64), generator=g).to(bf).to(dev)
-        unit_fn = lambda: pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, latents=x, num_inference_steps=n, guidance_scale=0.0,  # noqa: E731
-                               height=1024, width=1024, output_type="raw").images
-    elif args.config == "wan":
-        pipe = factory.build_wan_pipeline(device=dev, tiny=args.tiny, seed=9)
-        if args.tiny:
+
+        def unit(n, graph=not no_graph):
+            return lambda: pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, latents=x, num_inference_steps=n, guidance_scale=0.0,
+                                height=1024, width=1024, output_type="raw", use_graph=graph).images
+    elif config == "wan":
+        if tiny:
             raise SystemExit("--config wan has no --tiny form here (tests/ cover the tiny pipeline)")
+        pipe = factory.build_wan_pipeline(device=dev, tiny=False, seed=9)
         pe, ne = (torch.randn((1, 512, 4096), generator=g).to(bf).to(dev) for _ in range(2))
         x = torch.randn((1, 16, 21, 60, 104), generator=g).to(bf).to(dev)
-        unit_fn = lambda: pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=x, num_inference_steps=n, guidance_scale=5.0,  # noqa: E731
-                               height=480, width=832, num_frames=81).images
+
+        def unit(n, graph=not no_graph):
+            return lambda: pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=x, num_inference_steps=n, guidance_scale=5.0,
+                                height=480, width=832, num_frames=81, use_graph=graph).images
     else:
-        pipe = factory.build_ddpm_pipeline(device=dev, tiny=args.tiny, seed=0)
-        unit_fn = lambda: pipe(batch_size=1, generator=torch.Generator().manual_seed(rank), num_inference_steps=n,  # noqa: E731
-                               output_type="pt", use_graph=not args.no_graph).images
-    log("warm-up")
+        pipe = factory.build_ddpm_pipeline(device=dev, tiny=tiny, seed=0)
+
+        def unit(n, graph=not no_graph):
+            return lambda: pipe(batch_size=1, generator=torch.Generator().manual_seed(rank), num_inference_steps=n,
+                                output_type="pt", use_graph=graph).images
+    return pipe, unit
+
+
+def _other_kernels(unit):
+    """`roofline.kernels` of another config: HIP events around every launch of the kernel families in ONE eager sampler step
+    (+ the decode where the unit has one): the algorithmic work is summed from the launches themselves."""
+    run = unit(1, False)
+    run()                                   # untimed warm pass (variant lookup)
+    fam = instrumented_pass(run)
+    kernels = []
+    for name, kern, bound in (("igemm", "igemm_bf16_kernel + igemm2_bf16_kernel (Linear, Conv2d, paired launches)", "mfma"),
+                              ("attention", "attn2_fwd_kernel / attn_fwd_kernel (flash attention forward)", "mfma"),
+                              ("groupnorm", "gn_stats_kernel + gn_apply_kernel", "hbm"), ("layernorm", "layernorm_kernel", "hbm")):
+        if name in fam:
+            kernels.append(_kernel_entry(name, kern, bound, fam[name], {"scope": "one sampler step + decode, eager"}))
+    return kernels
+
+
+def _other_cpu_baseline(config, unit_tflop, n_steps):
+    """`cpu_baseline` of another config, kind "reference": the reference classes (oracle/_ref archive, random weights) on the host
+    cores in fp32 on a BOUNDED sample of the same workload (oracle.ref_runtime.cpu_step_seconds says which)."""
+    from diffusers_amd import init as dinit
+    from oracle import ref_runtime as RR
+    unit_name = "videos/s" if config == "wan" else "images/s"
+    ref = RR.load_reference() if RR.available() else None
+    if ref is None:
+        return {"value": None, "unit": unit_name, "cores": None, "kind": "reference", "sample": "not measured: the reference archive did not ship"}
+    cfgs = {"sd15": {"unet": dinit.SD15_UNET, "vae": dinit.SD_VAE}, "ddpm": {"unet": dinit.DDPM_CAT},
+            "flux": {"transformer": dinit.FLUX_SCHNELL}, "wan": {"transformer": dinit.WAN_1_3B}}[config]
+    threads = _host_threads()
+    ts, tfl_s, td, tfl_d, what = RR.cpu_step_seconds(ref, config, cfgs, threads)
+    cpu_tflops = (tfl_s + tfl_d) / (ts + td)
+    if config in ("sd15", "ddpm"):
+        secs = n_steps * ts + td                       # the steps of a unit are cost-identical: the only extrapolation
+    else:
+        secs = unit_tflop / cpu_tflops                 # depth- / length-reduced sample: scaled by algorithmic FLOPs
+    return {"value": 1.0 / secs, "unit": unit_name, "cores": threads, "kind": "reference", "extrapolated": True,
+            "seconds_per_unit": secs, "cpu_tflops": cpu_tflops,
+            "sample": what + ", fp32, huggingface/diffusers 0.40.0.dev0 on torch CPU"}
+
+
+def measure_other_config(config, dev, rank, world, args, units, warmup, n_steps=None, extrapolate_from=None, legs=True):
+    """One BASELINE config other than the headline under the driver contract's timing rule: `warmup` untimed units, `units` timed
+    units between synchronisations (+ barriers when world > 1), max over ranks.  ``extrapolate_from`` = k: a unit is timed with k
+    sampler steps and scaled to the config's step count (flagged) -- the 50-step Wan video inside the default run.
+    ``legs``: per-family `roofline.kernels` and the `cpu_baseline` (rank 0, world == 1)."""
+    from diffusers_amd import distributed as D
+    metric, unit_name, what, default_steps, tflop_of = OTHER_CONFIGS[config]
+    n = n_steps or default_steps
+    run_steps = extrapolate_from or n
+    pipe, unit = _build_other(config, dev, rank, args.tiny, args.no_graph)
+    fn = unit(run_steps)
     out = None
-    for _ in range(max(args.warmup, 1)):          # at least one: variant lookup, graph capture
-        out = unit_fn()
+    for _ in range(max(warmup, 1)):          # at least one: variant lookup, graph capture
+        out = fn()
     _sync()
     if world > 1:
         torch.distributed.barrier()
     _sync()
-    log("timed region")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = unit_fn()
+    for _ in range(units):
+        out = fn()
     _sync()
     mine_s = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()
     _sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
-    value = world * args.steps / elapsed
+    scale = n / run_steps if extrapolate_from else 1.0
+    value = world * units / (elapsed * scale)
     tfl = tflop_of(n)
     ach = value / world * tfl
-    result = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
-              "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-              "dtype": "bf16", "data": "synthetic (seeded random weights, embeddings, latents)",
-              "config": {"workload": what.format(n=n), "global_batch": world, "parallelism": f"dp{world} (independent prompts, replicas)",
-                         "denoise_steps": n, "output_finite": bool(torch.isfinite(out.float()).all()),
-                         "rank_seconds_per_unit": mine_s / args.steps, "tuned_live": _tuned_live(),
-                         "algorithmic_tflop_per_unit": tfl},
-              "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                           "traffic": None, "kernel": "whole unit (end to end): algorithmic TFLOP of SURVEY.md 8d / wall time"},
-              "cpu_baseline": {"value": None, "unit": unit, "cores": None, "kind": "reference",
-                               "sample": "not measured for this config (the headline config carries the CPU leg)"}}
+    res = {"metric": metric, "value": value, "unit": unit_name, "n_gpus": world, "steps": units, "warmup": max(warmup, 1),
+           "ms_per_step": 1000.0 * elapsed * scale / units, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic (seeded random weights, embeddings, latents)",
+           "config": {"workload": what.format(n=n), "global_batch": world, "parallelism": f"dp{world} (independent prompts, replicas)",
+                      "denoise_steps": n, "output_finite": bool(torch.isfinite(out.float()).all()),
+                      "rank_seconds_per_unit": mine_s * scale / units, "tuned_live": _tuned_live(),
+                      "algorithmic_tflop_per_unit": tfl},
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                        "traffic": None, "kernel": "whole unit (end to end): algorithmic TFLOP of SURVEY.md 8d / wall time"}}
+    if extrapolate_from:
+        res["config"]["extrapolated"] = (f"timed with {run_steps} sampler steps per unit and scaled to {n} (the steps are cost-identical; "
+                                         f"`python bench.py --config {config}` runs the full unit)")
+    if legs and rank == 0 and world == 1 and not args.tiny:
+        try:
+            res["roofline"]["kernels"] = _other_kernels(unit)
+        except Exception as e:  # a diagnostic must not cost the line
+            res["roofline"]["kernels_error"] = f"{type(e).__name__}: {e}"
+        if not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = _other_cpu_baseline(config, tfl, n)
+            except Exception as e:
+                res["cpu_baseline"] = {"value": None, "unit": unit_name, "cores": None, "kind": "reference",
+                                       "sample": f"not measured: {type(e).__name__}: {e}"}
+    if "cpu_baseline" not in res:
+        res["cpu_baseline"] = {"value": None, "unit": unit_name, "cores": None, "kind": "reference",
+                               "sample": "not measured in this run (rank 0 at N = 1 without --no-cpu-baseline measures it)"}
+    del pipe
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_other_config(args, argv):
+    """`--config sd15 | flux | wan | ddpm`: the same contract (W untimed units, K timed units between barriers, max over ranks, ONE
+    JSON line from rank 0) on the other BASELINE configs; one prompt per rank, no collective in the data path.  `roofline` is the
+    whole unit against the MFMA peak (algorithmic TFLOP of SURVEY.md 8d / wall time) with per-family `kernels` from one eager
+    step; `cpu_baseline` is the reference classes on a bounded sample of the same workload."""
+    from diffusers_amd import distributed as D
+    rank, world, local = D.init_from_env()
+    dev = _device(local)
+    log(f"rank {rank}/{world}: {args.config} on {dev}")
+    result = measure_other_config(args.config, dev, rank, world, args, args.steps, args.warmup, n_steps=args.denoise_steps)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     return result
+
+
+def other_configs_leg(dev, args):
+    """The other four BASELINE configs inside the default run (rank 0, N = 1, outside the timed region): three timed units each
+    (Wan: two units of 3 sampler steps, scaled to 50 and flagged), each with its per-family kernels and its CPU baseline."""
+    out = []
+    for cfg, units, extra in (("sd15", 3, {}), ("flux", 3, {}), ("ddpm", 3, {}), ("wan", 2, {"extrapolate_from": 3})):
+        log(f"other_configs leg: {cfg}")
+        try:
+            r = measure_other_config(cfg, dev, 0, 1, args, units, 1, **extra)
+            out.append({k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline",
+                                          "cpu_baseline")})
+            log(f"other_configs: {cfg} {r['value']:.4g} {r['unit']}")
+        except Exception as e:  # never lose the headline line to a side leg
+            out.append({"metric": OTHER_CONFIGS[cfg][0], "value": None, "error": f"{type(e).__name__}: {e}"})
+            log(f"other_configs: {cfg} failed: {type(e).__name__}: {e}")
+    return out
+
+
+def dropin_leg(unet, vae, inp, steps, hw, ref_img_fp32, engine_images_per_s):
+    """The drop-in promise, timed at full size (rank 0, N = 1, outside the timed region): the REAL reference
+    `StableDiffusionXLPipeline.__call__` (pipeline_stable_diffusion_xl.py:823-1308, from the oracle/_ref archive) over ENGINE `unet` /
+    `vae` / `scheduler` objects in its component slots (pipeline_utils.py:224-252): every step is the reference's own Python --
+    cat([latents] * 2), scale_model_input, unet(...), torch CFG combine, scheduler.step -- launching the HIP kernels eagerly.
+    images/s, the ratio to the engine's graphed pipeline, PSNR against the all-reference fp32 run of the parity leg."""
+    import diffusers_amd as da
+    from diffusers_amd import factory
+    from oracle import ref_runtime as RR
+    ref = RR.load_reference()
+    dev = inp["latents"].device
+    bf = torch.bfloat16
+    sch = da.EulerDiscreteScheduler(**factory.SDXL_SCHEDULER)
+    pipe = RR.engine_under_reference_sdxl(ref, unet, vae, sch, dev, bf, int(inp["pooled"].shape[-1]))
+    RR.run_sdxl(pipe, inp, 2, GUIDANCE, hw, bf)                 # warm-up
+    torch.cuda.synchronize()
+    best = None
+    img = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        img, _ = RR.run_sdxl(pipe, inp, steps, GUIDANCE, hw, bf)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out = {"images_per_s": 1.0 / best, "seconds_per_image": best, "unit": "images/s", "steps": steps,
+           "vs_engine_pipeline": (1.0 / best) / engine_images_per_s,
+           "what": "stock diffusers 0.40.0.dev0 StableDiffusionXLPipeline.__call__ (oracle/_ref archive) over engine UNet2DConditionModel / "
+                   "AutoencoderKL / EulerDiscreteScheduler registered as its components; eager launches, best of two"}
+    if ref_img_fp32 is not None:
+        out["psnr_db_vs_reference_fp32"] = _psnr01(img.float() * 2.0 - 1.0, ref_img_fp32)
+    return out
 
 
 def main(argv=None):
@@ -725,9 +861,19 @@ def main(argv=None):
             # the engine's own image / latents for the parity check: the same call as the timed one
             eng_lat = one_image("latent").clone()
             eng_img = one_image("raw")
-            parity, base, vs = reference_legs(eng_img, eng_lat, unet_sd, vae_sd, full_u, full_v, ucfg, vcfg, mine,
-                                              args.denoise_steps, value)
+            parity, base, vs, img_f = reference_legs(eng_img, eng_lat, unet_sd, vae_sd, full_u, full_v, ucfg, vcfg, mine,
+                                                     args.denoise_steps, value)
             result["parity"], result["torch_rocm_baseline"], result["vs_torch_rocm"] = parity, base, vs
+            if parity.get("kind") == "reference":
+                log("dropin leg: the reference pipeline's own __call__ over engine components, full size")
+                try:
+                    result["dropin"] = dropin_leg(unet, vae, mine, args.denoise_steps, hw, img_f, value)
+                    log(f"dropin: {result['dropin']['seconds_per_image']:.2f} s / image = {result['dropin']['vs_engine_pipeline']:.3f} x the "
+                        f"graphed engine pipeline, {result['dropin'].get('psnr_db_vs_reference_fp32')} dB vs the reference in fp32")
+                except Exception as e:  # never lose the measured line to a side leg
+                    result["dropin"] = {"images_per_s": None, "error": f"{type(e).__name__}: {e}"}
+                    log(f"dropin leg failed: {result['dropin']['error']}")
+            del img_f
         if world == 1 and not args.no_cpu_baseline:
             full = dict(UD)
             full.update(ucfg)
@@ -750,6 +896,10 @@ def main(argv=None):
                                           "sample": f"not measured: {e}"}
             finally:
                 signal.alarm(0)
+        if world == 1 and not args.no_other_configs:
+            del pipe, unet, vae
+            torch.cuda.empty_cache()
+            result["other_configs"] = other_configs_leg(dev, args)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
