@@ -51,3 +51,7 @@ if [[ $WHAT == *normsdef* ]]; then
   timeout 120 python tools/bench_norms_r4.py $O/norms_r4b.jsonl > $O/norms_r4b.log 2>&1; echo "norms rc=$?"
   grep "sum over\|layernorm" $O/norms_r4b.jsonl | cut -c1-200
 fi
+if [[ $WHAT == *benchfull* ]]; then
+  timeout 1500 python bench.py --steps 3 --warmup 1 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"
+  cut -c1-300 $O/bench_full.json; grep "^\[bench" $O/bench_full.err | tail -40
+fi
