@@ -60,6 +60,21 @@ def build_unet(ref, cfg: dict, state_dict: dict, device, dtype) -> "torch.nn.Mod
     return m.to(dtype).eval()
 
 
+def build_model(ref, cls_name: str, cfg: dict, state_dict: dict, device, dtype, keep_fp32=()) -> "torch.nn.Module":
+    """Any reference model class (`FluxTransformer2DModel`, `WanTransformer3DModel`, `UNet2DModel`, ...) built on ``device`` and
+    filled with the given reference-format weights (strict).  ``keep_fp32``: parameter-name fragments the reference keeps in fp32
+    whatever ``dtype`` is (`_keep_in_fp32_modules`, e.g. Wan's scale_shift_table / norms)."""
+    with torch.device(device):            # (not the meta device: non-persistent buffers such as Wan's rope tables must be built)
+        m = getattr(ref, cls_name)(**_lists(cfg))
+
+    def cast(k, v):
+        return v.to(device=device, dtype=torch.float32 if any(f in k for f in keep_fp32) else dtype)
+    missing, unexpected = m.load_state_dict({k: cast(k, v) for k, v in state_dict.items()}, strict=False, assign=True)
+    if missing or unexpected:
+        raise RuntimeError(f"reference {cls_name} state_dict mismatch: missing {missing[:3]} unexpected {unexpected[:3]}")
+    return m.eval()
+
+
 def build_vae(ref, cfg: dict, decoder_state_dict: dict, device, dtype) -> "torch.nn.Module":
     """`AutoencoderKL(**cfg)`; the engine's state dicts hold the DECODER half (decoder.*, post_quant_conv.*): the encoder keeps its
     default initialisation -- it is not on the path."""

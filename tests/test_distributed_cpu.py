@@ -125,6 +125,34 @@ def test_bench_main_world2_gloo(tmp_path):
     assert rec["config"]["tuned_live"] == 0      # reported so that a tuning pass on 8 ranks at once cannot hide in a scaling run
 
 
+def test_bench_main_world8_gloo(tmp_path):
+    """The launch the driver's 8-GPU scaling run will make, on CPU stand-ins (no 8-GPU node was available to any
+    round, so the first real run must not fail on plumbing): eight ranks under torch.distributed.run, one prompt per rank (seeds
+    1234 ... 1241 through the ONE broadcast from rank 0), rccl_ranks == 8, eight per-rank rates, no rank tuning GEMM variants live."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "tests" / "bench_cpu_worker.py"), "--gpus", "8", "--steps", "1", "--warmup",
+           "1", "--tiny", "--no-graph", "--denoise-steps", "2"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["steps"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["rccl_ranks"] == 8 and len(rec["config"]["images_per_s_per_rank"]) == 8
+    assert rec["config"]["global_batch"] == 8 and rec["config"]["tuned_live"] == 0
+    assert 0 < rec["value"] <= sum(rec["config"]["images_per_s_per_rank"]) * 1.001
+    assert "other_configs" not in rec and "dropin" not in rec          # the side legs belong to rank 0 at N = 1 only
+    # every rank built its own prompt from the broadcast: the synthetic inputs of prompt i are seeded 1234 + i
+    import bench
+    inp = bench.synth_inputs(8, True, "cpu")
+    assert inp["latents"].shape[0] == 8 and not torch.equal(inp["latents"][0], inp["latents"][7])
+
+
 @pytest.mark.parametrize("config,unit", [("sd15", "images/s"), ("ddpm", "images/s")])
 def test_bench_other_configs_world2_gloo(tmp_path, config, unit):
     """`bench.py --config sd15 | ddpm` (the other BASELINE configs under the driver contract), world size 2

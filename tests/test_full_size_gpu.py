@@ -5,8 +5,12 @@ configs really run (S = 4096 SDXL, 4608 Flux, 32 760 Wan).
 The reference here is the oracle restatement of the reference modules (oracle/reference_math.py: plain torch ops, pinned to
 the live reference by tests/test_oracle_vs_golden.py) executed by PyTorch-ROCm ON THE GPU in fp32 -- the same graph the CPU
 tests run, at sizes a CPU cannot finish in the test budget -- with its bf16 run printed as the noise floor that defines the
-"stated bf16 tolerance" of BASELINE.json (SURVEY.md 8d PSNR protocol).  Tolerances: U-Net rel-rms <= 2.5e-2 vs fp32 (the
-bound of every model test in this suite); images PSNR >= 40 dB on [0, 1] (BASELINE.json's target, MSE <= 1e-4)."""
+"stated bf16 tolerance" of BASELINE.json (SURVEY.md 8d PSNR protocol).  Since round 4 Flux / Wan / SD1.5 are compared against the
+REAL reference classes (oracle/_ref archive) where it shipped, the oracle graph otherwise.
+
+Tolerances are tied to the measured floor: a model's rel-rms vs fp32 must stay within 1.2 x the rel-rms of the
+reference's own bf16 run printed next to it (and under 2.5e-2 in any case); an image's PSNR within 1 dB below the bf16 reference's
+PSNR (and >= 40 dB, BASELINE.json's target, MSE <= 1e-4).  A kernel change that costs 3 dB fails here."""
 import numpy as np
 import pytest
 import torch
@@ -16,6 +20,25 @@ from conftest import rel_rms
 pytestmark = pytest.mark.gpu
 bf16 = torch.bfloat16
 DEV = "cuda"
+FLOOR_FACTOR = 1.2     # model rel-rms vs fp32 <= FLOOR_FACTOR x the bf16 reference's own rel-rms vs fp32
+FLOOR_DB = 1.0         # image PSNR vs fp32 >= the bf16 reference's PSNR vs fp32 - FLOOR_DB
+
+
+def _gate_model(rr, rf, what):
+    assert rr < 2.5e-2 and rr <= FLOOR_FACTOR * rf, f"{what}: rel-rms {rr:.3e} vs fp32 exceeds {FLOOR_FACTOR} x the bf16 reference's {rf:.3e}"
+
+
+def _gate_image(ps, pf, what):
+    assert ps >= 40.0 and ps >= pf - FLOOR_DB, f"{what}: PSNR {ps:.1f} dB (bf16 reference: {pf:.1f} dB, gate: floor - {FLOOR_DB} dB and 40 dB)"
+
+
+def _reference():
+    """The reference package from the shipped archive, or None (then the oracle graph is the comparator)."""
+    from oracle import ref_runtime as RR
+    try:
+        return RR.load_reference() if RR.available() else None
+    except Exception:
+        return None
 
 
 def _psnr01(a, b):
@@ -67,7 +90,7 @@ def test_sdxl_unet_full_size_vs_fp32_reference_on_device(sdxl):
             print(f"[parity] SDXL U-Net 128x128 latents, t={t:.0f}: engine vs fp32 rel_rms = {rr:.3e}; "
                   f"torch-bf16 vs fp32 (noise floor) = {rf:.3e}")
             assert y.shape == ref.shape and torch.isfinite(y.float()).all()
-            assert rr < 2.5e-2
+            _gate_model(rr, rf, f"SDXL U-Net t={t:.0f}")
     del sd32
 
 
@@ -86,7 +109,7 @@ def test_sdxl_vae_full_size_decode_psnr(sdxl):
     print(f"[parity] SDXL VAE decode 1024x1024: engine vs fp32 PSNR = {ps:.1f} dB (rel_rms {rr:.3e}); "
           f"torch-bf16 vs fp32 (noise floor) = {pf:.1f} dB; ref rms {float(ref.pow(2).mean().sqrt()):.3f}")
     assert img.shape == (1, 3, 1024, 1024) and torch.isfinite(img.float()).all()
-    assert ps >= 40.0
+    _gate_image(ps, pf, "SDXL VAE decode")
     assert rr < 2.5e-2
 
 
@@ -117,7 +140,8 @@ def test_sdxl_pipeline_50_steps_psnr_vs_fp32_reference(sdxl):
           f"(noise floor) = {pf:.1f} dB, engine vs torch-bf16 = {_psnr01(img, img_b):.1f} dB; final latents rel_rms "
           f"engine {rl:.3e} / torch-bf16 {rlf:.3e}")
     assert torch.isfinite(img.float()).all() and torch.isfinite(img_f).all()
-    assert ps >= 40.0, f"PSNR {ps:.1f} dB < 40 dB (noise floor of the bf16 reference: {pf:.1f} dB)"
+    _gate_image(ps, pf, "SDXL 50-step image")
+    assert rl <= FLOOR_FACTOR * rlf, f"final latents rel-rms {rl:.3e} vs fp32 exceeds {FLOOR_FACTOR} x the bf16 reference's {rlf:.3e}"
     lat_eager = pipe(latents=inp["latents"].clone(), output_type="latent", use_graph=False,
                      **dict(kw, num_inference_steps=3)).images.clone()
     lat_graph = pipe(latents=inp["latents"].clone(), output_type="latent", use_graph=True,
@@ -221,16 +245,36 @@ def test_flux_schnell_full_size_forward_vs_fp32_reference_on_device():
     txt_ids = torch.zeros(512, 3)
     y = tr(hidden_states=hs, encoder_hidden_states=ehs, pooled_projections=pooled, timestep=ts, img_ids=img_ids, txt_ids=txt_ids).sample
     torch.cuda.synchronize()
+    refpkg = _reference()
     with torch.no_grad():
-        floor = R.flux_forward(sd, cfg, hs, ehs, pooled, ts.to(DEV), img_ids.to(DEV), txt_ids.to(DEV))
-        sd32 = {k: v.float() for k, v in sd.items()}
-        del sd
-        ref = R.flux_forward(sd32, cfg, hs.float(), ehs.float(), pooled.float(), ts.to(DEV), img_ids.to(DEV), txt_ids.to(DEV))
+        if refpkg is not None:
+            # the REAL FluxTransformer2DModel (transformer_flux.py:671-821) on PyTorch-ROCm: bf16 (the noise floor), then fp32
+            from oracle import ref_runtime as RR
+            kind = "reference class"
+
+            def run(dtype):
+                m = RR.build_model(refpkg, "FluxTransformer2DModel", dinit.FLUX_SCHNELL, sd, DEV, dtype)
+                out = m(hidden_states=hs.to(dtype), encoder_hidden_states=ehs.to(dtype), pooled_projections=pooled.to(dtype),
+                        timestep=ts.to(DEV).to(dtype), img_ids=img_ids.to(DEV), txt_ids=txt_ids.to(DEV), guidance=None, return_dict=False)[0]
+                del m
+                torch.cuda.empty_cache()
+                return out
+            floor = run(bf16)
+            ref = run(torch.float32)
+            del sd
+        else:
+            kind = "oracle graph"
+            floor = R.flux_forward(sd, cfg, hs, ehs, pooled, ts.to(DEV), img_ids.to(DEV), txt_ids.to(DEV))
+            sd32 = {k: v.float() for k, v in sd.items()}
+            del sd
+            ref = R.flux_forward(sd32, cfg, hs.float(), ehs.float(), pooled.float(), ts.to(DEV), img_ids.to(DEV), txt_ids.to(DEV))
+            del sd32
     rr, rf = rel_rms(y, ref), rel_rms(floor, ref)
-    print(f"[parity] FLUX.1-schnell full-size forward (4096 + 512 tokens): engine vs fp32 rel_rms = {rr:.3e}; "
+    print(f"[parity] FLUX.1-schnell full-size forward (4096 + 512 tokens) vs the {kind}: engine vs fp32 rel_rms = {rr:.3e}; "
           f"torch-bf16 vs fp32 (noise floor) = {rf:.3e}")
-    assert y.shape == ref.shape and torch.isfinite(y.float()).all() and rr < 2.5e-2
-    del sd32, tr
+    assert y.shape == ref.shape and torch.isfinite(y.float()).all()
+    _gate_model(rr, rf, "FLUX.1-schnell forward")
+    del tr
     torch.cuda.empty_cache()
 
 
@@ -250,15 +294,39 @@ def test_wan13_full_size_forward_vs_fp32_reference_on_device():
     ts = torch.tensor([500])
     y = tr(hidden_states=hs, timestep=ts, encoder_hidden_states=ehs).sample
     torch.cuda.synchronize()
+    refpkg = _reference()
+    kind, floor, ref = "oracle graph", None, None
     with torch.no_grad():
-        floor = R.wan_forward(sd, cfg, hs, ts.to(DEV), ehs)
-        sd32 = {k: v.float() for k, v in sd.items()}
-        ref = R.wan_forward(sd32, cfg, hs.float(), ts.to(DEV), ehs.float())
+        if refpkg is not None:
+            # the REAL WanTransformer3DModel (transformer_wan.py:629-735); its fp32 attention over 32 760 tokens goes through
+            # torch SDPA -- if that path cannot run here (memory / backend), the oracle graph below is the comparator
+            from oracle import ref_runtime as RR
+            try:
+                def run(dtype):
+                    m = RR.build_model(refpkg, "WanTransformer3DModel", dinit.WAN_1_3B, sd, DEV, dtype,
+                                       keep_fp32=("time_embedder", "scale_shift_table", "norm1", "norm2", "norm3"))
+                    out = m(hidden_states=hs.to(dtype), timestep=ts.to(DEV), encoder_hidden_states=ehs.to(dtype), return_dict=False)[0]
+                    del m
+                    torch.cuda.empty_cache()
+                    return out
+                floor = run(bf16)
+                ref = run(torch.float32)
+                kind = "reference class"
+            except Exception as e:
+                print(f"[parity] reference WanTransformer3DModel could not run at full size ({type(e).__name__}: {e}); using the oracle graph")
+                floor = ref = None
+                torch.cuda.empty_cache()
+        if ref is None:
+            floor = R.wan_forward(sd, cfg, hs, ts.to(DEV), ehs)
+            sd32 = {k: v.float() for k, v in sd.items()}
+            ref = R.wan_forward(sd32, cfg, hs.float(), ts.to(DEV), ehs.float())
+            del sd32
     rr, rf = rel_rms(y, ref), rel_rms(floor, ref)
-    print(f"[parity] Wan2.1-T2V-1.3B full-size forward (32 760 tokens): engine vs fp32 rel_rms = {rr:.3e}; "
+    print(f"[parity] Wan2.1-T2V-1.3B full-size forward (32 760 tokens) vs the {kind}: engine vs fp32 rel_rms = {rr:.3e}; "
           f"torch-bf16 vs fp32 (noise floor) = {rf:.3e}")
-    assert y.shape == ref.shape and torch.isfinite(y.float()).all() and rr < 2.5e-2
-    del sd32, sd, tr
+    assert y.shape == ref.shape and torch.isfinite(y.float()).all()
+    _gate_model(rr, rf, "Wan2.1-T2V-1.3B forward")
+    del sd, tr
     torch.cuda.empty_cache()
 
 
@@ -299,8 +367,75 @@ def test_sd15_full_size_50_step_ddim_image_psnr():
                 e2 = R.unet_forward(u, ucfg, torch.cat([x, x]), float(t_), ctx, None)
                 x = sch.step(OS.cfg_combine(e2[:1], e2[1:], gs), t_, x)
             return R.vae_decode(v_, vcfg, x / vcfg["scaling_factor"])
+    refpkg = _reference()
+    kind = "oracle loop"
+    if refpkg is not None:
+        # the REAL StableDiffusionPipeline.__call__ (pipeline_stable_diffusion.py:775-1090) over the reference's own classes
+        from oracle import ref_runtime as RR
+        kind = "reference pipeline"
+
+        def loop(dtype):  # noqa: F811
+            ru = RR.build_model(refpkg, "UNet2DConditionModel", dinit.SD15_UNET, usd, DEV, dtype)
+            rv = RR.build_vae(refpkg, dinit.SD_VAE, vsd, DEV, dtype)
+            rp = refpkg.StableDiffusionPipeline(vae=rv, text_encoder=None, tokenizer=None, unet=ru,
+                                                scheduler=refpkg.DDIMScheduler(**factory.SD15_SCHEDULER), safety_checker=None,
+                                                feature_extractor=None, requires_safety_checker=False)
+            rp.set_progress_bar_config(disable=True)
+            with torch.no_grad():
+                im = rp(prompt_embeds=pe.to(dtype), negative_prompt_embeds=ne.to(dtype), latents=lat.to(dtype).clone(),
+                        num_inference_steps=steps, guidance_scale=gs, eta=0.0, output_type="pt", height=512, width=512).images
+            del rp, ru, rv
+            torch.cuda.empty_cache()
+            return im.float() * 2.0 - 1.0
     ref, floor = loop(torch.float32), loop(bf16)
     ps, pf = _psnr01(img, ref), _psnr01(floor, ref)
-    print(f"[parity] SD1.5 512x512, 50 DDIM steps, CFG 7.5: image PSNR engine vs fp32 = {ps:.1f} dB, torch-bf16 vs fp32 "
+    print(f"[parity] SD1.5 512x512, 50 DDIM steps, CFG 7.5 vs the {kind}: image PSNR engine vs fp32 = {ps:.1f} dB, torch-bf16 vs fp32 "
           f"(noise floor) = {pf:.1f} dB, engine vs torch-bf16 = {_psnr01(img, floor):.1f} dB")
-    assert img.shape == ref.shape and torch.isfinite(img.float()).all() and ps >= 40.0
+    assert img.shape == ref.shape and torch.isfinite(img.float()).all()
+    _gate_image(ps, pf, "SD1.5 50-step image")
+
+
+
+def test_flux_schnell_full_size_4_step_image_psnr_vs_reference_pipeline():
+    """BASELINE config 4 end to end: FLUX.1-schnell, 1024 x 1024, 4 FlowMatchEuler steps, no CFG -- the engine FluxPipeline's image
+    against the REAL reference FluxPipeline.__call__ (pipeline_flux.py:653-1010 over FluxTransformer2DModel / AutoencoderKL /
+    FlowMatchEulerDiscreteScheduler from the archive) in fp32 on this GPU, its bf16 run as the noise floor."""
+    refpkg = _reference()
+    if refpkg is None:
+        pytest.skip("reference archive oracle/_ref/diffusers_ref.zip did not ship")
+    from diffusers_amd import factory, init as dinit
+    from oracle import ref_runtime as RR
+    from diffusers_amd.pipelines import FluxPipeline
+    from diffusers_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    sched_kw = dict(shift=1.0, use_dynamic_shifting=False)
+    tr, tsd = factory.build_flux_transformer(dinit.FLUX_SCHNELL, seed=5, device=DEV, init_device=DEV)
+    vae, vsd = factory.build_vae(dinit.FLUX_VAE, seed=6, device=DEV, init_device=DEV)
+    pipe = FluxPipeline(scheduler=FlowMatchEulerDiscreteScheduler(**sched_kw), vae=vae, transformer=tr)
+    g = torch.Generator("cpu").manual_seed(1234)
+    pe = torch.randn((1, 512, 4096), generator=g).to(bf16).to(DEV)
+    pooled = torch.randn((1, 768), generator=g).to(bf16).to(DEV)
+    x = torch.randn((1, 4096, 64), generator=g).to(bf16).to(DEV)
+    img = pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, latents=x, num_inference_steps=4, guidance_scale=0.0, height=1024, width=1024,
+               output_type="raw").images
+    del pipe, tr, vae
+    torch.cuda.empty_cache()
+
+    def run(dtype):
+        rtr = RR.build_model(refpkg, "FluxTransformer2DModel", dinit.FLUX_SCHNELL, tsd, DEV, dtype)
+        rvae = RR.build_vae(refpkg, dinit.FLUX_VAE, vsd, DEV, dtype)
+        sch = refpkg.FlowMatchEulerDiscreteScheduler(**sched_kw)
+        rp = refpkg.FluxPipeline(sch, rvae, None, None, None, None, rtr)
+        rp.set_progress_bar_config(disable=True)
+        with torch.no_grad():
+            im = rp(prompt_embeds=pe.to(dtype), pooled_prompt_embeds=pooled.to(dtype), latents=x.to(dtype).clone(), num_inference_steps=4,
+                    guidance_scale=0.0, height=1024, width=1024, output_type="pt").images
+        del rp, rtr, rvae
+        torch.cuda.empty_cache()
+        return im.float() * 2.0 - 1.0
+    floor = run(bf16)
+    ref = run(torch.float32)
+    ps, pf = _psnr01(img, ref), _psnr01(floor, ref)
+    print(f"[parity] FLUX.1-schnell 1024x1024, 4 steps vs the reference FluxPipeline: image PSNR engine vs fp32 = {ps:.1f} dB, "
+          f"torch-bf16 vs fp32 (noise floor) = {pf:.1f} dB, engine vs torch-bf16 = {_psnr01(img, floor):.1f} dB")
+    assert img.shape == ref.shape and torch.isfinite(img.float()).all()
+    _gate_image(ps, pf, "FLUX.1-schnell 4-step image")

@@ -87,3 +87,35 @@ def test_reference_classes_accept_the_engine_state_dicts_at_full_size():
     rr = float((got.float() - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
     print(f"[parity] full SDXL U-Net (64x64 latents) engine vs the REAL reference class in fp32: rel-rms {rr:.3e}")
     assert rr < 2.5e-2
+
+
+
+def test_engine_components_under_the_reference_pipeline_at_full_size():
+    """The drop-in at BASELINE size: SDXL-base U-Net + VAE engine objects in the component slots of the
+    reference `StableDiffusionXLPipeline`, its own `__call__` at 1024 x 1024 (8 steps here; bench.py's `dropin` leg times the 50-step
+    call): image PSNR against the all-reference fp32 run within 1 dB of the all-reference bf16 run's, and the engine's own graphed
+    pipeline on the same inputs lands on the same image."""
+    import diffusers_amd as da
+    da_, factory, ref, ucfg, vcfg, unet, usd, vae, vsd, inp = _setup(tiny=False)
+    steps, hw = 8, 1024
+    rpipe = RR.build_sdxl_pipeline(ref, ucfg, vcfg, usd, vsd, factory.SDXL_SCHEDULER, DEV, torch.float32)
+    want, _ = RR.run_sdxl(rpipe, inp, steps, 5.0, hw, torch.float32)
+    rpipe.to(bf16)
+    floor, _ = RR.run_sdxl(rpipe, inp, steps, 5.0, hw, bf16)
+    del rpipe
+    torch.cuda.empty_cache()
+    dpipe = RR.engine_under_reference_sdxl(ref, unet, vae, da.EulerDiscreteScheduler(**factory.SDXL_SCHEDULER), DEV, bf16, 1280)
+    assert str(dpipe._execution_device).startswith("cuda")
+    got, _ = RR.run_sdxl(dpipe, inp, steps, 5.0, hw, bf16)
+    ps, pf = _psnr(got, want), _psnr(floor, want)
+    print(f"[drop-in] full size, {steps} steps: engine under the reference SDXL __call__ vs the all-reference fp32 run: PSNR {ps:.1f} dB "
+          f"(all-reference bf16 run: {pf:.1f} dB)")
+    assert got.shape == want.shape == (1, 3, hw, hw) and ps >= 40.0 and ps >= pf - 1.0
+    from diffusers_amd.pipelines import StableDiffusionXLPipeline
+    epipe = StableDiffusionXLPipeline(vae=vae, unet=unet, scheduler=da.EulerDiscreteScheduler(**factory.SDXL_SCHEDULER))
+    img = epipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+                pooled_prompt_embeds=inp["pooled"], negative_pooled_prompt_embeds=inp["negative_pooled"],
+                latents=inp["latents"].clone(), num_inference_steps=steps, guidance_scale=5.0, height=hw, width=hw, output_type="pt").images
+    ps2 = _psnr(img, want)
+    print(f"[drop-in] full size: engine pipeline vs the all-reference fp32 run: PSNR {ps2:.1f} dB; vs engine-under-reference: {_psnr(img, got):.1f} dB")
+    assert ps2 >= 40.0 and ps2 >= pf - 1.0
