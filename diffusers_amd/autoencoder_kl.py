@@ -77,13 +77,23 @@ class VaeAttention:
         else:
             if self.heads != 1:
                 raise ValueError("VaeAttention GEMM path supports a single head")
+            # One head of D = 512: scores GEMM (fp32) -> row softmax -> P.V GEMM, in blocks of QBLK query rows so that the score
+            # matrix held at any time is QBLK x S (268 MB at S = 16 384 instead of 1 GB + 0.5 GB of probabilities).  Measured
+            # (profiles/README.md): the two GEMMs run at ~900 TFLOP/s here; a flash kernel at D = 512 would either recompute Q.K^T per
+            # 128-wide output slice (2.5x the flops) or exchange partial scores between waves every tile -- slower than this path.
             o = torch.empty((B * S, C), device=x.device, dtype=bf16)
+            QBLK = 4096
+            nb = min(QBLK, S)
+            scores = torch.empty((nb, S), device=x.device, dtype=torch.float32)
+            probs = torch.empty((nb, S), device=x.device, dtype=bf16)
             for b in range(B):
-                q = qk[b * S:(b + 1) * S, :self.inner]
                 k = qk[b * S:(b + 1) * S, self.inner:]
-                scores = ops.linear(q, k, alpha=self.scale, out_f32=True)         # [S][S] fp32
-                probs = ops.softmax_rows(scores)                                  # [S][S] bf16
-                ops.linear(probs, vt[:, b * S:(b + 1) * S], out=o[b * S:(b + 1) * S])
+                for q0 in range(0, S, nb):
+                    n = min(nb, S - q0)
+                    q = qk[b * S + q0:b * S + q0 + n, :self.inner]
+                    ops.linear(q, k, alpha=self.scale, out_f32=True, out=scores[:n])       # [n][S] fp32
+                    ops.softmax_rows(scores[:n], out=probs[:n])                             # [n][S] bf16
+                    ops.linear(probs[:n], vt[:, b * S:(b + 1) * S], out=o[b * S + q0:b * S + q0 + n])
         y = ops.linear(o, self.wo, self.bo, residual=res)
         return y.view(B, H, W_, C)
 

@@ -705,7 +705,7 @@ extern "C" int da_attention_bf16(const da_attention_params* pp, void* stream) {
   if (p.Skv_alloc < p.Skv || (p.Skv_alloc & 7)) return DA_ERR_INVALID;
   if (p.ring_slots != 0 && (p.ring_slots < 2 || p.ring_slots > 4)) return DA_ERR_INVALID;
   if (p.q_block != 0 && p.q_block != 64 && p.q_block != 128 && p.q_block != 256) return DA_ERR_INVALID;
-  if (p.algo < 0 || p.algo > 3) return DA_ERR_INVALID;
+  if (p.algo < 0 || p.algo > 5) return DA_ERR_INVALID;
   if (p.pv_delay < -1 || p.pv_delay > 2) return DA_ERR_INVALID;
   if (p.bias && ((p.bias_row_stride != 0 && p.bias_row_stride < ((p.Skv + 63) & ~63)) || (p.bias_row_stride & 3) || (p.bias_batch_stride & 3) ||
                  (p.bias_head_stride & 3) || p.scale == 0.0f))

@@ -63,7 +63,11 @@ __device__ __forceinline__ int k_swz(int row) {
 // with Q pre-multiplied by scale * log2(e): the scores leave the MFMA as s * c - m and the 32 v_fma_f32 per tile in front of the
 // exponentials disappear (two more MFMAs per tile instead).  m is kept bf16-exact; the softmax is invariant to the shift, so
 // its rounding is harmless; the pre-multiplied Q is rounded to bf16 once more than the reference's (scores within bf16 noise).
-template <int D, int NW, int NS, bool AUG>
+// RSM: the row sum l of the online softmax comes out of the matrix pipe: one more A fragment of ones next to the V^T fragments of every
+// P.V k-step accumulates sum_k P^T[k][q] into a 17th / 33rd accumulator tile (every row of it holds the row sums), so the 32 v_add_f32
+// per tile disappear (4 more MFMAs per tile instead).  l is then the sum of the bf16-ROUNDED probabilities -- exactly the weights
+// the second product applies to V -- and it is rescaled with O when the running shift moves.
+template <int D, int NW, int NS, bool AUG, bool RSM>
 // min waves per SIMD: D = 64 / four waves: three workgroups per CU (<= 168 registers); eight waves: one workgroup = two per SIMD
 __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 1)) void attn2_fwd_kernel(const da_attention_params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -174,14 +178,19 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
     }
   }
   // AUG: the extra k-step.  A = K side: 1.0 at k = 0 for every key row; B = Q side: -m of the lane's query at k = 0.
-  const bf16x8_t kx = __builtin_bit_cast(bf16x8_t, make_uint4(hi == 0 ? 0x3F80u : 0u, 0u, 0u, 0u));
+  // (the A side is all ones: the B side is zero everywhere but at k = 0 of the hi = 0 lanes, so the step still contributes -m only;
+  //  the same fragment feeds the row-sum product of RSM)
   bf16x8_t qx = __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u));
+  const bf16x8_t ones8 = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
 
   f32x16_t o[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  f32x16_t osum;             // RSM: row sums, accumulated by the matrix pipe
+#pragma unroll
+  for (int r = 0; r < 16; ++r) osum[r] = 0.f;
   float m_run = AUG ? 0.f : -1e30f, l_run = 0.f;
 
   // fragment addresses (bytes inside a ring slot): 4 K and 4 V^T lane-constant offsets, the rest are immediates
@@ -218,18 +227,25 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
     const unsigned char* sbp = smem + prv;
     f32x16_t s[2];
     {
-      bf16x8_t kf[NQK];
+      // K fragments in batches of KB (all of them where the registers allow): the reads the first MFMAs wait for go out first
+      constexpr int KB = (AUG && RSM && D == 64 && NW == 4) ? NQK / 2 : (D == 128 ? NQK / 2 : NQK);
+      bf16x8_t kf[KB];
 #pragma unroll
-      for (int k = 0; k < NQK; ++k) kf[k] = kfrag(sb, k);      // the reads the first MFMAs wait for go out first
+      for (int k = 0; k < KB; ++k) kf[k] = kfrag(sb, k);
       if (j + PD < ntiles) issue(j + PD, nxt);
       const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if constexpr (AUG) {
-        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx, qx, zero16, 0, 0, 0);
-        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx, qx, zero16, 0, 0, 0);
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, qx, zero16, 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, qx, zero16, 0, 0, 0);
       }
 #pragma unroll
-      for (int k = 0; k < NQK; ++k)
-        s[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k], qf[k >> 1], (!AUG && k < 2) ? zero16 : s[k & 1], 0, 0, 0);
+      for (int k0 = 0; k0 < NQK; k0 += KB) {
+#pragma unroll
+        for (int k = k0; k < k0 + KB; ++k) {
+          s[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k - k0], qf[k >> 1], (!AUG && k < 2) ? zero16 : s[k & 1], 0, 0, 0);
+          if (k + KB < NQK) kf[k - k0] = kfrag(sb, k + KB);       // the next batch's fragment takes the register just consumed
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     // ragged last tile: keys past Skv never win the maximum and exponentiate to exactly 0 (wave-uniform branch)
@@ -245,7 +261,12 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
     }
     float alpha = 1.f;
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
-    bf16x8_t pn[4];
+    auto pack_p = [&](int u) {
+      const int b8 = 8 * (u & 1);
+      const uint4 pk = make_uint4(pack_bf2(s[u >> 1][b8 + 0], s[u >> 1][b8 + 1]), pack_bf2(s[u >> 1][b8 + 2], s[u >> 1][b8 + 3]),
+                                  pack_bf2(s[u >> 1][b8 + 4], s[u >> 1][b8 + 5]), pack_bf2(s[u >> 1][b8 + 6], s[u >> 1][b8 + 7]));
+      pf[u] = __builtin_bit_cast(bf16x8_t, pk);
+    };
     auto slice = [&](int sl) {
       if (sl == 0) {
         float mx0 = fmaxf(s[0][0], s[0][1]), mx1 = fmaxf(s[1][0], s[1][1]);
@@ -286,20 +307,19 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
         for (int r = r0; r < r0 + 8; ++r) {
           const float e = AUG ? __builtin_amdgcn_exp2f(s[st][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sl2, -m_run));
           s[st][r] = e;
-          ps[r & 3] += e;
+          if constexpr (!RSM) ps[r & 3] += e;
         }
+        if constexpr (!RSM) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(ps[u]));   // the adds stay in this slice
+          for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(ps[u]));   // the adds stay in this slice
+        }
       } else if (sl >= 5 && sl <= 6) {
+        // P^T of tile j is packed straight into `pf`: fragment u of tile j - 1 is consumed by the P.V MFMAs of slices 2u and 2u + 1,
+        // so fragments 0 / 1 are free from slice 4 on, fragment 2 from slice 6 on, fragment 3 behind slice 7 (packed after the loop)
 #pragma unroll
-        for (int u = 2 * (sl - 5); u < 2 * (sl - 5) + 2; ++u) {
-          const int b8 = 8 * (u & 1);
-          const uint4 pk = make_uint4(pack_bf2(s[u >> 1][b8 + 0], s[u >> 1][b8 + 1]), pack_bf2(s[u >> 1][b8 + 2], s[u >> 1][b8 + 3]),
-                                      pack_bf2(s[u >> 1][b8 + 4], s[u >> 1][b8 + 5]), pack_bf2(s[u >> 1][b8 + 6], s[u >> 1][b8 + 7]));
-          pn[u] = __builtin_bit_cast(bf16x8_t, pk);
-        }
+        for (int u = (sl == 5 ? 0 : 2); u < (sl == 5 ? 2 : 3); ++u) pack_p(u);
       } else if (sl == 7) {
-        l_run = l_run * alpha + ((ps[0] + ps[1]) + (ps[2] + ps[3]));
+        if constexpr (!RSM) l_run = l_run * alpha + ((ps[0] + ps[1]) + (ps[2] + ps[3]));
       }
     };
     if constexpr (HAS_PREV) {
@@ -315,6 +335,9 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
         for (int q = 0; q < PER; ++q) {
           const int k = sl * PER + q;
           o[k % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q], pf[k / DT], o[k % DT], 0, 0, 0);
+          if constexpr (RSM) {
+            if (k % DT == 0) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[k / DT], osum, 0, 0, 0);
+          }
         }
         slice(sl);
         __builtin_amdgcn_sched_barrier(0);
@@ -328,8 +351,9 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    pack_p(3);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(pn[u]));
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(pf[u]));
     __builtin_amdgcn_sched_barrier(0);
     // rescale AFTER tile j - 1's product has been added: O_j-1 complete, then * alpha_j, then (next iteration) + P_j V_j.
     // alpha is exactly 1.0f unless the deferred-maximum branch ran (x * 1.0f is exact: same bits either way).
@@ -338,9 +362,11 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
       for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    }
+      if constexpr (RSM) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) pf[u] = pn[u];
+        for (int r = 0; r < 16; ++r) osum[r] *= alpha;
+      }
+    }
     prv = cur;
     cur = (cur + C::STAGE == RING) ? 0 : cur + C::STAGE;
     nxt = (nxt + C::STAGE == RING) ? 0 : nxt + C::STAGE;
@@ -353,11 +379,17 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
     const unsigned char* sbl = smem + prv;
 #pragma unroll
     for (int k = 0; k < NPV; ++k) o[k % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(sbl, k), pf[k / DT], o[k % DT], 0, 0, 0);
+    if constexpr (RSM) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[u], osum, 0, 0, 0);
+    }
   }
 
   // ---- epilogue: O^T registers -> LDS (per wave) -> whole rows, 16 bytes per lane ----
   float l_tot;
-  {
+  if constexpr (RSM) {
+    l_tot = osum[0];           // every row of the tile holds the sums over BOTH halves' keys (the MFMA contracts all 16 k of a step)
+  } else {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     l_tot = __uint_as_float(r[0]) + __uint_as_float(r[1]);
   }
@@ -404,11 +436,11 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int D, int NW, int NS, bool AUG>
+template <int D, int NW, int NS, bool AUG, bool RSM>
 int launch(const da_attention_params& p, hipStream_t s) {
   using C = Cfg<D>;
   const size_t lds = (size_t)NS * C::STAGE;
-  auto kern = attn2_fwd_kernel<D, NW, NS, AUG>;
+  auto kern = attn2_fwd_kernel<D, NW, NS, AUG, RSM>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DA_ERR_LAUNCH;
@@ -442,15 +474,20 @@ int da_attn2_dispatch(const da_attention_params& p, hipStream_t s) {
     const long long blocks256 = (long long)p.B * p.H * ((p.Sq + 255) / 256);
     qb = (p.D == 128 && blocks256 >= 192) ? 256 : 128;
   }
-  const bool aug = p.algo == 3;
+  const bool aug = p.algo == 3 || p.algo == 5, rsm = p.algo == 4 || p.algo == 5;
+#define DA_A2V(D_, NW_, NS_)                                                                                          \
+  return aug ? (rsm ? da_attn2::launch<D_, NW_, NS_, true, true>(p, s) : da_attn2::launch<D_, NW_, NS_, true, false>(p, s)) \
+             : (rsm ? da_attn2::launch<D_, NW_, NS_, false, true>(p, s) : da_attn2::launch<D_, NW_, NS_, false, false>(p, s))
 #define DA_A2(D_, NW_)                                                                                               \
-  return ns == 3 ? (aug ? da_attn2::launch<D_, NW_, 3, true>(p, s) : da_attn2::launch<D_, NW_, 3, false>(p, s))     \
-                 : (aug ? da_attn2::launch<D_, NW_, 4, true>(p, s) : da_attn2::launch<D_, NW_, 4, false>(p, s))
+  do {                                                                                                               \
+    if (ns == 3) { DA_A2V(D_, NW_, 3); } else { DA_A2V(D_, NW_, 4); }                                                \
+  } while (0)
   if (p.D == 64) {
     if (qb == 256) DA_A2(64, 8);
     DA_A2(64, 4);
   }
   if (qb == 256) DA_A2(128, 8);
   DA_A2(128, 4);
+#undef DA_A2V
 #undef DA_A2
 }

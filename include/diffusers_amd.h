@@ -249,7 +249,9 @@ typedef struct da_attention_params {
                through ring_slots = 2 / q_block = 64 / pv_delay != 0 -- else the first-generation kernel;
                1 = first generation (attention.hip) always; 2 = second generation or DA_ERR_UNSUPPORTED;
                3 = second generation with the softmax shift folded into the Q.K^T product ("AUG": Q pre-multiplied by
-               scale * log2 e and rounded to bf16 once more, -m as one extra k-step).
+               scale * log2 e and rounded to bf16 once more, -m as one extra k-step);
+               4 = second generation with the row sum taken by the matrix pipe ("RSM": a ones row next to V^T, l = the sum of the
+               bf16-rounded probabilities); 5 = both.
                The generations agree to bf16 rounding of the output, not bit for bit (different shift, different order of
                the row sum); within the second generation q_block 128 / 256 and ring_slots 3 / 4 are bit-identical. */
 } da_attention_params;

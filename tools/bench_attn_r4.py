@@ -79,6 +79,10 @@ def main():
             "v2 256q ring4": dict(algo=2, q_block=256, ring_slots=4),
             "v2aug 128q ring3": dict(algo=3, q_block=128, ring_slots=3),
             "v2aug 256q ring3": dict(algo=3, q_block=256, ring_slots=3),
+            "v2rsm 128q ring3": dict(algo=4, q_block=128, ring_slots=3),
+            "v2rsm 256q ring3": dict(algo=4, q_block=256, ring_slots=3),
+            "v2augrsm 128q ring3": dict(algo=5, q_block=128, ring_slots=3),
+            "v2augrsm 256q ring3": dict(algo=5, q_block=256, ring_slots=3),
             "default": dict(),
         }
         n = 6 if S > 8192 else 30
@@ -99,7 +103,7 @@ def main():
                 rec["v2aug variants bit-identical"] = bool(torch.equal(outs["v2aug 128q ring3"], outs["v2aug 256q ring3"]))
         if check:
             ref = ref_fp32(q, k, vt, B, H, D, S, Skv, sa)
-            for vn in ("v1 default", "v2 128q ring3", "v2aug 128q ring3", "default"):
+            for vn in ("v1 default", "v2 128q ring3", "v2aug 128q ring3", "v2rsm 128q ring3", "v2augrsm 128q ring3", "default"):
                 if vn in outs:
                     rec["relrms " + vn] = float(f"{relrms(outs[vn], ref):.3e}")
                     rec["finite " + vn] = bool(torch.isfinite(outs[vn].float()).all())

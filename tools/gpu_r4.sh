@@ -55,3 +55,8 @@ if [[ $WHAT == *benchfull* ]]; then
   timeout 1500 python bench.py --steps 3 --warmup 1 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"
   cut -c1-300 $O/bench_full.json; grep "^\[bench" $O/bench_full.err | tail -40
 fi
+if [[ $WHAT == *fulltest* ]]; then
+  timeout 2400 python -m pytest tests -m gpu -q -s --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
+  grep -E "passed|failed|FAILED|Error" $O/pytest_gpu.log | tail -20
+  grep -E "\[parity\] (SDXL|FLUX|Wan|SD1.5|full)|\[drop-in\]" $O/pytest_gpu.log | tail -40
+fi
