@@ -253,7 +253,7 @@ def roofline_leg(pipe, mine, world, images_per_s):
                 traffic, note = tr["igemm_bytes_per_launch"], tr.get("source", str(TRAFFIC_FILE.name))
             else:
                 note = (f"stale: {TRAFFIC_FILE.name} was measured on build {tr.get('build_fingerprint', 'unstamped (round 2)')}, "
-                        f"this library is {fp}; re-run tools/gpu_r3.sh traffic")
+                        f"this library is {fp}; re-run tools/gpu_r4.sh traffic")
         except (ValueError, KeyError) as e:
             note = f"unreadable {TRAFFIC_FILE.name}: {e}"
     kernels = [_kernel_entry("igemm", "igemm_bf16_kernel + igemm2_bf16_kernel (Linear, Conv2d, paired Q|K + V^T)", "mfma", fam["igemm"])]

@@ -79,6 +79,10 @@ def _nbytes16(t: torch.Tensor) -> int:
     return (t.numel() * t.element_size()) & ~15
 
 
+# A/B knob: bytes of the next weight a launch may pull (0 = all the kernel's per-wave budget covers; 16 MiB = the round-3 reach)
+PREFETCH_CAP_BYTES = int(float(os.environ.get("DIFFUSERS_AMD_PREFETCH_CAP_MB", "0")) * (1 << 20)) & ~1023
+
+
 def _prefetch_hook(p: "L.GemmParams", x: torch.Tensor, w: torch.Tensor) -> None:
     pf = _prefetch_state
     if pf is None:
@@ -97,7 +101,7 @@ def _prefetch_hook(p: "L.GemmParams", x: torch.Tensor, w: torch.Tensor) -> None:
         return
     nxt = pf.seq[(i + 1) % len(pf.seq)]
     if nxt is not None:
-        p.prefetch, p.prefetch_bytes = nxt
+        p.prefetch, p.prefetch_bytes = nxt[0], (min(nxt[1], PREFETCH_CAP_BYTES) if PREFETCH_CAP_BYTES else nxt[1])
         pf.applied += 1
 
 
