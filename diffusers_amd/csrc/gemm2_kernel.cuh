@@ -24,6 +24,7 @@
 // to every other K2 shape; against the first family the fp32 summation order differs (last-bit differences before the
 // bf16 rounding of the output).
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.cuh"
@@ -1076,6 +1077,10 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
 
 // ---- host side ----
 inline int choose_xcd_gx2(int tiles_m, int tiles_n, int BM, int BN) {   // as da_gemm::choose_xcd_gx
+  // experiments: DA_XCD_GX = 1 / 2 / 4 / 8 pins the number of XCD columns (1: every XCD owns whole row panels -- it reads rows the
+  // previous launch's same-numbered XCD wrote; 8: whole column panels -- each weight row is fetched by one XCD only)
+  static const int forced = [] { const char* v = getenv("DA_XCD_GX"); return v ? atoi(v) : 0; }();
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
   int best = 1;
   double best_cost = 1e300;
   for (int gx = 1; gx <= 8; gx *= 2) {

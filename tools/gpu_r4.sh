@@ -108,3 +108,14 @@ if [[ $WHAT == *pfab* ]]; then
     DIFFUSERS_AMD_PREFETCH_CAP_MB=$cap timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_pf$cap.json 2> $O/bench_pf$cap.err; echo "prefetch cap $cap MB rc=$? $(cut -c1-140 $O/bench_pf$cap.json | grep -o '"value": [0-9.]*')"
   done
 fi
+if [[ $WHAT == *xcd* ]]; then
+  rm -f $O/xcd_r4.jsonl
+  for gx in auto 1 2 4 8; do
+    if [[ $gx == auto ]]; then timeout 120 python tools/bench_xcd_r4.py $O/xcd_r4.jsonl > $O/xcd_r4.log 2>&1; else DA_XCD_GX=$gx timeout 120 python tools/bench_xcd_r4.py $O/xcd_r4.jsonl >> $O/xcd_r4.log 2>&1; fi
+  done
+  cat $O/xcd_r4.jsonl
+  for gx in 1 4; do
+    DA_XCD_GX=$gx timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_gx$gx.json 2> $O/bench_gx$gx.err; echo "DA_XCD_GX=$gx rc=$? $(cut -c1-140 $O/bench_gx$gx.json | grep -o '"value": [0-9.]*')"
+  done
+  timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_gxauto.json 2> $O/bench_gxauto.err; echo "auto rc=$? $(cut -c1-140 $O/bench_gxauto.json | grep -o '"value": [0-9.]*')"
+fi
