@@ -119,3 +119,18 @@ if [[ $WHAT == *xcd* ]]; then
   done
   timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_gxauto.json 2> $O/bench_gxauto.err; echo "auto rc=$? $(cut -c1-140 $O/bench_gxauto.json | grep -o '"value": [0-9.]*')"
 fi
+if [[ $WHAT == *pmcshapes* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc_shapes; mkdir -p $O/pmc_shapes
+  : > $O/r04_fetch_by_shape.md
+  for gx in auto 1 8; do
+    if [[ $gx == auto ]]; then unset DA_XCD_GX; else export DA_XCD_GX=$gx; fi
+    DIFFUSERS_AMD_TUNE=0 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_shapes/gx$gx -o s -- python $R/tools/pmc_shapes_r4.py run $O/pmc_shapes/manifest_$gx.json > $O/pmc_shapes/gx$gx.log 2>&1; echo "pmc shapes gx=$gx rc=$?"
+    python $R/tools/pmc_shapes_r4.py report $O/pmc_shapes/manifest_$gx.json $(find $O/pmc_shapes/gx$gx -name '*counter_collection.csv') >> $O/r04_fetch_by_shape.md 2>> $O/pmc_shapes/gx$gx.log
+    echo >> $O/r04_fetch_by_shape.md
+  done
+  unset DA_XCD_GX
+  find $O/pmc_shapes -name '*kernel_trace*' -delete
+  cd $R
+  cat $O/r04_fetch_by_shape.md
+fi
