@@ -49,6 +49,7 @@ class GemmParams(C.Structure):
         ("stats_out", C.c_void_p), ("stats_ld", C.c_int), ("ln_stats", C.c_void_p), ("ln_stats_ld", C.c_int),
         ("ln_parts", C.c_int), ("ln_s", C.c_void_p), ("ln_c", C.c_void_p), ("ln_eps", C.c_float), ("k_valid", C.c_int),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_longlong),
+        ("vt", C.c_void_p), ("vt_col0", C.c_int), ("ld_vt", C.c_longlong),
     ]
 
 

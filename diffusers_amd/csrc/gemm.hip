@@ -108,6 +108,7 @@ bool tile_ok(const da_gemm_params& p, int tile) {
     const bool geglu_ok = tile == DA_TILE_K2_128x128 || tile == DA_TILE_K1_256x128 || tile == DA_TILE_K1_128x256 ||
                           tile == DA_TILE_K1_256x256 || tile == DA_TILE_K1_256x320 || (tile == DA_TILE_K1_128x320 && !p.conv);
     // LayerNorm fold (round 4): nn.Linear, the tiles of the SDXL transformer blocks (gemm2_kernel.cuh dispatch_lnf)
+    if (p.vt) return !p.conv && p.split_k <= 1 && !geglu && (tile == DA_TILE_K2_128x80 || tile == DA_TILE_K2_128x160);
     if (p.stats_out || p.ln_stats) {
       if (p.conv || p.split_k > 1) return false;
       if (p.stats_out && (geglu || (tile != DA_TILE_K2_128x80 && tile != DA_TILE_K2_128x160))) return false;
@@ -116,6 +117,7 @@ bool tile_ok(const da_gemm_params& p, int tile) {
     return p.split_k <= 1 && (!geglu || geglu_ok) &&
            !(p.conv && (tile == DA_TILE_K2_80x128 || tile == DA_TILE_K1_256x256 || tile == DA_TILE_K1_256x320));
   }
+  if (p.vt) return false;   // the transposed column block exists in the second family only
   // GEGLU pairs (value, gate) 32-column tiles inside one wave: the wave must own an even number of them
   if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) &&
       (tile == DA_TILE_128x64 || tile == DA_TILE_64x64 || tile == DA_TILE_128x128_W8))

@@ -862,6 +862,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
         if (m0 + row >= p.M || no0 + c * 8 >= Nout) continue;
         *(uint4*)((uint16_t*)p.C + (size_t)(m0 + row) * p.ldc + no0 + c * 8) = *(const uint4*)(smem + row * OROW + c * 16);
       }
+      DA2_TRACE_END();
       return;
     }
     // packed weight rows: per 64 = [32 value | 32 gate]  ->  16-column tiles (4u, 4u+1) = value, (4u+2, 4u+3) = gate
@@ -1039,6 +1040,36 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       }
     }
   };
+  // LNF instantiations: a tile that lies in the transposed column block (da_gemm_params.vt: the V columns of a fused Q | K | V
+  // projection) writes vt[(n - vt_col0)][m] straight from the MFMA layout -- the 16 lanes of a kq group hold 16 consecutive tokens of
+  // one channel: 32 contiguous bytes per (channel, kq) -- with the alpha / LayerNorm-fold / bias part of the epilogue only.
+  if constexpr (LNF && !GIL) {
+    if (p.vt && n0 >= p.vt_col0) {
+      uint16_t* __restrict__ vt = (uint16_t*)p.vt;
+#pragma unroll
+      for (int ih = 0; ih < MH; ++ih) {
+        const int m = row_of(ih);
+#pragma unroll
+        for (int jh = 0; jh < NH; ++jh) {
+          const int n = col_of(jh);
+          if (n >= p.N) continue;
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
+          ln_apply4(o, ih, n);
+          const uint2 bv = bias_v[jh];
+          o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y);
+          if (m < p.M) {
+            uint16_t* dst = vt + (size_t)(n - p.vt_col0) * p.ld_vt + m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(size_t)e * p.ld_vt] = f2bf(o[e]);
+          }
+        }
+      }
+      DA2_TRACE_END();
+      return;
+    }
+  }
   {
     using std::integral_constant;
     auto by_act = [&](auto&& f, auto... tail) __attribute__((always_inline)) {
@@ -1139,6 +1170,12 @@ inline int dispatch_lnf(const da_gemm_params& p, int tile, int staging, hipStrea
                  : (staging == DA_STAGE_LDS_DIRECT3 || staging == DA_STAGE_PINGPONG3) ? 3 : 0;
   const bool pp = staging == DA_STAGE_PINGPONG || staging == DA_STAGE_PINGPONG3;
   if (ns == 0) return DA_ERR_UNSUPPORTED;
+  if (p.vt) {
+    const int bn = tile == DA_TILE_K2_128x80 ? 80 : tile == DA_TILE_K2_128x160 ? 160 : 0;
+    if (bn == 0 || geglu || p.stats_out || p.residual || p.gate || p.rowvec || p.bias_rows || p.out_f32 || p.act != DA_ACT_NONE ||
+        p.vt_col0 <= 0 || p.vt_col0 >= p.N || (p.vt_col0 % bn) || (p.vt_col0 & 15) || p.ld_vt < p.M || p.out_scale != 1.0f)
+      return DA_ERR_UNSUPPORTED;
+  }
   if (p.stats_out) {
     // statistics come out of the row-contiguous store path only: 16-byte aligned bf16 rows (and residual rows)
     if (geglu || p.out_f32 || (p.ldc & 7) || ((size_t)p.C & 15) || (p.N & 7) || p.gate ||
@@ -1166,7 +1203,7 @@ inline int dispatch_lnf(const da_gemm_params& p, int tile, int staging, hipStrea
 template <bool CONV>
 int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
   if (p.split_k > 1 || !staging_fits(p)) return DA_ERR_UNSUPPORTED;
-  if (p.stats_out || p.ln_stats) {
+  if (p.stats_out || p.ln_stats || p.vt) {
     if constexpr (CONV) return DA_ERR_UNSUPPORTED;
     else return dispatch_lnf(p, tile, staging, s);
   }

@@ -236,6 +236,7 @@ class Attention:
         else:
             self.wqk = torch.cat([wq, wk], dim=0).contiguous()
             self.wv = wv
+            self.wqkv_ln = self.fold1 = None        # set by fold_norm1(): (gamma o [Wq; Wk; Wv]) and its s / c vectors
         self.to_out = Linear(w, prefix + ".to_out.0")
         self.to_out.weight = pad_head_cols(self.to_out.weight, heads, d, dp)
         self.scale = self.head_dim ** -0.5
@@ -254,6 +255,15 @@ class Attention:
         """Cross-attention only: fold the LayerNorm in front of the block (attention.py:1030) into to_q."""
         self.wq_ln, self.fold = ops.fold_layernorm(self.wq, norm.weight, norm.bias, norm.eps)
 
+    def fold_norm1(self, norm: "LayerNorm") -> None:
+        """Self-attention only: fold norm1 (attention.py:986) into ONE fused to_q | to_k | to_v projection whose V block leaves the
+        GEMM transposed (ops.linear_qkv): replaces the LayerNorm launch and the paired Q|K + V^T launch.  Needs a column origin
+        2 * inner that the transposed-block tiles divide (a multiple of 80: SDXL's 1280 / 640 do; SD1.5's 320-wide level too)."""
+        if (2 * self.inner) % 80 != 0:
+            return
+        wqkv = torch.cat([self.wqk, self.wv], dim=0).contiguous()
+        self.wqkv_ln, self.fold1 = ops.fold_layernorm(wqkv, norm.weight, norm.bias, norm.eps)
+
     def __call__(self, x, batch: int, seq: int, residual, kv: Optional[CrossKV] = None, stats=None, stats_out=None):
         """x: [batch*seq][C], already normalised -- or, with ``stats`` (ops.RowStats of x), the un-normalised tokens of a
         cross-attention whose norm was folded into to_q; returns to_out(attn) + residual (``stats_out``: the row statistics
@@ -266,9 +276,14 @@ class Attention:
                               q_batch_stride=seq * self.inner, k_batch_stride=kv.skv_alloc * self.inner,
                               vt_ld=batch * kv.skv_alloc, vt_batch_stride=kv.skv_alloc, scale=self.scale, bias=kv.bias)
         else:
-            # [M][2*inner] and [inner][M]: two problems, ONE launch (neither fills the 256 CUs alone at SDXL's sizes:
-            # 160 + 80 tiles of 128x256); bit-identical to two launches
-            qk, vt = ops.linear_pair({"x": x, "w": self.wqk}, {"x": self.wv, "w": x})
+            if stats is not None:
+                # norm1 folded: x is the UN-normalised residual stream, `stats` its row statistics (written by the GEMM that
+                # produced it); ONE launch yields [M][2*inner] and the transposed [inner][M]
+                qk, vt = ops.linear_qkv(x, self.wqkv_ln, 2 * self.inner, ln=(stats, self.fold1))
+            else:
+                # [M][2*inner] and [inner][M]: two problems, ONE launch (neither fills the 256 CUs alone at SDXL's sizes:
+                # 160 + 80 tiles of 128x256); bit-identical to two launches
+                qk, vt = ops.linear_pair({"x": x, "w": self.wqk}, {"x": self.wv, "w": x})
             o = ops.attention(qk, qk[:, self.inner:], vt, B=batch, H=Hh, D=D, Sq=seq, Skv=seq, Skv_alloc=seq,
                               q_row_stride=2 * self.inner, k_row_stride=2 * self.inner,
                               q_batch_stride=seq * 2 * self.inner, k_batch_stride=seq * 2 * self.inner,
@@ -322,8 +337,13 @@ class BasicTransformerBlock:
         self.ff = FeedForwardGEGLU(w, prefix + ".ff", norm=self.norm3 if self.folded == 1 else None)
         if self.folded:
             self.attn2.fold_norm(self.norm2)
+            self.attn1.fold_norm1(self.norm1)
+        self.folds_norm1 = bool(self.folded) and self.attn1.wqkv_ln is not None
 
-    def __call__(self, x, batch, seq, kv: CrossKV):
+    def __call__(self, x, batch, seq, kv: CrossKV, stats_in=None, stats_out=None):
+        """``stats_in``: row statistics of ``x`` written by the launch that produced it (the previous block's FF-down, or proj_in):
+        norm1 is then applied inside the fused Q | K | V projection instead of as a kernel.  ``stats_out``: the FF-down of this
+        block writes the statistics of ITS output there (for the next block's norm1)."""
         mode = int(ops.LN_FOLD)
         if mode and (not self.folded or (mode == 1 and self.folded != 1)):
             raise RuntimeError("ops.LN_FOLD was switched on after this model was loaded: the folded weights are built at "
@@ -332,21 +352,28 @@ class BasicTransformerBlock:
             x = self.attn1(self.norm1(x), batch, seq, residual=x)
             x = self.attn2(self.norm2(x), batch, seq, residual=x, kv=kv)
             return self.ff(self.norm3(x), residual=x)
+        use1 = stats_in is not None and self.folds_norm1
         if mode == 2:
             # norm2 never runs as a kernel: attn1.to_out also writes the row statistics of the residual stream it produces and
-            # attn2.to_q applies the normalisation in its epilogue
+            # attn2.to_q applies the normalisation in its epilogue; norm1 likewise when the producer of x left its statistics
             st1 = ops.RowStats(x.shape[0], x.device)
-            x = self.attn1(self.norm1(x), batch, seq, residual=x, stats_out=st1)
+            if use1:
+                x = self.attn1(x, batch, seq, residual=x, stats=stats_in, stats_out=st1)
+            else:
+                x = self.attn1(self.norm1(x), batch, seq, residual=x, stats_out=st1)
             x = self.attn2(x, batch, seq, residual=x, kv=kv, stats=st1)
-            return self.ff(self.norm3(x), residual=x)
+            return self.ff(self.norm3(x), residual=x, stats_out=stats_out)
         # norm2 and norm3 never run as kernels: attn1.to_out / attn2.to_out also write the row statistics of the
         # residual stream they produce, and attn2.to_q / the GEGLU projection apply the normalisation in their epilogue
         # (ops.linear(ln=)).  norm1 stays a kernel: its consumers are the Q|K projection AND the swapped V^T product,
         # where the normalised tokens are the column operand.
         st1, st2 = ops.RowStats(x.shape[0], x.device), ops.RowStats(x.shape[0], x.device)
-        x = self.attn1(self.norm1(x), batch, seq, residual=x, stats_out=st1)
+        if use1:
+            x = self.attn1(x, batch, seq, residual=x, stats=stats_in, stats_out=st1)
+        else:
+            x = self.attn1(self.norm1(x), batch, seq, residual=x, stats_out=st1)
         x = self.attn2(x, batch, seq, residual=x, kv=kv, stats=st1, stats_out=st2)
-        return self.ff(x, residual=x, stats=st2)
+        return self.ff(x, residual=x, stats=st2, stats_out=stats_out)
 
 
 class Transformer2DModel:
@@ -370,9 +397,15 @@ class Transformer2DModel:
         B, H, W_, C = x.shape
         res = x.view(B * H * W_, C)
         h = self.norm(x).view(B * H * W_, C)
-        h = ops.linear(h, self.proj_in_w, self.proj_in_b)
-        for blk, kv in zip(self.blocks, kvs):
-            h = blk(h, B, H * W_, kv)
+        # LayerNorm fold (ops.LN_FOLD): the launch that produces a block's input -- proj_in, then each block's FF-down -- also writes
+        # the row statistics the block's norm1 needs (applied inside its fused Q | K | V projection)
+        chain = bool(ops.LN_FOLD) and ops.LN_FOLD_NORM1 and all(b.folds_norm1 for b in self.blocks)
+        st = ops.RowStats(h.shape[0], h.device) if chain else None
+        h = ops.linear(h, self.proj_in_w, self.proj_in_b, stats_out=st)
+        for i, (blk, kv) in enumerate(zip(self.blocks, kvs)):
+            nxt = ops.RowStats(h.shape[0], h.device) if chain and i + 1 < len(self.blocks) else None
+            h = blk(h, B, H * W_, kv, stats_in=st, stats_out=nxt)
+            st = nxt
         h = ops.linear(h, self.proj_out_w, self.proj_out_b, residual=res)
         return h.view(B, H, W_, C)
 

@@ -135,6 +135,7 @@ def splitk_error(device=None) -> bool:
 # applies them; measured: to_out > LayerNorm > to_q 42.7 -> 32.5 us per chain at the 1280 level, 40.7 -> 32.7 at 640,
 # profiles/r04b_layernorm_fold_k2.jsonl); 1 (or True) = norm2 and norm3 (the GEGLU projection as the second consumer).
 LN_FOLD = int(os.environ.get("DIFFUSERS_AMD_LN_FOLD", "2"))
+LN_FOLD_NORM1 = os.environ.get("DIFFUSERS_AMD_LN_FOLD_NORM1", "1") == "1"   # with LN_FOLD: norm1 too, through the fused Q | K | V projection
 LN_FOLD_K2 = os.environ.get("DIFFUSERS_AMD_LN_FOLD_K2", "1") == "1"   # folded launches may use the second kernel family (round 4)
 STATS_MAX_PARTS = 64          # DA_LN_MAX_PARTS: slots per row of a statistics buffer
 STATS_MAX_CONSUMED = 24       # 4 * DA_LN_PAIR_LOADS: partials per row a consumer launch reads
@@ -236,13 +237,60 @@ def _rows2d(t: torch.Tensor, name: str) -> int:
 # ----------------------------------------------------------------------------------------------------------------------
 # GEMM / conv
 # ----------------------------------------------------------------------------------------------------------------------
+QKV_CANDIDATES = ((L.TILE_K2_128x80, L.STAGE_PINGPONG), (L.TILE_K2_128x80, L.STAGE_PINGPONG3), (L.TILE_K2_128x160, L.STAGE_PINGPONG),
+                  (L.TILE_K2_128x160, L.STAGE_LDS_DIRECT))
+
+
+def qkv_variant(p: "L.GemmParams", stream: int):
+    """(tile, staging) of a fused Q | K | V projection (da_gemm_params.vt): the per-shape table under the key ``qkv:<shape>``,
+    else measured now among the four variants that carry the transposed column block (outside graph capture; HIP events, three
+    launches each), else the first candidate whose columns divide the transposed block's origin."""
+    key = "qkv:" + tuning.key_of(p)
+    ent = tuning.table().get(key) if TUNING else None
+    if ent is not None:
+        return ent[0], ent[1]
+    ok = [(t, s) for t, s in QKV_CANDIDATES if p.vt_col0 % (80 if t == L.TILE_K2_128x80 else 160) == 0]
+    if not ok:
+        raise ValueError(f"linear(vt_out=): column origin {p.vt_col0} is not a multiple of 80 or 160")
+    if not (TUNING and tuning.LIVE) or torch.cuda.is_current_stream_capturing():
+        return ok[0]
+    lib, best = L.load(), None
+    for t, s in ok:
+        p.tile, p.staging, p.split_k = t, s, 1
+        if lib.da_gemm_bf16(C.byref(p), stream) != 0:
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            lib.da_gemm_bf16(C.byref(p), stream)
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 3
+        if best is None or us < best[2]:
+            best = (t, s, us)
+    if best is None:
+        raise RuntimeError("linear(vt_out=): no kernel variant accepted this problem")
+    tuning.table()[key] = (best[0], best[1], best[2], 1)
+    tuning.mark_dirty()
+    return best[0], best[1]
+
+
+def linear_qkv(x: torch.Tensor, wqkv: torch.Tensor, col0: int, bias: Optional[torch.Tensor] = None, ln: Optional[tuple] = None):
+    """Fused to_q | to_k | to_v (attention_processor.py:2743-2751) in ONE GEMM: returns (qk [M][col0], vt [N - col0][M]) -- the V
+    columns leave the epilogue transposed, the layout the flash kernel consumes.  ``ln``: LayerNorm fold (see :func:`linear`)."""
+    M = x.shape[0]
+    vt = torch.empty((wqkv.shape[0] - col0, M), device=x.device, dtype=bf16)
+    qk = linear(x, wqkv, bias, ln=ln, vt_out=(vt, col0))
+    return qk, vt
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
            residual: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
            alpha: float = 1.0, out_scale: float = 1.0, out: Optional[torch.Tensor] = None, out_f32: bool = False,
            bias_rows: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
            tile: Optional[int] = None, staging: Optional[int] = None, split_k: Optional[int] = None,
            stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None, k_valid: int = 0,
-           prefetch: Optional[torch.Tensor] = None) -> torch.Tensor:
+           prefetch: Optional[torch.Tensor] = None, vt_out: Optional[tuple] = None) -> torch.Tensor:
     """out[M][N] = epilogue(alpha * x[M][K] @ w[N][K]^T).  For act == GEGLU, w/bias are in the packed layout of
     :func:`pack_geglu` and the output has N/2 columns.  ``k_valid`` > 0: columns k >= k_valid of BOTH operands are
     zero padding (da_gemm_params.k_valid): the kernel skips the MFMA steps that would multiply them.
@@ -253,7 +301,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     p, st = _linear_params(x, w, bias, act=act, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch,
                            alpha=alpha, out_scale=out_scale, out=out, out_f32=out_f32, bias_rows=bias_rows, gate=gate,
                            tile=tile, staging=staging, split_k=split_k, stats_out=stats_out, ln=ln, k_valid=k_valid,
-                           prefetch=prefetch)
+                           prefetch=prefetch, vt_out=vt_out)
     if p is None:
         return st     # the skinny-M path ran
     _launch_gemm(p, st, "da_gemm_bf16(linear)")
@@ -296,7 +344,7 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
                    out: Optional[torch.Tensor] = None, out_f32: bool = False, bias_rows: Optional[torch.Tensor] = None,
                    gate: Optional[torch.Tensor] = None, tile: Optional[int] = None, staging: Optional[int] = None,
                    split_k: Optional[int] = None, stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None,
-                   k_valid: int = 0, prefetch: Optional[torch.Tensor] = None):
+                   k_valid: int = 0, prefetch: Optional[torch.Tensor] = None, vt_out: Optional[tuple] = None):
     """Checks + da_gemm_params of one nn.Linear problem; returns (params, stream), or (None, result) when the skinny-M
     kernel handled it."""
     _req(x, "x"), _req(w, "w")
@@ -305,6 +353,14 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     if K != Kw:
         raise ValueError(f"linear: K mismatch {K} vs {Kw}")
     n_out = N // 2 if act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH) else N
+    if vt_out is not None:      # (vt [N - col0][>= M] bf16, col0): columns >= col0 leave transposed, C holds the first col0 columns
+        vt_t, vt_col0 = vt_out
+        _req(vt_t, "vt_out")
+        if vt_t.dim() != 2 or vt_t.stride(1) != 1 or vt_t.shape[0] != N - vt_col0 or vt_t.shape[1] < M or not 0 < vt_col0 < N:
+            raise ValueError("linear(vt_out=): expected (bf16 [N - col0][>= M], col0)")
+        if M <= 8 or act != L.ACT_NONE or residual is not None or gate is not None or rowvec is not None or stats_out is not None:
+            raise ValueError("linear(vt_out=): plain / LayerNorm-folded projections of more than 8 rows only")
+        n_out = vt_col0
     if M <= 8 and act in (L.ACT_NONE, L.ACT_SILU, L.ACT_GELU_TANH) and rowvec is None and not out_f32 \
             and alpha == 1.0 and out_scale == 1.0 and bias_rows is None and gate is None and stats_out is None and ln is None:
         return None, linear_small_m(x, w, bias, act_out=act, residual=residual, out=out)
@@ -344,7 +400,12 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
             raise ValueError("linear(ln=): statistics / fold vectors do not match this problem (was the producer run?)")
         p.ln_stats, p.ln_stats_ld, p.ln_parts = rs.buf.data_ptr(), rs.buf.shape[1] * 2, rs.parts
         p.ln_s, p.ln_c, p.ln_eps = fold.s.data_ptr(), fold.c.data_ptr(), fold.eps
+    if vt_out is not None:
+        p.vt, p.vt_col0, p.ld_vt = vt_out[0].data_ptr(), int(vt_out[1]), vt_out[0].stride(0)
     tile_given = tile is not None
+    if vt_out is not None and tile is None:
+        tile, staging = qkv_variant(p, st)       # the transposed column block exists on two tiles of the second family only
+        split_k = 1
     if (stats_out is not None or ln is not None) and tile is None:
         # The LayerNorm fold lives in its own kernel instantiations (a subset of the variants).  Round 4: the second kernel family
         # carries it on the tiles the SDXL transformer blocks use -- when the per-shape table sends the SAME problem without the
@@ -378,7 +439,7 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
             raise ValueError(f"linear(stats_out=): {stats_out.parts} column tiles: the consumer reads at most "
                              f"{STATS_MAX_CONSUMED} partials per row (use a wider tile for this producer)")
     p._out = out            # keeps the output (and through it nothing else) alive next to the raw pointers
-    p._keep = (x, w, bias, residual, rowvec, bias_rows, gate, stats_out, ln)
+    p._keep = (x, w, bias, residual, rowvec, bias_rows, gate, stats_out, ln, vt_out)
     return p, st
 
 

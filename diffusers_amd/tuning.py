@@ -101,6 +101,13 @@ FAMILY = os.environ.get("DIFFUSERS_AMD_GEMM_FAMILY", "1")
 _FAMILY_CODE = {"all": L.TILE_AUTO, "1": -1, "k2": -2}
 
 
+def mark_dirty() -> None:
+    """An entry was added outside :func:`tune` (ops.qkv_variant): DIFFUSERS_AMD_TUNE_SAVE writes the table at exit."""
+    global _dirty, LIVE_COUNT
+    _dirty = True
+    LIVE_COUNT += 1
+
+
 def pair_key(pa: "L.GemmParams", pb: "L.GemmParams") -> str:
     return "pair:" + key_of(pa) + "|" + key_of(pb)
 

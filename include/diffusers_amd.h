@@ -170,6 +170,15 @@ typedef struct da_gemm_params {
                                inside a denoising step every weight is otherwise met cold (5 GB of weights per step against a 256 MB
                                cache).  Speed only; the bytes are never interpreted. */
   long long prefetch_bytes; /* multiple of 16 */
+  /* Transposed column block (round 4, second kernel family, nn.Linear): output columns n >= vt_col0 are written TRANSPOSED,
+   * vt[(n - vt_col0) * ld_vt + m] (bf16), instead of into C -- the fused Q | K | V projection of a self-attention layer
+   * (attention_processor.py:2743-2751: to_q / to_k / to_v on the same input) in ONE GEMM whose V block leaves in the
+   * [channel][token] layout the flash kernel consumes, replacing the paired Q|K + swapped V^T launch.  vt_col0 must be a multiple
+   * of the tile's column count (80 / 160) and of 16; C needs only vt_col0 columns.  bias / alpha / the LayerNorm fold apply to
+   * those columns as to the others; residual, gate, activation and statistics do not combine with it. */
+  void* vt;
+  int vt_col0;
+  long long ld_vt;
 } da_gemm_params;
 
 /* number of stats partials per row the launch *p (tile resolved as da_gemm_bf16 resolves it) writes to stats_out */

@@ -67,7 +67,7 @@ def conv2d_nhwc(x, w, bias=None, *, ksize=3, x2=None, stride=1, up=False, pad=No
 
 def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch=0, alpha=1.0, out_scale=1.0, out=None,
            out_f32=False, bias_rows=None, gate=None, tile=None, staging=None, split_k=None, stats_out=None, ln=None,
-           k_valid=0):
+           k_valid=0, vt_out=None):
     assert x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: K % 64, N % 4"
     if k_valid:
         assert 0 < k_valid <= x.shape[1] and not x[:, k_valid:].any() and not w[:, k_valid:].any()
@@ -105,6 +105,12 @@ def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch
             y = y.to(bf16).float()
     if residual is not None:
         y = y + residual.float()
+    if vt_out is not None:      # transposed column block (da_gemm_params.vt): columns >= col0 -> vt[n - col0][m], the rest -> C
+        vt, col0 = vt_out
+        assert act == ACT_NONE and residual is None and gate is None and rowvec is None and stats_out is None and col0 % 16 == 0
+        assert vt.shape[0] == y.shape[1] - col0 and vt.shape[1] >= M and vt.dtype == bf16
+        vt[:, :M] = y[:, col0:].t().to(bf16)
+        y = y[:, :col0]
     res = _store(y * out_scale, out, torch.float32 if out_f32 else bf16)
     if stats_out is not None:   # LayerNorm fold, producer: partial (sum, sum of squares) of the STORED values; the stand-in
         assert act != ACT_GEGLU and not out_f32 and stats_out.buf.shape[0] == M     # writes two parts (column halves)
@@ -120,6 +126,11 @@ def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch
 def linear_pair(a, b):
     """da_gemm_pair_bf16: two independent problems, results identical to two linear() calls."""
     return linear(**a), linear(**b)
+
+
+def linear_qkv(x, wqkv, col0, bias=None, ln=None):
+    vt = torch.empty((wqkv.shape[0] - col0, x.shape[0]), dtype=bf16)
+    return linear(x, wqkv, bias, ln=ln, vt_out=(vt, col0)), vt
 
 
 def linear_small_m(x, w, bias=None, *, act_in=0, act_out=0, residual=None, out=None):
@@ -440,7 +451,7 @@ def cfg_rescale(eps2b, guidance, guidance_rescale, out=None):
 
 def install(monkeypatch, ops_module):
     """Replace the kernels behind ``ops_module`` with the stand-ins above (pack_* helpers are pure torch and stay)."""
-    for name in ("conv2d_nhwc", "linear", "linear_pair", "linear_small_m", "rms_norm", "attention", "softmax_rows", "group_norm_nhwc", "layer_norm",
+    for name in ("conv2d_nhwc", "linear", "linear_pair", "linear_qkv", "linear_small_m", "rms_norm", "attention", "softmax_rows", "group_norm_nhwc", "layer_norm",
                  "rmsnorm_rope_", "rmsnorm_channels", "timestep_embedding", "permute_0213", "frames_to_ncthw",
                  "conv_thin_in", "conv_thin_out", "bcast_add_f32", "patchify3d", "unpatchify3d", "transpose",
                  "mul_scalar", "cast_f32_bf16", "cfg_rescale", "require_hip", "euler_scale_model_input", "euler_step", "x0_linear_step",

@@ -310,3 +310,51 @@ def test_k2_layernorm_fold_producer_and_consumers(M, C, N):
     ya = ops.linear(xa, wl, b, ln=(st, fold))
     refa = F.layer_norm(xa.float(), (C,), gamma.float(), beta.float(), 1e-5) @ w.float().t() + b.float()
     assert_close_bf16(ya, refa, "LN fold, automatic variant choice", rel_rms_max=6e-3)
+
+
+@pytest.mark.parametrize("M,C,inner", [(2048, 1280, 1280), (8192, 640, 640), (520, 320, 320)])
+def test_k2_fused_qkv_projection_with_transposed_v_block(M, C, inner):
+    """da_gemm_params.vt (round 4): the fused to_q | to_k | to_v projection of a self-attention layer in ONE launch -- columns
+    [0, 2 * inner) into C, the V block transposed into vt[channel][token] -- on every variant that carries it, plain and with the
+    LayerNorm fold (norm1 applied inside the launch from the producer's statistics); against the separate projections of the
+    reference processor (attention_processor.py:2743-2751) in fp32, and bit-identical across variants."""
+    ops, L = _ops()
+    a, wprod, res = rnd((M, 192), 71), rnd((C, 192), 72, 192 ** -0.5), rnd((M, C), 73)
+    gamma, beta = rnd((C,), 74) * 0.3 + 1.0, rnd((C,), 75) * 0.2
+    wqkv = rnd((3 * inner, C), 76, C ** -0.5)
+    st = ops.RowStats(M, DEV)
+    x = ops.linear(a, wprod, residual=res, tile=L.TILE_K2_128x80, staging=L.STAGE_PINGPONG, stats_out=st)
+    xf = x.float()
+    # plain
+    ref = xf @ wqkv.float().t()
+    base = None
+    n_ok = 0
+    for tile, stg in ops.QKV_CANDIDATES:
+        vt = torch.full((inner, M), float("nan"), device=DEV, dtype=bf16)
+        try:
+            qk = ops.linear(x, wqkv, tile=tile, staging=stg, vt_out=(vt, 2 * inner))
+        except RuntimeError as e:
+            assert "DA_ERR_UNSUPPORTED" in str(e), e
+            continue
+        n_ok += 1
+        assert qk.shape == (M, 2 * inner)
+        assert_close_bf16(qk, ref[:, :2 * inner], f"fused QKV (Q|K block) {L.TILE_NAMES[tile]}/{stg} M{M}", rtol=8e-3, atol_rms=4e-3)
+        assert_close_bf16(vt.t(), ref[:, 2 * inner:], f"fused QKV (V^T block) {L.TILE_NAMES[tile]}/{stg} M{M}", rtol=8e-3, atol_rms=4e-3)
+        if base is None:
+            base = (qk.clone(), vt.clone())
+        assert torch.equal(qk, base[0]) and torch.equal(vt, base[1]), "variants of the fused projection differ"
+    assert n_ok >= 2
+    # the separate K2 launches give the same bits as the fused one (same tiles, same summation order)
+    sep = ops.linear(x, wqkv[:2 * inner].contiguous(), tile=L.TILE_K2_128x80, staging=L.STAGE_PINGPONG)
+    assert torch.equal(sep, base[0])
+    # with the LayerNorm fold
+    wl, fold = ops.fold_layernorm(wqkv, gamma, beta, 1e-5)
+    ln_ref = F.layer_norm(xf, (C,), gamma.float(), beta.float(), 1e-5) @ wqkv.float().t()
+    qk, vt = ops.linear_qkv(x, wl, 2 * inner, ln=(st, fold))
+    assert_close_bf16(qk, ln_ref[:, :2 * inner], f"fused QKV + LN fold (Q|K) M{M} C{C}", rel_rms_max=6e-3)
+    assert_close_bf16(vt.t(), ln_ref[:, 2 * inner:], f"fused QKV + LN fold (V^T) M{M} C{C}", rel_rms_max=6e-3)
+    # refusals: a column origin the tiles do not divide, an activation, a residual
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.linear(x, wqkv, tile=L.TILE_K2_128x80, staging=L.STAGE_PINGPONG, vt_out=(torch.empty((3 * inner - 64, M), device=DEV, dtype=bf16), 64))
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.linear(x, wqkv, residual=rnd((M, 2 * inner), 77), vt_out=(torch.empty((inner, M), device=DEV, dtype=bf16), 2 * inner))

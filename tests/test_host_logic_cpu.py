@@ -47,6 +47,54 @@ def test_unet2d_condition(golden, name, added, fold, monkeypatch):
     assert y.shape == g["out"].shape and rr < TOL
 
 
+MID_SDXL_UNET = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(320, 640), layers_per_block=1,
+                     cross_attention_dim=64, attention_head_dim=(5, 10), down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                     up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D"), transformer_layers_per_block=(2, 2),
+                     use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=32,
+                     projection_class_embeddings_input_dim=256)
+
+
+@pytest.mark.parametrize("fold", [0, 2, 1])
+def test_norm1_fold_through_the_fused_qkv_projection(fold, monkeypatch):
+    """SDXL's head geometry (heads of 64, inner widths 320 / 640: 2 * inner is a multiple of 80) at a small size: with the LayerNorm
+    fold on, the producer of every block input (proj_in, then each FF-down) writes row statistics and norm1 is applied inside ONE
+    fused Q | K | V projection whose V block leaves transposed (ops.linear_qkv) -- no norm1 launch, no paired Q|K + V^T launch.
+    Against the fp32 oracle graph; and the folded and unfolded engines agree with each other far inside that bound."""
+    from diffusers_amd.unet_2d_condition import UNet2DConditionModel, _DEFAULTS as UD
+    from oracle import reference_math as R
+    monkeypatch.setattr(ops, "LN_FOLD", fold)
+    calls = {"qkv": 0, "pair": 0, "ln": 0}
+    for name, key in (("linear_qkv", "qkv"), ("linear_pair", "pair"), ("layer_norm", "ln")):
+        orig = getattr(ops, name)
+
+        def wrap(*a, _o=orig, _k=key, **k):
+            calls[_k] += 1
+            return _o(*a, **k)
+        monkeypatch.setattr(ops, name, wrap)
+    unet = UNet2DConditionModel(**MID_SDXL_UNET)
+    sd = dinit.random_state_dict(dinit.unet_param_shapes(unet.config), seed=3)
+    unet.load_state_dict(sd, device="cpu")
+    g = torch.Generator().manual_seed(11)
+    sample = torch.randn((2, 4, 8, 8), generator=g).to(bf16)
+    ehs = torch.randn((2, 7, 64), generator=g).to(bf16)
+    added = {"text_embeds": torch.randn((2, 64), generator=g).to(bf16), "time_ids": torch.tensor([[64., 64., 0., 0., 64., 64.]]).repeat(2, 1)}
+    y = unet(sample, torch.tensor(300.0), ehs, added_cond_kwargs=added).sample
+    blocks = sum(len(tr.blocks) for tr in unet._transformers())
+    if fold:
+        assert calls["qkv"] == blocks and calls["pair"] == 0, calls       # every self-attention took the fused projection
+        assert calls["ln"] == (blocks if fold == 2 else 0), calls         # norm3 stays a kernel in mode 2; nothing is left in mode 1
+    else:
+        assert calls["qkv"] == 0 and calls["pair"] == blocks and calls["ln"] == 3 * blocks, calls
+    cfg = dict(UD)
+    cfg.update(MID_SDXL_UNET)
+    with torch.no_grad():
+        ref = R.unet_forward({k: v.float() for k, v in sd.items()}, cfg, sample.float(), 300.0, ehs.float(),
+                             {"text_embeds": added["text_embeds"].float(), "time_ids": added["time_ids"]})
+    rr = _rel(y, ref)
+    print(f"[host] SDXL head geometry, LN fold mode {fold}: rel rms vs the fp32 oracle = {rr:.3e}; launches {calls}")
+    assert y.shape == ref.shape and rr < TOL
+
+
 def test_unet_forward_under_inference_mode_and_cache_reset_on_reload(golden):
     """the drop-in forward keyed its conditioning cache on `tensor._version`, which raises for tensors
     created under torch.inference_mode() (a common wrapper around pipelines); and the cache survived a second

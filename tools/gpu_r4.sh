@@ -134,3 +134,21 @@ if [[ $WHAT == *pmcshapes* ]]; then
   cd $R
   cat $O/r04_fetch_by_shape.md
 fi
+if [[ $WHAT == *qkv* ]]; then
+  timeout 600 python -m pytest tests/test_gemm_k2_gpu.py -m gpu -q -s --timeout 300 -k "fused_qkv or layernorm_fold" > $O/pytest_qkv.log 2>&1; echo "pytest qkv rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert" $O/pytest_qkv.log | tail -12
+  rm -f $O/qkv_r4.jsonl
+  timeout 300 python tools/bench_qkv_r4.py $O/qkv_r4.jsonl > $O/qkv_r4.log 2>&1; echo "qkv bench rc=$?"; tail -3 $O/qkv_r4.log | cut -c1-300
+  cat $O/qkv_r4.jsonl
+  for n1 in 0 1 0 1; do
+    DIFFUSERS_AMD_LN_FOLD_NORM1=$n1 DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_qkv_r4.json timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_n1_$n1.json 2> $O/bench_n1_$n1.err; echo "norm1 fold $n1 rc=$? $(cut -c1-140 $O/bench_n1_$n1.json | grep -o '"value": [0-9.]*') $(grep -o '"tuned_live": [0-9]*' $O/bench_n1_$n1.json)"
+  done
+  python - <<PYEOF
+import json
+try:
+    b = json.load(open("$O/tuned_qkv_r4.json"))
+    print({k: v for k, v in b["entries"].items() if k.startswith("qkv:")})
+except Exception as e:
+    print("no table:", e)
+PYEOF
+fi

@@ -70,7 +70,26 @@ int main(int argc, char** argv) {
   p.M = M; p.N = N; p.K = K;
   p.lda = K; p.ldw = K; p.ldc = N;
   p.alpha = 1.f; p.out_scale = 1.f;
-  if (epi) { p.bias = B; p.residual = R; p.ldr = N; }
+  // epilogue modes: 0 plain, 1 bias + residual, 2 GEGLU (+ bias), 3 GEGLU with the LayerNorm fold, 4 bias + residual + statistics out,
+  // 5 plain with the LayerNorm fold (to_q)
+  float *lnstats = nullptr, *lns = nullptr, *lnc = nullptr, *stats_out = nullptr;
+  if (epi == 1 || epi == 4) { p.bias = B; p.residual = R; p.ldr = N; }
+  if (epi == 2 || epi == 3) { p.bias = B; p.act = DA_ACT_GEGLU; p.ldc = N / 2; }
+  if (epi == 3 || epi == 5) {
+    std::vector<float> hs((size_t)M * 128), hv(N, 0.01f);
+    for (size_t i = 0; i < hs.size(); i += 2) { hs[i] = 0.1f * K / 16; hs[i + 1] = 1.0f * K / 16; }
+    CK(hipMalloc(&lnstats, hs.size() * 4));
+    CK(hipMalloc(&lns, N * 4));
+    CK(hipMalloc(&lnc, N * 4));
+    CK(hipMemcpy(lnstats, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(lns, hv.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(lnc, hv.data(), N * 4, hipMemcpyHostToDevice));
+    p.ln_stats = lnstats; p.ln_stats_ld = 128; p.ln_parts = 16; p.ln_s = lns; p.ln_c = lnc; p.ln_eps = 1e-5f;
+  }
+  if (epi == 4) {
+    CK(hipMalloc(&stats_out, (size_t)M * 128 * 4));
+    p.stats_out = stats_out; p.stats_ld = 128;
+  }
   hipStream_t s;
   CK(hipStreamCreate(&s));
   hipEvent_t e0, e1;
@@ -104,7 +123,7 @@ int main(int argc, char** argv) {
       const unsigned long long first = *std::min_element(t0s.begin(), t0s.end()), last_in = *std::max_element(t0s.begin(), t0s.end());
       const unsigned long long end = *std::max_element(t7s.begin(), t7s.end()), first_out = *std::min_element(t7s.begin(), t7s.end());
       std::printf("\n## M %d N %d K %d tile %d staging %d epilogue %s, %s operands: %zu waves, event time %.2f us\n", M, N, K, tile, staging,
-                  epi ? "bias+residual" : "plain", cold ? "cold (flushed)" : "warm", t0s.size(), ms * 1e3);
+                  (epi == 0 ? "plain" : epi == 1 ? "bias+residual" : epi == 2 ? "GEGLU" : epi == 3 ? "GEGLU + LN fold" : epi == 4 ? "bias+residual+stats" : "LN fold"), cold ? "cold (flushed)" : "warm", t0s.size(), ms * 1e3);
       std::printf("| stage | median cyc | p10 | p90 |\n|---|---:|---:|---:|\n");
       for (int i = 0; i < 7; ++i)
         std::printf("| %s | %llu | %llu | %llu |\n", names[i], pct(stage[i], 0.5), pct(stage[i], 0.1), pct(stage[i], 0.9));
