@@ -427,7 +427,9 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   for (int jh = 0; jh < NH; ++jh) bias_v[jh] = make_uint2(0, 0);
   // LayerNorm fold, consumer side: the 24 (sum, sum of squares) slots of a row this lane finishes are read by its four kq lanes,
   // six slots (three 16-byte loads) each; rows hold DA_LN_MAX_PARTS slots, the ones past ln_parts are masked when summed.
-  constexpr bool LN_PF = LNF && MH == 1;                  // (more rows per lane: no registers to carry them through the K loop -- loaded behind it)
+  // The slots are requested with the other epilogue operands (behind the first LDS-DMA) and REDUCED to (mean, rstd) right behind the
+  // first rendezvous -- they have landed with pair 0 -- so that only two floats per row ride through the K loop.
+  constexpr bool LN_PF = LNF;
   float4 lnq[LN_PF ? MH : 1][3];
 #pragma unroll
   for (int ih = 0; ih < (LN_PF ? MH : 1); ++ih)
@@ -436,8 +438,9 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   auto ln_load = [&](int ih, float4* dst) {
     const int m = min(row_of(ih), p.M - 1);
     const float* sp = p.ln_stats + (size_t)m * p.ln_stats_ld + 12 * kq;
+    // only the 16-byte pairs that hold valid slots are fetched (16 partials = the first 128-byte line of the row)
 #pragma unroll
-    for (int u = 0; u < 3; ++u) dst[u] = *(const float4*)(sp + 4 * u);
+    for (int u = 0; u < 3; ++u) dst[u] = (6 * kq + 2 * u < p.ln_parts) ? *(const float4*)(sp + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   // Issued right behind the FIRST pair's LDS-DMA (the matrix stream starts first; these loads are older than pairs 1 .. and
   // therefore covered by every counted wait that covers pair 0).
@@ -547,6 +550,34 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   DA2_TRACE(3);                                           // first pair landed for everybody
+  // LayerNorm fold, consumer side: mean / rstd of the MH rows this lane finishes.  Each kq lane adds its six slots in slot order,
+  // the four lanes of a row combine as (a + b) + (c + d): the same bits in all four.
+  float ln_mu[MH], ln_rs[MH];
+#pragma unroll
+  for (int ih = 0; ih < MH; ++ih) ln_mu[ih] = 0.f, ln_rs[ih] = 1.f;
+  const bool ln_on = LNF && p.ln_stats != nullptr;
+  if constexpr (LNF) {
+    if (ln_on) {
+      const float inv_c = 1.0f / (float)p.K;              // the normalised dimension is this GEMM's K
+#pragma unroll
+      for (int ih = 0; ih < MH; ++ih) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int q = 6 * kq + 2 * u;
+          s1 += (q < p.ln_parts ? lnq[ih][u].x : 0.f) + (q + 1 < p.ln_parts ? lnq[ih][u].z : 0.f);
+          s2 += (q < p.ln_parts ? lnq[ih][u].y : 0.f) + (q + 1 < p.ln_parts ? lnq[ih][u].w : 0.f);
+        }
+        s1 += __shfl_xor(s1, 16, 64);
+        s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float mean = s1 * inv_c;
+        ln_mu[ih] = mean;
+        ln_rs[ih] = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + p.ln_eps);
+      }
+    }
+  }
   if constexpr (STREAMW) {
     // ---- streaming-W loop: per slice 2 k-steps x NT W fragments, each read once and used by MT MFMAs ----
     constexpr int QD = 2;                                 // W fragments in flight ahead of the MFMAs that use them
@@ -744,41 +775,6 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
     }
   }
   DA2_TRACE(5);                                           // partial sums exchanged
-  // LayerNorm fold, consumer side: mean / rstd of the MH rows this lane finishes.  Each kq lane adds its six slots in slot order,
-  // the four lanes of a row combine as (a + b) + (c + d): the same bits in all four.
-  float ln_mu[MH], ln_rs[MH];
-#pragma unroll
-  for (int ih = 0; ih < MH; ++ih) ln_mu[ih] = 0.f, ln_rs[ih] = 1.f;
-  const bool ln_on = LNF && p.ln_stats != nullptr;
-  if constexpr (LNF) {
-    if (ln_on) {
-      const float inv_c = 1.0f / (float)p.K;              // the normalised dimension is this GEMM's K
-#pragma unroll
-      for (int ih = 0; ih < MH; ++ih) {
-        float4 v[3];
-        if constexpr (LN_PF) {
-#pragma unroll
-          for (int u = 0; u < 3; ++u) v[u] = lnq[ih][u];
-        } else {
-          ln_load(ih, v);
-        }
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int q = 6 * kq + 2 * u;
-          s1 += (q < p.ln_parts ? v[u].x : 0.f) + (q + 1 < p.ln_parts ? v[u].z : 0.f);
-          s2 += (q < p.ln_parts ? v[u].y : 0.f) + (q + 1 < p.ln_parts ? v[u].w : 0.f);
-        }
-        s1 += __shfl_xor(s1, 16, 64);
-        s2 += __shfl_xor(s2, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        const float mean = s1 * inv_c;
-        ln_mu[ih] = mean;
-        ln_rs[ih] = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + p.ln_eps);
-      }
-    }
-  }
   // o[0..3] = alpha * acc of row tile ih, columns n .. n + 3  ->  LayerNorm-folded value (identity without ln_stats)
   auto ln_apply4 = [&](float* o, int ih, int n) __attribute__((always_inline)) {
     if constexpr (LNF) {

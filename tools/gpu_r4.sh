@@ -152,3 +152,8 @@ except Exception as e:
     print("no table:", e)
 PYEOF
 fi
+if [[ $WHAT == *modeab* ]]; then
+  for mode in 2 1 2 1; do
+    DIFFUSERS_AMD_LN_FOLD=$mode timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_mode$mode.json 2> $O/bench_mode$mode.err; echo "fold mode $mode rc=$? $(cut -c1-140 $O/bench_mode$mode.json | grep -o '"value": [0-9.]*') $(grep -o '"tuned_live": [0-9]*' $O/bench_mode$mode.json)"
+  done
+fi
