@@ -444,18 +444,20 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   };
   // Issued right behind the FIRST pair's LDS-DMA (the matrix stream starts first; these loads are older than pairs 1 .. and
   // therefore covered by every counted wait that covers pair 0).
+  float4 lnsc_v = make_float4(0.f, 0.f, 0.f, 0.f);
   auto prefetch_epilogue_operands = [&]() {
     if constexpr (LNF) {
       if (p.ln_stats) {
         // the block's BN columns of s and c go to LDS once (every lane of the epilogue reads 2 x 16 bytes per 4-column group:
         // from global memory that was a chain of L2 round trips, + 10 us on the GEGLU projection); visible after the first
         // rendezvous of the K loop, read after the last
-        float* lnsc = (float*)(smem + NSLOT * PAIR + DUMP);
+        // (requested here, written to LDS behind the first rendezvous -- by then it has landed with pair 0; writing it at once
+        // parked every workgroup for the round trip in front of its K loop: + 2.7 k cycles per workgroup,
+        // profiles/r04i_gemm_stage_trace_lnfold.md)
         if (t < BN / 2) {
           const int j = t < BN / 4 ? t : t - BN / 4;        // 16-byte group of s (first BN / 4 threads) or c
           const int n = min(n0 + 4 * j, p.N - 4);
-          const float4 v = *(const float4*)((t < BN / 4 ? p.ln_s : p.ln_c) + n);
-          *(float4*)(lnsc + (t < BN / 4 ? 0 : BN) + 4 * j) = v;
+          lnsc_v = *(const float4*)((t < BN / 4 ? p.ln_s : p.ln_c) + n);
         }
       }
     }
@@ -558,6 +560,11 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   const bool ln_on = LNF && p.ln_stats != nullptr;
   if constexpr (LNF) {
     if (ln_on) {
+      if (t < BN / 2) {
+        float* lnsc = (float*)(smem + NSLOT * PAIR + DUMP);
+        const int j = t < BN / 4 ? t : t - BN / 4;
+        *(float4*)(lnsc + (t < BN / 4 ? 0 : BN) + 4 * j) = lnsc_v;
+      }
       const float inv_c = 1.0f / (float)p.K;              // the normalised dimension is this GEMM's K
 #pragma unroll
       for (int ih = 0; ih < MH; ++ih) {
