@@ -437,10 +437,12 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
     for (int u = 0; u < 3; ++u) lnq[ih][u] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto ln_load = [&](int ih, float4* dst) {
     const int m = min(row_of(ih), p.M - 1);
-    const float* sp = p.ln_stats + (size_t)m * p.ln_stats_ld + 12 * kq;
-    // only the 16-byte pairs that hold valid slots are fetched (16 partials = the first 128-byte line of the row)
+    const float* sp = p.ln_stats + (size_t)m * p.ln_stats_ld;
+    // Unconditional loads (a predicated load whose other arm writes zeros makes the compiler wait for the load before the zero
+    // write: vmcnt(0) in the prologue); a pair past the valid slots re-reads the row's first pair instead (masked when summed), so
+    // that 16 partials touch only the first 128-byte line of the row.
 #pragma unroll
-    for (int u = 0; u < 3; ++u) dst[u] = (6 * kq + 2 * u < p.ln_parts) ? *(const float4*)(sp + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 3; ++u) dst[u] = *(const float4*)(sp + ((6 * kq + 2 * u < p.ln_parts) ? 12 * kq + 4 * u : 0));
   };
   // Issued right behind the FIRST pair's LDS-DMA (the matrix stream starts first; these loads are older than pairs 1 .. and
   // therefore covered by every counted wait that covers pair 0).
@@ -486,11 +488,12 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
         for (int ih = 0; ih < MH; ++ih)
 #pragma unroll
           for (int t = 0; t < TT; ++t) {
-            const int q = lane + 64 * t;
-            if (NPIECE % 64 == 0 || q < NPIECE) {
-              const int m = min(band_row0(ih) + q / PPR, p.M - 1), n = min(band_col0 + (q % PPR) * 8, p.N - 8);
-              resw[ih][t] = *(const uint4*)(resid + (size_t)m * p.ldr + n);
-            }
+            // every lane loads (a piece index past the band is clamped to the last piece; its value is never used): a load under a
+            // lane predicate made the compiler park the wave on vmcnt(0) in the prologue -- behind pair 0's LDS-DMA -- before it
+            // could reuse the address registers (profiles/r04i_gemm_stage_trace_lnfold.md, "ring issue" + 1 k cycles)
+            const int q = (NPIECE % 64 == 0) ? lane + 64 * t : min(lane + 64 * t, NPIECE - 1);
+            const int m = min(band_row0(ih) + q / PPR, p.M - 1), n = min(band_col0 + (q % PPR) * 8, p.N - 8);
+            resw[ih][t] = *(const uint4*)(resid + (size_t)m * p.ldr + n);
           }
       }
     }
