@@ -157,3 +157,12 @@ if [[ $WHAT == *modeab* ]]; then
     DIFFUSERS_AMD_LN_FOLD=$mode timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_mode$mode.json 2> $O/bench_mode$mode.err; echo "fold mode $mode rc=$? $(cut -c1-140 $O/bench_mode$mode.json | grep -o '"value": [0-9.]*') $(grep -o '"tuned_live": [0-9]*' $O/bench_mode$mode.json)"
   done
 fi
+if [[ $WHAT == *pmcattn* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc_attn; mkdir -p $O/pmc_attn
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -f csv -d $O/pmc_attn/sq -o a -- python $R/tools/pmc_attn_r4.py run $O/pmc_attn/manifest.json > $O/pmc_attn/sq.log 2>&1; echo "pmc attn rc=$?"
+  cd $R
+  python tools/pmc_attn_r4.py report $O/pmc_attn/manifest.json $(find $O/pmc_attn/sq -name '*counter_collection.csv' | head -1) > $O/r04_pmc_attention.md 2>> $O/pmc_attn/sq.log
+  find $O/pmc_attn -name '*kernel_trace*' -delete
+  cat $O/r04_pmc_attention.md | cut -c1-330; tail -2 $O/pmc_attn/sq.log | cut -c1-200
+fi
