@@ -143,13 +143,16 @@ def instrumented_pass(run):
         return wrapper
 
     def lin_work(a, k, out):
-        x, w = a[0], a[1]
+        x = a[0] if a else k["x"]
+        w = a[1] if len(a) > 1 else k["w"]
         if x.shape[0] <= 8:
             return None  # skinny path: not the igemm kernel
         # (flops, algorithmic bytes = each operand and the output once)
         return 2.0 * x.shape[0] * w.shape[0] * x.shape[1], 2.0 * (x.numel() + w.numel() + out.numel())
 
     def pair_work(a, k, out):
+        if any(prob["x"].shape[0] <= 8 for prob in a):
+            return None  # linear_pair falls back to two skinny linear() calls: neither the igemm kernel nor one launch
         tot_f = tot_b = 0.0
         for prob, o in zip(a, out):
             x, w = prob["x"], prob["w"]

@@ -22,6 +22,7 @@ from __future__ import annotations
 import hashlib
 import json
 import os
+import warnings
 from collections.abc import Mapping
 from pathlib import Path
 from typing import Dict, Iterator, List, Optional
@@ -76,7 +77,7 @@ _LORA_TAGS = ((".lora_A.weight", ".lora_B.weight"), (".lora_A.default.weight", "
               (".lora_down.weight", ".lora_up.weight"))
 
 
-def _lora_pairs(lora_sd: Mapping, prefixes=("unet.", "transformer.")) -> Dict[str, dict]:
+def _lora_pairs(lora_sd: Mapping, prefixes=("unet.", "transformer."), strict: bool = False) -> Dict[str, dict]:
     """module path -> {"A": [r][in...], "B": [out][r...], "alpha": float | None} from a LoRA state dict in PEFT
     (``lora_A.weight`` / ``lora_B.weight``), legacy diffusers (``lora.down.weight`` / ``lora.up.weight``, attention-processor
     ``to_q_lora.down.weight``) or kohya-after-conversion naming.
@@ -84,7 +85,8 @@ def _lora_pairs(lora_sd: Mapping, prefixes=("unet.", "transformer.")) -> Dict[st
     Component filter, as ``load_lora_adapter`` does it (loaders/peft.py:194-195): when the dict carries component prefixes
     (a pipeline-level file: ``unet.`` / ``transformer.`` / ``text_encoder.`` ...), only the keys under one of ``prefixes``
     (this model's) are kept, with the prefix removed; the other components' keys are ignored, not an error.  A dict with no
-    component prefix at all is taken to be this model's own."""
+    component prefix at all is taken to be this model's own.  A prefixed dict with nothing for this model warns and returns an
+    empty mapping like the reference (``strict=True``: raises)."""
     out: Dict[str, dict] = {}
     keys = list(lora_sd)
     prefixed = any(k.startswith(COMPONENT_PREFIXES) for k in keys)
@@ -125,8 +127,13 @@ def _lora_pairs(lora_sd: Mapping, prefixes=("unet.", "transformer.")) -> Dict[st
     if bad:
         raise ValueError(f"LoRA state dict has unpaired matrices for {bad[:4]}")
     if prefixed and not out:
-        raise ValueError(f"No LoRA keys found under {prefixes} (loaders/peft.py:359-366); the file's components are "
-                         f"{sorted({k.split('.', 1)[0] for k in keys})}")
+        # e.g. a text-encoder-only file handed to the pipeline-level loader: the reference logs and moves on
+        # (loaders/peft.py:359-366), so that loading such a file succeeds and simply leaves this model untouched
+        msg = (f"No LoRA keys found under {prefixes}; the file's components are "
+               f"{sorted({k.split('.', 1)[0] for k in keys})}")
+        if strict:
+            raise ValueError(msg)
+        warnings.warn(msg + " -- this model is left unchanged", stacklevel=2)
     return out
 
 
@@ -301,8 +308,11 @@ class PretrainedMixin:
         model is re-packed from ``W + lora_scale * (alpha / r) * B A`` and the result copied over the tensors the kernels
         (and any captured HIP graph) already point at.  Adapters do not stack: fusing replaces a previously fused one."""
         base = base_state_dict if base_state_dict is not None else self._base_view()
-        self._repack_in_place(LoraFusedView(base, lora_state_dict, lora_scale))
-        self._lora = {"scale": float(lora_scale), "modules": len(_lora_pairs(lora_state_dict))}
+        view = LoraFusedView(base, lora_state_dict, lora_scale)
+        if not view.pairs:
+            return self            # a file for other components only (warned about above): nothing to fuse, as in the reference
+        self._repack_in_place(view)
+        self._lora = {"scale": float(lora_scale), "modules": len(view.pairs)}
         return self
 
     def unfuse_lora(self, base_state_dict: Optional[Mapping] = None):

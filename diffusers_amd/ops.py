@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
+import weakref
 from typing import Optional
 
 import torch
@@ -30,18 +32,28 @@ TUNING = True  # per-shape (tile, staging) from diffusers_amd.tuning when the ca
 # launch i + 1, the last one that of launch 0 (the next step).  The weight of a launch is whichever operand the MODEL owns.  A sequence that does not reproduce the recorded one switches the
 # hints off for the rest of that step (they are a speed hint: results never depend on them).
 PREFETCH = os.environ.get("DIFFUSERS_AMD_PREFETCH", "1") != "0"
-_prefetch_state = None
+_prefetch_tls = threading.local()     # the active trace of THIS thread (two pipelines may step on two threads)
 
 
 class WeightPrefetch:
-    def __init__(self, models=()):
-        self.models = tuple(m for m in models if m is not None)   # whose tensors count as weights (never an activation address:
-        self.ptrs = set()                                          # a hint captured into a HIP graph must stay valid for ever)
+    def __init__(self, models=(), owner=None, slots=()):
+        """`models`: whose tensors count as weights -- either given directly, or looked up as attributes `slots` of `owner` at
+        every refresh() (a pipeline whose `unet` is re-assigned later must neither keep the old model alive nor hint at it)."""
+        self._models = tuple(m for m in models if m is not None)
+        self._owner = weakref.ref(owner) if owner is not None else None
+        self._slots = tuple(slots)
+        self.ptrs = set()      # never an activation address: a hint captured into a HIP graph must stay valid for ever
         self.seq = []          # per implicit-GEMM launch of one step, in issue order: (ptr, bytes) of its weight, or None
         self.mode = None
         self.idx = 0
         self.ok = True
         self.applied = 0       # hints handed out by the last "apply" pass (diagnostics)
+
+    @property
+    def models(self):
+        owner = self._owner() if self._owner is not None else None
+        found = tuple(m for m in (getattr(owner, n, None) for n in self._slots) if m is not None) if owner is not None else ()
+        return self._models + found
 
     def refresh(self):
         from .packed_cache import packed_tensors
@@ -55,23 +67,22 @@ class weight_prefetch:
         self.pf, self.mode = pf, mode
 
     def __enter__(self):
-        global _prefetch_state
-        self.prev = _prefetch_state
+        self.prev = getattr(_prefetch_tls, "pf", None)
         if self.pf is not None and PREFETCH:
             pf = self.pf
             pf.mode, pf.idx, pf.applied = self.mode, 0, 0
+            pf.ok = True                                           # a mismatch switches the hints off for ONE step, not for ever
             if self.mode == "record":
-                pf.seq, pf.ok = [], True
+                pf.seq = []
                 pf.refresh()
-            _prefetch_state = pf
+            _prefetch_tls.pf = pf
         return self.pf
 
     def __exit__(self, *exc):
-        global _prefetch_state
         pf = self.pf
-        if pf is not None and PREFETCH and _prefetch_state is pf and pf.mode == "apply" and pf.idx != len(pf.seq):
+        if pf is not None and PREFETCH and getattr(_prefetch_tls, "pf", None) is pf and pf.mode == "apply" and pf.idx != len(pf.seq):
             pf.ok = False                                          # not the step that was recorded
-        _prefetch_state = self.prev
+        _prefetch_tls.pf = self.prev
         return False
 
 
@@ -84,7 +95,7 @@ PREFETCH_CAP_BYTES = int(float(os.environ.get("DIFFUSERS_AMD_PREFETCH_CAP_MB", "
 
 
 def _prefetch_hook(p: "L.GemmParams", x: torch.Tensor, w: torch.Tensor) -> None:
-    pf = _prefetch_state
+    pf = getattr(_prefetch_tls, "pf", None)
     if pf is None:
         return
     # the weight is whichever operand the model owns (the swapped V^T projections pass it as `x`)

@@ -73,7 +73,7 @@ def _pf(pipe) -> "ops.WeightPrefetch":
     """The pipeline's weight-prefetch trace (ops.weight_prefetch): recorded by one eager step, applied to every later one."""
     pf = getattr(pipe, "_weight_prefetch", None)
     if pf is None:
-        pf = pipe._weight_prefetch = ops.WeightPrefetch([getattr(pipe, n, None) for n in ("unet", "transformer")])
+        pf = pipe._weight_prefetch = ops.WeightPrefetch(owner=pipe, slots=("unet", "transformer"))
     return pf
 
 

@@ -492,3 +492,33 @@ def test_weight_prefetch_record_apply_state_machine():
     with ops.weight_prefetch(pf, "apply"):
         got = step(launches)
     assert got == [(None, 0), (w[2].data_ptr(), nb), (w[0].data_ptr(), nb)]
+    # a mismatch costs the hints of ONE step: the next step that reproduces the recording is served again
+    with ops.weight_prefetch(pf, "apply"):
+        step(launches[:1])
+    assert not pf.ok
+    with ops.weight_prefetch(pf, "apply"):
+        assert step(launches) == got and pf.ok
+    # the active trace is per thread: another thread's launches neither see nor advance it
+    import threading
+    seen = []
+    with ops.weight_prefetch(pf, "apply"):
+        t = threading.Thread(target=lambda: seen.append(step(launches)))
+        t.start(); t.join()
+        assert pf.idx == 0 and step(launches) == got
+    assert seen == [[(None, 0)] * 3]
+    # models are looked up on the owner at refresh time and the owner is not kept alive
+    import gc, weakref
+
+    class Pipe:
+        pass
+    pipe = Pipe()
+    pipe.unet = object()
+    pf2 = ops.WeightPrefetch(owner=pipe, slots=("unet", "transformer"))
+    first = pipe.unet
+    assert pf2.models == (first,)
+    pipe.unet = object()
+    assert pf2.models == (pipe.unet,) and pf2.models[0] is not first
+    ref = weakref.ref(pipe)
+    del pipe
+    gc.collect()
+    assert ref() is None and pf2.models == ()

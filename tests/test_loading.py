@@ -170,8 +170,17 @@ def test_lora_files_with_other_components_and_legacy_processor_names(tmp_path):
     # a module whose own name contains "_lora" is not renamed
     assert list(_lora_pairs({"unet.my_lora_block.proj.lora_A.weight": torch.zeros(2, 4),
                              "unet.my_lora_block.proj.lora_B.weight": torch.zeros(4, 2)})) == ["my_lora_block.proj"]
+    # a file for other components only: warn and leave the model alone, as loaders/peft.py:359-366 does (strict: raise)
+    te_only = {"text_encoder.x.lora_A.weight": torch.zeros(2, 4), "text_encoder.x.lora_B.weight": torch.zeros(4, 2)}
+    with pytest.warns(UserWarning, match="No LoRA keys"):
+        assert _lora_pairs(te_only) == {}
     with pytest.raises(ValueError, match="No LoRA keys"):
-        _lora_pairs({"text_encoder.x.lora_A.weight": torch.zeros(2, 4), "text_encoder.x.lora_B.weight": torch.zeros(4, 2)})
+        _lora_pairs(te_only, strict=True)
+    before = {k: t.clone() for k, t in packed_cache.packed_tensors(model).items()}
+    state = model._lora
+    with pytest.warns(UserWarning, match="No LoRA keys"):
+        model.load_lora_adapter(te_only)
+    assert model._lora == state and all(torch.equal(t, before[k]) for k, t in packed_cache.packed_tensors(model).items())
 
 
 def test_in_memory_models_need_a_base_for_lora():
