@@ -5,6 +5,7 @@ There is NO fallback: if ``libdiffusers_amd.so`` is missing or a symbol is absen
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
@@ -67,6 +68,23 @@ class AttentionParams(C.Structure):
     ]
 
 
+# ---- launch plans (include/diffusers_amd.h "launch plans"; csrc/plan.hip) ----
+PLAN_MAX_ARGS = 16
+FN_IDS = {name: i + 1 for i, name in enumerate((
+    "da_gemm_bf16", "da_gemm_pair_bf16", "da_attention_bf16", "da_groupnorm_nhwc_bf16", "da_rmsnorm_bf16", "da_layernorm_bf16",
+    "da_rmsnorm_rope_bf16", "da_softmax_rows_f32_bf16", "da_rmsnorm_channels_bf16", "da_euler_scale_model_input", "da_euler_step",
+    "da_x0_linear_step", "da_flowmatch_step", "da_unipc_flow_step", "da_advance_step", "da_cfg_rescale", "da_cast_f32_bf16",
+    "da_mul_scalar", "da_bcast_add_f32", "da_patchify3d_bf16", "da_unpatchify3d_bf16", "da_transpose_bf16",
+    "da_nhwc_take_nchw_bf16", "da_nhwc_take_postprocess", "da_permute_0213_bf16", "da_image_postprocess",
+    "da_frames_to_ncthw_bf16", "da_timestep_embedding", "da_linear_small_m_bf16", "da_conv_thin_in_bf16",
+    "da_conv_thin_out_bf16"))}
+FN_COUNT = len(FN_IDS) + 1
+
+
+class PlanOp(C.Structure):
+    _fields_ = [("fn", C.c_int), ("reserved", C.c_int), ("arg", C.c_ulonglong * PLAN_MAX_ARGS)]
+
+
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
@@ -109,16 +127,26 @@ SIGNATURES = {
     "da_linear_small_m_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "da_conv_thin_in_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "da_conv_thin_out_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "da_plan_create": (_i, [C.POINTER(PlanOp), _i, C.POINTER(C.c_void_p)]),
+    "da_plan_launch": (_i, [_vp, _vp, C.POINTER(C.c_int)]),
+    "da_plan_relocate": (_i, [_vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_ulonglong), C.POINTER(C.c_void_p),
+                              C.POINTER(C.c_int)]),
+    "da_plan_op_count": (_i, [_vp]),
+    "da_plan_destroy": (None, [_vp]),
+    "da_plan_arg_count": (_i, [_i]),
+    "da_plan_arg_kinds": (C.c_char_p, [_i]),
 }
 
 _lib = None
+_tls = threading.local()     # .recorder: the plan recorder of this thread (diffusers_amd/plan.py), if one is active
 
 
 def load() -> C.CDLL:
     """Load libdiffusers_amd.so (building is a separate, explicit step: ``python -m diffusers_amd.build``)."""
     global _lib
+    rec = getattr(_tls, "recorder", None)
     if _lib is not None:
-        return _lib
+        return _lib if rec is None else rec.proxy
     if not LIB_PATH.exists():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m diffusers_amd.build` "
@@ -135,7 +163,7 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
-    return lib
+    return lib if rec is None else rec.proxy
 
 
 def check(status: int, what: str) -> None:

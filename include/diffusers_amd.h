@@ -416,6 +416,77 @@ int da_conv_thin_in_bf16(const void* x, const void* w, const void* bias, void* y
 int da_conv_thin_out_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
                           int Cout, int out_f32, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Launch plans: a recorded sequence of the launch entry points above, owned by the library and replayed by ONE call --
+ * the C-ABI form of the denoising step the Python pipelines capture into a HIP graph (the reference's per-step work,
+ * pipeline_stable_diffusion_xl.py:1186-1250: scale_model_input, the U-Net forward, the CFG combine, scheduler.step; and the
+ * decode, :1283-1299), so that a host with no Python (examples/abi_demo.cpp) runs a whole model step.
+ *
+ * An op names an entry point (DA_FN_*) and carries its arguments in declaration order, the trailing stream excluded, one
+ * 64-bit slot each: device and host pointers as addresses, int / long long sign-extended, float as its 32 bits (upper half
+ * ignored).  da_plan_create() copies what the call passes by host address -- the da_gemm_params / da_attention_params
+ * structs, the two small host arrays of da_rmsnorm_rope_bf16 -- so the caller's copies may go away; DEVICE addresses are kept
+ * as given and must stay valid for as long as the plan is launched (the buffers of a step: weights, activations,
+ * workspaces).  da_plan_launch() issues the ops in order on `stream` (no synchronisation; results are those of the same calls
+ * made one by one: bit-identical) and stops at the first failing op (its index in *failed_op, its code returned).
+ * da_plan_relocate() rewrites every device address that falls into [old_base[r], old_base[r] + bytes[r]) to the same offset
+ * in new_base[r] -- for a plan recorded by one process and replayed by another; *unmatched counts the non-NULL addresses no
+ * region covered (left as they were).  A plan is immutable while launched; launches of one plan from several threads are
+ * safe, relocate / destroy are not concurrent with them.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define DA_FN_GEMM 1                      /* da_gemm_bf16 */
+#define DA_FN_GEMM_PAIR 2                 /* da_gemm_pair_bf16 */
+#define DA_FN_ATTENTION 3                 /* da_attention_bf16 */
+#define DA_FN_GROUPNORM_NHWC 4            /* da_groupnorm_nhwc_bf16 */
+#define DA_FN_RMSNORM 5                   /* da_rmsnorm_bf16 */
+#define DA_FN_LAYERNORM 6                 /* da_layernorm_bf16 */
+#define DA_FN_RMSNORM_ROPE 7              /* da_rmsnorm_rope_bf16 */
+#define DA_FN_SOFTMAX_ROWS 8              /* da_softmax_rows_f32_bf16 */
+#define DA_FN_RMSNORM_CHANNELS 9          /* da_rmsnorm_channels_bf16 */
+#define DA_FN_EULER_SCALE_MODEL_INPUT 10  /* da_euler_scale_model_input */
+#define DA_FN_EULER_STEP 11               /* da_euler_step */
+#define DA_FN_X0_LINEAR_STEP 12           /* da_x0_linear_step */
+#define DA_FN_FLOWMATCH_STEP 13           /* da_flowmatch_step */
+#define DA_FN_UNIPC_FLOW_STEP 14          /* da_unipc_flow_step */
+#define DA_FN_ADVANCE_STEP 15             /* da_advance_step */
+#define DA_FN_CFG_RESCALE 16              /* da_cfg_rescale */
+#define DA_FN_CAST_F32_BF16 17            /* da_cast_f32_bf16 */
+#define DA_FN_MUL_SCALAR 18               /* da_mul_scalar */
+#define DA_FN_BCAST_ADD_F32 19            /* da_bcast_add_f32 */
+#define DA_FN_PATCHIFY3D 20               /* da_patchify3d_bf16 */
+#define DA_FN_UNPATCHIFY3D 21             /* da_unpatchify3d_bf16 */
+#define DA_FN_TRANSPOSE 22                /* da_transpose_bf16 */
+#define DA_FN_NHWC_TAKE_NCHW 23           /* da_nhwc_take_nchw_bf16 */
+#define DA_FN_NHWC_TAKE_POSTPROCESS 24    /* da_nhwc_take_postprocess */
+#define DA_FN_PERMUTE_0213 25             /* da_permute_0213_bf16 */
+#define DA_FN_IMAGE_POSTPROCESS 26        /* da_image_postprocess */
+#define DA_FN_FRAMES_TO_NCTHW 27          /* da_frames_to_ncthw_bf16 */
+#define DA_FN_TIMESTEP_EMBEDDING 28       /* da_timestep_embedding */
+#define DA_FN_LINEAR_SMALL_M 29           /* da_linear_small_m_bf16 */
+#define DA_FN_CONV_THIN_IN 30             /* da_conv_thin_in_bf16 */
+#define DA_FN_CONV_THIN_OUT 31            /* da_conv_thin_out_bf16 */
+#define DA_FN_COUNT 32
+#define DA_PLAN_MAX_ARGS 16
+
+typedef struct da_plan_op {
+  int fn;       /* DA_FN_* */
+  int reserved; /* 0 */
+  unsigned long long arg[DA_PLAN_MAX_ARGS];
+} da_plan_op;
+typedef struct da_plan da_plan;
+
+int da_plan_create(const da_plan_op* ops, int n_ops, da_plan** out);
+int da_plan_launch(const da_plan* plan, void* stream, int* failed_op);
+int da_plan_relocate(da_plan* plan, int n_regions, const void* const* old_base, const unsigned long long* bytes,
+                     void* const* new_base, int* unmatched);
+int da_plan_op_count(const da_plan* plan);
+void da_plan_destroy(da_plan* plan);
+/* Argument layout of entry point `fn` as da_plan_op.arg[] holds it: the number of slots, and one character per slot --
+ * p device pointer, i / n int, l long long, f float, G da_gemm_params*, A da_attention_params*, I host int array and Q host
+ * array of device pointers (both of length n, the call's `parts`).  -1 / NULL for an unknown fn. */
+int da_plan_arg_count(int fn);
+const char* da_plan_arg_kinds(int fn);
+
 #ifdef __cplusplus
 }
 #endif

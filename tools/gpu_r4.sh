@@ -51,9 +51,29 @@ if [[ $WHAT == *normsdef* ]]; then
   timeout 120 python tools/bench_norms_r4.py $O/norms_r4b.jsonl > $O/norms_r4b.log 2>&1; echo "norms rc=$?"
   grep "sum over\|layernorm" $O/norms_r4b.jsonl | cut -c1-200
 fi
+if [[ $WHAT == *traffic* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc_traffic; mkdir -p $O/pmc_traffic
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_traffic/fetch -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/fetch.log 2>&1; echo "pmc fetch rc=$?"
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_traffic/write -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/write.log 2>&1; echo "pmc write rc=$?"
+  cd $R
+  # algorithmic bytes per launch: from this call's bench line if there is one, else from the last committed line
+  ALGO=$(python -c "import json;print(json.load(open('$O/bench_full.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null || python -c "import json;print(json.load(open('$R/profiles/r04k_bench_line_full.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null)
+  python tools/pmc_traffic.py $O/pmc_traffic/fetch $O/pmc_traffic/write $O/r04_sdxl_traffic.md $O/sdxl_traffic.json "$ALGO" 140
+  cp $O/sdxl_traffic.json $R/profiles/sdxl_traffic.json   # a later `benchfull` stage of this call reads it (roofline.traffic)
+  find $O/pmc_traffic -name '*kernel_trace*' -delete
+  find $O/pmc_traffic -name '*counter_collection.csv' -size +8M -delete
+  tail -4 $O/pmc_traffic/fetch.log | cut -c1-200
+fi
 if [[ $WHAT == *benchfull* ]]; then
   timeout 1500 python bench.py --steps 3 --warmup 1 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"
   cut -c1-300 $O/bench_full.json; grep "^\[bench" $O/bench_full.err | tail -40
+fi
+if [[ $WHAT == *plantest* ]]; then
+  timeout 900 python -m pytest tests/test_plan_gpu.py -m gpu -q -s --timeout 600 > $O/pytest_plan.log 2>&1; echo "pytest plan rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|\[plan\]|differ|launches" $O/pytest_plan.log | tail -30
+  timeout 300 python tools/make_plan_demo.py $O/step.daplan > $O/make_plan.log 2>&1; echo "make plan rc=$?"; tail -3 $O/make_plan.log | cut -c1-600
+  rm -f $O/step.daplan
 fi
 if [[ $WHAT == *fulltest* ]]; then
   timeout 2400 python -m pytest tests -m gpu -q -s --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
@@ -68,18 +88,6 @@ if [[ $WHAT == *prof* ]]; then
   find $O/prof -name '*kernel_trace*' -size +30M -delete
   cd $R
   python tools/prof_summary.py $(find $O/prof -name '*kernel_stats.csv' | head -1) "r04 sdxl bench (--steps 1 --warmup 1)" > $O/prof_summary.md 2>> $O/prof.log; head -60 $O/prof_summary.md
-fi
-if [[ $WHAT == *traffic* ]]; then
-  cd /tmp && export TMPDIR=/tmp
-  rm -rf $O/pmc_traffic; mkdir -p $O/pmc_traffic
-  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_traffic/fetch -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/fetch.log 2>&1; echo "pmc fetch rc=$?"
-  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_traffic/write -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/write.log 2>&1; echo "pmc write rc=$?"
-  cd $R
-  ALGO=$(python -c "import json;print(json.load(open('$O/bench_full.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null)
-  python tools/pmc_traffic.py $O/pmc_traffic/fetch $O/pmc_traffic/write $O/r04_sdxl_traffic.md $O/sdxl_traffic.json "$ALGO" 140
-  find $O/pmc_traffic -name '*kernel_trace*' -delete
-  find $O/pmc_traffic -name '*counter_collection.csv' -size +8M -delete
-  tail -4 $O/pmc_traffic/fetch.log | cut -c1-200
 fi
 if [[ $WHAT == *tunemissing* ]]; then
   # shapes the shipped table does not hold yet (this round: the query-blocked VAE attention GEMMs) are tuned live with both kernel
@@ -165,4 +173,20 @@ if [[ $WHAT == *pmcattn* ]]; then
   python tools/pmc_attn_r4.py report $O/pmc_attn/manifest.json $(find $O/pmc_attn/sq -name '*counter_collection.csv' | head -1) > $O/r04_pmc_attention.md 2>> $O/pmc_attn/sq.log
   find $O/pmc_attn -name '*kernel_trace*' -delete
   cat $O/r04_pmc_attention.md | cut -c1-330; tail -2 $O/pmc_attn/sq.log | cut -c1-200
+fi
+if [[ $WHAT == *tuneothers* ]]; then
+  # shapes of the other BASELINE configs that the shipped table does not hold (bench.py reports them as config.tuned_live)
+  rm -f $O/tuned_others_r4.json
+  for cfg in sd15 flux ddpm; do
+    DIFFUSERS_AMD_GEMM_FAMILY=all DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_others_r4.json timeout 600 python bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline > $O/tuneothers_$cfg.json 2>> $O/tuneothers.err; echo "tuneothers $cfg rc=$? $(grep -o '"tuned_live": [0-9]*' $O/tuneothers_$cfg.json)"
+    python - <<PYEOF
+import json
+a = json.load(open("$R/diffusers_amd/tuned/gfx950.json"))
+try:
+    b = json.load(open("$O/tuned_others_r4.json"))
+except Exception as e:
+    b = {"entries": {}}
+print("  new after $cfg:", {k: v for k, v in b["entries"].items() if k not in a["entries"]})
+PYEOF
+  done
 fi
