@@ -190,3 +190,7 @@ print("  new after $cfg:", {k: v for k, v in b["entries"].items() if k not in a[
 PYEOF
   done
 fi
+if [[ $WHAT == *planbench* ]]; then
+  rm -f $O/plan_r4.jsonl
+  timeout 600 python tools/bench_plan_r4.py $O/plan_r4.jsonl > $O/plan_r4.log 2>&1; echo "plan bench rc=$?"; tail -3 $O/plan_r4.log | cut -c1-900
+fi
