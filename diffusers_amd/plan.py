@@ -34,8 +34,8 @@ _NO_KERNEL = {
     "empty", "empty_strided", "empty_like", "new_empty", "new_empty_strided", "view", "_unsafe_view", "reshape", "_reshape_alias",
     "as_strided", "permute", "transpose", "t", "slice", "select", "expand", "squeeze", "unsqueeze", "detach", "alias", "unbind",
     "split", "split_with_sizes", "narrow", "unfold", "flatten", "unflatten", "view_as", "contiguous", "lift_fresh", "sym_size",
-    "sym_stride", "sym_numel", "sym_storage_offset", "is_contiguous", "size", "stride", "numel", "dim", "_local_scalar_dense_noop",
-    "chunk", "movedim", "swapaxes", "resize_",
+    "sym_stride", "sym_numel", "sym_storage_offset", "is_contiguous", "size", "stride", "numel", "dim", "chunk", "movedim",
+    "swapaxes", "resize_",
 }
 
 
@@ -206,11 +206,15 @@ class Plan:
             found[segs[i][0]] = segs[i][1]
         return sorted(found.items())
 
-    def save(self, path, outputs: Sequence[torch.Tensor], stream: Optional[int] = None) -> dict:
+    def save(self, path, outputs: Sequence[torch.Tensor], stream: Optional[int] = None, max_bytes: int = 1 << 30) -> dict:
         """Write the plan for a host without Python (``examples/abi_demo.cpp``): the ops with their parameter structs, the
         contents of every device region they touch AS THEY ARE NOW (= the state the replay starts from: restore the inputs
         before calling), and the bytes of ``outputs`` after one launch from that state.  The state is put back afterwards."""
         regs = self.regions()
+        total = sum(n for _, n in regs)
+        if total > max_bytes:
+            raise ValueError(f"the plan's device regions hold {total / 2**30:.1f} GiB (whole allocator segments: weights included); "
+                             f"raise max_bytes to write them, or ship the weights separately and relocate onto them")
         torch.cuda.synchronize()
         views = [_device_bytes(b, n) for b, n in regs]
         before = [v.cpu() for v in views]
