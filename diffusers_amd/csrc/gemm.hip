@@ -108,11 +108,13 @@ bool tile_ok(const da_gemm_params& p, int tile) {
     const bool geglu_ok = tile == DA_TILE_K2_128x128 || tile == DA_TILE_K1_256x128 || tile == DA_TILE_K1_128x256 ||
                           tile == DA_TILE_K1_256x256 || tile == DA_TILE_K1_256x320 || (tile == DA_TILE_K1_128x320 && !p.conv);
     // LayerNorm fold (round 4): nn.Linear, the tiles of the SDXL transformer blocks (gemm2_kernel.cuh dispatch_lnf)
-    if (p.vt) return !p.conv && p.split_k <= 1 && !geglu && (tile == DA_TILE_K2_128x80 || tile == DA_TILE_K2_128x160);
+    const bool lnf_lin = tile == DA_TILE_K2_128x80 || tile == DA_TILE_K2_128x160;          // producer and consumer
+    const bool lnf_cons = lnf_lin || tile == DA_TILE_K1_128x256 || tile == DA_TILE_K1_256x128;   // consumer / transposed block only
+    if (p.vt) return !p.conv && p.split_k <= 1 && !geglu && !p.stats_out && lnf_cons;
     if (p.stats_out || p.ln_stats) {
       if (p.conv || p.split_k > 1) return false;
-      if (p.stats_out && (geglu || (tile != DA_TILE_K2_128x80 && tile != DA_TILE_K2_128x160))) return false;
-      return geglu ? tile == DA_TILE_K1_128x320 : (tile == DA_TILE_K2_128x80 || tile == DA_TILE_K2_128x160);
+      if (p.stats_out && (geglu || !lnf_lin)) return false;
+      return geglu ? tile == DA_TILE_K1_128x320 : lnf_cons;
     }
     return p.split_k <= 1 && (!geglu || geglu_ok) &&
            !(p.conv && (tile == DA_TILE_K2_80x128 || tile == DA_TILE_K1_256x256 || tile == DA_TILE_K1_256x320));

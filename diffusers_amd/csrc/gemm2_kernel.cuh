@@ -1177,7 +1177,8 @@ inline int dispatch_lnf(const da_gemm_params& p, int tile, int staging, hipStrea
   const bool pp = staging == DA_STAGE_PINGPONG || staging == DA_STAGE_PINGPONG3;
   if (ns == 0) return DA_ERR_UNSUPPORTED;
   if (p.vt) {
-    const int bn = tile == DA_TILE_K2_128x80 ? 80 : tile == DA_TILE_K2_128x160 ? 160 : 0;
+    const int bn = tile == DA_TILE_K2_128x80 ? 80 : tile == DA_TILE_K2_128x160 ? 160 : tile == DA_TILE_K1_128x256 ? 256
+                   : tile == DA_TILE_K1_256x128 ? 128 : 0;
     if (bn == 0 || geglu || p.stats_out || p.residual || p.gate || p.rowvec || p.bias_rows || p.out_f32 || p.act != DA_ACT_NONE ||
         p.vt_col0 <= 0 || p.vt_col0 >= p.N || (p.vt_col0 % bn) || (p.vt_col0 & 15) || p.ld_vt < p.M || p.out_scale != 1.0f)
       return DA_ERR_UNSUPPORTED;
@@ -1202,6 +1203,16 @@ inline int dispatch_lnf(const da_gemm_params& p, int tile, int staging, hipStrea
     case DA_TILE_K1_128x320:
       if (!geglu || p.stats_out || ns != 2 || pp || (p.ldc & 7) || ((size_t)p.C & 15) || (p.N & 15)) break;
       return launch<1, 4, 2, 2, 10, 2, false, false, false, true, true>(p, s);
+    // consumer-only instantiations of two eight-wave tiles: the fused Q | K | V projection (M 2048 x N 3840: 240 tiles of 128 x 256,
+    // one round of the 256 CUs, where 128 x 160 needs 1.5 and 128 x 80 three)
+    case DA_TILE_K1_128x256:
+      if (geglu || p.stats_out || pp) break;
+      return ns == 2 ? launch<1, 2, 4, 4, 4, 2, false, false, false, false, true>(p, s)
+                     : launch<1, 2, 4, 4, 4, 3, false, false, false, false, true>(p, s);
+    case DA_TILE_K1_256x128:
+      if (geglu || p.stats_out || pp) break;
+      return ns == 2 ? launch<1, 4, 2, 4, 4, 2, false, false, false, false, true>(p, s)
+                     : launch<1, 4, 2, 4, 4, 3, false, false, false, false, true>(p, s);
   }
   return DA_ERR_UNSUPPORTED;
 }

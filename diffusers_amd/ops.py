@@ -249,20 +249,29 @@ def _rows2d(t: torch.Tensor, name: str) -> int:
 # GEMM / conv
 # ----------------------------------------------------------------------------------------------------------------------
 QKV_CANDIDATES = ((L.TILE_K2_128x80, L.STAGE_PINGPONG), (L.TILE_K2_128x80, L.STAGE_PINGPONG3), (L.TILE_K2_128x160, L.STAGE_PINGPONG),
-                  (L.TILE_K2_128x160, L.STAGE_LDS_DIRECT))
+                  (L.TILE_K2_128x160, L.STAGE_LDS_DIRECT), (L.TILE_K1_128x256, L.STAGE_LDS_DIRECT), (L.TILE_K1_128x256, L.STAGE_LDS_DIRECT3),
+                  (L.TILE_K1_256x128, L.STAGE_LDS_DIRECT), (L.TILE_K1_256x128, L.STAGE_LDS_DIRECT3))
+QKV_RETUNE = os.environ.get("DIFFUSERS_AMD_QKV_RETUNE", "0") == "1"   # measure again what the shipped table pins (tools/gpu_r4.sh qkv)
+_qkv_retuned = set()
+QKV_TILE_COLS = {L.TILE_K2_128x80: 80, L.TILE_K2_128x160: 160, L.TILE_K1_128x256: 256, L.TILE_K1_256x128: 128}
 
 
 def qkv_variant(p: "L.GemmParams", stream: int):
     """(tile, staging) of a fused Q | K | V projection (da_gemm_params.vt): the per-shape table under the key ``qkv:<shape>``,
-    else measured now among the four variants that carry the transposed column block (outside graph capture; HIP events, three
+    else measured now among the variants that carry the transposed column block (outside graph capture; HIP events, three
     launches each), else the first candidate whose columns divide the transposed block's origin."""
     key = "qkv:" + tuning.key_of(p)
     ent = tuning.table().get(key) if TUNING else None
-    if ent is not None:
+    if ent is not None and not (QKV_RETUNE and key not in _qkv_retuned):
         return ent[0], ent[1]
-    ok = [(t, s) for t, s in QKV_CANDIDATES if p.vt_col0 % (80 if t == L.TILE_K2_128x80 else 160) == 0]
+    _qkv_retuned.add(key)
+    # The one-K-group tiles (k1:*) add the K slices in another order than the two-K-group tiles: a live, timing-dependent choice
+    # stays inside the k2 tiles (every variant bit-identical) unless DIFFUSERS_AMD_GEMM_FAMILY=all asked for the whole field
+    # (tools/gpu_r4.sh qkv: that is how the shipped table's entries were measured).
+    field = QKV_CANDIDATES if tuning.FAMILY == "all" else tuple(c for c in QKV_CANDIDATES if c[0] < L.TILE_K1_128x320)
+    ok = [(t, s) for t, s in field if p.vt_col0 % QKV_TILE_COLS[t] == 0]
     if not ok:
-        raise ValueError(f"linear(vt_out=): column origin {p.vt_col0} is not a multiple of 80 or 160")
+        raise ValueError(f"linear(vt_out=): column origin {p.vt_col0} is not a multiple of a tile width {sorted(set(QKV_TILE_COLS.values()))}")
     if not (TUNING and tuning.LIVE) or torch.cuda.is_current_stream_capturing():
         return ok[0]
     lib, best = L.load(), None

@@ -327,9 +327,11 @@ def test_k2_fused_qkv_projection_with_transposed_v_block(M, C, inner):
     xf = x.float()
     # plain
     ref = xf @ wqkv.float().t()
-    base = None
+    bases = {}                                   # per kernel family: two K-groups (k2) and one (k1) add the K slices in different orders
     n_ok = 0
     for tile, stg in ops.QKV_CANDIDATES:
+        if (2 * inner) % ops.QKV_TILE_COLS[tile]:
+            continue
         vt = torch.full((inner, M), float("nan"), device=DEV, dtype=bf16)
         try:
             qk = ops.linear(x, wqkv, tile=tile, staging=stg, vt_out=(vt, 2 * inner))
@@ -340,10 +342,28 @@ def test_k2_fused_qkv_projection_with_transposed_v_block(M, C, inner):
         assert qk.shape == (M, 2 * inner)
         assert_close_bf16(qk, ref[:, :2 * inner], f"fused QKV (Q|K block) {L.TILE_NAMES[tile]}/{stg} M{M}", rtol=8e-3, atol_rms=4e-3)
         assert_close_bf16(vt.t(), ref[:, 2 * inner:], f"fused QKV (V^T block) {L.TILE_NAMES[tile]}/{stg} M{M}", rtol=8e-3, atol_rms=4e-3)
-        if base is None:
-            base = (qk.clone(), vt.clone())
-        assert torch.equal(qk, base[0]) and torch.equal(vt, base[1]), "variants of the fused projection differ"
-    assert n_ok >= 2
+        fam = "k1" if tile >= L.TILE_K1_128x320 else "k2"
+        if fam not in bases:
+            bases[fam] = (qk.clone(), vt.clone())
+        assert torch.equal(qk, bases[fam][0]) and torch.equal(vt, bases[fam][1]), f"{fam} variants of the fused projection differ"
+    assert n_ok >= 2 and "k2" in bases
+    base = bases["k2"]
+    if M % 128 == 0 and (2 * inner) % 256 == 0:
+        assert "k1" in bases, "the one-round tiles of the fused projection refused an aligned problem"
+    # the LayerNorm fold on every variant, each against fp32
+    wl_, fold_ = ops.fold_layernorm(wqkv, gamma, beta, 1e-5)
+    ln_ref_ = F.layer_norm(xf, (C,), gamma.float(), beta.float(), 1e-5) @ wqkv.float().t()
+    for tile, stg in ops.QKV_CANDIDATES:
+        if (2 * inner) % ops.QKV_TILE_COLS[tile]:
+            continue
+        vt = torch.full((inner, M), float("nan"), device=DEV, dtype=bf16)
+        try:
+            qk = ops.linear(x, wl_, ln=(st, fold_), tile=tile, staging=stg, vt_out=(vt, 2 * inner))
+        except RuntimeError as e:
+            assert "DA_ERR_UNSUPPORTED" in str(e), e
+            continue
+        assert_close_bf16(qk, ln_ref_[:, :2 * inner], f"fused QKV + LN fold (Q|K) {L.TILE_NAMES[tile]}/{stg} M{M}", rel_rms_max=6e-3)
+        assert_close_bf16(vt.t(), ln_ref_[:, 2 * inner:], f"fused QKV + LN fold (V^T) {L.TILE_NAMES[tile]}/{stg} M{M}", rel_rms_max=6e-3)
     # the separate K2 launches give the same bits as the fused one (same tiles, same summation order)
     sep = ops.linear(x, wqkv[:2 * inner].contiguous(), tile=L.TILE_K2_128x80, staging=L.STAGE_PINGPONG)
     assert torch.equal(sep, base[0])

@@ -148,7 +148,19 @@ if [[ $WHAT == *qkv* ]]; then
   rm -f $O/qkv_r4.jsonl
   timeout 300 python tools/bench_qkv_r4.py $O/qkv_r4.jsonl > $O/qkv_r4.log 2>&1; echo "qkv bench rc=$?"; tail -3 $O/qkv_r4.log | cut -c1-300
   cat $O/qkv_r4.jsonl
-  for n1 in 0 1 0 1; do
+  # the shipped table's choice, then the whole field (both kernel families) measured again in situ
+  for rt in 0 1 0 1; do
+    DIFFUSERS_AMD_QKV_RETUNE=$rt DIFFUSERS_AMD_GEMM_FAMILY=all DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_qkv_rt$rt.json timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_rt_$rt.json 2> $O/bench_rt_$rt.err; echo "qkv retune $rt rc=$? $(cut -c1-140 $O/bench_rt_$rt.json | grep -o '"value": [0-9.]*') $(grep -o '"tuned_live": [0-9]*' $O/bench_rt_$rt.json)"
+  done
+  python - <<PYEOF
+import json
+try:
+    b = json.load(open("$O/tuned_qkv_rt1.json"))
+    print({k: v for k, v in b["entries"].items() if k.startswith("qkv:")})
+except Exception as e:
+    print("no table:", e)
+PYEOF
+  for n1 in; do
     DIFFUSERS_AMD_LN_FOLD_NORM1=$n1 DIFFUSERS_AMD_TUNE_SAVE=$O/tuned_qkv_r4.json timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_n1_$n1.json 2> $O/bench_n1_$n1.err; echo "norm1 fold $n1 rc=$? $(cut -c1-140 $O/bench_n1_$n1.json | grep -o '"value": [0-9.]*') $(grep -o '"tuned_live": [0-9]*' $O/bench_n1_$n1.json)"
   done
   python - <<PYEOF
