@@ -69,6 +69,22 @@ def decode_postprocessed(vae, latents: torch.Tensor, output_type: str, **decode_
     return [Image.fromarray(a.squeeze(-1), mode="L") if a.shape[-1] == 1 else Image.fromarray(a) for a in arr]
 
 
+def _capture_step(pipe, step, mode):
+    """What `_denoise` replays once per step: the captured HIP graph (``use_graph=True``), or -- ``use_graph="plan"`` -- the
+    step's launch list owned by the C library (diffusers_amd/plan.py, include/diffusers_amd.h "launch plans": the same launches
+    in the same order, issued by `da_plan_launch` instead of the graph executor; what a host without Python replays).  `step` has
+    run once already (warm-up); the caller restores the latents and the step counter afterwards, as it does after a capture."""
+    if mode == "plan":
+        from . import plan as P
+        with ops.weight_prefetch(_pf(pipe), "apply"):
+            pl, _ = P.record(step)
+        return pl
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(pipe), "apply"):
+        step()
+    return g
+
+
 def _pf(pipe) -> "ops.WeightPrefetch":
     """The pipeline's weight-prefetch trace (ops.weight_prefetch): recorded by one eager step, applied to every later one."""
     pf = getattr(pipe, "_weight_prefetch", None)
@@ -143,7 +159,7 @@ class _LatentDiffusionBase:
                 with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
                     self._step(latents, cond, guidance_scale, do_cfg)
             return latents
-        key = self._make_graph_key(latents, cond, guidance_scale, do_cfg)
+        key = self._make_graph_key(latents, cond, guidance_scale, do_cfg) + (use_graph == "plan",)
         if self._graph is None or self._graph_key != key:
             # warm-up on a side stream (lazy one-time driver calls must not happen during capture), then capture
             saved = latents.clone()
@@ -155,9 +171,7 @@ class _LatentDiffusionBase:
             torch.cuda.current_stream().wait_stream(s)
             latents.copy_(saved)
             sch.reset(0)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(self), "apply"):
-                self._step(latents, cond, guidance_scale, do_cfg)
+            g = _capture_step(self, lambda: self._step(latents, cond, guidance_scale, do_cfg), use_graph)
             self._graph, self._graph_key = g, key
             self._static = {"latents": latents, "cond": cond, "noise_table": self._noise_table}
             latents.copy_(saved)
@@ -425,7 +439,7 @@ class FluxPipeline:
                 with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
                     self._step(latents, pe, cond)
             return latents
-        key = (tuple(latents.shape), tuple(pe.shape), sch.device_table.data_ptr(), sch.device_step.data_ptr())
+        key = (tuple(latents.shape), tuple(pe.shape), sch.device_table.data_ptr(), sch.device_step.data_ptr(), use_graph == "plan")
         if self._graph is None or self._graph_key != key:
             saved = latents.clone()
             s = torch.cuda.Stream()
@@ -436,9 +450,7 @@ class FluxPipeline:
             torch.cuda.current_stream().wait_stream(s)
             latents.copy_(saved)
             sch.reset(0)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(self), "apply"):
-                self._step(latents, pe, cond)
+            g = _capture_step(self, lambda: self._step(latents, pe, cond), use_graph)
             self._graph, self._graph_key = g, key
             self._static = {"latents": latents, "pe": pe, "cond": cond}
             latents.copy_(saved)
@@ -573,7 +585,7 @@ class WanPipeline:
                 with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
                     self._step(latents, cond, guidance_scale, do_cfg)
             return latents
-        key = (tuple(latents.shape), float(guidance_scale), do_cfg, cond["St"], sch.device_table.data_ptr())
+        key = (tuple(latents.shape), float(guidance_scale), do_cfg, cond["St"], sch.device_table.data_ptr(), use_graph == "plan")
         if self._graph is None or self._graph_key != key:
             saved = latents.clone()
             s = torch.cuda.Stream()
@@ -584,9 +596,7 @@ class WanPipeline:
             torch.cuda.current_stream().wait_stream(s)
             latents.copy_(saved)
             sch.reset(0)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(self), "apply"):
-                self._step(latents, cond, guidance_scale, do_cfg)
+            g = _capture_step(self, lambda: self._step(latents, cond, guidance_scale, do_cfg), use_graph)
             self._graph, self._graph_key = g, key
             self._static = {"latents": latents, "cond": cond}
             latents.copy_(saved)
@@ -707,7 +717,7 @@ class DDPMPipeline:
                 with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
                     self._step(image, noise_table)
         else:
-            key = (tuple(shape), len(ts), sch.device_table.data_ptr())
+            key = (tuple(shape), len(ts), sch.device_table.data_ptr(), use_graph == "plan")
             if getattr(self, "_graph_key", None) != key:
                 saved = image.clone()
                 s = torch.cuda.Stream()
@@ -718,9 +728,7 @@ class DDPMPipeline:
                 torch.cuda.current_stream().wait_stream(s)
                 image.copy_(saved)
                 sch.reset(0)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(self), "apply"):
-                    self._step(image, noise_table)
+                g = _capture_step(self, lambda: self._step(image, noise_table), use_graph)
                 self._graph, self._graph_key = g, key
                 self._static = {"image": image, "noise": noise_table}
                 image.copy_(saved)

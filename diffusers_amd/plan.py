@@ -157,6 +157,8 @@ class Plan:
             where = self.names[failed.value] if 0 <= failed.value < len(self.names) else "?"
             L.check(rc, f"da_plan_launch (op {failed.value}: {where})")
 
+    replay = launch        # the name torch.cuda.CUDAGraph gives the same act (pipelines replay either)
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.da_plan_destroy(self._h)
