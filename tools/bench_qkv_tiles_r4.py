@@ -1,3 +1,9 @@
+#!/usr/bin/env python
+"""Every (tile, ring) variant of the second GEMM family on the plain nn.Linear shapes of the fused Q | K | V projection (and, for
+comparison, of the Q | K block and of one projection): [warm, 12 distinct weights back to back] microseconds per launch.  This is
+the probe that showed the eight-waves-per-slice tiles winning wherever they cover the problem in ONE round of the 256 CUs
+(M 2048 x N 3840: 240 tiles of 256 x 128 at 23.4 us against 29.8 us on 128 x 160 and 32.2 us on 128 x 80); the result is
+profiles/r04m_fused_qkv_one_round_tiles.jsonl.  One JSON object per shape."""
 import json, sys
 from pathlib import Path
 import torch
