@@ -211,9 +211,13 @@ extern "C" int da_gemm_tune(const da_gemm_params* pp, const da_gemm_params* pair
   static const int stagings[] = {DA_STAGE_LDS_DIRECT, DA_STAGE_LDS_DIRECT3, DA_STAGE_LDS_DIRECT4, DA_STAGE_LDS_DIRECT6,
                                  DA_STAGE_LDS_DIRECT8, DA_STAGE_PINGPONG, DA_STAGE_PINGPONG3};
   constexpr int n_stagings = sizeof(stagings) / sizeof(stagings[0]);
-  const int max_split = (best_split && !pair && p.workspace && p.sync_flags) ? 4 : 1;
+  // split factors tried next to the unsplit variants (round 4: up to 8 -- the 8 x 8 / 16 x 16 levels of the SD1.5 and DDPM
+  // U-Nets are 3 x 3 convs with M = 64 .. 512 rows and K = 4.6 k .. 23 k: 8 .. 80 tiles walking 72 .. 360 K slices each)
+  static const int splits[] = {1, 2, 3, 4, 6, 8};
+  const int n_splits = (best_split && !pair && p.workspace && p.sync_flags) ? (int)(sizeof(splits) / sizeof(splits[0])) : 1;
   const int family = pp->tile;   // DA_TILE_AUTO: every variant; DA_TILE_FAMILY_1 / DA_TILE_FAMILY_K2: one kernel family only
-  for (int split = 1; split <= max_split; ++split) {
+  for (int spi = 0; spi < n_splits; ++spi) {
+    const int split = splits[spi];
     p.split_k = split;
     for (int tile = 1; tile < kNumTiles; ++tile) {
       if ((family == DA_TILE_FAMILY_1 && is_k2(tile)) || (family == DA_TILE_FAMILY_K2 && !is_k2(tile))) continue;

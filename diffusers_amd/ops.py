@@ -186,7 +186,10 @@ def _select_variant(p: "L.GemmParams", tile: Optional[int], staging: Optional[in
     p.split_k = 1
     auto = (TUNING and tile is None and staging is None and split_k is None and DEFAULT_TILE == L.TILE_AUTO
             and DEFAULT_STAGING == L.STAGE_LDS_DIRECT)
-    want_ws = device is not None and ((auto and tuning.SPLIT_K) or (split_k or 1) > 1)
+    ent = tuning.table().get(tuning.key_of(p)) if auto else None
+    # the split-K workspace rides along when the caller asks for a split, when the live tuner may try one, and when the shipped
+    # table holds one for this shape (the small-M, deep-K convs of the SD1.5 / DDPM U-Nets)
+    want_ws = device is not None and ((auto and (tuning.SPLIT_K or (ent is not None and ent[3] > 1))) or (split_k or 1) > 1)
     if want_ws and not inplace:
         ws, flags = splitk_workspace(device, stream)
         p.workspace, p.sync_flags, p.workspace_bytes = ws.data_ptr(), flags.data_ptr(), ws.numel()

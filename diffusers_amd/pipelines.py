@@ -75,7 +75,11 @@ def _capture_step(pipe, step, mode):
     in the same order, issued by `da_plan_launch` instead of the graph executor; what a host without Python replays).  `step` has
     run once already (warm-up); the caller restores the latents and the step counter afterwards, as it does after a capture."""
     if mode == "plan":
-        from . import plan as P
+        from . import plan as P, tuning
+        if any(v[3] > 1 for v in tuning.table().values()):
+            # split-K launches take their workspace per (device, stream); the warm-up ran on a side stream, and allocating (and
+            # zeroing) this stream's inside the recording would be a torch operator the plan cannot replay
+            ops.splitk_workspace(pipe.device, torch.cuda.current_stream().cuda_stream)
         with ops.weight_prefetch(_pf(pipe), "apply"):
             pl, _ = P.record(step)
         return pl

@@ -206,7 +206,7 @@ int da_gemm_pair_bf16(const da_gemm_params* a, const da_gemm_params* b, void* st
  * it per problem shape, the role torch's cublasLt/hipblasLt heuristic cache plays for F.linear / F.conv2d in the
  * reference).  Synchronises the stream; must not be called while the stream is being captured into a graph. */
 /* `pair` (may be NULL): time the two problems as ONE da_gemm_pair_bf16 launch.  `best_split` (may be NULL): when given and
- * p->workspace / p->sync_flags are set, split_k = 2, 3, 4 variants of every admissible tile are timed as well and the
+ * p->workspace / p->sync_flags are set, split_k = 2, 3, 4, 6, 8 variants of every admissible tile are timed as well and the
  * winner's split factor is returned (1 = unsplit); otherwise only split_k = 1 is considered. */
 int da_gemm_tune(const da_gemm_params* p, const da_gemm_params* pair, void* stream, int iters, void* scratch,
                  size_t scratch_bytes, int* best_tile, int* best_staging, int* best_split, float* best_us);

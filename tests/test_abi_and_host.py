@@ -386,8 +386,12 @@ def test_tuning_keys_bucket_giant_row_counts_only():
     assert tuning.key_of(p) == k81
     table = json.loads((Path(tuning.__file__).parent / "tuned" / "gfx950.json").read_text())
     assert table["arch"] == "gfx950" and len(table["entries"]) >= 250
-    for key, (tile, staging, us) in table["entries"].items():
+    sdxl = set(json.loads((Path(__file__).parent / "golden" / "sdxl_gemm_shape_keys.json").read_text())["keys"])
+    for key, (tile, staging, us, *split) in table["entries"].items():
         assert 1 <= tile < len(L.TILE_NAMES) and 0 <= staging <= 7 and us > 0, key
+        # a split-K factor (fourth field, 2 .. 8): first kernel family only, and never on an SDXL shape (the headline path keeps one
+        # summation order; the split variants serve the small-M, deep-K convs of the SD1.5 / DDPM U-Nets)
+        assert split == [] or (len(split) == 1 and 2 <= split[0] <= 8 and tile < L.FIRST_K2_TILE and key not in sdxl), key
 
 
 def test_torch_library_ops_are_registered_with_fake_kernels():

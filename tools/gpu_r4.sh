@@ -206,3 +206,71 @@ if [[ $WHAT == *planbench* ]]; then
   rm -f $O/plan_r4.jsonl
   timeout 600 python tools/bench_plan_r4.py $O/plan_r4.jsonl > $O/plan_r4.log 2>&1; echo "plan bench rc=$?"; tail -3 $O/plan_r4.log | cut -c1-900
 fi
+if [[ $WHAT == *profothers* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  for cfg in sd15 ddpm; do
+    rm -rf $O/prof_$cfg
+    timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_$cfg -o $cfg -- python $R/bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_$cfg.log 2>&1; echo "prof $cfg rc=$?"
+    find $O/prof_$cfg -name '*kernel_trace*' -size +30M -delete
+    python $R/tools/prof_summary.py $(find $O/prof_$cfg -name '*kernel_stats.csv' | head -1) "r04 $cfg bench (--steps 1 --warmup 1)" > $O/prof_summary_$cfg.md 2>> $O/prof_$cfg.log; head -34 $O/prof_summary_$cfg.md | cut -c1-190
+  done
+  cd $R
+fi
+if [[ $WHAT == *retunesmall* ]]; then
+  # the small-M, deep-K shapes of the SD1.5 / DDPM U-Nets (fewer tiles than CUs): tuned again with the split-K variants (2..8)
+  # and both kernel families competing; SDXL's entries are left alone
+  python - <<PYEOF
+import json, re
+R, O = "$R", "$O"
+d = json.load(open(f"{R}/diffusers_amd/tuned/gfx950.json"))
+sdxl = set(json.load(open(f"{R}/tests/golden/sdxl_gemm_shape_keys.json"))["keys"])
+BM = {"128x128": (128, 128), "64x128": (64, 128), "128x64": (128, 64), "64x64": (64, 64), "256x128": (256, 128), "128x256": (128, 256),
+      "256x256": (256, 256), "128x128w8": (128, 128), "k2:128x128": (128, 128), "k2:128x80": (128, 80), "k2:128x160": (128, 160),
+      "k2:80x128": (80, 128), "k2:128x64": (128, 64), "k1:128x320": (128, 320), "k1:256x128": (256, 128), "k1:128x256": (128, 256),
+      "k1:256x160": (256, 160), "k1:256x256": (256, 256), "k1:256x320": (256, 320)}
+drop = []
+for k, v in d["entries"].items():
+    if k in sdxl or k.startswith(("pair:", "qkv:")):
+        continue
+    m = re.match(r"conv(\d):M(\d+):N(\d+):C(\d+)\+(\d+)", k)
+    if m:
+        ks, M, N, C1, C2 = map(int, m.groups()); K = ks * ks * (C1 + C2)
+    else:
+        m = re.match(r"lin:M(\d+):N(\d+):K(\d+)", k)
+        if not m:
+            continue
+        M, N, K = map(int, m.groups())
+    bm, bn = BM[d["tiles"][v[0]]]
+    tiles = -(-M // bm) * -(-N // bn)
+    if tiles < 200 and K >= 1024 and M <= 8192:
+        drop.append(k)
+for k in drop:
+    del d["entries"][k]
+json.dump(d, open(f"{O}/table_pruned.json", "w"))
+print("entries to tune again:", len(drop))
+PYEOF
+  cp $O/table_pruned.json $O/table_retuned.json
+  for cfg in sd15 ddpm; do
+    DIFFUSERS_AMD_SPLITK=1 DIFFUSERS_AMD_GEMM_FAMILY=all DIFFUSERS_AMD_TUNE_DB=$O/table_retuned.json DIFFUSERS_AMD_TUNE_SAVE=$O/table_retuned.json timeout 900 python bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline > $O/retune_$cfg.json 2> $O/retune_$cfg.err; echo "retune $cfg rc=$? $(grep -o '"value": [0-9.]*' $O/retune_$cfg.json | head -1) $(grep -o '"tuned_live": [0-9]*' $O/retune_$cfg.json)"
+  done
+  python - <<PYEOF
+import json
+a = json.load(open("$R/diffusers_amd/tuned/gfx950.json"))["entries"]
+b = json.load(open("$O/table_retuned.json"))
+T = b["tiles"]
+n = 0
+for k, v in sorted(b["entries"].items()):
+    o = a.get(k)
+    if o is None or o[:2] != v[:2] or (len(v) > 3) != (len(o) > 3):
+        n += 1
+        print(f"  {k:58s} {T[o[0]] if o else '-':11s} st{o[1] if o else '-'} {o[2] if o else 0:7.1f}us -> {T[v[0]]:11s} st{v[1]} split {v[3] if len(v) > 3 else 1} {v[2]:7.1f}us")
+print("changed:", n)
+PYEOF
+  for rep in 1 2; do
+    for tb in $R/diffusers_amd/tuned/gfx950.json $O/table_retuned.json; do
+      for cfg in sd15 ddpm; do
+        DIFFUSERS_AMD_TUNE_DB=$tb timeout 600 python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/ab_$cfg.json 2> $O/ab_$cfg.err; echo "$(basename $tb) $cfg rc=$? $(grep -o '"value": [0-9.]*' $O/ab_$cfg.json | head -1) $(grep -o '"tuned_live": [0-9]*' $O/ab_$cfg.json) $(grep -o '"psnr[a-z_]*": [0-9.]*' $O/ab_$cfg.json | head -2 | tr '\n' ' ')"
+      done
+    done
+  done
+fi
