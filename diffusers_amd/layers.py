@@ -132,11 +132,17 @@ class ResnetBlock2D:
         self.out_scale = 1.0 / output_scale_factor
 
     def __call__(self, x, temb=None, skip=None):
-        # temb: [B][temb_channels] bf16 (already the raw embedding; SiLU is fused into the skinny linear)
+        # temb: [B][temb_channels] bf16 (already the raw embedding; SiLU is fused into the skinny linear), or the projections of
+        # every block of the model computed by one launch (TimeProjections below): this block's columns of that tensor
         h = self.norm1(x, silu=True, x2=skip)
         tvec = None
         if self.has_temb and temb is not None:
-            tvec = ops.linear_small_m(temb, self.time_emb_proj.weight, self.time_emb_proj.bias, act_in=L.ACT_SILU)
+            if isinstance(temb, ProjectedTemb):
+                tvec = temb.all[:, self.temb_off:self.temb_off + self.temb_c]
+            elif self.time_emb_proj is None:
+                raise ValueError("ResnetBlock2D: this block's time_emb_proj lives in the model's TimeProjections; pass its output")
+            else:
+                tvec = ops.linear_small_m(temb, self.time_emb_proj.weight, self.time_emb_proj.bias, act_in=L.ACT_SILU)
         h = self.conv1(h, rowvec=tvec)
         h = self.norm2(h, silu=True)
         if self.shortcut is not None:
@@ -146,6 +152,42 @@ class ResnetBlock2D:
                 raise ValueError("ResnetBlock2D: concat input requires a conv_shortcut")
             res = x
         return self.conv2(h, residual=res, out_scale=self.out_scale)
+
+
+class ProjectedTemb:
+    """[B][sum of the blocks' channels] bf16: time_emb_proj(SiLU(temb)) of every ResnetBlock2D of a model, side by side."""
+
+    def __init__(self, t: torch.Tensor):
+        self.all = t
+
+
+class TimeProjections:
+    """``time_emb_proj(nonlinearity(temb))`` (resnet.py:345-349) of EVERY ResnetBlock2D of a U-Net as ONE skinny GEMM per forward:
+    the blocks' weights stacked along the output dimension [sum C_i][temb_channels].  The embedding is the same vector for all of
+    them, so the 19 (SDXL) / 24 (SD1.5) / 34 (ddpm-cat) latency-bound launches of a step become one that streams the same bytes;
+    every output column is computed by its own wave from its own weight row, so the values are bit-identical to the per-block
+    launches.  Each block reads its columns of the result as the conv's per-batch row vector (`ld_rowvec` = the full width)."""
+
+    def __init__(self, resnets):
+        rs = [r for r in resnets if r.has_temb]
+        self.weight = self.bias = None
+        if not rs:
+            return
+        biased = [r.time_emb_proj.bias is not None for r in rs]
+        if any(biased) and not all(biased):
+            return                                   # (no such model in scope: the blocks keep their own launches)
+        self.weight = torch.cat([r.time_emb_proj.weight for r in rs], dim=0).contiguous()
+        self.bias = torch.cat([r.time_emb_proj.bias for r in rs], dim=0).contiguous() if all(biased) else None
+        off = 0
+        for r in rs:
+            r.temb_off, r.temb_c = off, r.time_emb_proj.weight.shape[0]
+            off += r.temb_c
+            r.time_emb_proj = None                   # one copy of the weight: the stacked one
+
+    def __call__(self, temb: torch.Tensor):
+        if self.weight is None:
+            return temb
+        return ProjectedTemb(ops.linear_small_m(temb, self.weight, self.bias, act_in=L.ACT_SILU))
 
 
 class Downsample2D:

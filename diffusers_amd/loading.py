@@ -262,7 +262,7 @@ class PretrainedMixin:
         cfg.update(config_overrides)
         from . import ops
         fp = checkpoint_fingerprint(files, extra=cls.__name__ + json.dumps(cfg, sort_keys=True, default=str)
-                                    + (f"+lnfold{int(ops.LN_FOLD)}qkv" if ops.LN_FOLD else ""))   # the fold changes the packed inventory
+                                    + (f"+lnfold{int(ops.LN_FOLD)}qkv" if ops.LN_FOLD else "") + "+tembcat")   # the fold / the stacked time projections change the packed inventory
         cdir = Path(cache_dir) if cache_dir is not None else d / PACKED_DIR
         cfile = cdir / f"{cls.__name__}-{fp}.safetensors"
         model = None

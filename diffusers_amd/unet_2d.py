@@ -18,7 +18,7 @@ from . import ops
 from .config_utils import check_to
 from .loading import PretrainedMixin
 from .autoencoder_kl import VaeAttention
-from .layers import Downsample2D, GroupNorm, ResnetBlock2D, TimestepEmbedding, Upsample2D, Weights
+from .layers import Downsample2D, GroupNorm, ResnetBlock2D, TimeProjections, TimestepEmbedding, Upsample2D, Weights
 from .unet_2d_condition import FrozenConfig
 
 bf16 = torch.bfloat16
@@ -117,6 +117,9 @@ class UNet2DModel(PretrainedMixin):
             if i != n - 1:
                 st["up"] = Upsample2D(w, f"{pre}.upsamplers.0")
             self.up.append(st)
+        # every block's time_emb_proj in one launch per forward (layers.TimeProjections), blocks in forward order
+        self.time_proj = TimeProjections([r for st in self.down for r in st["resnets"]] + [self.mid_res0, self.mid_res1] +
+                                         [r for st in self.up for r in st["resnets"]])
         self.conv_norm_out = GroupNorm(w, "conv_norm_out", groups, eps)
         self.conv_out_w = ops.pack_conv_weight(w.get("conv_out.weight"))
         self.conv_out_b = w.get("conv_out.bias")
@@ -155,7 +158,7 @@ class UNet2DModel(PretrainedMixin):
                 t = t.expand(B)
             t_emb = ops.timestep_embedding(t.contiguous(), c.block_out_channels[0], batch=B,
                                            flip_sin_to_cos=c.flip_sin_to_cos, shift=float(c.freq_shift))
-        emb = self.time_embedding(t_emb)
+        emb = self.time_proj(self.time_embedding(t_emb))     # the resnets below take their columns of this
         x = ops.conv_thin_in(sample.contiguous(), self.conv_in_w, self.conv_in_b, ksize=3, in_nchw=True)
         skips = [x]
         for st in self.down:

@@ -15,7 +15,7 @@ import torch
 from . import ops
 from .config_utils import check_to
 from .loading import PretrainedMixin
-from .layers import (Downsample2D, GroupNorm, ResnetBlock2D, TimestepEmbedding, Transformer2DModel,
+from .layers import (Downsample2D, GroupNorm, ResnetBlock2D, TimeProjections, TimestepEmbedding, Transformer2DModel,
                      Upsample2D, Weights, encoder_mask_bias, pad_encoder_states)
 
 bf16 = torch.bfloat16
@@ -158,6 +158,9 @@ class UNet2DConditionModel(PretrainedMixin):
             if i != n - 1:
                 stage["up"] = Upsample2D(w, f"{pre}.upsamplers.0")
             self.up.append(stage)
+        # every block's time_emb_proj in one launch per forward (layers.TimeProjections), blocks in forward order
+        self.time_proj = TimeProjections([r for st in self.down for r in st["resnets"]] + self.mid["resnets"] +
+                                         [r for st in self.up for r in st["resnets"]])
 
         self.conv_norm_out = GroupNorm(w, "conv_norm_out", groups, eps)
         self.conv_out_w = ops.pack_conv_weight(w.get("conv_out.weight"))
@@ -324,6 +327,7 @@ class UNet2DConditionModel(PretrainedMixin):
             t_emb = ops.timestep_embedding(t.contiguous(), c.block_out_channels[0], batch=B,
                                            flip_sin_to_cos=c.flip_sin_to_cos, shift=float(c.freq_shift))
         emb = self.time_embedding(t_emb, residual=conditioning["aug_emb"])  # emb + aug_emb fused as residual
+        emb = self.time_proj(emb)                    # the resnets below take their columns of this
 
         # 2. conv_in: NCHW -> channels-last
         x = ops.conv_thin_in(sample.contiguous(), self.conv_in_w, self.conv_in_b, ksize=3, in_nchw=True)

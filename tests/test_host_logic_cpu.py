@@ -95,6 +95,56 @@ def test_norm1_fold_through_the_fused_qkv_projection(fold, monkeypatch):
     assert y.shape == ref.shape and rr < TOL
 
 
+def test_time_projections_of_every_resnet_are_one_launch(monkeypatch):
+    """layers.TimeProjections (resnet.py:345-349): the time_emb_proj of every ResnetBlock2D of a U-Net is ONE skinny GEMM per
+    forward over the stacked weights, each block reading its columns of the result -- the same values as the per-block launches
+    (checked against a model whose blocks keep their own projections), with the stacked weight the only copy the model holds."""
+    from diffusers_amd import layers, packed_cache
+    from diffusers_amd.unet_2d import UNet2DModel
+    from diffusers_amd.unet_2d_condition import UNet2DConditionModel
+    calls = []
+    orig = ops.linear_small_m
+
+    def wrap(x, w, *a, **k):
+        calls.append(tuple(w.shape))
+        return orig(x, w, *a, **k)
+    monkeypatch.setattr(ops, "linear_small_m", wrap)
+    g = torch.Generator().manual_seed(11)
+    sample = torch.randn((2, 4, 8, 8), generator=g).to(bf16)
+    ehs = torch.randn((2, 7, 64), generator=g).to(bf16)
+    added = {"text_embeds": torch.randn((2, 64), generator=g).to(bf16), "time_ids": torch.tensor([[64., 64., 0., 0., 64., 64.]]).repeat(2, 1)}
+
+    def build(stacked):
+        keep = layers.TimeProjections.__init__
+        if not stacked:
+            layers.TimeProjections.__init__ = lambda self, resnets: setattr(self, "weight", None)   # blocks keep their own launches
+        try:
+            unet = UNet2DConditionModel(**MID_SDXL_UNET)
+            unet.load_state_dict(dinit.random_state_dict(dinit.unet_param_shapes(unet.config), seed=3), device="cpu")
+        finally:
+            layers.TimeProjections.__init__ = keep
+        return unet
+    unet = build(True)
+    n_res = sum(len(st["resnets"]) for st in unet.down + unet.up) + 2
+    calls.clear()
+    y = unet(sample, torch.tensor(300.0), ehs, added_cond_kwargs=added).sample
+    stacked_rows = unet.time_proj.weight.shape[0]
+    assert sum(1 for c in calls if c[0] == stacked_rows) == 1 and len(calls) <= 6, calls      # + time / add embedding MLPs
+    assert stacked_rows == sum(r.temb_c for st in unet.down + unet.up for r in st["resnets"]) + sum(r.temb_c for r in unet.mid["resnets"])
+    assert all(r.time_emb_proj is None for st in unet.down + unet.up for r in st["resnets"])
+    assert not any("time_emb_proj" in k for k in packed_cache.packed_tensors(unet)) and "time_proj.weight" in packed_cache.packed_tensors(unet)
+    plain = build(False)
+    calls.clear()
+    y0 = plain(sample, torch.tensor(300.0), ehs, added_cond_kwargs=added).sample
+    assert len(calls) >= n_res and torch.equal(y, y0)
+    # the unconditional U-Net of DDPMPipeline takes the same path
+    u2 = UNet2DModel(**dinit.TINY_DDPM)
+    u2.load_state_dict(dinit.random_state_dict(dinit.unet2d_param_shapes(u2.config), seed=0), device="cpu")
+    calls.clear()
+    u2(torch.randn((1, 3, 32, 32), generator=g).to(bf16), torch.tensor(10.0))
+    assert sum(1 for c in calls if c[0] == u2.time_proj.weight.shape[0]) == 1 and len(calls) <= 3, calls
+
+
 def test_unet_forward_under_inference_mode_and_cache_reset_on_reload(golden):
     """the drop-in forward keyed its conditioning cache on `tensor._version`, which raises for tensors
     created under torch.inference_mode() (a common wrapper around pipelines); and the cache survived a second
