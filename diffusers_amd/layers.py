@@ -7,6 +7,7 @@ images [B][H][W][C], tokens [B*S][C].
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -171,7 +172,7 @@ class TimeProjections:
     def __init__(self, resnets):
         rs = [r for r in resnets if r.has_temb]
         self.weight = self.bias = None
-        if not rs:
+        if not rs or os.environ.get("DIFFUSERS_AMD_TEMB_STACK", "1") == "0":      # A/B knob: the blocks keep their own launches
             return
         biased = [r.time_emb_proj.bias is not None for r in rs]
         if any(biased) and not all(biased):

@@ -274,3 +274,13 @@ PYEOF
     done
   done
 fi
+if [[ $WHAT == *tembab* ]]; then
+  for rep in 1 2; do
+    for st in 0 1; do
+      for cfg in sdxl sd15 ddpm; do
+        EXTRA="--no-reference --no-other-configs"; [[ $cfg != sdxl ]] && EXTRA=""
+        DIFFUSERS_AMD_TEMB_STACK=$st timeout 600 python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-roofline $EXTRA > $O/temb_$cfg.json 2> $O/temb_$cfg.err; echo "stacked time projections $st $cfg rc=$? $(grep -o '"value": [0-9.]*' $O/temb_$cfg.json | head -1)"
+      done
+    done
+  done
+fi
