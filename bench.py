@@ -120,9 +120,13 @@ def synth_inputs(n_prompts, tiny, device):
 HBM_PEAK_GBS = 8000.0                       # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
 
 
-def instrumented_pass(run):
-    """Roofline legs: run() eagerly with a HIP-event pair around every launch of the kernel families that carry the path, on
-    the stream the kernels are launched on.  Returns {family: [launches, ms, algorithmic flop, algorithmic bytes]}:
+def instrumented_pass(run, attach=True):
+    """Roofline legs: run() eagerly with a HIP-event pair for every launch of the kernel families that carry the path, on
+    the stream the kernels are launched on.  ``attach`` (default): the pair is ATTACHED to the launch (da_set_launch_events ->
+    hipExtLaunchKernelGGL stamps the events with the dispatch's own begin / end: the kernel's duration as rocprofv3 reports it);
+    ``attach=False``: the pair is recorded from the host either side of the call, which also counts the marker packets' own
+    processing (+ 1-3 us per launch: it weighs most on the 10 us launches).  Returns {family: [launches, ms, algorithmic flop,
+    algorithmic bytes]}:
       igemm      every Linear / Conv2d launch INCLUDING the paired Q|K + V^T launches (ops.linear_pair)
       attention  flash attention forward (4 B H Sq Skv D flop)
       groupnorm  GroupNorm (+ SiLU): read for the statistics, read + write for the apply pass = 6 B per element
@@ -132,12 +136,23 @@ def instrumented_pass(run):
     names = ("linear", "linear_pair", "conv2d_nhwc", "attention", "group_norm_nhwc", "layer_norm")
     orig = {n: getattr(ops, n) for n in names}
 
+    from diffusers_amd import _lib as L
+    lib = L.load()
+
     def timed(fn, work_of, family):
         def wrapper(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = fn(*a, **k)
-            e1.record()
+            if attach:
+                e1.record()                          # (both handles exist now; the launch below records them again)
+                L.check(lib.da_set_launch_events(e0.cuda_event, e1.cuda_event), "da_set_launch_events")
+                try:
+                    out = fn(*a, **k)
+                finally:
+                    lib.da_set_launch_events(None, None)
+            else:
+                out = fn(*a, **k)
+                e1.record()
             records.append((family, e0, e1, work_of(a, k, out)))
             return out
         return wrapper
@@ -203,6 +218,27 @@ def instrumented_pass(run):
     return fam
 
 
+TIMING_ATTACHED = ("HIP events attached to the launches (da_set_launch_events -> hipExtLaunchKernelGGL: begin / end of the dispatch, "
+                   "the duration rocprofv3 reports)")
+TIMING_HOST = "HIP event pair recorded from the host either side of every launch (includes the marker packets' processing)"
+
+
+def measured_families(run):
+    """(families, timing note, families by the host-recorded pairs or None): the attached-event pass, checked -- every interval
+    positive and the total not above the host-recorded total, which brackets the same kernels from further out -- else the host pass
+    alone (a runtime without hipExtLaunchKernelGGL support must not cost the line)."""
+    host = instrumented_pass(run, attach=False)
+    try:
+        att = instrumented_pass(run, attach=True)
+        ok = all(k in att and att[k][0] == host[k][0] and 0.0 < att[k][1] <= host[k][1] * 1.05 for k in host)
+    except Exception as e:
+        log(f"attached timing events unavailable ({type(e).__name__}: {e}); host-recorded pairs")
+        ok = False
+    if ok:
+        return att, TIMING_ATTACHED, host
+    return host, TIMING_HOST, None
+
+
 def _kernel_entry(name, kernel, bound, rec, extra=None):
     n, ms, fl, nb = rec
     e = {"name": name, "kernel": kernel, "bound": bound, "launches": n, "ms": ms, "avg_launch_us": 1000.0 * ms / max(n, 1)}
@@ -244,7 +280,7 @@ def roofline_leg(pipe, mine, world, images_per_s):
         with _ops.weight_prefetch(pf, "apply"):
             pipe._step(lat, cond, GUIDANCE, True)
     one_step()  # untimed warm pass
-    fam = instrumented_pass(one_step)
+    fam, timing, fam_host = measured_families(one_step)
     n, ms, fl, nbytes = fam["igemm"]
     ach = fl / (ms * 1e-3) / 1e12
     fp = build_fingerprint()
@@ -287,8 +323,14 @@ def roofline_leg(pipe, mine, world, images_per_s):
                         "groupnorm_frac_of_hbm_peak": vn[3] / max(vn[1], 1e-9) / 1e6 / HBM_PEAK_GBS})
     except Exception as e:  # a diagnostic must not cost the line
         kernels.append({"name": "vae_decode", "error": f"{type(e).__name__}: {e}"})
+    host_pair = None
+    if fam_host is not None:       # the same launches by the host-recorded pairs (what rounds 1-3 reported)
+        host_pair = {k: {"avg_launch_us": 1000.0 * v[1] / max(v[0], 1),
+                         **({"achieved": v[2] / (v[1] * 1e-3) / 1e12, "frac": v[2] / (v[1] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS}
+                            if k in ("igemm", "attention") else {})} for k, v in fam_host.items()}
     return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": note, "build_fingerprint": fp,
+            "frac": ach / MFMA_PEAK_TFLOPS, "timing": timing, "host_event_pairs": host_pair,
+            "traffic": traffic, "traffic_source": note, "build_fingerprint": fp,
             "kernel": "igemm_bf16_kernel + igemm2_bf16_kernel (Linear + Conv2d implicit GEMM, paired launches included)",
             "launches_per_denoise_step": n, "avg_launch_us": 1000.0 * ms / max(n, 1),
             "algorithmic_tflop_per_denoise_step": fl / 1e12,
@@ -586,13 +628,13 @@ def _other_kernels(unit):
     (+ the decode where the unit has one): the algorithmic work is summed from the launches themselves."""
     run = unit(1, False)
     run()                                   # untimed warm pass (variant lookup)
-    fam = instrumented_pass(run)
+    fam, timing, _ = measured_families(run)
     kernels = []
     for name, kern, bound in (("igemm", "igemm_bf16_kernel + igemm2_bf16_kernel (Linear, Conv2d, paired launches)", "mfma"),
                               ("attention", "attn2_fwd_kernel / attn_fwd_kernel (flash attention forward)", "mfma"),
                               ("groupnorm", "gn_stats_kernel + gn_apply_kernel", "hbm"), ("layernorm", "layernorm_kernel", "hbm")):
         if name in fam:
-            kernels.append(_kernel_entry(name, kern, bound, fam[name], {"scope": "one sampler step + decode, eager"}))
+            kernels.append(_kernel_entry(name, kern, bound, fam[name], {"scope": "one sampler step + decode, eager", "timing": timing}))
     return kernels
 
 

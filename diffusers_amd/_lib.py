@@ -91,6 +91,7 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     "da_version": (_i, []),
     "da_last_error": (C.c_char_p, []),
+    "da_set_launch_events": (_i, [_vp, _vp]),
     "da_gemm_bf16": (_i, [C.POINTER(GemmParams), _vp]),
     "da_gemm_pair_bf16": (_i, [C.POINTER(GemmParams), C.POINTER(GemmParams), _vp]),
     "da_gemm_stats_parts": (_i, [C.POINTER(GemmParams)]),

@@ -2,6 +2,7 @@
 // Written for wave64 + MFMA only; there is no other target.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "diffusers_amd.h"
 
@@ -14,10 +15,23 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // hipGetLastError() is per-thread and sticky: PyTorch's allocator leaves benign hipErrorNotReady results from
 // hipEventQuery behind, so the error slot is cleared right before every launch and read right after it.
+// da_set_launch_events() (version.hip): a caller may arm a start / stop event pair for this thread's next launches; such a launch
+// goes through hipExtLaunchKernelGGL, which stamps the events with the dispatch's OWN begin / end (what rocprofv3 reports as the
+// kernel's duration) instead of the completion of separate marker packets either side of it.  One thread-local load otherwise.
+extern "C" int da_take_launch_events(hipEvent_t* start, hipEvent_t* stop);
+template <typename F, typename... Args>
+inline void da_launch_with_events(hipEvent_t start, hipEvent_t stop, F kernel, const dim3& grid, const dim3& block, uint32_t shmem,
+                                  hipStream_t stream, Args... args) {
+  hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, start, stop, 0, args...);
+}
 #define DA_LAUNCH(...)                                      \
   do {                                                      \
     (void)hipGetLastError();                                \
-    hipLaunchKernelGGL(__VA_ARGS__);                        \
+    hipEvent_t es__ = nullptr, ee__ = nullptr;              \
+    if (__builtin_expect(da_take_launch_events(&es__, &ee__), 0)) \
+      da_launch_with_events(es__, ee__, __VA_ARGS__);       \
+    else                                                    \
+      hipLaunchKernelGGL(__VA_ARGS__);                      \
   } while (0)
 
 extern "C" void da_set_last_error(int hip_error);  // version.hip: remembered for da_last_error()

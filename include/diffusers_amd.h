@@ -87,6 +87,13 @@ extern "C" {
 #define DA_STAGE_PINGPONG3 7   /* K2 tiles: 3-pair ring, ditto */
 
 int da_version(void);
+/* Timing hook (no reference counterpart; bench.py's roofline legs): arm two HIP events (hipEvent_t, created by the caller with
+ * timing enabled) for the calling thread.  The NEXT kernel this library launches on that thread records `start_event` at the begin
+ * of its dispatch, and every launch until the pair is cleared with (NULL, NULL) records `stop_event` at the end of its dispatch
+ * (hipExtLaunchKernelGGL): after a synchronisation their elapsed time is the execution time of the entry point's kernel(s) as the
+ * profiler reports it -- an event pair recorded around the call from the host also counts the marker packets' own processing.
+ * Both or neither must be NULL.  Launch results do not depend on it. */
+int da_set_launch_events(void* start_event, void* stop_event);
 /* name of the HIP runtime error behind this thread's most recent DA_ERR_LAUNCH (diagnostics only) */
 const char* da_last_error(void);
 
