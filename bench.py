@@ -12,7 +12,10 @@ launcher re-executes itself under ``torch.distributed.run`` with N ranks (the re
 same way, docs/source/en/training/distributed_inference.md:62-108).  Rank 0 prints ONE JSON line.
 
 Besides the contract keys the line carries, all measured OUTSIDE the timed region on rank 0 at N = 1:
-  roofline            dominant kernel (igemm_bf16_kernel), HIP events around every launch of one eager denoising step
+  roofline            dominant kernel family (igemm_bf16_kernel + igemm2_bf16_kernel) over the launches of one eager denoising step,
+                      timed with HIP events ATTACHED to every launch (da_set_launch_events: the dispatch's own begin / end, the
+                      duration rocprofv3 reports; `timing` says which method ran, `host_event_pairs` carries the host-recorded
+                      pairs of the same launches -- the method of rounds 1-3 -- as a cross-check); `kernels`: one entry per family
   parity              PSNR of the engine's 50-step image against the REFERENCE PACKAGE itself (StableDiffusionXLPipeline over
                       the reference's own classes, from the oracle/_ref archive) run by PyTorch-ROCm in fp32 on this GPU on
                       the same weights / latents / embeddings, with the bf16 run of the same pipeline as noise floor
