@@ -230,32 +230,135 @@ class Plan:
         for v, b in zip(views, before):
             v.copy_(b)
         torch.cuda.synchronize()
-        lib = self._lib
-        with open(path, "wb") as f:
-            f.write(MAGIC)
-            f.write(struct.pack("<III", len(regs), len(self.names), len(outs)))
-            for (b, n), data in zip(regs, before):
-                f.write(struct.pack("<QQ", b, n))
-                f.write(data.numpy().tobytes())
-            host = iter(self._host)
-            for op in self.ops[:len(self.names)]:
-                kinds = lib.da_plan_arg_kinds(op.fn).decode()
-                f.write(struct.pack("<ii", op.fn, len(kinds)))
-                f.write(struct.pack(f"<{L.PLAN_MAX_ARGS}Q", *op.arg))
-                parts = 0
-                for i, k in enumerate(kinds):           # host blobs follow the op in argument order: u32 bytes + data
-                    if k == "n":
-                        parts = op.arg[i]
-                    if k in "GAIQ":
-                        obj = next(host)
-                        blob = bytes(obj) if k in "GA" else bytes(obj)[: parts * (4 if k == "I" else 8)]
-                        f.write(struct.pack("<I", len(blob)))
-                        f.write(blob)
-            for ptr, n, data in outs:
-                f.write(struct.pack("<QQ", ptr, n))
-                f.write(data.numpy().tobytes())
+        host_blobs = []
+        host = iter(self._host)
+        for op in self.ops[:len(self.names)]:
+            kinds = self._lib.da_plan_arg_kinds(op.fn).decode()
+            parts, blobs = 0, []
+            for i, k in enumerate(kinds):
+                if k == "n":
+                    parts = op.arg[i]
+                if k in "GAIQ":
+                    obj = next(host)
+                    blobs.append(bytes(obj) if k in "GA" else bytes(obj)[: parts * (4 if k == "I" else 8)])
+            host_blobs.append(blobs)
+        write_file(path, [(b, n, data.numpy().tobytes()) for (b, n), data in zip(regs, before)],
+                   [(op.fn, list(op.arg), blobs) for op, blobs in zip(self.ops[:len(self.names)], host_blobs)],
+                   [(ptr, data.numpy().tobytes()) for ptr, n, data in outs])
         return {"regions": len(regs), "region_bytes": sum(n for _, n in regs), "ops": len(self.names), "outputs": len(outs),
                 "file_bytes": Path(path).stat().st_size}
+
+
+def write_file(path, regions, ops, outputs) -> None:
+    """The plan file ``examples/abi_demo.cpp`` reads.  Little endian:
+    ``"DAPLAN01"``, u32 regions, u32 ops, u32 outputs;
+    per region: u64 base address in the recording process, u64 bytes, the bytes;
+    per op: i32 DA_FN_*, i32 argument count, 16 x u64 argument slots, then -- in argument order -- one (u32 bytes, bytes) blob per
+    argument the slot passes by HOST address (the da_gemm_params / da_attention_params struct, the host arrays of
+    da_rmsnorm_rope_bf16; the slot's recorded address is meaningless to the reader);
+    per output: u64 device address (inside a region), u64 bytes, the expected bytes."""
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<III", len(regions), len(ops), len(outputs)))
+        for base, n, data in regions:
+            if len(data) != n:
+                raise ValueError("region size and contents disagree")
+            f.write(struct.pack("<QQ", base, n))
+            f.write(data)
+        lib = L._lib if L._lib is not None else L.load()
+        for fn, args, blobs in ops:
+            kinds = lib.da_plan_arg_kinds(fn)
+            if kinds is None or len(args) != L.PLAN_MAX_ARGS or len(blobs) != sum(k in "GAIQ" for k in kinds.decode()):
+                raise ValueError(f"op {fn}: not an entry point of this library, or its host blobs do not match its argument kinds")
+            f.write(struct.pack("<ii", fn, len(kinds)))
+            f.write(struct.pack(f"<{L.PLAN_MAX_ARGS}Q", *args))
+            for blob in blobs:
+                f.write(struct.pack("<I", len(blob)))
+                f.write(blob)
+        for ptr, data in outputs:
+            f.write(struct.pack("<QQ", ptr, len(data)))
+            f.write(data)
+
+
+def read_file(path) -> dict:
+    """Inverse of :func:`write_file`: ``{"regions": [(base, bytes, data)], "ops": [(fn, [16 slots], [blobs])], "outputs": [(ptr,
+    data)]}``.  Raises ``ValueError`` on anything that is not a well-formed plan file of THIS ABI (struct sizes are checked the way
+    abi_demo.cpp checks them)."""
+    lib = L._lib if L._lib is not None else L.load()
+    raw = Path(path).read_bytes()
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        if pos + n > len(raw):
+            raise ValueError("truncated plan file")
+        out = raw[pos:pos + n]
+        pos += n
+        return out
+    if take(8) != MAGIC:
+        raise ValueError("not a plan file")
+    n_reg, n_ops, n_out = struct.unpack("<III", take(12))
+    regions, ops, outputs = [], [], []
+    for _ in range(n_reg):
+        base, n = struct.unpack("<QQ", take(16))
+        regions.append((base, n, take(n)))
+    want = {"G": C.sizeof(L.GemmParams), "A": C.sizeof(L.AttentionParams)}
+    for o in range(n_ops):
+        fn, nargs = struct.unpack("<ii", take(8))
+        kinds = lib.da_plan_arg_kinds(fn)
+        if kinds is None or len(kinds) != nargs:
+            raise ValueError(f"op {o}: entry point {fn} is not one this library replays")
+        args = list(struct.unpack(f"<{L.PLAN_MAX_ARGS}Q", take(8 * L.PLAN_MAX_ARGS)))
+        blobs = []
+        for k in kinds.decode():
+            if k in "GAIQ":
+                (n,) = struct.unpack("<I", take(4))
+                if k in want and n != want[k]:
+                    raise ValueError(f"op {o}: a {n}-byte parameter struct where this ABI has {want[k]}")
+                blobs.append(take(n))
+        ops.append((fn, args, blobs))
+    for _ in range(n_out):
+        ptr, n = struct.unpack("<QQ", take(16))
+        outputs.append((ptr, take(n)))
+    if pos != len(raw):
+        raise ValueError("trailing bytes after the last output")
+    return {"regions": regions, "ops": ops, "outputs": outputs}
+
+
+def create_from_file(path, new_bases=None):
+    """``(da_plan handle, file contents)`` of a plan file: what abi_demo.cpp does, from Python -- the ops rebuilt with their host
+    blobs, `da_plan_create`, and (``new_bases``: one device address per region, e.g. ``tensor.data_ptr()`` of buffers holding the
+    regions' contents) `da_plan_relocate` onto the caller's memory.  The caller launches with ``da_plan_launch`` and destroys the
+    handle with ``da_plan_destroy``."""
+    lib = L._lib if L._lib is not None else L.load()
+    doc = read_file(path)
+    keep, arr = [], (L.PlanOp * max(1, len(doc["ops"])))()
+    for i, (fn, args, blobs) in enumerate(doc["ops"]):
+        arr[i].fn = fn
+        it = iter(blobs)
+        for j, k in enumerate(lib.da_plan_arg_kinds(fn).decode()):
+            if k in "GAIQ":
+                buf = C.create_string_buffer(next(it))
+                keep.append(buf)
+                arr[i].arg[j] = C.addressof(buf)
+            else:
+                arr[i].arg[j] = args[j]
+    h = C.c_void_p()
+    L.check(lib.da_plan_create(arr, len(doc["ops"]), C.byref(h)), "da_plan_create")
+    if new_bases is not None:
+        n = len(doc["regions"])
+        if len(new_bases) != n:
+            lib.da_plan_destroy(h)
+            raise ValueError(f"{n} regions in the file, {len(new_bases)} new base addresses")
+        old = (C.c_void_p * n)(*[r[0] for r in doc["regions"]])
+        size = (C.c_ulonglong * n)(*[r[1] for r in doc["regions"]])
+        new = (C.c_void_p * n)(*new_bases)
+        miss = C.c_int(0)
+        L.check(lib.da_plan_relocate(h, n, old, size, new, C.byref(miss)), "da_plan_relocate")
+        if miss.value:
+            lib.da_plan_destroy(h)
+            raise ValueError(f"{miss.value} device addresses of the plan lie in no region of the file")
+    return h, doc
 
 
 class _RawDevice:

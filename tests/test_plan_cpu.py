@@ -150,3 +150,61 @@ def test_recording_is_per_thread_and_exclusive():
             with P.recording(private_pool=False):
                 pass
     assert L.load() is L._lib and rec.ops == []
+
+
+def test_plan_file_round_trip_and_python_side_loader(tmp_path):
+    """The plan file format (plan.write_file / read_file, the one examples/abi_demo.cpp parses): a synthetic two-region, three-op
+    file survives a round trip byte for byte, a loader rebuilds the da_plan from it and relocates it onto new base addresses, and
+    malformed files are refused with a reason (wrong magic, truncation, a parameter struct of another ABI, an address outside the
+    file's regions)."""
+    lib = L.load()
+    g = L.GemmParams()
+    g.A, g.W, g.C, g.M, g.N, g.K = 0x10000, 0x20000, 0x10800, 64, 64, 64
+    a = L.AttentionParams()
+    a.q, a.k, a.vt, a.out = 0x10100, 0x10200, 0x10300, 0x10400
+    col = (C.c_int * 2)(0, 64)
+    wts = (C.c_void_p * 2)(0x20040, None)
+    rope = [0x10020, 128, 16, 16, 2, 64, 2, 0xAAAA, 0xBBBB, 0, 0x20080, 0x200c0, 0, 1] + [0, 0]
+    regions = [(0x10000, 0x1000, bytes(range(256)) * 16), (0x20000, 0x100, b"\x07" * 0x100)]
+    ops = [(L.FN_IDS["da_gemm_bf16"], [0x1234] + [0] * 15, [bytes(g)]),
+           (L.FN_IDS["da_attention_bf16"], [0x5678] + [0] * 15, [bytes(a)]),
+           (L.FN_IDS["da_rmsnorm_rope_bf16"], rope, [bytes(col), bytes(wts)])]
+    outs = [(0x10800, b"\x01\x02\x03\x04")]
+    path = tmp_path / "p.daplan"
+    P.write_file(path, regions, ops, outs)
+    doc = P.read_file(path)
+    assert doc["regions"] == regions and doc["outputs"] == outs
+    assert [(fn, blobs) for fn, _, blobs in doc["ops"]] == [(fn, blobs) for fn, _, blobs in ops]
+    assert doc["ops"][2][1] == rope
+    h, _ = P.create_from_file(path, new_bases=[0x70000, 0x80000])
+    assert lib.da_plan_op_count(h) == 3
+    # every address moved with its region: nothing is left inside the old ranges, everything is inside the new ones
+    n = 2
+    miss = C.c_int(-1)
+    old = (C.c_void_p * n)(0x10000, 0x20000)
+    size = (C.c_ulonglong * n)(0x1000, 0x100)
+    new = (C.c_void_p * n)(0x10000, 0x20000)
+    assert lib.da_plan_relocate(h, n, old, size, new, C.byref(miss)) == L.DA_OK and miss.value == 3 + 4 + 4   # gemm 3, attention 4, rope 4
+    old = (C.c_void_p * n)(0x70000, 0x80000)
+    assert lib.da_plan_relocate(h, n, old, size, new, C.byref(miss)) == L.DA_OK and miss.value == 0
+    lib.da_plan_destroy(h)
+    with pytest.raises(ValueError, match="lie in no region"):
+        P.write_file(path, regions[:1], ops, outs)
+        P.create_from_file(path, new_bases=[0x70000])
+    P.write_file(path, regions, ops, outs)
+    raw = path.read_bytes()
+    bad = tmp_path / "bad.daplan"
+    bad.write_bytes(b"NOTAPLAN" + raw[8:])
+    with pytest.raises(ValueError, match="not a plan file"):
+        P.read_file(bad)
+    bad.write_bytes(raw[:-2])
+    with pytest.raises(ValueError, match="truncated"):
+        P.read_file(bad)
+    bad.write_bytes(raw + b"\x00")
+    with pytest.raises(ValueError, match="trailing"):
+        P.read_file(bad)
+    with pytest.raises(ValueError, match="host blobs"):
+        P.write_file(bad, regions, [(L.FN_IDS["da_gemm_bf16"], [0] * 16, [])], outs)
+    P.write_file(bad, regions, [(L.FN_IDS["da_gemm_bf16"], [0] * 16, [bytes(g)[:-8]])], outs)
+    with pytest.raises(ValueError, match="parameter struct"):
+        P.read_file(bad)

@@ -69,6 +69,20 @@ def test_plan_file_runs_in_a_process_without_python(tmp_path):
     print(f"[plan] {info}\n{r.stdout}")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("0 differ") == 2
+    # the same file through the Python-side loader: fresh buffers holding the regions' contents, da_plan_relocate onto them, launch
+    import ctypes as C
+    from diffusers_amd import _lib as L
+    doc = P.read_file(path)
+    bufs = [torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda() for _, _, data in doc["regions"]]
+    h, _ = P.create_from_file(path, new_bases=[b.data_ptr() for b in bufs])
+    failed = C.c_int(-1)
+    L.check(L.load().da_plan_launch(h, torch.cuda.current_stream().cuda_stream, C.byref(failed)), "da_plan_launch")
+    torch.cuda.synchronize()
+    L.load().da_plan_destroy(h)
+    for ptr, want in doc["outputs"]:
+        r = next(i for i, (b, n, _) in enumerate(doc["regions"]) if b <= ptr < b + n)
+        off = ptr - doc["regions"][r][0]
+        assert bytes(bufs[r][off:off + len(want)].cpu().numpy().tobytes()) == want
     # and the built-in checks of the program (direct calls + a plan built in C++)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "identical bytes" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
