@@ -120,7 +120,8 @@ def test_fuse_lora_repacks_in_place(tmp_path, fmt):
                "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_v",
                "down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_q",     # also feeds the folded LayerNorm vectors
                "down_blocks.1.attentions.0.transformer_blocks.0.ff.net.0.proj",
-               "mid_block.attentions.0.proj_in", "down_blocks.0.resnets.0.conv1"]
+               "mid_block.attentions.0.proj_in", "down_blocks.0.resnets.0.conv1",
+               "up_blocks.0.resnets.1.time_emb_proj"]       # one block's rows of the model's stacked time projections
     lora, dense = _lora_for(sd, targets, fmt=fmt)
     model.fuse_lora(lora, lora_scale=0.7)
     fused_sd = dict(sd)
