@@ -97,12 +97,52 @@ def _pf(pipe) -> "ops.WeightPrefetch":
     return pf
 
 
+class _StepCallbacks:
+    """``callback_on_step_end`` of the reference pipelines (pipeline_stable_diffusion_xl.py:857-858, :1239-1247; pipeline_stable_diffusion.py:1064-1071,
+    pipeline_flux.py:938-945, pipeline_wan.py:637-644): after every denoising step -- a replayed graph, a replayed plan or an eager step alike -- the
+    callable gets ``(pipe, step_index, timestep, {"latents": latents})``; a ``"latents"`` entry in the dict it returns replaces the
+    loop's latents (copied into the buffer the captured step reads), and setting ``pipe._interrupt = True`` ends the loop after
+    the current step (``interrupt`` property, :817-819 / :1198).  ``latents`` is the only tensor the engine's loop can hand out or
+    take back: the text conditioning is packed once before the loop (K / V^T projections hoisted out of it), so the reference's
+    other names (``prompt_embeds``, ``add_text_embeds``, ...) are refused by name."""
+    _callback_tensor_inputs = ["latents"]
+    _interrupt = False
+    _step_callback = None
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    def _arm_callback(self, callback_on_step_end, callback_on_step_end_tensor_inputs):
+        self._interrupt = False
+        names = callback_on_step_end_tensor_inputs
+        if hasattr(callback_on_step_end, "tensor_inputs"):            # PipelineCallback / MultiPipelineCallbacks objects (:1041-1042)
+            names = callback_on_step_end.tensor_inputs
+        names = ["latents"] if names is None else list(names)
+        bad = [k for k in names if k not in self._callback_tensor_inputs]
+        if bad:
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found {bad}")
+        self._step_callback = (callback_on_step_end, names) if callback_on_step_end is not None else None
+
+    def _after_step(self, i: int, latents: torch.Tensor) -> bool:
+        """Runs the armed callback after step ``i``; False = the loop stops here."""
+        if self._step_callback is None:
+            return True
+        fn, names = self._step_callback
+        out = fn(self, i, self.scheduler.timesteps[i], {k: latents for k in names})
+        if out is not None:
+            new = out.pop("latents", latents)
+            if new is not latents:
+                latents.copy_(new.to(device=latents.device, dtype=latents.dtype))
+        return not self._interrupt
+
+
 @dataclass
 class PipelineOutput:
     images: torch.Tensor
 
 
-class _LatentDiffusionBase:
+class _LatentDiffusionBase(_StepCallbacks):
     def __init__(self, vae: AutoencoderKL, unet: UNet2DConditionModel, scheduler):
         self.vae, self.unet, self.scheduler = vae, unet, scheduler
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
@@ -162,6 +202,8 @@ class _LatentDiffusionBase:
             for i in range(num_steps):
                 with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
                     self._step(latents, cond, guidance_scale, do_cfg)
+                if not self._after_step(i, latents):
+                    break
             return latents
         key = self._make_graph_key(latents, cond, guidance_scale, do_cfg) + (use_graph == "plan",)
         if self._graph is None or self._graph_key != key:
@@ -191,9 +233,13 @@ class _LatentDiffusionBase:
                     a.vt.copy_(b.vt)
             if old["aug_emb"] is not None:
                 old["aug_emb"].copy_(cond["aug_emb"])
-        for _ in range(num_steps):
+        done = 0
+        for i in range(num_steps):
             self._graph.replay()
-        sch._step_index = num_steps
+            done = i + 1
+            if not self._after_step(i, latents):
+                break
+        sch._step_index = done
         return latents
 
     def _decode(self, latents, output_type):
@@ -251,9 +297,11 @@ class StableDiffusionXLPipeline(_LatentDiffusionBase):
                  original_size: Optional[Tuple[int, int]] = None, crops_coords_top_left: Tuple[int, int] = (0, 0),
                  target_size: Optional[Tuple[int, int]] = None, generator=None, use_graph: bool = True,
                  prompt_2=None, negative_prompt=None, negative_prompt_2=None, num_images_per_prompt: int = 1,
-                 clip_skip=None, guidance_rescale: float = 0.0):
+                 clip_skip=None, guidance_rescale: float = 0.0, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs=None):
         do_cfg = guidance_scale > 1.0
         self._guidance_rescale = float(guidance_rescale)    # pipeline_stable_diffusion_xl.py:849, :1227-1229
+        self._arm_callback(callback_on_step_end, callback_on_step_end_tensor_inputs)
         if prompt is not None:
             if prompt_embeds is not None:
                 raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one "
@@ -321,8 +369,10 @@ class StableDiffusionPipeline(_LatentDiffusionBase):
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, eta: float = 0.0,
                  latents: Optional[torch.Tensor] = None, prompt_embeds=None, negative_prompt_embeds=None,
                  output_type: str = "pt", return_dict: bool = True, generator=None, use_graph: bool = True,
-                 negative_prompt=None, num_images_per_prompt: int = 1, clip_skip=None, guidance_rescale: float = 0.0):
+                 negative_prompt=None, num_images_per_prompt: int = 1, clip_skip=None, guidance_rescale: float = 0.0,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=None):
         self._guidance_rescale = float(guidance_rescale)    # pipeline_stable_diffusion.py:1057-1059
+        self._arm_callback(callback_on_step_end, callback_on_step_end_tensor_inputs)
         if eta < 0.0 or eta > 1.0:
             raise ValueError("eta (DDIM) must be in [0, 1]")
         do_cfg = guidance_scale > 1.0
@@ -382,7 +432,7 @@ def calculate_shift(image_seq_len, base_seq_len: int = 256, max_seq_len: int = 4
     return image_seq_len * m + b
 
 
-class FluxPipeline:
+class FluxPipeline(_StepCallbacks):
     """pipelines/flux/pipeline_flux.py:654-980 for pre-computed prompt embeddings (FLUX.1-schnell protocol: no true-CFG,
     no guidance embedding).  The step body -- transformer forward + FlowMatch-Euler update -- is captured once in a HIP
     graph and replayed; latents stay in the packed (B, (h/2)(w/2), 64) layout of the reference throughout the loop."""
@@ -442,6 +492,8 @@ class FluxPipeline:
             for i in range(num_steps):
                 with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
                     self._step(latents, pe, cond)
+                if not self._after_step(i, latents):
+                    break
             return latents
         key = (tuple(latents.shape), tuple(pe.shape), sch.device_table.data_ptr(), sch.device_step.data_ptr(), use_graph == "plan")
         if self._graph is None or self._graph_key != key:
@@ -468,9 +520,13 @@ class FluxPipeline:
                 st["cond"]["cos"].copy_(cond["cos"])
                 st["cond"]["sin"].copy_(cond["sin"])
             latents = st["latents"]
-        for _ in range(num_steps):
+        done = 0
+        for i in range(num_steps):
             self._graph.replay()
-        sch._step_index = num_steps
+            done = i + 1
+            if not self._after_step(i, latents):
+                break
+        sch._step_index = done
         return latents
 
     @torch.no_grad()
@@ -479,7 +535,9 @@ class FluxPipeline:
                  guidance_scale: float = 3.5, num_images_per_prompt: int = 1, generator=None,
                  latents: Optional[torch.Tensor] = None, prompt_embeds=None, pooled_prompt_embeds=None,
                  negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, output_type: str = "pt",
-                 return_dict: bool = True, max_sequence_length: int = 512, use_graph: bool = True):
+                 return_dict: bool = True, max_sequence_length: int = 512, use_graph: bool = True,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=None):
+        self._arm_callback(callback_on_step_end, callback_on_step_end_tensor_inputs)      # pipeline_flux.py:626-627, :938-945
         if prompt is not None:
             if prompt_embeds is not None:
                 raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one "
@@ -539,7 +597,7 @@ class FluxPipeline:
         return PipelineOutput(images=images)
 
 
-class WanPipeline:
+class WanPipeline(_StepCallbacks):
     """pipelines/wan/pipeline_wan.py:380-700 (Wan 2.1 T2V) for pre-computed prompt embeddings: the denoising loop.
     The reference runs the transformer twice per step (cond / uncond, :613-632); here the two are one batch-2 call
     (identical arithmetic per sample, twice the GEMM M) and ``uncond + g (cond - uncond)`` is fused into the FlowMatch
@@ -588,6 +646,8 @@ class WanPipeline:
             for i in range(num_steps):
                 with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
                     self._step(latents, cond, guidance_scale, do_cfg)
+                if not self._after_step(i, latents):
+                    break
             return latents
         key = (tuple(latents.shape), float(guidance_scale), do_cfg, cond["St"], sch.device_table.data_ptr(), use_graph == "plan")
         if self._graph is None or self._graph_key != key:
@@ -612,9 +672,13 @@ class WanPipeline:
                 k0.copy_(k1)
                 v0.copy_(v1)
             latents = st["latents"]
-        for _ in range(num_steps):
+        done = 0
+        for i in range(num_steps):
             self._graph.replay()
-        sch._step_index = num_steps
+            done = i + 1
+            if not self._after_step(i, latents):
+                break
+        sch._step_index = done
         return latents
 
     @torch.no_grad()
@@ -622,7 +686,9 @@ class WanPipeline:
                  num_inference_steps: int = 50, guidance_scale: float = 5.0, num_videos_per_prompt: int = 1,
                  generator=None, latents: Optional[torch.Tensor] = None, prompt_embeds=None,
                  negative_prompt_embeds=None, output_type: str = "latent", return_dict: bool = True,
-                 use_graph: bool = True, max_sequence_length: int = 512):
+                 use_graph: bool = True, max_sequence_length: int = 512, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs=None):
+        self._arm_callback(callback_on_step_end, callback_on_step_end_tensor_inputs)      # pipeline_wan.py:401-402, :637-644
         if prompt is not None:
             if prompt_embeds is not None:
                 raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one "

@@ -572,3 +572,47 @@ def test_weight_prefetch_record_apply_state_machine():
     del pipe
     gc.collect()
     assert ref() is None and pf2.models == ()
+
+
+def test_callback_on_step_end_and_interrupt(golden):
+    """`callback_on_step_end` of the reference pipelines (pipeline_stable_diffusion_xl.py:1239-1247): called after every step with
+    (pipe, i, t, {"latents": ...}); a returned "latents" replaces the loop's; `pipe._interrupt = True` stops the loop (:1198); names
+    other than "latents" are refused like an unknown name is in the reference (:636-641)."""
+    from diffusers_amd import factory
+    g = golden("tiny_sdxl_pipeline")
+    pipe = factory.build_sdxl_pipeline(device="cpu", tiny=True, seed=0)
+    kw = dict(prompt_embeds=_t(g, "prompt_embeds"), negative_prompt_embeds=_t(g, "negative_prompt_embeds"),
+              pooled_prompt_embeds=_t(g, "pooled"), negative_pooled_prompt_embeds=_t(g, "negative_pooled"),
+              num_inference_steps=4, guidance_scale=5.0, height=128, width=128, use_graph=False, output_type="latent")
+    base = pipe(latents=_t(g, "latents").clone(), **kw).images.clone()
+    seen = []
+
+    def watch(p, i, t, kwargs):
+        assert p is pipe and set(kwargs) == {"latents"}
+        seen.append((i, float(t), kwargs["latents"].clone()))
+        return {}
+    out = pipe(latents=_t(g, "latents").clone(), callback_on_step_end=watch, **kw).images
+    assert [s[0] for s in seen] == [0, 1, 2, 3] and [s[1] for s in seen] == [float(t) for t in pipe.scheduler.timesteps]
+    assert torch.equal(out, base) and torch.equal(seen[-1][2], base) and not torch.equal(seen[0][2], seen[1][2])
+    # a callback that hands back other latents: the next step starts from them
+    out2 = pipe(latents=_t(g, "latents").clone(), callback_on_step_end=lambda p, i, t, kw_: {"latents": kw_["latents"] * 0.5} if i == 1 else kw_,
+                **kw).images
+    assert not torch.equal(out2, base) and torch.isfinite(out2.float()).all()
+    # interrupt after the second step: the loop stops, the scheduler says how far it got, the next call starts clean
+    def stop(p, i, t, kwargs):
+        if i == 1:
+            p._interrupt = True
+        return kwargs
+    part = pipe(latents=_t(g, "latents").clone(), callback_on_step_end=stop, **kw).images
+    assert pipe.interrupt and pipe.scheduler.step_index == 2 and torch.equal(part, seen[1][2])
+    again = pipe(latents=_t(g, "latents").clone(), **kw).images
+    assert not pipe.interrupt and torch.equal(again, base)
+    with pytest.raises(ValueError, match="callback_on_step_end_tensor_inputs"):
+        pipe(latents=_t(g, "latents").clone(), callback_on_step_end=watch, callback_on_step_end_tensor_inputs=["prompt_embeds"], **kw)
+
+    class Obj:                                   # a PipelineCallback-style object carries its own tensor_inputs (callbacks.py)
+        tensor_inputs = ["latents"]
+
+        def __call__(self, p, i, t, kwargs):
+            return kwargs
+    assert torch.equal(pipe(latents=_t(g, "latents").clone(), callback_on_step_end=Obj(), **kw).images, base)

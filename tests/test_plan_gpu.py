@@ -153,3 +153,34 @@ def test_every_pipeline_replays_its_step_as_a_plan(name):
     again = run("plan")                                       # second call: the recorded plan is reused on refreshed static inputs
     assert torch.equal(graph, eager) and torch.equal(planned, graph) and torch.equal(again, graph)
     print(f"[plan] {name}: {len(pipe._graph)} launches per step by da_plan_launch, image bit-identical to the HIP graph and to the eager loop")
+
+
+@pytest.mark.parametrize("mode", [True, "plan"])
+def test_step_callbacks_between_graph_and_plan_replays(mode):
+    """callback_on_step_end (pipeline_stable_diffusion_xl.py:1239-1247) between the replays of the captured step: the latents a
+    callback sees after each step, a replacement it hands back and an interrupt behave as in the eager loop, bit for bit."""
+    make, kw = next((m, k) for n, m, k in _pipelines() if n == "sdxl")
+    pipe = make()
+    kw = dict(kw, output_type="latent")
+
+    def run(use_graph, cb):
+        k = {a: (b.clone() if torch.is_tensor(b) else b) for a, b in kw.items()}
+        return pipe(use_graph=use_graph, callback_on_step_end=cb, **k).images.clone()
+
+    def script(log):
+        def cb(p, i, t, kwargs):
+            log.append((i, float(t), kwargs["latents"].clone()))
+            if i == 1:
+                return {"latents": kwargs["latents"] * 0.5}
+            if i == 2:
+                p._interrupt = True
+            return kwargs
+        return cb
+    want_log, got_log = [], []
+    want = run(False, script(want_log))
+    got = run(mode, script(got_log))
+    assert len(want_log) == len(got_log) == 3 and pipe.scheduler.step_index == 3
+    for a, b in zip(want_log, got_log):
+        assert a[:2] == b[:2] and torch.equal(a[2], b[2])
+    assert torch.equal(want, got)
+    assert torch.equal(run(mode, None), run(False, None))        # and an un-hooked call afterwards runs all four steps again
