@@ -196,14 +196,17 @@ def _resolve_dir(name_or_path, subfolder: Optional[str]) -> Path:
     return p
 
 
-def _weight_files(d: Path, variant: Optional[str]) -> List[Path]:
-    stem = WEIGHTS_NAME + (f".{variant}" if variant else "")
+def _weight_files(d: Path, variant: Optional[str], stem: str = WEIGHTS_NAME) -> List[Path]:
+    """The safetensors file(s) of a component directory (``stem`` = "diffusion_pytorch_model" for diffusers models, "model" for
+    transformers ones)."""
+    base = stem
+    stem = base + (f".{variant}" if variant else "")
     single = d / f"{stem}.safetensors"
     if single.exists():
         return [single]
     index = d / f"{stem}.safetensors.index.json"
     if not index.exists():       # the reference writes the variant before ".index.json" for sharded checkpoints
-        index = d / f"{WEIGHTS_NAME}.safetensors.index{'.' + variant if variant else ''}.json"
+        index = d / f"{base}.safetensors.index{'.' + variant if variant else ''}.json"
     if index.exists():
         files = sorted(set(json.loads(index.read_text())["weight_map"].values()))
         return [d / f for f in files]

@@ -20,6 +20,7 @@ import torch
 
 from . import ops
 from .autoencoder_kl import AutoencoderKL
+from .pipeline_loading import PipelineLoadingMixin
 from .schedulers import (DDIMScheduler, DDPMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler,
                          UniPCMultistepScheduler)
 from .transformer_flux import FluxTransformer2DModel
@@ -142,7 +143,7 @@ class PipelineOutput:
     images: torch.Tensor
 
 
-class _LatentDiffusionBase(_StepCallbacks):
+class _LatentDiffusionBase(_StepCallbacks, PipelineLoadingMixin):
     def __init__(self, vae: AutoencoderKL, unet: UNet2DConditionModel, scheduler):
         self.vae, self.unet, self.scheduler = vae, unet, scheduler
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
@@ -432,7 +433,7 @@ def calculate_shift(image_seq_len, base_seq_len: int = 256, max_seq_len: int = 4
     return image_seq_len * m + b
 
 
-class FluxPipeline(_StepCallbacks):
+class FluxPipeline(_StepCallbacks, PipelineLoadingMixin):
     """pipelines/flux/pipeline_flux.py:654-980 for pre-computed prompt embeddings (FLUX.1-schnell protocol: no true-CFG,
     no guidance embedding).  The step body -- transformer forward + FlowMatch-Euler update -- is captured once in a HIP
     graph and replayed; latents stay in the packed (B, (h/2)(w/2), 64) layout of the reference throughout the loop."""
@@ -597,7 +598,7 @@ class FluxPipeline(_StepCallbacks):
         return PipelineOutput(images=images)
 
 
-class WanPipeline(_StepCallbacks):
+class WanPipeline(_StepCallbacks, PipelineLoadingMixin):
     """pipelines/wan/pipeline_wan.py:380-700 (Wan 2.1 T2V) for pre-computed prompt embeddings: the denoising loop.
     The reference runs the transformer twice per step (cond / uncond, :613-632); here the two are one batch-2 call
     (identical arithmetic per sample, twice the GEMM M) and ``uncond + g (cond - uncond)`` is fused into the FlowMatch
@@ -743,7 +744,7 @@ class WanPipeline(_StepCallbacks):
         return PipelineOutput(images=latents)
 
 
-class DDPMPipeline:
+class DDPMPipeline(PipelineLoadingMixin):
     """pipelines/ddpm/pipeline_ddpm.py:40-130: unconditional ancestral sampling.  The initial image and the per-step
     variance noise are drawn on the host from ``generator`` in fp32 in the reference's order (initial image first, then
     one draw per step with t > 0) and rounded to bf16, so a seeded run consumes the same random stream as the
