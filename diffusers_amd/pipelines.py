@@ -194,7 +194,7 @@ class _LatentDiffusionBase(_StepCallbacks, PipelineLoadingMixin):
         return (tuple(latents.shape), float(guidance_scale), bool(do_cfg), cond["kvs"][0][0].skv if cond["kvs"] else 0,
                 sch.device_table.data_ptr(), sch.device_step.data_ptr(),
                 self._noise_table.data_ptr() if self._noise_table is not None else 0, float(self._eta),
-                float(self._guidance_rescale))
+                float(self._guidance_rescale), id(self.unet))       # (a captured step points into THIS model's packed weights)
 
     def _denoise(self, latents, cond, num_steps, guidance_scale, do_cfg, use_graph):
         sch = self.scheduler
@@ -496,7 +496,8 @@ class FluxPipeline(_StepCallbacks, PipelineLoadingMixin):
                 if not self._after_step(i, latents):
                     break
             return latents
-        key = (tuple(latents.shape), tuple(pe.shape), sch.device_table.data_ptr(), sch.device_step.data_ptr(), use_graph == "plan")
+        key = (tuple(latents.shape), tuple(pe.shape), sch.device_table.data_ptr(), sch.device_step.data_ptr(), use_graph == "plan",
+               id(self.transformer))                        # (a captured step points into THIS model's packed weights)
         if self._graph is None or self._graph_key != key:
             saved = latents.clone()
             s = torch.cuda.Stream()
@@ -650,7 +651,8 @@ class WanPipeline(_StepCallbacks, PipelineLoadingMixin):
                 if not self._after_step(i, latents):
                     break
             return latents
-        key = (tuple(latents.shape), float(guidance_scale), do_cfg, cond["St"], sch.device_table.data_ptr(), use_graph == "plan")
+        key = (tuple(latents.shape), float(guidance_scale), do_cfg, cond["St"], sch.device_table.data_ptr(), use_graph == "plan",
+               id(self.transformer))
         if self._graph is None or self._graph_key != key:
             saved = latents.clone()
             s = torch.cuda.Stream()
@@ -788,7 +790,7 @@ class DDPMPipeline(PipelineLoadingMixin):
                 with ops.weight_prefetch(_pf(self), "apply" if i else "record"):
                     self._step(image, noise_table)
         else:
-            key = (tuple(shape), len(ts), sch.device_table.data_ptr(), use_graph == "plan")
+            key = (tuple(shape), len(ts), sch.device_table.data_ptr(), use_graph == "plan", id(self.unet))
             if getattr(self, "_graph_key", None) != key:
                 saved = image.clone()
                 s = torch.cuda.Stream()

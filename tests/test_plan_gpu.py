@@ -184,3 +184,23 @@ def test_step_callbacks_between_graph_and_plan_replays(mode):
         assert a[:2] == b[:2] and torch.equal(a[2], b[2])
     assert torch.equal(want, got)
     assert torch.equal(run(mode, None), run(False, None))        # and an un-hooked call afterwards runs all four steps again
+
+
+def test_swapping_the_model_recaptures_the_step():
+    """A captured step (graph or plan) points into one model's packed weights: after `pipe.unet = other` the next call must capture
+    again, not replay the old model (the capture key carries the model's identity)."""
+    from diffusers_amd import factory
+    make, kw = next((m, k) for n, m, k in _pipelines() if n == "sdxl")
+    pipe = make()
+    other = factory.build_sdxl_pipeline(device="cuda", tiny=True, seed=7).unet
+
+    def run(mode):
+        k = {a: (b.clone() if torch.is_tensor(b) else b) for a, b in kw.items()}
+        return pipe(use_graph=mode, **k).images.clone()
+    for mode in (True, "plan"):
+        first = run(mode)
+        keep, pipe.unet = pipe.unet, other
+        swapped = run(mode)
+        assert not torch.equal(swapped, first) and torch.equal(swapped, run(False))
+        pipe.unet = keep
+        assert torch.equal(run(mode), first)
