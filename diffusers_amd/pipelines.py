@@ -70,6 +70,17 @@ def decode_postprocessed(vae, latents: torch.Tensor, output_type: str, **decode_
     return [Image.fromarray(a.squeeze(-1), mode="L") if a.shape[-1] == 1 else Image.fromarray(a) for a in arr]
 
 
+def denoising_end_steps(scheduler, denoising_end) -> int:
+    """Steps of the scheduler's current schedule that run when the loop stops at the fraction ``denoising_end`` of the training
+    timesteps (pipeline_stable_diffusion_xl.py:1164-1183: base + refiner workflows): those whose timestep is at or above the cut-off."""
+    n = len(scheduler.timesteps)
+    if denoising_end is None or not isinstance(denoising_end, float) or not 0.0 < denoising_end < 1.0:
+        return n
+    n_train = scheduler.config.num_train_timesteps
+    cutoff = int(round(n_train - denoising_end * n_train))
+    return len([t for t in scheduler.timesteps.tolist() if t >= cutoff])
+
+
 def _capture_step(pipe, step, mode):
     """What `_denoise` replays once per step: the captured HIP graph (``use_graph=True``), or -- ``use_graph="plan"`` -- the
     step's launch list owned by the C library (diffusers_amd/plan.py, include/diffusers_amd.h "launch plans": the same launches
@@ -299,9 +310,11 @@ class StableDiffusionXLPipeline(_LatentDiffusionBase):
                  target_size: Optional[Tuple[int, int]] = None, generator=None, use_graph: bool = True,
                  prompt_2=None, negative_prompt=None, negative_prompt_2=None, num_images_per_prompt: int = 1,
                  clip_skip=None, guidance_rescale: float = 0.0, callback_on_step_end=None,
-                 callback_on_step_end_tensor_inputs=None):
+                 callback_on_step_end_tensor_inputs=None, timesteps=None, sigmas=None, denoising_end: Optional[float] = None):
         do_cfg = guidance_scale > 1.0
         self._guidance_rescale = float(guidance_rescale)    # pipeline_stable_diffusion_xl.py:849, :1227-1229
+        if timesteps is not None and sigmas is not None:    # retrieve_timesteps, :142-143
+            raise ValueError("Only one of `timesteps` or `sigmas` can be passed. Please choose one to set custom values")
         self._arm_callback(callback_on_step_end, callback_on_step_end_tensor_inputs)
         if prompt is not None:
             if prompt_embeds is not None:
@@ -322,7 +335,15 @@ class StableDiffusionXLPipeline(_LatentDiffusionBase):
         original_size = original_size or (height, width)
         target_size = target_size or (height, width)
         B = prompt_embeds.shape[0]
-        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        # retrieve_timesteps (:144-167): a custom timestep / sigma schedule replaces the step count; denoising_end (:1164-1183) then
+        # keeps the leading steps down to its cut-off (the loop below simply runs fewer replays of the same captured step)
+        if timesteps is not None:
+            self.scheduler.set_timesteps(timesteps=timesteps, device=dev)
+        elif sigmas is not None:
+            self.scheduler.set_timesteps(sigmas=sigmas, device=dev)
+        else:
+            self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        num_inference_steps = denoising_end_steps(self.scheduler, denoising_end)
         shape = (B, self.unet.config.in_channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
         if latents is None:
             gdev = generator.device if generator is not None else torch.device("cpu")

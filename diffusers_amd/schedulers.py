@@ -196,13 +196,29 @@ class EulerDiscreteScheduler(_SchedulerBase):
 
     def set_timesteps(self, num_inference_steps: int = None, device=None, timesteps=None, sigmas=None):
         c = self.config
-        if timesteps is not None or sigmas is not None:
-            raise NotImplementedError("custom timesteps / sigmas are not supported by the HIP EulerDiscreteScheduler")
-        if num_inference_steps is None:
+        # custom schedules (scheduling_euler_discrete.py:378-407): `timesteps` = the model timesteps, sigmas interpolated from the
+        # training ladder; `sigmas` = the whole ladder INCLUDING its terminal value, timesteps found by inverting log sigma(t)
+        if num_inference_steps is None and timesteps is None and sigmas is None:
             raise ValueError("Must pass exactly one of `num_inference_steps` or `timesteps` or `sigmas.")
+        if num_inference_steps is not None and (timesteps is not None or sigmas is not None):
+            raise ValueError("Can only pass one of `num_inference_steps` or `timesteps` or `sigmas`.")
+        if timesteps is not None and c.use_karras_sigmas:
+            raise ValueError("Cannot set `timesteps` with `config.use_karras_sigmas = True`.")
+        if timesteps is not None and c.use_exponential_sigmas:
+            raise ValueError("Cannot set `timesteps` with `config.use_exponential_sigmas = True`.")
+        if num_inference_steps is None:
+            num_inference_steps = len(timesteps) if timesteps is not None else len(sigmas) - 1
         self.num_inference_steps = num_inference_steps
         n_train = c.num_train_timesteps
-        if c.timestep_spacing == "linspace":
+        base = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        if sigmas is not None:
+            sig_full = np.array(sigmas).astype(np.float32)
+            ts = np.array([_sigma_to_t(s_, np.log(base)) for s_ in sig_full[:-1]])
+            self._finish_timesteps(sig_full, ts, num_inference_steps, device)
+            return
+        if timesteps is not None:
+            ts = np.array(timesteps).astype(np.float32)
+        elif c.timestep_spacing == "linspace":
             ts = np.linspace(0, n_train - 1, num_inference_steps, dtype=np.float32)[::-1].copy()
         elif c.timestep_spacing == "leading":
             ratio = n_train // num_inference_steps
@@ -215,7 +231,6 @@ class EulerDiscreteScheduler(_SchedulerBase):
         else:
             raise ValueError(f"{c.timestep_spacing} is not supported. Please make sure to choose one of 'linspace', "
                              "'leading' or 'trailing'.")
-        base = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sig = np.interp(ts, np.arange(0, len(base)), base)
         if c.use_karras_sigmas or c.use_exponential_sigmas:
             # a re-spaced sigma ladder between the interpolated extremes (scheduling_euler_discrete.py:446-452, :520-585);
@@ -236,7 +251,10 @@ class EulerDiscreteScheduler(_SchedulerBase):
             last = 0
         else:
             raise ValueError(f"`final_sigmas_type` must be one of 'zero', or 'sigma_min', but got {c.final_sigmas_type}")
-        sig = np.concatenate([sig, [last]]).astype(np.float32)
+        self._finish_timesteps(np.concatenate([sig, [last]]).astype(np.float32), ts, num_inference_steps, device)
+
+    def _finish_timesteps(self, sig, ts, num_inference_steps, device):
+        """Sigma ladder (terminal value included) + model timesteps -> the scheduler's state and the device coefficient table."""
         self.sigmas = torch.from_numpy(sig).to(dtype=torch.float32)  # kept on CPU like the reference
         self.timesteps = torch.from_numpy(ts.astype(np.float32)).to(device=device)
         self._timesteps_host = ts.astype(np.float32)

@@ -371,6 +371,54 @@ def test_scheduler_from_config_round_trip_and_reference_config():
         S.EulerDiscreteScheduler.from_config(dict(ref_like, rescale_betas_zero_snr=True))
 
 
+def test_euler_custom_timesteps_and_sigmas_tables(golden, monkeypatch):
+    """`set_timesteps(timesteps=...)` / `set_timesteps(sigmas=...)` (scheduling_euler_discrete.py:378-407: custom schedules such as the
+    "align your steps" ladders): sigma ladder, model timesteps and init_noise_sigma bit-equal to the reference's
+    (tests/golden/euler_custom.npz, oracle/make_golden_euler_custom.py), the device table rows follow them, and the reference's
+    argument checks are kept."""
+    from diffusers_amd import schedulers as S
+
+    def fake_upload(self, rows, device):
+        self._table, self._step_dev = torch.from_numpy(rows), torch.zeros((), dtype=torch.int32)
+    monkeypatch.setattr(S._SchedulerBase, "_upload", fake_upload)
+    g = golden("euler_custom")
+    base = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1, timestep_spacing="leading")
+    TS = {"ays_sdxl": [999, 845, 730, 587, 443, 310, 193, 116, 53, 13], "three": [901, 501, 101]}
+    SG = {"ays_sdxl": [14.615, 6.315, 3.771, 2.181, 1.342, 0.862, 0.555, 0.380, 0.234, 0.113, 0.0], "short": [10.0, 2.5, 0.7, 0.0]}
+
+    def check(sch, key):
+        assert np.array_equal(sch.sigmas.numpy(), g[key + "_sigmas"]), key
+        assert np.array_equal(sch.timesteps.numpy(), g[key + "_timesteps"]), key
+        assert np.float32(float(sch.init_noise_sigma)) == g[key + "_init_noise_sigma"], key
+        t = sch._table.view(-1, 8)
+        assert sch.num_inference_steps == t.shape[0] == len(sch.timesteps)
+        assert torch.equal(t[:, 0], sch.sigmas[:-1]) and torch.equal(t[:, 1], sch.sigmas[1:]) and torch.equal(t[:, 7], sch.timesteps.float())
+    for name, ts in TS.items():
+        for spacing in ("leading", "trailing"):
+            sch = S.EulerDiscreteScheduler(**dict(base, timestep_spacing=spacing))
+            sch.set_timesteps(timesteps=ts, device="cpu")
+            check(sch, f"timesteps_{name}_{spacing}")
+    for name, sg in SG.items():
+        sch = S.EulerDiscreteScheduler(**base)
+        sch.set_timesteps(sigmas=sg, device="cpu")
+        check(sch, f"sigmas_{name}")
+    sch = S.EulerDiscreteScheduler(**base)
+    with pytest.raises(ValueError, match="exactly one"):
+        sch.set_timesteps(device="cpu")
+    with pytest.raises(ValueError, match="Can only pass one"):
+        sch.set_timesteps(10, device="cpu", timesteps=[1.0])
+    with pytest.raises(ValueError, match="use_karras_sigmas"):
+        S.EulerDiscreteScheduler(**dict(base, use_karras_sigmas=True)).set_timesteps(timesteps=[10.0], device="cpu")
+    # the SDXL pipeline's `denoising_end` keeps the steps at or above the cut-off timestep (pipeline_stable_diffusion_xl.py:1164-1183)
+    from diffusers_amd.pipelines import denoising_end_steps
+    for n in (50, 30):
+        sch = S.EulerDiscreteScheduler(**base)
+        sch.set_timesteps(n, device="cpu")
+        for frac in (0.8, 0.5, 0.25):
+            assert denoising_end_steps(sch, frac) == int(g[f"denoising_end_{n}_{frac}"]), (n, frac)
+    assert denoising_end_steps(sch, None) == 30 and denoising_end_steps(sch, 1.0) == 30
+
+
 def test_tuning_keys_bucket_giant_row_counts_only():
     """Variant-table keys: exact shapes up to 2^20 rows (every entry of the shipped table), top-three-bit buckets above --
     the 81 / 80 / 79-frame temporal taps of one video conv share an entry, SDXL's 1024^2-pixel convs keep theirs."""

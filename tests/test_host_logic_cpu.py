@@ -616,3 +616,30 @@ def test_callback_on_step_end_and_interrupt(golden):
         def __call__(self, p, i, t, kwargs):
             return kwargs
     assert torch.equal(pipe(latents=_t(g, "latents").clone(), callback_on_step_end=Obj(), **kw).images, base)
+
+
+def test_sdxl_custom_schedules_and_denoising_end(golden):
+    """`timesteps=` / `sigmas=` / `denoising_end=` of StableDiffusionXLPipeline.__call__ (retrieve_timesteps,
+    pipeline_stable_diffusion_xl.py:142-167; :1164-1183): the custom ladder reaches the scheduler, and a denoising_end cut runs the
+    leading steps only -- the latents a callback sees after that many steps of the full run."""
+    from diffusers_amd import factory
+    g = golden("tiny_sdxl_pipeline")
+    pipe = factory.build_sdxl_pipeline(device="cpu", tiny=True, seed=0)
+    kw = dict(prompt_embeds=_t(g, "prompt_embeds"), negative_prompt_embeds=_t(g, "negative_prompt_embeds"),
+              pooled_prompt_embeds=_t(g, "pooled"), negative_pooled_prompt_embeds=_t(g, "negative_pooled"),
+              guidance_scale=5.0, height=128, width=128, use_graph=False, output_type="latent")
+    seen = []
+    full = pipe(latents=_t(g, "latents").clone(), num_inference_steps=4,
+                callback_on_step_end=lambda p, i, t, k: seen.append(k["latents"].clone()) or k, **kw).images
+    assert len(seen) == 4 and torch.equal(seen[-1], full)
+    # leading spacing, 4 steps: timesteps 751, 501, 251, 1 -> a cut at half of the training range keeps the first two
+    part = pipe(latents=_t(g, "latents").clone(), num_inference_steps=4, denoising_end=0.5, **kw).images
+    assert pipe.scheduler.step_index == 2 and torch.equal(part, seen[1])
+    ts = [901.0, 601.0, 301.0, 1.0]
+    a = pipe(latents=_t(g, "latents").clone(), timesteps=ts, **kw).images
+    assert pipe.scheduler.timesteps.tolist() == ts and pipe.scheduler.step_index == 4 and not torch.equal(a, full)
+    sg = [14.6, 5.0, 1.5, 0.4, 0.0]
+    b = pipe(latents=_t(g, "latents").clone(), sigmas=sg, **kw).images
+    assert torch.allclose(pipe.scheduler.sigmas, torch.tensor(sg)) and pipe.scheduler.step_index == 4 and torch.isfinite(b.float()).all()
+    with pytest.raises(ValueError, match="Only one of `timesteps` or `sigmas`"):
+        pipe(latents=_t(g, "latents").clone(), timesteps=ts, sigmas=sg, **kw)
