@@ -70,6 +70,17 @@ def decode_postprocessed(vae, latents: torch.Tensor, output_type: str, **decode_
     return [Image.fromarray(a.squeeze(-1), mode="L") if a.shape[-1] == 1 else Image.fromarray(a) for a in arr]
 
 
+def _per_prompt(t: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
+    """``num_images_per_prompt`` copies of each row of caller-supplied embeddings, the copies of one prompt adjacent -- what the
+    reference's ``encode_prompt`` does to ``prompt_embeds`` it is handed (pipeline_stable_diffusion_xl.py:488-516:
+    ``repeat(1, n, 1).view(bs * n, seq, -1)``; pooled: ``repeat(1, n).view(bs * n, -1)``)."""
+    if t is None or n == 1:
+        return t
+    if n < 1:
+        raise ValueError("num_images_per_prompt must be >= 1")
+    return t.repeat_interleave(n, dim=0)
+
+
 def denoising_end_steps(scheduler, denoising_end) -> int:
     """Steps of the scheduler's current schedule that run when the loop stops at the fraction ``denoising_end`` of the training
     timesteps (pipeline_stable_diffusion_xl.py:1164-1183: base + refiner workflows): those whose timestep is at or above the cut-off."""
@@ -323,6 +334,10 @@ class StableDiffusionXLPipeline(_LatentDiffusionBase):
             prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = \
                 self.encode_prompt(prompt, prompt_2, self.device, num_images_per_prompt, do_cfg, negative_prompt,
                                    negative_prompt_2, clip_skip)
+        else:
+            prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = (
+                _per_prompt(t, num_images_per_prompt) for t in (prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds,
+                                                                negative_pooled_prompt_embeds))
         if prompt_embeds is None or pooled_prompt_embeds is None:
             raise ValueError("Provide either `prompt` (with the text encoders given to the pipeline) or `prompt_embeds` "
                              "and `pooled_prompt_embeds`.")
@@ -404,6 +419,8 @@ class StableDiffusionPipeline(_LatentDiffusionBase):
                                  "of the two.")
             prompt_embeds, negative_prompt_embeds = self.encode_prompt(prompt, self.device, num_images_per_prompt, do_cfg,
                                                                         negative_prompt, clip_skip)
+        else:
+            prompt_embeds, negative_prompt_embeds = (_per_prompt(t, num_images_per_prompt) for t in (prompt_embeds, negative_prompt_embeds))
         if prompt_embeds is None:
             raise ValueError("Provide either `prompt` (with the text encoder given to the pipeline) or `prompt_embeds`.")
         if do_cfg and negative_prompt_embeds is None:
@@ -572,6 +589,8 @@ class FluxPipeline(_StepCallbacks, PipelineLoadingMixin):
             prompt_embeds, pooled_prompt_embeds, _ = encode_prompt_flux(
                 self.tokenizer, self.text_encoder, self.tokenizer_2, self.text_encoder_2, prompt, prompt_2, self.device,
                 num_images_per_prompt, max_sequence_length)
+        else:
+            prompt_embeds, pooled_prompt_embeds = (_per_prompt(t, num_images_per_prompt) for t in (prompt_embeds, pooled_prompt_embeds))
         if prompt_embeds is None or pooled_prompt_embeds is None:
             raise ValueError("Provide either `prompt` (with the text encoders given to the pipeline) or `prompt_embeds` "
                              "and `pooled_prompt_embeds`.")
@@ -724,6 +743,8 @@ class WanPipeline(_StepCallbacks, PipelineLoadingMixin):
             prompt_embeds, negative_prompt_embeds = encode_prompt_wan(
                 self.tokenizer, self.text_encoder, prompt, negative_prompt, guidance_scale > 1.0, num_videos_per_prompt,
                 max_sequence_length, self.device)
+        else:
+            prompt_embeds, negative_prompt_embeds = (_per_prompt(t, num_videos_per_prompt) for t in (prompt_embeds, negative_prompt_embeds))
         if prompt_embeds is None:
             raise ValueError("Provide either `prompt` (with the text encoder given to the pipeline) or `prompt_embeds`.")
         if output_type not in ("latent", "pt", "raw", "np"):
