@@ -366,6 +366,10 @@ class StableDiffusionXLPipeline(_LatentDiffusionBase):
         # (like the reference's prepare_latents, user-supplied latents are taken as they are: no shape check,
         #  pipeline_stable_diffusion_xl.py:707-727)
         latents = latents.to(device=dev, dtype=bf16).contiguous()
+        if latents.shape[0] != B:
+            # (the reference's prepare_latents takes supplied latents unchecked and fails inside the U-Net; here a stale batch would
+            #  meet a captured step of another size)
+            raise ValueError(f"`latents` holds {latents.shape[0]} samples, the prompt embeddings (x num_images_per_prompt) {B}")
         latents = ops.mul_scalar(latents, float(self.scheduler.init_noise_sigma))
 
         pe = prompt_embeds.to(device=dev, dtype=bf16)
@@ -435,6 +439,10 @@ class StableDiffusionPipeline(_LatentDiffusionBase):
             gdev = generator.device if generator is not None else torch.device("cpu")
             latents = torch.randn(shape, generator=generator, device=gdev, dtype=bf16)
         latents = latents.to(device=dev, dtype=bf16).contiguous()
+        if latents.shape[0] != B:
+            # (the reference's prepare_latents takes supplied latents unchecked and fails inside the U-Net; here a stale batch would
+            #  meet a captured step of another size)
+            raise ValueError(f"`latents` holds {latents.shape[0]} samples, the prompt embeddings (x num_images_per_prompt) {B}")
         latents = ops.mul_scalar(latents, float(self.scheduler.init_noise_sigma))
         pe = prompt_embeds.to(device=dev, dtype=bf16)
         if do_cfg:
