@@ -2,12 +2,15 @@
 
 B4  ``mi355x_flash_attention`` -- an attention BACKEND function with the reference's backend signature and (B, S, H, D)
     layout (models/attention_dispatch.py:494-515; registered backends are called by ``dispatch_attention_fn`` from
-    Flux / Wan and ~90 newer models).  ``register_backend()`` shows the registration a reference maintainer would add.
+    Flux / Wan and ~90 newer models).  ``register_backend()`` performs the registration a reference maintainer would add:
+    a backend name of its own (``AttentionBackendName("mi355x")``), after which the reference's PUBLIC calls work unchanged --
+    ``with attention_backend("mi355x"):`` (attention_dispatch.py:370-389) and ``model.set_attention_backend("mi355x")``
+    (modeling_utils.py:598-660).
 B3  ``MI355XAttnProcessor`` -- an attention PROCESSOR for the reference ``Attention`` module
     (models/attention_processor.py:52-309; contract of AttnProcessor2_0.__call__, :2696-2787): installed with
     ``model.set_attn_processor(MI355XAttnProcessor())`` it replaces q/k/v projections, SDPA and to_out of every
-    attention layer of a reference UNet2DConditionModel / AutoencoderKL by the HIP kernels, leaving the rest of the
-    reference module graph untouched.
+    attention layer of a reference UNet2DConditionModel by the HIP kernels, leaving the rest of the reference module
+    graph untouched.
 
 Both raise for arguments the kernels do not implement (masks, dropout, causal, GQA, LSE); neither has a fallback.
 """
@@ -21,13 +24,45 @@ from . import ops
 from .layers import KERNEL_HEAD_DIMS
 
 bf16 = torch.bfloat16
+BACKEND_NAME = "mi355x"
+# slots of the reference's closed Enum that are neither gated on an optional package (_check_attention_backend_requirements,
+# attention_dispatch.py:518-585) nor resolved through the Hub (_HUB_KERNELS_REGISTRY, :321-366): safe to take over when a
+# process cannot extend the Enum (e.g. DIFFUSERS_ATTN_BACKEND, which is parsed at import time)
+UNGATED_SLOTS = ("_native_flash", "_native_efficient", "_native_math", "_native_cudnn", "native")
+
+
+def _rows_view(t: torch.Tensor, name: str):
+    """(B, S, H, D) -> (tensor, row stride, batch stride) with heads packed along a row (stride(2) == D, stride(3) == 1) and
+    16-byte aligned strides: what ``da_attention_bf16`` addresses directly.  Slices of a fused projection ([.., 3*H*D] rows) and
+    plain contiguous tensors pass through untouched; anything else is made contiguous (one copy)."""
+    B, S, H, D = t.shape
+    ok = t.stride(3) == 1 and (H == 1 or t.stride(2) == D) and t.stride(1) % 8 == 0 and (B == 1 or t.stride(0) % 8 == 0) \
+        and t.data_ptr() % 16 == 0 and t.stride(1) >= H * D
+    if not ok:
+        t = t.contiguous()
+    return t, t.stride(1), (t.stride(0) if B > 1 else S * t.stride(1))
+
+
+def _is_vt_layout(v: torch.Tensor) -> bool:
+    """True when the (B, S, H, D) ``value`` is a VIEW of a [H*D][B*S_alloc] channel-major buffer (keys contiguous), i.e. the
+    caller already holds V^T (``vt.view(H, D, B, Sa)[..., :S].permute(2, 3, 0, 1)``): nothing to transpose."""
+    B, S, H, D = v.shape
+    ld = v.stride(3)
+    return v.stride(1) == 1 and ld % 8 == 0 and ld >= B * S and v.stride(2) == D * ld and \
+        (B == 1 or (v.stride(0) % 8 == 0 and v.stride(0) >= S)) and v.data_ptr() % 16 == 0
 
 
 def mi355x_flash_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                            attn_mask: Optional[torch.Tensor] = None, dropout_p: float = 0.0, is_causal: bool = False,
                            scale: Optional[float] = None, enable_gqa: bool = False, return_lse: bool = False,
                            _parallel_config=None) -> torch.Tensor:
-    """query (B, Sq, H, D), key / value (B, Skv, H, D) bf16 HIP tensors -> (B, Sq, H, D)."""
+    """query (B, Sq, H, D), key / value (B, Skv, H, D) bf16 HIP tensors -> (B, Sq, H, D).
+
+    HBM passes besides the flash kernel itself: none for query / key when their rows are addressable as they are (see
+    :func:`_rows_view`); ONE for value -- the kernel consumes V^T ([channel][key], keys contiguous) and the reference's
+    callers hold V token-major, so V is transposed once (read + write of V: 28 MB next to Flux's 246 us kernel) unless the
+    caller passes a view that already is V^T (:func:`_is_vt_layout`).  A key count that is not a multiple of 8 additionally
+    costs a zero-padded copy of K (the kernel reads whole 16-byte key chunks)."""
     if attn_mask is not None or dropout_p != 0.0 or is_causal or enable_gqa or return_lse or _parallel_config is not None:
         raise ValueError("mi355x_flash_attention: attn_mask / dropout / causal / GQA / LSE / context parallel are not supported")
     if query.dim() != 4 or key.shape != value.shape or query.shape[0] != key.shape[0] or query.shape[2:] != key.shape[2:]:
@@ -37,47 +72,127 @@ def mi355x_flash_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
     if D not in KERNEL_HEAD_DIMS:
         raise ValueError(f"mi355x_flash_attention: head_dim {D} not in {KERNEL_HEAD_DIMS}")
     for t_, n in ((query, "query"), (key, "key"), (value, "value")):
-        if t_.dtype != bf16 or not t_.is_cuda:
-            raise ValueError(f"mi355x_flash_attention: {n} must be a bf16 HIP tensor")
+        ops.require_hip(t_, f"mi355x_flash_attention: {n}")          # bf16 on a HIP device, or it raises
     inner = H * D
-    q2 = query.contiguous().view(B * Sq, inner)
+    q, q_rs, q_bs = _rows_view(query, "query")
     sa = (Skv + 7) // 8 * 8
     if sa == Skv:
-        k2 = key.contiguous().view(B * Skv, inner)
-        v2 = value.contiguous().view(B * Skv, inner)
-    else:  # pad the key axis to a multiple of 8 (16-byte aligned V^T rows); the kernel masks keys >= Skv
-        k2 = torch.zeros((B, sa, inner), device=key.device, dtype=bf16)
-        v2 = torch.zeros((B, sa, inner), device=key.device, dtype=bf16)
-        k2[:, :Skv] = key.reshape(B, Skv, inner)
-        v2[:, :Skv] = value.reshape(B, Skv, inner)
-        k2, v2 = k2.view(B * sa, inner), v2.view(B * sa, inner)
-    vt = ops.transpose(v2)                                                    # [inner][B*sa]
-    o = ops.attention(q2, k2, vt, B=B, H=H, D=D, Sq=Sq, Skv=Skv, Skv_alloc=sa, q_row_stride=inner, k_row_stride=inner,
-                      q_batch_stride=Sq * inner, k_batch_stride=sa * inner, vt_ld=B * sa, vt_batch_stride=sa,
-                      scale=scale)
+        k, k_rs, k_bs = _rows_view(key, "key")
+        if _is_vt_layout(value):
+            vt, vt_ld, vt_bs = value, value.stride(3), (value.stride(0) if B > 1 else sa)
+        else:
+            v, v_rs, v_bs = _rows_view(value, "value")
+            vt = torch.empty((inner, B * sa), device=value.device, dtype=bf16)
+            if B == 1 or v_bs == Skv * v_rs:
+                ops.transpose(v.as_strided((B * Skv, inner), (v_rs, 1)), out=vt)              # one launch for the whole batch
+            else:
+                for b in range(B):
+                    ops.transpose(v[b].as_strided((Skv, inner), (v_rs, 1)), out=vt[:, b * sa:(b + 1) * sa])
+            vt_ld, vt_bs = B * sa, sa
+    else:  # ragged key count: the kernel masks keys >= Skv but reads 16-byte chunks, so K rows / V^T columns up to `sa` must exist
+        k = torch.zeros((B, sa, inner), device=key.device, dtype=bf16)
+        k[:, :Skv] = key.reshape(B, Skv, inner)
+        k_rs, k_bs = inner, sa * inner
+        vt = torch.zeros((inner, B * sa), device=value.device, dtype=bf16)
+        for b in range(B):
+            ops.transpose(value[b].reshape(Skv, inner), out=vt[:, b * sa:b * sa + Skv])
+        vt_ld, vt_bs = B * sa, sa
+    o = ops.attention(q, k, vt, B=B, H=H, D=D, Sq=Sq, Skv=Skv, Skv_alloc=sa, q_row_stride=q_rs, k_row_stride=k_rs,
+                      q_batch_stride=q_bs, k_batch_stride=k_bs, vt_ld=vt_ld, vt_batch_stride=vt_bs, scale=scale)
     return o.view(B, Sq, H, D)
 
 
-def register_backend(registry=None, name=None):
+_SUPPORTED_ARGS = {"query", "key", "value", "attn_mask", "dropout_p", "is_causal", "scale", "enable_gqa", "return_lse",
+                   "_parallel_config"}
+
+
+def _extend_enum(enum_cls, member_name: str, value: str):
+    """Add ``member_name = value`` to a ``(str, Enum)`` class at run time -- what the one-line patch
+    ``MI355X = "mi355x"`` in ``AttentionBackendName`` (attention_dispatch.py:212-257) does at import time."""
+    if value in enum_cls._value2member_map_:
+        return enum_cls._value2member_map_[value]
+    m = str.__new__(enum_cls, value)
+    m._name_, m._value_ = member_name, value
+    enum_cls._member_map_[member_name] = m
+    enum_cls._member_names_.append(member_name)
+    enum_cls._value2member_map_[value] = m
+    return m
+
+
+def register_backend(registry=None, name=None, *, slot: Optional[str] = None):
     """Register :func:`mi355x_flash_attention` with the reference's ``_AttentionBackendRegistry``
-    (attention_dispatch.py:257-283).  ``AttentionBackendName`` is a closed Enum, so the function takes over an existing
-    slot (default: ``AITER_FA2_HUB``), after which ``model.set_attention_backend("aiter_fa2_hub")`` /
-    ``DIFFUSERS_ATTN_BACKEND=aiter_fa2_hub``
-    routes every ``dispatch_attention_fn`` call to the HIP kernel."""
+    (attention_dispatch.py:257-283) and return the backend's name.
+
+    Default: a NEW member ``AttentionBackendName.MI355X = "mi355x"`` is added to the reference's Enum (it is closed in the
+    source; INTEGRATION.md shows the static one-line patch), which no requirement check gates and no Hub download resolves
+    -- so ``attention_backend("mi355x")`` and ``model.set_attention_backend("mi355x")`` route every
+    ``dispatch_attention_fn`` call (transformer_flux.py:121-130, transformer_wan.py:133-160) to the HIP kernel.
+    ``slot=`` instead takes over one of the reference's ungated slots (:data:`UNGATED_SLOTS`), for processes that select the
+    backend with ``DIFFUSERS_ATTN_BACKEND`` (parsed before anything can extend the Enum).  Slots the reference gates on the
+    ``kernels`` package / a Hub download (``aiter_fa2_hub`` ...) are refused: the public API would raise before dispatching."""
     if registry is None:
         from diffusers.models.attention_dispatch import AttentionBackendName, _AttentionBackendRegistry
-        registry, name = _AttentionBackendRegistry, (name or AttentionBackendName.AITER_FA2_HUB)
+        registry = _AttentionBackendRegistry
+        if slot is not None:
+            if slot not in UNGATED_SLOTS:
+                raise ValueError(f"register_backend: slot {slot!r} is gated by the reference (kernels package / Hub download / "
+                                 f"optional library); choose one of {UNGATED_SLOTS}")
+            name = AttentionBackendName(slot)
+        elif name is None:
+            name = _extend_enum(AttentionBackendName, "MI355X", BACKEND_NAME)
+    elif name is None:
+        raise ValueError("register_backend: a custom registry needs an explicit name")
     registry._backends[name] = mi355x_flash_attention
     registry._constraints[name] = []
-    registry._supported_arg_names[name] = {"query", "key", "value", "attn_mask", "dropout_p", "is_causal", "scale",
-                                           "enable_gqa", "return_lse", "_parallel_config"}
+    registry._supported_arg_names[name] = set(_SUPPORTED_ARGS)
     return name
+
+
+class _Packed:
+    """Packed projection weights of one reference ``Attention`` module, rebuilt when a parameter changes (``_version`` /
+    storage): Q|K rows fused for self-attention (one paired launch with the swapped V^T problem, as layers.Attention)."""
+    __slots__ = ("key", "wqk", "bqk", "ehs", "ehs_version", "kv")
+
+    def __init__(self):
+        self.key = self.wqk = self.bqk = self.ehs = self.kv = None
+        self.ehs_version = -1
+
+
+def _param_key(*params):
+    return tuple((p.data_ptr(), p._version) if p is not None else None for p in params)
 
 
 class MI355XAttnProcessor:
     """Processor for the reference ``Attention`` module, AttnProcessor2_0 contract (attention_processor.py:2705-2787):
     optional spatial 4-D input, optional group_norm, q/k/v Linear (optional bias), SDPA, to_out[0], residual,
-    ``rescale_output_factor``.  Weights are read from the module (bf16, on the HIP device) at call time."""
+    ``rescale_output_factor``.  Weights are read from the module (bf16, on the HIP device); their fused / padded forms are
+    cached on the processor per module and rebuilt when a parameter is modified.
+
+    Launches per call -- self-attention: ONE paired GEMM (Q|K next to V^T = W_v . X^T, no transpose pass), flash attention,
+    to_out with the residual in its epilogue; cross-attention: to_q, flash attention, to_out -- K and V^T of the text
+    embeddings are computed once per (module, ``encoder_hidden_states`` tensor) and reused while the caller passes the
+    same, unmodified tensor (the reference loop passes one ``prompt_embeds`` for all steps,
+    pipeline_stable_diffusion_xl.py:1193-1215)."""
+
+    def __init__(self):
+        self._packs = {}
+
+    def _pack(self, attn) -> _Packed:
+        pk = self._packs.get(id(attn))
+        key = _param_key(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_q.bias, attn.to_k.bias, attn.to_v.bias)
+        if pk is None or pk.key != key:
+            pk = _Packed()
+            pk.key = key
+            self._packs[id(attn)] = pk
+        return pk
+
+    @staticmethod
+    def _fused_qk(attn, pk: _Packed):
+        if pk.wqk is None:      # built on the first self-attention call of this module
+            pk.wqk = torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach()], dim=0).contiguous()
+            if attn.to_q.bias is not None:
+                pk.bqk = torch.cat([attn.to_q.bias.detach(), attn.to_k.bias.detach()]).contiguous()
+        return pk.wqk, pk.bqk
 
     def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
                  attention_mask: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -97,23 +212,52 @@ class MI355XAttnProcessor:
         gn = getattr(attn, "group_norm", None)
         if gn is not None:   # nn.GroupNorm over channels of the token tensor == channels-last GroupNorm
             x = ops.group_norm_nhwc(x, gn.weight, gn.bias, gn.num_groups, gn.eps)
-        ctx = x if encoder_hidden_states is None else encoder_hidden_states.contiguous()
-        Skv = ctx.shape[1]
         heads = attn.heads
-        x2, c2 = x.view(B * S, C), ctx.view(B * Skv, ctx.shape[-1])
-        q = ops.linear(x2, attn.to_q.weight, attn.to_q.bias)
-        k = ops.linear(c2, attn.to_k.weight, attn.to_k.bias)
-        v = ops.linear(c2, attn.to_v.weight, attn.to_v.bias)
-        inner = q.shape[-1]
+        inner = attn.to_q.weight.shape[0]
         D = inner // heads
-        o = mi355x_flash_attention(q.view(B, S, heads, D), k.view(B, Skv, heads, D), v.view(B, Skv, heads, D),
-                                   scale=getattr(attn, "scale", None))
-        out = ops.linear(o.view(B * S, inner), attn.to_out[0].weight, attn.to_out[0].bias).view(B, S, -1)
+        if D not in KERNEL_HEAD_DIMS:
+            raise ValueError(f"MI355XAttnProcessor: head_dim {D} not in {KERNEL_HEAD_DIMS} (the model classes zero-pad 40 / 80)")
+        scale = getattr(attn, "scale", None)
+        x2 = x.view(B * S, C)
+        pk = self._pack(attn)
+        if encoder_hidden_states is None:
+            if S % 8 != 0:
+                raise ValueError("MI355XAttnProcessor: self-attention needs a token count that is a multiple of 8")
+            # [M][2*inner] and V^T [inner][M]: two problems, one launch (no transpose pass; to_v.bias is a ROW bias of V^T)
+            wqk, bqk = self._fused_qk(attn, pk)
+            qk, vt = ops.linear_pair({"x": x2, "w": wqk, "bias": bqk},
+                                     {"x": attn.to_v.weight, "w": x2, "bias_rows": attn.to_v.bias})
+            o = ops.attention(qk, qk[:, inner:], vt, B=B, H=heads, D=D, Sq=S, Skv=S, Skv_alloc=S, q_row_stride=2 * inner,
+                              k_row_stride=2 * inner, q_batch_stride=S * 2 * inner, k_batch_stride=S * 2 * inner,
+                              vt_ld=B * S, vt_batch_stride=S, scale=scale)
+        else:
+            ehs = encoder_hidden_states
+            if pk.ehs is not ehs or pk.ehs_version != ehs._version:
+                from .layers import pad_encoder_states
+                if ehs.shape[0] != B:
+                    raise ValueError("MI355XAttnProcessor: encoder_hidden_states batch does not match hidden_states")
+                pad, skv, skv_alloc = pad_encoder_states(ehs)      # zero rows up to a multiple of 16 keys (tiny: 77 x 2048)
+                k = ops.linear(pad, attn.to_k.weight, attn.to_k.bias)
+                vt = ops.linear(attn.to_v.weight, pad, bias_rows=attn.to_v.bias)        # [inner][B*skv_alloc] = V^T
+                pk.ehs, pk.ehs_version, pk.kv = ehs, ehs._version, (k, vt, skv, skv_alloc)
+            k, vt, skv, skv_alloc = pk.kv
+            q = ops.linear(x2, attn.to_q.weight, attn.to_q.bias)
+            o = ops.attention(q, k, vt, B=B, H=heads, D=D, Sq=S, Skv=skv, Skv_alloc=skv_alloc, q_row_stride=inner,
+                              k_row_stride=inner, q_batch_stride=S * inner, k_batch_stride=skv_alloc * inner,
+                              vt_ld=B * skv_alloc, vt_batch_stride=skv_alloc, scale=scale)
+        rs = getattr(attn, "rescale_output_factor", 1.0)
+        fuse_res = input_ndim == 3 and getattr(attn, "residual_connection", False)
+        # to_out[0] (+ the residual and 1 / rescale_output_factor in the GEMM epilogue when the tokens are already row-major);
+        # to_out[1] is Dropout: identity at inference
+        out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias,
+                         residual=residual.reshape(B * S, -1) if fuse_res else None,
+                         out_scale=(1.0 / rs) if (fuse_res and rs != 1.0) else 1.0).view(B, S, -1)
+        if fuse_res:
+            return out
         if input_ndim == 4:
             out = out.transpose(-1, -2).reshape(Bn, Cn, Hn, Wn)
         if getattr(attn, "residual_connection", False):
             out = out + residual
-        rs = getattr(attn, "rescale_output_factor", 1.0)
         if rs != 1.0:
             out = out / rs
         return out

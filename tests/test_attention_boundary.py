@@ -1,0 +1,323 @@
+"""Boundaries B3 / B4 of SURVEY.md 8b through the reference's PUBLIC API, on REAL reference modules.
+
+B4: ``register_backend()`` then ``with attention_backend("mi355x"):`` (models/attention_dispatch.py:370-389) and
+    ``model.set_attention_backend("mi355x")`` (models/modeling_utils.py:598-660) on a real ``FluxTransformer2DModel`` /
+    ``WanTransformer3DModel``: every ``dispatch_attention_fn`` call (transformer_flux.py:121-130) lands in
+    ``da_attention_bf16`` (counted), and the bf16 forward agrees with the model's own fp32 run within 1.2 x the bf16 floor
+    (the same model in bf16 on the reference's native backend).
+B3: ``unet.set_attn_processor(MI355XAttnProcessor())`` (models/attention.py:64-96 / unets/unet_2d_condition.py) on a real
+    reference ``UNet2DConditionModel`` -- contract of tests/models/unets/test_models_unet_2d_condition.py:760-825.
+
+The same bodies run twice: on CPU here (reference from /root/reference/src, kernels = the torch stand-ins of
+tests/ops_emulation.py -- checks the binding, the layouts and the strides) and on the GPU box (reference from
+oracle/_ref/diffusers_ref.zip, the HIP kernels)."""
+import importlib
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import ref_runtime as RR
+
+REF = Path("/root/reference/src")
+bf16 = torch.bfloat16
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+
+def _load_ref():
+    if REF.exists():
+        sys.path.insert(0, str(REF))
+        try:
+            import diffusers
+        finally:
+            sys.path.remove(str(REF))
+        return diffusers
+    ref = RR.load_reference()
+    if ref is None:
+        pytest.skip("neither /root/reference/src nor oracle/_ref/diffusers_ref.zip is present")
+    return ref
+
+
+class _Counter:
+    def __init__(self, monkeypatch):
+        from diffusers_amd import ops
+        self.n = 0
+        self.shapes = []
+        inner = ops.attention
+
+        def counted(q, k, vt, **kw):
+            self.n += 1
+            self.shapes.append((kw["B"], kw["H"], kw["Sq"], kw["Skv"], kw["D"]))
+            return inner(q, k, vt, **kw)
+        monkeypatch.setattr(ops, "attention", counted)
+
+
+def _env(monkeypatch, dev):
+    """CPU: install the kernel stand-ins; GPU: the real library.  Returns the attention-launch counter."""
+    from diffusers_amd import ops
+    if dev == "cpu":
+        import ops_emulation
+        ops_emulation.install(monkeypatch, ops)
+        monkeypatch.setattr(ops, "TUNING", False)
+    return _Counter(monkeypatch)
+
+
+def _as_lists(c):
+    return {k: (list(v) if isinstance(v, tuple) else v) for k, v in c.items()}
+
+
+def _flux(ref, cfg, dev, seed=0):
+    torch.manual_seed(seed)
+    m = ref.FluxTransformer2DModel(**_as_lists(cfg)).eval()
+    return m.to(dev)
+
+
+def _flux_inputs(cfg, dev, s_img, s_txt, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    B = 1
+    hs = torch.randn((B, s_img, cfg["in_channels"]), generator=g)
+    ehs = torch.randn((B, s_txt, cfg["joint_attention_dim"]), generator=g)
+    pooled = torch.randn((B, cfg["pooled_projection_dim"]), generator=g)
+    side = int(s_img ** 0.5)
+    img_ids = torch.zeros((s_img, 3))
+    img_ids[:, 1] = torch.arange(side).repeat_interleave(side)[:s_img]
+    img_ids[:, 2] = torch.arange(side).repeat(side)[:s_img]
+    return dict(hidden_states=hs.to(dev), encoder_hidden_states=ehs.to(dev), pooled_projections=pooled.to(dev),
+                timestep=torch.tensor([0.7]).to(dev), img_ids=img_ids.to(dev), txt_ids=torch.zeros((s_txt, 3)).to(dev))
+
+
+def _cast(kw, dtype):
+    return {k: (v.to(dtype) if v.is_floating_point() and k not in ("img_ids", "txt_ids") else v) for k, v in kw.items()}
+
+
+def _run_flux_backend(monkeypatch, dev, cfg, s_img, s_txt, gate):
+    from diffusers_amd.attention_backend import BACKEND_NAME, register_backend
+    ref = _load_ref()
+    cnt = _env(monkeypatch, dev)
+    from_ref = importlib.import_module(ref.__name__ + ".models.attention_dispatch")
+    name = register_backend()
+    assert name.value == BACKEND_NAME and from_ref.AttentionBackendName(BACKEND_NAME) is name
+    assert BACKEND_NAME in {m.value for m in from_ref.AttentionBackendName.__members__.values()}
+    model = _flux(ref, cfg, dev)
+    kw = _flux_inputs(cfg, dev, s_img, s_txt)
+    with torch.no_grad():
+        want = model(**kw, return_dict=False)[0]                                  # the model's own fp32 run
+        model.to(bf16)
+        kwb = _cast(kw, bf16)
+        floor = model(**kwb, return_dict=False)[0]                                # bf16, the reference's native backend
+        assert cnt.n == 0
+        with from_ref.attention_backend(BACKEND_NAME):                            # the public context manager
+            got_ctx = model(**kwb, return_dict=False)[0]
+        layers = cfg["num_layers"] + cfg["num_single_layers"]
+        assert cnt.n == layers, f"{cnt.n} flash launches for {layers} attention layers"
+        assert all(s == (1, cfg["num_attention_heads"], s_img + s_txt, s_img + s_txt, cfg["attention_head_dim"]) for s in cnt.shapes)
+        model.set_attention_backend(BACKEND_NAME)                                 # the public model method
+        try:
+            got_set = model(**kwb, return_dict=False)[0]
+        finally:
+            model.reset_attention_backend()
+            from_ref._AttentionBackendRegistry.set_active_backend(from_ref.AttentionBackendName.NATIVE)
+        assert cnt.n == 2 * layers
+        after = model(**kwb, return_dict=False)[0]                                # reset: native again, no launches
+        assert cnt.n == 2 * layers and torch.equal(after, floor)
+    rf, rc, rs = _rel(floor, want), _rel(got_ctx, want), _rel(got_set, want)
+    print(f"[B4] reference FluxTransformer2DModel (S {s_img}+{s_txt}, H {cfg['num_attention_heads']}, D {cfg['attention_head_dim']}) under "
+          f"attention_backend('{BACKEND_NAME}'): rel-rms vs its fp32 run {rc:.3e} (set_attention_backend: {rs:.3e}; native bf16 floor {rf:.3e})")
+    assert torch.equal(got_ctx, got_set)
+    assert rc <= gate(rf), (rc, rf)
+
+
+TINY_FLUX = dict(patch_size=1, in_channels=64, out_channels=None, num_layers=2, num_single_layers=2, attention_head_dim=64,
+                 num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=64, guidance_embeds=False,
+                 axes_dims_rope=(8, 28, 28))
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference sources not present")
+def test_backend_binds_through_the_public_api_cpu(monkeypatch):
+    _run_flux_backend(monkeypatch, "cpu", TINY_FLUX, s_img=64, s_txt=16, gate=lambda f: max(1.5 * f, 2.5e-2))
+
+
+@pytest.mark.gpu
+def test_backend_binds_through_the_public_api_tiny(monkeypatch):
+    _run_flux_backend(monkeypatch, "cuda", TINY_FLUX, s_img=64, s_txt=16, gate=lambda f: max(1.2 * f, 1.5e-2))
+
+
+@pytest.mark.gpu
+def test_backend_under_a_full_width_flux_block(monkeypatch):
+    """One double + one single block at FLUX.1 width (24 heads of 128, joint dim 4096) and the full 4096 + 512 sequence."""
+    cfg = dict(patch_size=1, in_channels=64, out_channels=None, num_layers=1, num_single_layers=1, attention_head_dim=128,
+               num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=False,
+               axes_dims_rope=(16, 56, 56))
+    _run_flux_backend(monkeypatch, "cuda", cfg, s_img=4096, s_txt=512, gate=lambda f: 1.2 * f)
+
+
+def _run_backend_gates(monkeypatch, dev):
+    """What the reference's public API does with the slots: gated slots are refused by register_backend (the API would raise
+    before dispatching); an ungated slot can be taken over; unsupported arguments raise from the backend itself."""
+    from diffusers_amd.attention_backend import UNGATED_SLOTS, mi355x_flash_attention, register_backend
+    ref = _load_ref()
+    _env(monkeypatch, dev)
+    ad = importlib.import_module(ref.__name__ + ".models.attention_dispatch")
+    with pytest.raises(ValueError, match="gated"):
+        register_backend(slot="aiter_fa2_hub")
+    saved = {k: dict(getattr(ad._AttentionBackendRegistry, k)) for k in ("_backends", "_constraints", "_supported_arg_names")}
+    try:
+        name = register_backend(slot=UNGATED_SLOTS[0])
+        assert ad._AttentionBackendRegistry._backends[name] is mi355x_flash_attention
+        q = torch.randn((1, 64, 2, 64), generator=torch.Generator().manual_seed(0)).to(bf16).to(dev)
+        with ad.attention_backend(UNGATED_SLOTS[0]):
+            o = ad.dispatch_attention_fn(q, q, q)
+            with pytest.raises(ValueError, match="not supported"):
+                ad.dispatch_attention_fn(q, q, q, is_causal=True)
+        want = torch.nn.functional.scaled_dot_product_attention(*(q.float().cpu().transpose(1, 2),) * 3).transpose(1, 2)
+        assert _rel(o, want) < 1e-2
+    finally:
+        for k, v in saved.items():
+            getattr(ad._AttentionBackendRegistry, k).clear()
+            getattr(ad._AttentionBackendRegistry, k).update(v)
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference sources not present")
+def test_backend_slots_and_refusals_cpu(monkeypatch):
+    _run_backend_gates(monkeypatch, "cpu")
+
+
+@pytest.mark.gpu
+def test_backend_slots_and_refusals(monkeypatch):
+    _run_backend_gates(monkeypatch, "cuda")
+
+
+def _run_backend_layouts(monkeypatch, dev):
+    """Strided inputs reach the kernel without copies: q / k / v as column blocks of one fused [B][S][3*H*D] projection, V
+    handed over as a view of a V^T buffer, a ragged key count, batch 2."""
+    from diffusers_amd import attention_backend as AB
+    cnt = _env(monkeypatch, dev)
+    g = torch.Generator().manual_seed(3)
+    B, S, H, D = 2, 72, 2, 64
+    qkv = torch.randn((B, S, 3 * H * D), generator=g).to(bf16).to(dev)
+    q, k, v = (qkv[..., i * H * D:(i + 1) * H * D].unflatten(-1, (H, D)) for i in range(3))
+
+    def sdpa(q_, k_, v_):
+        f = lambda t: t.float().cpu().transpose(1, 2)     # noqa: E731
+        return torch.nn.functional.scaled_dot_product_attention(f(q_), f(k_), f(v_)).transpose(1, 2)
+    copies = []
+    orig = torch.Tensor.contiguous
+    monkeypatch.setattr(torch.Tensor, "contiguous", lambda t, *a, **k_: (copies.append(t.is_contiguous()), orig(t, *a, **k_))[1])
+    o = AB.mi355x_flash_attention(q, k, v)
+    assert copies.count(False) == 0, "a fused-projection slice was copied"
+    monkeypatch.setattr(torch.Tensor, "contiguous", orig)
+    assert _rel(o, sdpa(q, k, v)) < 1e-2
+    vt = torch.zeros((H * D, B * S), dtype=bf16, device=dev)          # the caller already holds V^T
+    vt.copy_(v.reshape(B * S, H * D).t())
+    v_view = vt.view(H, D, B, S).permute(2, 3, 0, 1)
+    assert AB._is_vt_layout(v_view) and torch.equal(v_view, v)
+    o2 = AB.mi355x_flash_attention(q, k, v_view)
+    assert torch.equal(o2, o)
+    kr, vr = (torch.randn((B, 77, H, D), generator=g).to(bf16).to(dev) for _ in range(2))    # ragged key count
+    assert _rel(AB.mi355x_flash_attention(q, kr, vr), sdpa(q, kr, vr)) < 1e-2
+    assert cnt.n == 3
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference sources not present")
+def test_backend_layouts_cpu(monkeypatch):
+    _run_backend_layouts(monkeypatch, "cpu")
+
+
+@pytest.mark.gpu
+def test_backend_layouts(monkeypatch):
+    _run_backend_layouts(monkeypatch, "cuda")
+
+
+# ---- B3 ------------------------------------------------------------------------------------------------------------------------
+def _run_processor(monkeypatch, dev, cfg, hw, gate, cross_tokens=77):
+    from diffusers_amd.attention_backend import MI355XAttnProcessor
+    ref = _load_ref()
+    cnt = _env(monkeypatch, dev)
+    torch.manual_seed(0)
+    unet = ref.UNet2DConditionModel(**_as_lists(cfg)).eval().to(dev)
+    g = torch.Generator().manual_seed(5)
+    cd = cfg["cross_attention_dim"]
+    sample = torch.randn((2, 4, hw, hw), generator=g).to(dev)
+    ehs = torch.randn((2, cross_tokens, cd), generator=g).to(dev)
+    added = None
+    if cfg.get("addition_embed_type") == "text_time":
+        nt = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
+        added = {"text_embeds": torch.randn((2, nt), generator=g).to(dev),
+                 "time_ids": torch.tensor([[64., 64., 0., 0., 64., 64.]]).repeat(2, 1).to(dev)}
+
+    def fwd(dtype):
+        ak = None if added is None else {"text_embeds": added["text_embeds"].to(dtype), "time_ids": added["time_ids"].to(dtype)}
+        return unet(sample.to(dtype), torch.tensor(481.0).to(dev), encoder_hidden_states=ehs.to(dtype), added_cond_kwargs=ak,
+                    return_dict=False)[0]
+    with torch.no_grad():
+        want = fwd(torch.float32)
+        unet.to(bf16)
+        floor = fwd(bf16)
+        assert cnt.n == 0
+        n_attn = len(unet.attn_processors)
+        proc = MI355XAttnProcessor()
+        unet.set_attn_processor(proc)                                            # the public call (one shared processor)
+        assert all(p is proc for p in unet.attn_processors.values())
+        got = fwd(bf16)
+        assert cnt.n == n_attn, f"{cnt.n} flash launches for {n_attn} attention layers"
+        # cross-attention K / V^T are kept per module while the caller passes the same text-embedding tensor
+        from diffusers_amd import ops
+        lin = []
+        orig = ops.linear
+        monkeypatch.setattr(ops, "linear", lambda *a, **k_: (lin.append(a[0].shape), orig(*a, **k_))[1])
+        ehs_b = ehs.to(bf16)
+        a1 = unet(sample.to(bf16), torch.tensor(481.0).to(dev), encoder_hidden_states=ehs_b, return_dict=False,
+                  added_cond_kwargs=None if added is None else {k: v.to(bf16) for k, v in added.items()})[0]
+        n1 = len(lin)
+        lin.clear()
+        a2 = unet(sample.to(bf16), torch.tensor(481.0).to(dev), encoder_hidden_states=ehs_b, return_dict=False,
+                  added_cond_kwargs=None if added is None else {k: v.to(bf16) for k, v in added.items()})[0]
+        assert len(lin) == n1 - 2 * (n_attn // 2) and torch.equal(a1, a2)        # second call: no K / V^T launches
+        ehs_b.mul_(0.5)                                                          # in-place edit: version bump -> recomputed
+        lin.clear()
+        a3 = unet(sample.to(bf16), torch.tensor(481.0).to(dev), encoder_hidden_states=ehs_b, return_dict=False,
+                  added_cond_kwargs=None if added is None else {k: v.to(bf16) for k, v in added.items()})[0]
+        assert len(lin) == n1 and not torch.equal(a3, a2)
+        monkeypatch.setattr(ops, "linear", orig)
+        unet.set_attn_processor(importlib.import_module(ref.__name__ + ".models.attention_processor").AttnProcessor2_0())
+        back = fwd(bf16)
+        assert torch.equal(back, floor)
+    rf, rg = _rel(floor, want), _rel(got, want)
+    print(f"[B3] reference UNet2DConditionModel ({n_attn} attention layers) after set_attn_processor(MI355XAttnProcessor()): rel-rms vs its "
+          f"fp32 run {rg:.3e} (AttnProcessor2_0 in bf16: {rf:.3e})")
+    assert rg <= gate(rf), (rg, rf)
+
+
+TINY_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(64, 128), layers_per_block=1,
+                 cross_attention_dim=64, attention_head_dim=(1, 2), down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"),
+                 up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"), transformer_layers_per_block=(1, 2),
+                 use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=32,
+                 projection_class_embeddings_input_dim=256)
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference sources not present")
+def test_processor_on_the_reference_unet_cpu(monkeypatch):
+    _run_processor(monkeypatch, "cpu", TINY_UNET, hw=16, gate=lambda f: max(1.5 * f, 2.5e-2))
+
+
+@pytest.mark.gpu
+def test_processor_on_the_reference_unet_tiny(monkeypatch):
+    _run_processor(monkeypatch, "cuda", TINY_UNET, hw=16, gate=lambda f: max(1.2 * f, 1.5e-2))
+
+
+@pytest.mark.gpu
+def test_processor_on_the_reference_unet_sdxl_width(monkeypatch):
+    """SDXL's widths and head geometry (640 / 1280 channels, heads of 64, 2048-wide text states, 77 tokens) with one
+    transformer layer per block, at 64 x 64 latents: S = 1024 and 256."""
+    cfg = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=1,
+               cross_attention_dim=2048, attention_head_dim=(5, 10, 20),
+               down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+               up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"), transformer_layers_per_block=(1, 1, 1),
+               use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=256,
+               projection_class_embeddings_input_dim=2816)
+    _run_processor(monkeypatch, "cuda", cfg, hw=64, gate=lambda f: 1.2 * f)
