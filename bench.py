@@ -679,7 +679,7 @@ def measure_other_config(config, dev, rank, world, args, units, warmup, n_steps=
     for _ in range(max(warmup, 1)):          # at least one: variant lookup, graph capture
         out = fn()
     _sync()
-    if world > 1:
+    if _pg():
         torch.distributed.barrier()
     _sync()
     t0 = time.perf_counter()
@@ -687,7 +687,7 @@ def measure_other_config(config, dev, rank, world, args, units, warmup, n_steps=
         out = fn()
     _sync()
     mine_s = time.perf_counter() - t0
-    if world > 1:
+    if _pg():
         torch.distributed.barrier()
     _sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
@@ -738,7 +738,7 @@ def run_other_config(args, argv):
     result = measure_other_config(args.config, dev, rank, world, args, args.steps, args.warmup, n_steps=args.denoise_steps)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if _pg():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     return result
@@ -794,6 +794,11 @@ def dropin_leg(unet, vae, inp, steps, hw, ref_img_fp32, engine_images_per_s):
     return out
 
 
+def _pg() -> bool:
+    """A default process group exists: N > 1 ranks, or ONE rank started by a launcher (distributed.init_from_env)."""
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
@@ -822,7 +827,7 @@ def main(argv=None):
 
     # rank 0 owns the "prompts"; one broadcast of the embeddings over RCCL, then every rank keeps its shard
     inputs = synth_inputs(world, args.tiny, dev)
-    if world > 1:
+    if _pg():          # (also with ONE launched rank: the RCCL path of the 8-GPU job runs on a single-GPU box)
         if rank != 0:
             inputs = {k: torch.empty_like(v) for k, v in inputs.items()}
         D.broadcast_tensors(inputs, src=0)
@@ -854,7 +859,7 @@ def main(argv=None):
             img = one_image()
     _sync()
     log("timed region")
-    if world > 1:
+    if _pg():
         torch.distributed.barrier()
     _sync()
     t0 = time.perf_counter()
@@ -862,12 +867,12 @@ def main(argv=None):
         img = one_image()
     _sync()
     mine_s = time.perf_counter() - t0
-    if world > 1:
+    if _pg():
         torch.distributed.barrier()
     _sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     per_rank = [args.steps / mine_s]
-    if world > 1:
+    if _pg():
         tt = torch.tensor([args.steps / mine_s], dtype=torch.float64, device=dev)
         gathered = [torch.zeros_like(tt) for _ in range(world)]
         torch.distributed.all_gather(gathered, tt)
@@ -889,7 +894,8 @@ def main(argv=None):
                                if not args.tiny else "TINY plumbing config (not a benchmark)",
                    "global_batch": world, "parallelism": f"dp{world} (independent prompts, replicas)",
                    "denoise_steps": args.denoise_steps, "hip_graph": state["graph"], "output_finite": finite,
-                   "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+                   "rccl_ranks": torch.distributed.get_world_size() if _pg() else 1,
+                   "process_group": D.backend_name(),     # "nccl" = RCCL; None: a lone process without a launcher (no collectives)
                    "tuned_live": _tuned_live(),
                    "images_per_s_per_rank": per_rank},
     }
@@ -950,7 +956,7 @@ def main(argv=None):
             result["other_configs"] = other_configs_leg(dev, args)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if _pg():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     return result

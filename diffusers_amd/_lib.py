@@ -90,6 +90,8 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "da_version": (_i, []),
+    "da_sizeof_gemm_params": (C.c_size_t, []),
+    "da_sizeof_attention_params": (C.c_size_t, []),
     "da_last_error": (C.c_char_p, []),
     "da_set_launch_events": (_i, [_vp, _vp]),
     "da_gemm_bf16": (_i, [C.POINTER(GemmParams), _vp]),
@@ -138,6 +140,7 @@ SIGNATURES = {
     "da_plan_arg_kinds": (C.c_char_p, [_i]),
 }
 
+ABI_VERSION = 5              # include/diffusers_amd.h DA_ABI_VERSION
 _lib = None
 _tls = threading.local()     # .recorder: the plan recorder of this thread (diffusers_amd/plan.py), if one is active
 
@@ -163,6 +166,13 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.restype = res
         fn.argtypes = args
+    # ABI handshake (include/diffusers_amd.h DA_ABI_VERSION): the parameter structs carry no size field, so a library built from
+    # another header revision than these ctypes mirrors must be refused before the first launch reads a struct
+    got = (lib.da_version(), lib.da_sizeof_gemm_params(), lib.da_sizeof_attention_params())
+    want = (ABI_VERSION, C.sizeof(GemmParams), C.sizeof(AttentionParams))
+    if got != want:
+        raise RuntimeError(f"{LIB_PATH} has ABI (version, sizeof da_gemm_params, sizeof da_attention_params) = {got}, this package "
+                           f"expects {want}: rebuild the extension (`python -m diffusers_amd.build`)")
     _lib = lib
     return lib if rec is None else rec.proxy
 

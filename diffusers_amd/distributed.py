@@ -16,12 +16,16 @@ import torch.distributed as dist
 
 
 def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
-    """(rank, world_size, local_rank) from torchrun's env; initialises the default process group when world_size > 1.
-    backend defaults to "nccl" (= RCCL on ROCm) when a HIP device is present, else "gloo"."""
+    """(rank, world_size, local_rank) from torchrun's env; initialises the default process group when world_size > 1 -- and
+    also for ONE rank when the process was started by a launcher (RANK and WORLD_SIZE both exported, as
+    ``python -m torch.distributed.run --nproc-per-node 1`` does): a single-GPU box then runs the same RCCL initialisation,
+    broadcast, barrier and reductions the 8-GPU job runs, instead of skipping them.  backend defaults to "nccl" (= RCCL on
+    ROCm) when a HIP device is present, else "gloo"."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -42,7 +46,7 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
 
 def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0) -> Dict[str, torch.Tensor]:
     """Broadcast a dict of pre-allocated, identically shaped tensors from ``src`` (one collective per tensor)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():     # (a one-rank process group still runs the collective: same RCCL path as N ranks)
         return tensors
     for k in sorted(tensors):
         dist.broadcast(tensors[k], src=src)
@@ -58,7 +62,7 @@ def select_shard(tensors: Dict[str, torch.Tensor], idx: Sequence[int]) -> Dict[s
 def gather_images(local: torch.Tensor, n_items: int, dst: int = 0):
     """Gather per-rank image batches [n_local, ...] to ``dst`` and restore prompt order (round-robin sharding).
     Ranks may hold different counts; every rank pads to ceil(n_items / world)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     per = (n_items + world - 1) // world
@@ -77,8 +81,13 @@ def gather_images(local: torch.Tensor, n_items: int, dst: int = 0):
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def backend_name() -> str | None:
+    """"nccl" (RCCL) / "gloo" of the default process group, None without one."""
+    return dist.get_backend() if dist.is_initialized() else None

@@ -157,7 +157,12 @@ static int run_plan_file(const char* path) {
 }
 
 int main(int argc, char** argv) {
-  std::printf("libdiffusers_amd ABI version %d\n", da_version());
+  std::printf("libdiffusers_amd ABI version %d (header %d)\n", da_version(), DA_ABI_VERSION);
+  if (da_version() != DA_ABI_VERSION || da_sizeof_gemm_params() != sizeof(da_gemm_params) ||
+      da_sizeof_attention_params() != sizeof(da_attention_params)) {
+    std::fprintf(stderr, "ABI mismatch: the library was built from another revision of include/diffusers_amd.h\n");
+    return 3;
+  }
   if (argc > 1) return run_plan_file(argv[1]);
   const int M = 200, N = 128, K = 256;
   std::vector<uint16_t> x(M * K), w(N * K), b(N), y(M * N);

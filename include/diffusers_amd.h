@@ -86,7 +86,16 @@ extern "C" {
 #define DA_STAGE_PINGPONG 6    /* K2 tiles: 2-pair ring, the two K-groups half an iteration apart (each stages its own slices) */
 #define DA_STAGE_PINGPONG3 7   /* K2 tiles: 3-pair ring, ditto */
 
+/* ABI version: bumped on EVERY change of a parameter struct's layout or of an entry point's signature.  A host checks it once after
+ * loading the library -- `da_version() == DA_ABI_VERSION` of the header it was compiled against, and, for hosts that mirror the
+ * structs by hand (ctypes, JNI, cgo), `da_sizeof_*()` against their own sizeof -- because the structs carry no size field: a host
+ * built against an older header would pass shorter structs and the library would read garbage for the new members
+ * (da_gemm_params.vt is a STORE address).  History: 1 = rounds 1-3; 4 = round 4 (da_gemm_params.vt / vt_col0 / ld_vt,
+ * da_attention_params.algo); 5 = round 5 (this header). */
+#define DA_ABI_VERSION 5
 int da_version(void);
+size_t da_sizeof_gemm_params(void);
+size_t da_sizeof_attention_params(void);
 /* Timing hook (no reference counterpart; bench.py's roofline legs): arm two HIP events (hipEvent_t, created by the caller with
  * timing enabled) for the calling thread.  The NEXT kernel this library launches on that thread records `start_event` at the begin
  * of its dispatch, and every launch until the pair is cleared with (NULL, NULL) records `stop_event` at the end of its dispatch

@@ -1,5 +1,6 @@
 """CPU: the C-ABI library builds/loads and exports every symbol include/diffusers_amd.h declares; host-side logic of the
 product (schedule tables, parameter inventories, weight packing, argument validation) -- no kernel is launched."""
+import ctypes as C
 import re
 from pathlib import Path
 
@@ -26,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/diffusers_amd.h but not exported"
     assert sorted(L.SIGNATURES) == declared, "ctypes signature table and header disagree"
-    assert lib.da_version() >= 1
+    assert lib.da_version() == L.ABI_VERSION and lib.da_sizeof_gemm_params() == C.sizeof(L.GemmParams)
 
 
 def test_struct_layout_matches_header_field_order():

@@ -213,3 +213,24 @@ def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "2", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert Path(cmd[cmd.index("--master-port") + 2]).name == "bench.py"
+
+
+def test_bench_main_one_launched_rank_runs_the_collectives(tmp_path):
+    """ONE rank under torch.distributed.run (what `tests/test_distributed_gpu.py` does on the single-GPU box with RCCL): the process
+    group IS initialised and the broadcast / barrier / max-over-ranks / all_gather run through it instead of taking the
+    lone-process early-outs -- `config.process_group` names the backend (gloo here, nccl on the GPU)."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "tests" / "bench_cpu_worker.py"), "--gpus", "1", "--steps", "1", "--warmup",
+           "1", "--tiny", "--no-graph", "--denoise-steps", "2"]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["config"]["rccl_ranks"] == 1 and rec["config"]["process_group"] == "gloo"
+    assert len(rec["config"]["images_per_s_per_rank"]) == 1 and rec["config"]["tuned_live"] == 0

@@ -141,7 +141,7 @@ def test_plan_create_rejects_malformed_ops():
 def test_recording_is_per_thread_and_exclusive():
     import threading
     with P.recording(private_pool=False) as rec:
-        assert L.load() is rec.proxy and getattr(rec.proxy, "da_version")() == 1       # queries pass through
+        assert L.load() is rec.proxy and getattr(rec.proxy, "da_version")() == L.ABI_VERSION       # queries pass through
         seen = []
         t = threading.Thread(target=lambda: seen.append(L.load()))
         t.start(); t.join()
