@@ -87,6 +87,33 @@ def _tuned_live() -> int:
     return int(tuning.LIVE_COUNT)
 
 
+def box_mfma_probe(target_ms: float = 50.0):
+    """`config.box_mfma_tflops`: the register-only MFMA loop of the library (da_mfma_probe, csrc/version.hip) for ~50 ms BEFORE the
+    timed region -- matrix-pipe issue rate x the clock this box sustains under matrix load.  A normaliser for comparing lines
+    measured on different boxes of the pool (+- 8 % on one build), never a peak: fractions stay against 2.5 PFLOP/s."""
+    import ctypes
+    from diffusers_amd import _lib as L
+    lib = L.load()
+    sink = torch.zeros(4, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    flop = ctypes.c_double(0.0)
+    blocks, iters = 2048, 2000
+
+    def run(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.da_mfma_probe(blocks, n, sink.data_ptr(), ctypes.byref(flop), st), "da_mfma_probe")
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1), flop.value
+    run(200)                                     # clocks up, code object loaded
+    ms, fl = run(iters)
+    iters = max(200, int(iters * target_ms / max(ms, 1e-3)))
+    ms, fl = run(iters)
+    return {"tflops": fl / (ms * 1e-3) / 1e12, "ms": ms, "what": f"da_mfma_probe: {blocks} workgroups x 4 waves x {iters} x 16 "
+            "v_mfma_f32_32x32x16_bf16, registers only"}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -292,7 +319,9 @@ def roofline_leg(pipe, mine, world, images_per_s):
         try:
             tr = json.loads(TRAFFIC_FILE.read_text())
             if tr.get("build_fingerprint") == fp:
-                traffic, note = tr["igemm_bytes_per_launch"], tr.get("source", str(TRAFFIC_FILE.name))
+                traffic = tr["igemm_bytes_per_launch"]
+                note = (f"NOT measured in this run: replayed from {TRAFFIC_FILE.name}, measured on build {fp} (the library this run "
+                        f"loaded) on {tr.get('measured_on', 'an earlier date (unstamped)')} by " + tr.get("source", "rocprofv3 --pmc"))
             else:
                 note = (f"stale: {TRAFFIC_FILE.name} was measured on build {tr.get('build_fingerprint', 'unstamped (round 2)')}, "
                         f"this library is {fp}; re-run tools/gpu_r4.sh traffic")
@@ -566,6 +595,7 @@ def reference_legs(engine_img, engine_lat, unet_sd, vae_sd, ucfg, vcfg, ucfg_min
 
 
 # ---- the other BASELINE configs under the same driver contract ------------------------------------------
+WAN_VAE_DECODE_TFLOP = 275.0   # algorithmic (unpadded channels) flop of AutoencoderKLWan.decode at 21 x 60 x 104 latents
 OTHER_CONFIGS = {
     # name: (metric, unit, workload description, default sampler steps, algorithmic TFLOP per unit at that many steps)
     "sd15": ("images/sec @ stable-diffusion-v1-5 512x512 50-step DDIM CFG 7.5 bf16", "images/s",
@@ -575,8 +605,9 @@ OTHER_CONFIGS = {
              "FLUX.1-schnell transformer (11.9 B params) x {n} FlowMatchEuler steps, no CFG, 4096 image + 512 text tokens + 16-channel "
              "AutoencoderKL decode to 1024x1024; 1 prompt per GPU", 4, lambda n: n * 74.3846 + 10.5),
     "wan": ("videos/sec @ Wan2.1-T2V-1.3B 832x480x81 50-step CFG 5.0 bf16", "videos/s",
-            "Wan2.1-T2V-1.3B transformer x {n} FlowMatchEuler steps, CFG 5.0 (cond + uncond as one batch-2 call), 32 760 tokens, "
-            "latents out; 1 prompt per GPU", 50, lambda n: n * 2 * 283.0018),
+            "Wan2.1-T2V-1.3B as shipped (pipeline_wan.py:52-59, :560-661): transformer x {n} UniPC steps (flow_prediction, order 2, fp32 "
+            "latents), CFG 5.0 (cond + uncond as one batch-2 call), 32 760 tokens, + AutoencoderKLWan.decode of the 21 x 60 x 104 latents "
+            "to 81 x 480 x 832; 1 prompt per GPU", 50, lambda n: n * 2 * 283.0018 + WAN_VAE_DECODE_TFLOP),
     "ddpm": ("images/sec @ google/ddpm-cat-256 50-step DDPM", "images/s",
              "UNet2DModel (114 M params) x {n} ancestral DDPM steps at 256x256, batch 1 per GPU", 50, lambda n: n * 0.4970),
 }
@@ -610,13 +641,13 @@ def _build_other(config, dev, rank, tiny, no_graph):
     elif config == "wan":
         if tiny:
             raise SystemExit("--config wan has no --tiny form here (tests/ cover the tiny pipeline)")
-        pipe = factory.build_wan_pipeline(device=dev, tiny=False, seed=9)
+        pipe = factory.build_wan_pipeline(device=dev, tiny=False, seed=9, scheduler="unipc", with_vae=True)
         pe, ne = (torch.randn((1, 512, 4096), generator=g).to(bf).to(dev) for _ in range(2))
-        x = torch.randn((1, 16, 21, 60, 104), generator=g).to(bf).to(dev)
+        x = torch.randn((1, 16, 21, 60, 104), generator=g).to(dev)                      # fp32 latents (pipeline_wan.py:559-572)
 
-        def unit(n, graph=not no_graph):
+        def unit(n, graph=not no_graph, output_type="raw"):
             return lambda: pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=x, num_inference_steps=n, guidance_scale=5.0,
-                                height=480, width=832, num_frames=81, use_graph=graph).images
+                                height=480, width=832, num_frames=81, use_graph=graph, output_type=output_type).images
     else:
         pipe = factory.build_ddpm_pipeline(device=dev, tiny=tiny, seed=0)
 
@@ -692,6 +723,25 @@ def measure_other_config(config, dev, rank, world, args, units, warmup, n_steps=
     _sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     scale = n / run_steps if extrapolate_from else 1.0
+    side = {}
+    if config == "wan":
+        # the unit holds a decode that does not scale with the step count: time the latents-only unit next to it (outside the
+        # contract's timed region) -- decode = full - latents-only; an extrapolated unit scales only the sampler part
+        lat_fn = unit(run_steps, output_type="latent")
+        lat_fn()
+        _sync()
+        t1 = time.perf_counter()
+        for _ in range(units):
+            lat_fn()
+        _sync()
+        lat_s = (time.perf_counter() - t1) / units
+        full_s = elapsed / units
+        dec_s = max(full_s - lat_s, 0.0)
+        side = {"seconds_per_unit_latents_only": lat_s * scale, "seconds_decode": dec_s,
+                "videos_per_s_without_decode": 1.0 / (lat_s * scale), "seconds_per_sampler_step": lat_s / run_steps}
+        if extrapolate_from:
+            elapsed_n = units * (lat_s * scale + dec_s)
+            scale = elapsed_n / elapsed
     value = world * units / (elapsed * scale)
     tfl = tflop_of(n)
     ach = value / world * tfl
@@ -701,7 +751,7 @@ def measure_other_config(config, dev, rank, world, args, units, warmup, n_steps=
            "config": {"workload": what.format(n=n), "global_batch": world, "parallelism": f"dp{world} (independent prompts, replicas)",
                       "denoise_steps": n, "output_finite": bool(torch.isfinite(out.float()).all()),
                       "rank_seconds_per_unit": mine_s * scale / units, "tuned_live": _tuned_live(),
-                      "algorithmic_tflop_per_unit": tfl},
+                      "algorithmic_tflop_per_unit": tfl, **side},
            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                         "traffic": None, "kernel": "whole unit (end to end): algorithmic TFLOP of SURVEY.md 8d / wall time"}}
     if extrapolate_from:
@@ -842,6 +892,13 @@ def main(argv=None):
                     latents=mine["latents"].clone(), num_inference_steps=args.denoise_steps, guidance_scale=GUIDANCE,
                     height=hw, width=hw, output_type=output_type, use_graph=state["graph"]).images
 
+    box = None
+    if not args.tiny and dev.type == "cuda":
+        try:
+            box = box_mfma_probe()
+            log(f"box normaliser: {box['tflops']:.0f} TFLOP/s on the register-only MFMA loop ({box['ms']:.1f} ms)")
+        except Exception as e:  # a diagnostic must not cost the line
+            box = {"tflops": None, "error": f"{type(e).__name__}: {e}"}
     log("warm-up (tunes GEMM variants for unseen shapes, captures the denoising-step HIP graph)")
     img = None
     for _ in range(args.warmup):
@@ -897,6 +954,7 @@ def main(argv=None):
                    "rccl_ranks": torch.distributed.get_world_size() if _pg() else 1,
                    "process_group": D.backend_name(),     # "nccl" = RCCL; None: a lone process without a launcher (no collectives)
                    "tuned_live": _tuned_live(),
+                   "box_mfma_tflops": box["tflops"] if box else None, "box_mfma_probe": box,
                    "images_per_s_per_rank": per_rank},
     }
 

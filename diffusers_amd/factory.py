@@ -96,13 +96,21 @@ def build_wan_transformer(cfg: dict, seed: int = 9, device="cuda", init_device: 
 
 
 def build_wan_pipeline(device="cuda", tiny: bool = False, seed: int = 9, init_device: Optional[str] = None,
-                       flow_shift: float = 3.0, with_vae: bool = False):
-    """Wan2.1-T2V-1.3B (BASELINE config 5) or its tiny sibling with the FlowMatch-Euler scheduler of SURVEY.md 8d;
-    ``with_vae`` adds AutoencoderKLWan (seed + 12) so that ``output_type="pt"`` decodes the video."""
+                       flow_shift: float = 3.0, with_vae: bool = False, scheduler: str = "flowmatch"):
+    """Wan2.1-T2V-1.3B (BASELINE config 5) or its tiny sibling.  ``scheduler="unipc"``: the sampler the checkpoint ships
+    (pipeline_wan.py:52-59: UniPCMultistepScheduler, flow_prediction, use_flow_sigmas, flow_shift 3.0 for 480p), else the
+    FlowMatch-Euler scheduler of SURVEY.md 8d; ``with_vae`` adds AutoencoderKLWan (seed + 12) so that
+    ``output_type="raw" / "pt"`` decodes the video."""
     cfg = dinit.TINY_WAN if tiny else dinit.WAN_1_3B
     idev = init_device or ("cpu" if tiny else str(device))
     tr, _ = build_wan_transformer(cfg, seed=seed, device=device, init_device=idev)
-    sch = FlowMatchEulerDiscreteScheduler(shift=flow_shift, use_dynamic_shifting=False)
+    if scheduler == "unipc":
+        from .schedulers import UniPCMultistepScheduler
+        sch = UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=flow_shift)
+    elif scheduler == "flowmatch":
+        sch = FlowMatchEulerDiscreteScheduler(shift=flow_shift, use_dynamic_shifting=False)
+    else:
+        raise ValueError("scheduler must be 'unipc' or 'flowmatch'")
     vae = None
     if with_vae:
         vae, _ = build_wan_vae(dinit.TINY_WAN_VAE if tiny else dinit.WAN_VAE, seed=seed + 12, device=device, init_device=idev)

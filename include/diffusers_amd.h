@@ -103,6 +103,12 @@ size_t da_sizeof_attention_params(void);
  * profiler reports it -- an event pair recorded around the call from the host also counts the marker packets' own processing.
  * Both or neither must be NULL.  Launch results do not depend on it. */
 int da_set_launch_events(void* start_event, void* stop_event);
+/* Box normaliser (no reference counterpart; bench.py `config.box_mfma_tflops`): a register-only loop of
+ * v_mfma_f32_32x32x16_bf16 -- `blocks` workgroups of four waves, `iters` x 16 MFMAs per wave, no memory traffic.  Its rate is the
+ * matrix pipe's issue rate times the clock THIS box sustains under matrix load; the pool's boxes differ by +- 8 % on one build, so
+ * cross-box lines are compared after dividing by it.  *flop (may be NULL): the launch's work.  `sink`: any device address of >= 4
+ * bytes (never written). */
+int da_mfma_probe(int blocks, int iters, void* sink, double* flop, void* stream);
 /* name of the HIP runtime error behind this thread's most recent DA_ERR_LAUNCH (diagnostics only) */
 const char* da_last_error(void);
 

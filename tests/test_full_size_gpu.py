@@ -439,3 +439,48 @@ def test_flux_schnell_full_size_4_step_image_psnr_vs_reference_pipeline():
           f"torch-bf16 vs fp32 (noise floor) = {pf:.1f} dB, engine vs torch-bf16 = {_psnr01(img, floor):.1f} dB")
     assert img.shape == ref.shape and torch.isfinite(img.float()).all()
     _gate_image(ps, pf, "FLUX.1-schnell 4-step image")
+
+
+def test_wan_vae_full_resolution_decode_vs_the_reference_class():
+    """AutoencoderKLWan.decode (autoencoder_kl_wan.py:1187-1217) at the FULL width and resolution of BASELINE config 5 on a
+    reduced clip: 5 latent frames of 60 x 104 -> 17 frames of 480 x 832 (the full clip is 21 -> 81 frames of the same size; every
+    kernel shape, the 96 -> 128 channel padding, the KSKIP instantiation and the frame-shifted in-place accumulation of the causal
+    convs are the ones the 81-frame decode runs).  Engine (whole clip resident, one launch per temporal tap) vs the REAL reference
+    class in fp32 on this GPU (frame-by-frame feature cache), with the reference's own bf16 run as the floor."""
+    from diffusers_amd import factory, init as dinit
+    refpkg = _reference()
+    if refpkg is None:
+        pytest.skip("reference archive oracle/_ref/diffusers_ref.zip did not ship")
+    cfg = dinit.WAN_VAE
+    vae, sd = factory.build_wan_vae(cfg, seed=21, device=DEV, init_device=DEV)
+    g = torch.Generator("cpu").manual_seed(77)
+    z = torch.randn((1, 16, 5, 60, 104), generator=g)
+    mean = torch.tensor(cfg["latents_mean"]).view(1, 16, 1, 1, 1)
+    std = torch.tensor(cfg["latents_std"]).view(1, 16, 1, 1, 1)
+    z = (z * std + mean).to(DEV)                                          # de-normalised latents, as the pipeline hands them over
+
+    def run_ref(dtype):
+        m = refpkg.AutoencoderKLWan(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}).to(DEV)
+        own = m.state_dict()
+        unknown = [k for k in sd if k not in own]
+        assert not unknown, unknown[:3]
+        m.load_state_dict({k: v.to(DEV, torch.float32) for k, v in sd.items()}, strict=False)      # decoder half: the path
+        m = m.to(dtype).eval()
+        with torch.no_grad():
+            out = m.decode(z.to(dtype), return_dict=False)[0]
+        del m
+        torch.cuda.empty_cache()
+        return out
+    want = run_ref(torch.float32)
+    floor = run_ref(bf16)
+    got = vae.decode(z.to(bf16)).sample
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (1, 3, 17, 480, 832) and torch.isfinite(got.float()).all()
+    rr, rf = rel_rms(got, want), rel_rms(floor, want)
+    ps, pf = _psnr01(got, want), _psnr01(floor, want)
+    print(f"[parity] AutoencoderKLWan.decode at full width / 480 x 832, 5 -> 17 frames vs the REAL reference class in fp32: rel_rms {rr:.3e} "
+          f"(reference bf16: {rf:.3e}), PSNR {ps:.1f} dB (reference bf16: {pf:.1f} dB)")
+    assert rr < 3e-2 and rr <= 1.25 * rf, (rr, rf)
+    _gate_image(ps, pf, "AutoencoderKLWan.decode")
+    del vae, sd
+    torch.cuda.empty_cache()

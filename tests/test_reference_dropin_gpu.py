@@ -119,3 +119,108 @@ def test_engine_components_under_the_reference_pipeline_at_full_size():
     ps2 = _psnr(img, want)
     print(f"[drop-in] full size: engine pipeline vs the all-reference fp32 run: PSNR {ps2:.1f} dB; vs engine-under-reference: {_psnr(img, got):.1f} dB")
     assert ps2 >= 40.0 and ps2 >= pf - 1.0
+
+
+# ---- the other three pipeline families on hardware: the unchanged reference `__call__` over engine components ----
+def _families():
+    import diffusers_amd as da
+    from diffusers_amd import factory, init as dinit
+    from test_text_encoding import _as_lists, _clip, _t5, _t5_tokenizer, _tokenizer
+    return da, factory, dinit, _as_lists, _clip, _t5, _t5_tokenizer, _tokenizer
+
+
+def test_engine_under_the_reference_flux_pipeline_on_hardware():
+    """`FluxPipeline.__call__` (pipelines/flux/pipeline_flux.py:886-960) with engine FluxTransformer2DModel + AutoencoderKL +
+    FlowMatchEulerDiscreteScheduler in its component slots: latent packing, image ids, timestep / 1000, sigmas= schedule."""
+    da, factory, dinit, _as_lists, _clip, _t5, _t5_tokenizer, _tokenizer = _families()
+    ref = RR.load_reference()
+    tok, nv = _tokenizer()
+    tok2, nv2 = _t5_tokenizer()
+    torch.manual_seed(0)
+    rtr = ref.FluxTransformer2DModel(**_as_lists(dinit.TINY_FLUX)).eval().to(DEV)
+    rvae = ref.AutoencoderKL(**_as_lists(dinit.TINY_FLUX_VAE)).eval().to(DEV)
+    rs = ref.FlowMatchEulerDiscreteScheduler(shift=1.0, use_dynamic_shifting=False)
+    pipe = ref.FluxPipeline(scheduler=rs, vae=rvae, text_encoder=_clip(nv, 64, seed=3).to(DEV), tokenizer=tok,
+                            text_encoder_2=_t5(nv2, d=64, seed=4).to(DEV), tokenizer_2=tok2, transformer=rtr)
+    pipe.set_progress_bar_config(disable=True)
+    lat = torch.randn(1, 64, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    kw = dict(prompt="hello a cat", num_inference_steps=3, guidance_scale=0.0, height=32, width=32, output_type="pt", max_sequence_length=16)
+    with torch.no_grad():
+        want = pipe(latents=lat.clone(), **kw).images                          # all-reference, fp32
+        pipe.to(bf16)
+        floor = pipe(latents=lat.clone().to(bf16), **kw).images                # all-reference, bf16
+    tr = da.from_reference_config(da.FluxTransformer2DModel, rtr.config)
+    tr.load_state_dict(rtr.state_dict(), device=DEV)
+    vae = da.from_reference_config(da.AutoencoderKL, rvae.config)
+    vae.load_state_dict(rvae.state_dict(), device=DEV)
+    pipe.register_modules(transformer=tr, vae=vae, scheduler=da.FlowMatchEulerDiscreteScheduler.from_config(rs.config))
+    with torch.no_grad():
+        got = pipe(latents=lat.clone().to(bf16), **kw).images
+    ps, pf = _psnr(got, want), _psnr(floor, want)
+    print(f"[drop-in] engine under the reference FluxPipeline.__call__ on the GPU: PSNR {ps:.1f} dB vs the all-reference fp32 run "
+          f"(all-reference bf16: {pf:.1f} dB)")
+    assert got.shape == want.shape and ps >= 40.0
+
+
+def test_engine_under_the_reference_wan_pipeline_on_hardware():
+    """`WanPipeline.__call__` (pipelines/wan/pipeline_wan.py:560-661) as shipped -- UniPC (flow, order 2), two transformer calls per
+    step, fp32 latents, latent de-normalisation, AutoencoderKLWan.decode, video post-processing -- over engine components."""
+    da, factory, dinit, _as_lists, _clip, _t5, _t5_tokenizer, _tokenizer = _families()
+    ref = RR.load_reference()
+    tok, nv = _t5_tokenizer()
+    torch.manual_seed(0)
+    rtr = ref.WanTransformer3DModel(**_as_lists(dinit.TINY_WAN)).eval().to(DEV)
+    rvae = ref.AutoencoderKLWan(**_as_lists(dinit.TINY_WAN_VAE)).eval().to(DEV)
+    rs = ref.UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=3.0)
+    pipe = ref.WanPipeline(tokenizer=tok, text_encoder=_t5(nv, d=64, seed=5, umt5=True).to(DEV), vae=rvae, scheduler=rs, transformer=rtr)
+    pipe.set_progress_bar_config(disable=True)
+    lat = torch.randn(1, 16, 3, 8, 8, generator=torch.Generator().manual_seed(1)).to(DEV)
+    kw = dict(prompt="a cat on the mat", negative_prompt="red", num_inference_steps=3, guidance_scale=5.0, height=64, width=64,
+              num_frames=9, output_type="pt", max_sequence_length=16)
+    with torch.no_grad():
+        want = pipe(latents=lat.clone(), **kw).frames
+        pipe.to(bf16)
+        floor = pipe(latents=lat.clone(), **kw).frames
+    tr = da.from_reference_config(da.WanTransformer3DModel, rtr.config)
+    tr.load_state_dict(rtr.state_dict(), device=DEV)
+    vae = da.from_reference_config(da.AutoencoderKLWan, rvae.config)
+    vae.load_state_dict(rvae.state_dict(), device=DEV)
+    pipe.register_modules(transformer=tr, vae=vae, scheduler=da.UniPCMultistepScheduler.from_config(rs.config))
+    with torch.no_grad():
+        got = pipe(latents=lat.clone(), **kw).frames
+    ps, pf = _psnr(got, want), _psnr(floor, want)
+    print(f"[drop-in] engine under the reference WanPipeline.__call__ (UniPC + AutoencoderKLWan) on the GPU: PSNR {ps:.1f} dB vs the "
+          f"all-reference fp32 run (all-reference bf16: {pf:.1f} dB)")
+    assert got.shape == want.shape == (1, 9, 3, 64, 64) and ps >= 40.0
+
+
+def test_engine_under_the_reference_sd_pipeline_on_hardware():
+    """`StableDiffusionPipeline.__call__` (pipelines/stable_diffusion/pipeline_stable_diffusion.py:1030-1060) with DDIM over engine
+    UNet2DConditionModel (SD1.5 block layout) + AutoencoderKL + DDIMScheduler."""
+    da, factory, dinit, _as_lists, _clip, _t5, _t5_tokenizer, _tokenizer = _families()
+    ref = RR.load_reference()
+    tok, nv = _tokenizer()
+    torch.manual_seed(0)
+    runet = ref.UNet2DConditionModel(**_as_lists(dinit.TINY_SD15_UNET)).eval().to(DEV)
+    rvae = ref.AutoencoderKL(**_as_lists(dinit.TINY_VAE)).eval().to(DEV)
+    rs = ref.DDIMScheduler(**factory.SD15_SCHEDULER)
+    pipe = ref.StableDiffusionPipeline(vae=rvae, text_encoder=_clip(nv, 64, seed=3).to(DEV), tokenizer=tok, unet=runet, scheduler=rs,
+                                       safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    pipe.set_progress_bar_config(disable=True)
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(2)).to(DEV)
+    kw = dict(prompt="hello a cat", negative_prompt="cat", num_inference_steps=4, guidance_scale=7.5, height=32, width=32, output_type="pt")
+    with torch.no_grad():
+        want = pipe(latents=lat.clone(), **kw).images
+        pipe.to(bf16)
+        floor = pipe(latents=lat.clone().to(bf16), **kw).images
+    unet = da.from_reference_config(da.UNet2DConditionModel, runet.config)
+    unet.load_state_dict(runet.state_dict(), device=DEV)
+    vae = da.from_reference_config(da.AutoencoderKL, rvae.config)
+    vae.load_state_dict(rvae.state_dict(), device=DEV)
+    pipe.register_modules(unet=unet, vae=vae, scheduler=da.DDIMScheduler.from_config(rs.config))
+    with torch.no_grad():
+        got = pipe(latents=lat.clone().to(bf16), **kw).images
+    ps, pf = _psnr(got, want), _psnr(floor, want)
+    print(f"[drop-in] engine under the reference StableDiffusionPipeline.__call__ (DDIM) on the GPU: PSNR {ps:.1f} dB vs the all-reference "
+          f"fp32 run (all-reference bf16: {pf:.1f} dB)")
+    assert got.shape == want.shape and ps >= 40.0

@@ -1,0 +1,56 @@
+#!/bin/bash
+# Round-5 gpurun stages.  usage: gpu_r5.sh "boundary benchfast ..."
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+WHAT=${1:-boundary}
+if [[ $WHAT == *boundary* ]]; then
+  timeout 900 python -m pytest tests/test_attention_boundary.py tests/test_distributed_gpu.py -m gpu -q -s --timeout 600 > $O/pytest_boundary.log 2>&1; echo "pytest boundary rc=$?"
+  grep -E "passed|failed|FAILED|Error|\[B3\]|\[B4\]|\[rccl\]" $O/pytest_boundary.log | tail -30
+fi
+if [[ $WHAT == *dropin* ]]; then
+  timeout 900 python -m pytest tests/test_reference_dropin_gpu.py -m gpu -q -s --timeout 600 -k "flux or wan or sd_pipeline" > $O/pytest_dropin.log 2>&1; echo "pytest dropin rc=$?"
+  grep -E "passed|failed|FAILED|Error|\[drop-in\]" $O/pytest_dropin.log | tail -30
+  timeout 900 python -m pytest tests/test_full_size_gpu.py -m gpu -q -s --timeout 600 -k "wan_vae" > $O/pytest_wanvae.log 2>&1; echo "pytest wan vae rc=$?"
+  grep -E "passed|failed|FAILED|Error|\[parity\]" $O/pytest_wanvae.log | tail -30
+fi
+if [[ $WHAT == *benchfast* ]]; then
+  timeout 900 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-other-configs > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+  cut -c1-1400 $O/bench.json; grep "^\[bench" $O/bench.err | tail -20
+fi
+if [[ $WHAT == *wanbench* ]]; then
+  timeout 900 python bench.py --config wan --steps 1 --warmup 1 --denoise-steps ${WAN_STEPS:-6} --no-cpu-baseline > $O/bench_wan.json 2> $O/bench_wan.err; echo "wan rc=$?"
+  cut -c1-1600 $O/bench_wan.json; tail -3 $O/bench_wan.err | cut -c1-300
+fi
+if [[ $WHAT == *fulltest* ]]; then
+  timeout 2400 python -m pytest tests -m gpu -q -s --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
+  grep -E "passed|failed|FAILED|Error" $O/pytest_gpu.log | tail -20
+  grep -E "\[parity\] (SDXL|FLUX|Wan|SD1.5|full|Auto)|\[drop-in\]|\[B3\]|\[B4\]|\[rccl\]" $O/pytest_gpu.log | tail -60
+fi
+if [[ $WHAT == *benchfull* ]]; then
+  timeout 1500 python bench.py --steps 3 --warmup 1 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"
+  cut -c1-300 $O/bench_full.json; grep "^\[bench" $O/bench_full.err | tail -40
+fi
+if [[ $WHAT == *traffic* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc_traffic; mkdir -p $O/pmc_traffic
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_traffic/fetch -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/fetch.log 2>&1; echo "pmc fetch rc=$?"
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_traffic/write -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/write.log 2>&1; echo "pmc write rc=$?"
+  cd $R
+  ALGO=$(python -c "import json;print(json.load(open('$O/bench_full.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null || python -c "import json;print(json.load(open('$R/profiles/r04r_bench_line_full.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null)
+  python tools/pmc_traffic.py $O/pmc_traffic/fetch $O/pmc_traffic/write $O/r05_sdxl_traffic.md $O/sdxl_traffic.json "$ALGO" 140
+  cp $O/sdxl_traffic.json $R/profiles/sdxl_traffic.json   # a later `benchfull` stage of this call reads it (roofline.traffic)
+  find $O/pmc_traffic -name '*kernel_trace*' -delete
+  find $O/pmc_traffic -name '*counter_collection.csv' -size +8M -delete
+  tail -4 $O/pmc_traffic/fetch.log | cut -c1-200
+fi
+if [[ $WHAT == *prof* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/prof
+  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o sdxl -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-reference --no-other-configs > $O/prof.log 2>&1; echo "prof rc=$?"
+  grep '"metric"' $O/prof.log | cut -c1-200
+  find $O/prof -name '*kernel_trace*' -size +30M -delete
+  cd $R
+  python tools/prof_summary.py $(find $O/prof -name '*kernel_stats.csv' | head -1) "r05 sdxl bench (--steps 1 --warmup 1)" > $O/prof_summary.md 2>> $O/prof.log; head -60 $O/prof_summary.md
+fi

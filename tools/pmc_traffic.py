@@ -88,6 +88,7 @@ def main():
     out = {"build_fingerprint": stamp.read_text().strip()[:16] if stamp.exists() else "unknown",   # as bench.build_fingerprint()
            "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 2x FETCH_SIZE correction) on the SDXL "
                      f"denoising-step kernels launched eagerly (tools/pmc_one_step.py); profiles/{out_md.name}",
+           "measured_on": __import__("time").strftime("%Y-%m-%d"),
            "unit": "bytes", "families": rec}
     out["source"] = out["source"].replace("igemm_bf16_kernel", "igemm")
     if ig:
