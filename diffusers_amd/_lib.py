@@ -51,6 +51,8 @@ class GemmParams(C.Structure):
         ("ln_parts", C.c_int), ("ln_s", C.c_void_p), ("ln_c", C.c_void_p), ("ln_eps", C.c_float), ("k_valid", C.c_int),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_longlong),
         ("vt", C.c_void_p), ("vt_col0", C.c_int), ("ld_vt", C.c_longlong),
+        ("xa_k", C.c_void_p), ("xa_vt", C.c_void_p), ("xa_skv", C.c_int), ("xa_skv_alloc", C.c_int), ("xa_k_ld", C.c_int),
+        ("xa_vt_ld", C.c_longlong), ("xa_scale", C.c_float),
     ]
 
 

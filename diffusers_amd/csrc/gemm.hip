@@ -110,6 +110,7 @@ bool tile_ok(const da_gemm_params& p, int tile) {
     // LayerNorm fold (round 4): nn.Linear, the tiles of the SDXL transformer blocks (gemm2_kernel.cuh dispatch_lnf)
     const bool lnf_lin = tile == DA_TILE_K2_128x80 || tile == DA_TILE_K2_128x160;          // producer and consumer
     const bool lnf_cons = lnf_lin || tile == DA_TILE_K1_128x256 || tile == DA_TILE_K1_256x128;   // consumer / transposed block only
+    if (p.xa_k) return !p.conv && p.split_k <= 1 && !geglu && !p.stats_out && !p.vt && tile == DA_TILE_K2_128x128;
     if (p.vt) return !p.conv && p.split_k <= 1 && !geglu && !p.stats_out && lnf_cons;
     if (p.stats_out || p.ln_stats) {
       if (p.conv || p.split_k > 1) return false;
@@ -119,7 +120,7 @@ bool tile_ok(const da_gemm_params& p, int tile) {
     return p.split_k <= 1 && (!geglu || geglu_ok) &&
            !(p.conv && (tile == DA_TILE_K2_80x128 || tile == DA_TILE_K1_256x256 || tile == DA_TILE_K1_256x320));
   }
-  if (p.vt) return false;   // the transposed column block exists in the second family only
+  if (p.vt || p.xa_k) return false;   // the transposed column block / cross-attention epilogue exist in the second family only
   // GEGLU pairs (value, gate) 32-column tiles inside one wave: the wave must own an even number of them
   if ((p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) &&
       (tile == DA_TILE_128x64 || tile == DA_TILE_64x64 || tile == DA_TILE_128x128_W8))

@@ -137,8 +137,14 @@ __device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int
 //          Consumer (ln_stats): mean / rstd of the rows a lane finishes, formed from the producer's partials (loaded with the
 //          other epilogue operands, behind the first LDS-DMA), and rstd * (acc - mean * s[n]) + c[n] applied to every
 //          accumulator group in front of the bias.
+// XA > 0 (round 5; one instantiation: the 128 x 128 two-K-group tile with the LayerNorm fold) = cross-attention in the epilogue
+//          of attn2.to_q (attention_processor.py:2743-2777 with encoder_hidden_states of <= 16 * XA text tokens): after the exchange a
+//          wave holds the finished q of 32 queries x ONE 64-wide head in the MFMA C layout -- which IS the B-operand layout of
+//          S^T = K . Q^T for a permuted order of the head's channels -- so the 77-key attention (scores, softmax, P . V) runs on the
+//          wave's own registers against K / V^T of the tile's two heads (LDS-DMA into the free ring), and the launch writes
+//          softmax(q k^T) v instead of q: one launch where there were two (to_q, flash attention) and no q round trip.
 template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false,
-          bool LNF = false>
+          bool LNF = false, int XA = 0>
 __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert((KG == 1 || KG == 2) && KG * WM * WN == 8, "eight waves: one or two K-groups");
@@ -149,6 +155,8 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   static_assert(!STREAMW || (KG == 1 && NSLOT == 2 && !CONV), "streaming-W loop: one K-group, two-slice ring, nn.Linear");
   static_assert(!GIL || (KG == 1 && !CONV && WN == 2 && (NT % 2) == 0), "GEGLU-interleaved ownership: two wave columns, value / gate tile pairs");
   static_assert(!LNF || (!CONV && !STREAMW), "LayerNorm fold: nn.Linear instantiations of the ring loops");
+  static_assert(XA == 0 || (LNF && KG == 2 && WM == 2 && WN == 2 && MT == 4 && NT == 4 && NSLOT == 2 && XA <= 8),
+                "cross-attention epilogue: the 128 x 128 two-K-group tile (a wave finishes 32 rows x one 64-wide head)");
   constexpr int SW = PP ? 4 : 8;                          // waves that share the staging of one unit (PP: one slice, own group)
   constexpr int UX = PP ? PX : KG * PX, UW = PP ? PW : KG * PW;   // pieces of that unit
   constexpr int XI = (UX + SW - 1) / SW, WI = (UW + SW - 1) / SW;   // LDS-DMA instructions per wave per unit (upper bound)
@@ -156,6 +164,10 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   static_assert(NSLOT == 2 || NSLOT == 3, "ring of 2 or 3 slice pairs");
   constexpr int DUMP = 1024;                               // where the out-of-range pieces of ragged tiles and the prefetch land
   constexpr int LNSC = LNF ? 2 * BN * 4 : 0;               // LNF consumer: the block's s[n] / c[n] (fp32), behind the dump KiB
+  // XA: K / V^T of the tile's two heads in the upper half of the ring once the K loop is over (the lower half carries the partial-sum
+  // exchange, then the output staging)
+  constexpr int XA_K_OFF = 4 * MT * NT * 1024, XA_KB = XA * 16 * 128, XA_V_OFF = XA_K_OFF + 32768;
+  static_assert(XA == 0 || (2 * XA_KB <= 32768 && XA_V_OFF + 32768 <= NSLOT * PAIR), "cross-attention operands do not fit the ring");
   static_assert(NSLOT * PAIR + DUMP + LNSC <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
   static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows are staged in 8-row pieces");
   static_assert(!CONV || (UX % SW) == 0, "conv: the slice of an activation piece must be a compile-time constant");
@@ -731,6 +743,36 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (XA > 0) {
+      // The ring is free of readers: K ([16 XA keys][64 d], 128-byte rows) and V^T ([64 d][128 keys], 256-byte rows) of the tile's
+      // two heads go to its upper half by LDS-DMA while the partial sums cross the lower half.  16-byte slots XOR-swizzled on the
+      // SOURCE side (the LDS image of a DMA is lane-linear): K slot ^ ((row >> 1) & 7), V^T slot ^ (row & 15) -- the 8-byte
+      // fragment reads of the attention part are then conflict-free.  Keys past xa_skv_alloc arrive as hardware zeros (bit 31).
+      if (p.xa_k) {
+        constexpr int KP = 2 * XA, NPK = 2 * KP, NPV = 32, NP = NPK + NPV;
+        const int hb = n0 >> 6, bq = m0 / p.rows_per_batch;
+        __amdgpu_buffer_rsrc_t rs_k = uniform_rsrc(p.xa_k, 0x7fffffff), rs_v = uniform_rsrc(p.xa_vt, 0x7fffffff);
+#pragma unroll
+        for (int i = 0; i < (NP + 7) / 8; ++i) {
+          const int q = i * 8 + wave;                     // wave-uniform piece index
+          if (q < NPK) {
+            const int hh = q >= KP ? 1 : 0, r8 = q - hh * KP;
+            const int row = r8 * 8 + (lane >> 3);
+            const int sl = (lane & 7) ^ ((row >> 1) & 7);
+            const int off = ((bq * p.xa_skv_alloc + row) * p.xa_k_ld + (hb + hh) * 64 + sl * 8) * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, DA2_LDS(smem + XA_K_OFF + hh * XA_KB + r8 * 1024), 16,
+                                                     off | (row < p.xa_skv_alloc ? 0 : (int)0x80000000), 0, 0, 0);
+          } else if (q < NP) {
+            const int qv = q - NPK, hh = qv >> 4, r4 = qv & 15;
+            const int row = r4 * 4 + (lane >> 4);
+            const int sl = (lane & 15) ^ (row & 15);
+            const int off = (((hb + hh) * 64 + row) * (int)p.xa_vt_ld + bq * p.xa_skv_alloc + sl * 8) * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, DA2_LDS(smem + XA_V_OFF + hh * 16384 + r4 * 1024), 16,
+                                                     off | (sl * 8 < p.xa_skv_alloc ? 0 : (int)0x80000000), 0, 0, 0);
+          }
+        }
+      }
+    }
     f32x4_t* xch = (f32x4_t*)smem + (size_t)wq * (MT * NT) * 64 + lane;
 #pragma unroll
     for (int ih = 0; ih < MH; ++ih)
@@ -772,6 +814,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   // ---- optional: pull a later launch's weight towards the memory-side cache (da_gemm_params.prefetch).  Each wave sends up to
   // eight 1 KiB LDS-DMA reads of this workgroup's share into the scratch KiB; nothing waits for them (a kernel that loads its
   // residual in the epilogue would queue behind them: it skips the prefetch) ----
+  auto weight_prefetch = [&]() {
   if (p.prefetch && (PF || !p.residual)) {
     const int nchunk = (int)min((long long)0x7fffffff >> 10, p.prefetch_bytes >> 10);
     __amdgpu_buffer_rsrc_t rs_pf = uniform_rsrc(p.prefetch, (size_t)nchunk << 10);
@@ -784,6 +827,9 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       c += stride;
     }
   }
+  };
+  const bool xa_on = XA > 0 && p.xa_k != nullptr;
+  if (!xa_on) weight_prefetch();                          // (XA: behind the attention part -- its K / V^T wait is a vmcnt(0))
   DA2_TRACE(5);                                           // partial sums exchanged
   // o[0..3] = alpha * acc of row tile ih, columns n .. n + 3  ->  LayerNorm-folded value (identity without ln_stats)
   auto ln_apply4 = [&](float* o, int ih, int n) __attribute__((always_inline)) {
@@ -799,6 +845,112 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       }
     }
   };
+  // ---- XA: cross-attention on the wave's own q (32 queries x one head) ----
+  // keep[ih][jh][e] = q^T[d = 16 jh + 4 kq + e][query 16 ih + r16].  With the MFMA k index u (0 .. 7) of k-block kq mapped to
+  // d = 32 b + 16 (u / 4) + 4 kq + u % 4, the lane's eight values of keep[ih][2 b .. 2 b + 1] ARE the B fragment of S^T = K . Q^T for
+  // d-block b, and K's A fragment is two 8-byte reads of a key row; the C layout of S^T (keys 16 kt + 4 kq + e of query r16) is the
+  // B fragment of O^T = V^T . P^T under the same mapping applied to keys, and O^T comes out in the layout of `keep`: the ordinary
+  // store path finishes the launch.  Softmax over the <= 16 XA keys is exact (no running maximum): exp2 of scale * log2(e) * s.
+  if constexpr (XA > 0) {
+    if (xa_on) {
+      bf16x8_t qf[MH][2];
+#pragma unroll
+      for (int ih = 0; ih < MH; ++ih)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float o8[8];
+#pragma unroll
+          for (int hlf = 0; hlf < 2; ++hlf) {
+            const int jh = 2 * b + hlf;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
+            ln_apply4(o, ih, min(col_of(jh), p.N - 4));
+            const uint2 bv = bias_v[jh];
+            o8[4 * hlf + 0] = o[0] + bf_lo(bv.x); o8[4 * hlf + 1] = o[1] + bf_hi(bv.x);
+            o8[4 * hlf + 2] = o[2] + bf_lo(bv.y); o8[4 * hlf + 3] = o[3] + bf_hi(bv.y);
+          }
+          const uint4 pk = pack8(o8);                      // q rounded to bf16, as the reference's to_q output is
+          qf[ih][b] = __builtin_bit_cast(bf16x8_t, pk);
+        }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of K / V^T landed; my exchange reads retired
+      __builtin_amdgcn_s_barrier();                       // ... everybody's: K / V^T visible, the lower half of the ring is free
+      asm volatile("" ::: "memory");
+      const unsigned char* kb = smem + XA_K_OFF + wn * XA_KB;
+      const unsigned char* vb = smem + XA_V_OFF + wn * 16384;
+      f32x4_t sacc[XA][MH];
+#pragma unroll
+      for (int kt = 0; kt < XA; ++kt) {
+#pragma unroll
+        for (int ih = 0; ih < MH; ++ih) sacc[kt][ih] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int R = 16 * kt + r16, sw = (R >> 1) & 7;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const uint2 lo = *(const uint2*)(kb + R * 128 + (((4 * b + (kq >> 1)) ^ sw) << 4) + (kq & 1) * 8);
+          const uint2 hi = *(const uint2*)(kb + R * 128 + (((4 * b + 2 + (kq >> 1)) ^ sw) << 4) + (kq & 1) * 8);
+          const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+          for (int ih = 0; ih < MH; ++ih) sacc[kt][ih] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ih][b], sacc[kt][ih], 0, 0, 0);
+        }
+      }
+      constexpr int KBL = (XA + 1) / 2;                   // 32-key blocks of the P . V product
+      const float sl2 = p.xa_scale * 1.4426950408889634f;
+      bf16x8_t pf[MH][KBL];
+      float linv[MH];
+#pragma unroll
+      for (int ih = 0; ih < MH; ++ih) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < XA; ++kt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = (16 * kt + 4 * kq + e < p.xa_skv) ? sacc[kt][ih][e] * sl2 : -3.0e38f;
+            sacc[kt][ih][e] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < KBL; ++c) {
+          float p8[8];
+#pragma unroll
+          for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float pv = 0.f;
+              if (2 * c + hlf < XA) pv = __builtin_amdgcn_exp2f(sacc[2 * c + hlf < XA ? 2 * c + hlf : 0][ih][e] - mx);   // masked keys: exp2(-huge) = 0
+              p8[4 * hlf + e] = pv;
+              sum += pv;
+            }
+          pf[ih][c] = __builtin_bit_cast(bf16x8_t, pack8(p8));
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        linv[ih] = 1.0f / sum;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4_t oacc[MH];
+#pragma unroll
+        for (int ih = 0; ih < MH; ++ih) oacc[ih] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int Rd = 16 * dt + r16, sw = Rd & 15;
+#pragma unroll
+        for (int c = 0; c < KBL; ++c) {
+          const uint2 lo = *(const uint2*)(vb + Rd * 256 + (((4 * c + (kq >> 1)) ^ sw) << 4) + (kq & 1) * 8);
+          const uint2 hi = *(const uint2*)(vb + Rd * 256 + (((4 * c + 2 + (kq >> 1)) ^ sw) << 4) + (kq & 1) * 8);
+          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+          for (int ih = 0; ih < MH; ++ih) oacc[ih] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ih][c], oacc[ih], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ih = 0; ih < MH; ++ih)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) keep[ih][dt][e] = oacc[ih][e] * linv[ih];
+      }
+      weight_prefetch();
+    }
+  }
   // ---- epilogue: lane holds, for output row (r16 of a 16-row tile), channels 4 kq .. 4 kq + 3 of a 16-column tile ----
   const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
   const bool has_rowvec = p.rowvec != nullptr, has_res = p.residual != nullptr;
@@ -926,7 +1078,9 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
-      unsigned char* stg = smem + (KG == 2 ? 4 * MT * NT * 1024 : 0) + wave * (16 * ROWB);
+      // (XA: the bands go to the LOWER half of the ring -- K / V^T sit where they normally go; the barrier in front of the attention
+      // part has retired every wave's exchange reads)
+      unsigned char* stg = smem + ((KG == 2 && !xa_on) ? 4 * MT * NT * 1024 : 0) + wave * (16 * ROWB);
       unsigned char* stg_w = stg + r16 * ROWB + kq * 16;      // this lane's slot in the MFMA layout
       const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
 #pragma unroll
@@ -939,6 +1093,10 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
         for (int jh = 0; jh < NH; ++jh) {
           const int n = min(col_of(jh), p.N - 4);
           float o[4];
+          if (XA > 0 && xa_on) {                          // keep = the attention output: alpha / fold / bias went into q
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e];
+          } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = keep[ih][jh][e] * p.alpha;
           ln_apply4(o, ih, n);
@@ -946,6 +1104,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
           if constexpr (PF) rvv = rowvec_v[ih][jh];
           else if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
           epilogue4<ACT, GATE, false>(p, o, n, bidx, brow, bias_v[jh], rvv, make_uint2(0, 0));
+          }
           if constexpr (PACKED) {
             uint2 pk;
             pk.x = pack_bf2(o[0], o[1]);
@@ -1144,14 +1303,14 @@ inline bool staging_fits(const da_gemm_params& p) {
 }
 
 template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false,
-          bool LNF = false>
+          bool LNF = false, int XA = 0>
 int launch(const da_gemm_params& p, hipStream_t s) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int gx = choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
   constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + 1024 + (LNF ? 2 * BN * 4 : 0);   // ring + the scratch KiB (ragged pieces, prefetch) + s / c
-  auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP, STREAMW, GIL, LNF>;
+  auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP, STREAMW, GIL, LNF, XA>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1176,6 +1335,20 @@ inline int dispatch_lnf(const da_gemm_params& p, int tile, int staging, hipStrea
                  : (staging == DA_STAGE_LDS_DIRECT3 || staging == DA_STAGE_PINGPONG3) ? 3 : 0;
   const bool pp = staging == DA_STAGE_PINGPONG || staging == DA_STAGE_PINGPONG3;
   if (ns == 0) return DA_ERR_UNSUPPORTED;
+  if (p.xa_k) {
+    // cross-attention epilogue (XA): the 128 x 128 tile, heads of 64 channels, a row tile inside one batch, <= 80 text tokens,
+    // whole 16-byte output rows, nothing behind q but the attention
+    if (tile != DA_TILE_K2_128x128 || ns != 2 || geglu || !p.xa_vt || p.vt || p.stats_out || p.residual || p.gate || p.rowvec ||
+        p.bias_rows || p.out_f32 || p.act != DA_ACT_NONE || p.out_scale != 1.0f || (p.N & 127) || (p.ldc & 7) ||
+        ((size_t)p.C & 15) || p.rows_per_batch <= 0 || (p.rows_per_batch & 127) || (p.M % p.rows_per_batch) || p.xa_skv <= 0 ||
+        p.xa_skv > p.xa_skv_alloc || p.xa_skv_alloc > 80 || (p.xa_skv_alloc & 7) || (p.xa_k_ld & 7) || (p.xa_vt_ld & 7) ||
+        p.xa_k_ld < p.N || p.xa_vt_ld < (long long)(p.M / p.rows_per_batch) * p.xa_skv_alloc ||
+        ((size_t)p.xa_k & 15) || ((size_t)p.xa_vt & 15) ||
+        (size_t)(p.M / p.rows_per_batch) * p.xa_skv_alloc * p.xa_k_ld * 2 >= 0x7fffffffull || (size_t)p.N * p.xa_vt_ld * 2 >= 0x7fffffffull)
+      return DA_ERR_UNSUPPORTED;
+    return pp ? launch<2, 2, 2, 4, 4, 2, false, true, false, false, true, 5>(p, s)
+              : launch<2, 2, 2, 4, 4, 2, false, false, false, false, true, 5>(p, s);
+  }
   if (p.vt) {
     const int bn = tile == DA_TILE_K2_128x80 ? 80 : tile == DA_TILE_K2_128x160 ? 160 : tile == DA_TILE_K1_128x256 ? 256
                    : tile == DA_TILE_K1_256x128 ? 128 : 0;
@@ -1220,7 +1393,7 @@ inline int dispatch_lnf(const da_gemm_params& p, int tile, int staging, hipStrea
 template <bool CONV>
 int dispatch(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
   if (p.split_k > 1 || !staging_fits(p)) return DA_ERR_UNSUPPORTED;
-  if (p.stats_out || p.ln_stats || p.vt) {
+  if (p.stats_out || p.ln_stats || p.vt || p.xa_k) {
     if constexpr (CONV) return DA_ERR_UNSUPPORTED;
     else return dispatch_lnf(p, tile, staging, s);
   }

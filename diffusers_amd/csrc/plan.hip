@@ -96,7 +96,7 @@ void for_each_device_pointer(da_plan* plan, F&& f) {
     cv(g->A), cv(g->A2), cv(g->W), f(g->C), cv(g->bias), cv(g->rowvec), cv(g->residual), cv(g->bias_rows), cv(g->gate);
     f(g->workspace), f(g->sync_flags);
     { void* q = g->stats_out; f(q); g->stats_out = (float*)q; }
-    cf(g->ln_stats), cf(g->ln_s), cf(g->ln_c), cv(g->prefetch), f(g->vt);
+    cf(g->ln_stats), cf(g->ln_s), cf(g->ln_c), cv(g->prefetch), f(g->vt), cv(g->xa_k), cv(g->xa_vt);
   }
   for (auto& t : plan->attn) cv(t->q), cv(t->k), cv(t->vt), f(t->out), cv(t->bias);
   for (auto& v : plan->ptrs)

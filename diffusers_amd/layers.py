@@ -312,7 +312,13 @@ class Attention:
         cross-attention whose norm was folded into to_q; returns to_out(attn) + residual (``stats_out``: the row statistics
         of that result, for the next folded norm)."""
         Hh, D = self.heads, self.kdim
-        if self.cross:
+        if self.cross and ops.XATTN and kv.bias is None and ops.xattn_eligible(x.shape[0], self.inner, seq, D, kv.skv_alloc) \
+                and kv.k.shape[1] == self.inner:
+            # to_q and the 77-key attention in ONE launch (da_gemm_params.xa_*): the wave that finishes 32 queries x one head of q
+            # runs that head's softmax(q k^T) v on its own registers -- no attention launch, no q round trip
+            xa = {"k": kv.k, "vt": kv.vt, "skv": kv.skv, "skv_alloc": kv.skv_alloc, "seq": seq, "scale": self.scale}
+            o = ops.linear(x, self.wq_ln, ln=(stats, self.fold), xattn=xa) if stats is not None else ops.linear(x, self.wq, xattn=xa)
+        elif self.cross:
             q = ops.linear(x, self.wq_ln, ln=(stats, self.fold)) if stats is not None else ops.linear(x, self.wq)
             o = ops.attention(q, kv.k, kv.vt, B=batch, H=Hh, D=D, Sq=seq, Skv=kv.skv, Skv_alloc=kv.skv_alloc,
                               q_row_stride=self.inner, k_row_stride=self.inner,

@@ -298,6 +298,22 @@ def qkv_variant(p: "L.GemmParams", stream: int):
     return best[0], best[1]
 
 
+# cross-attention in the epilogue of attn2.to_q (round 5).  Opt-in: measured + 7 % on the link in a chain of launches at SDXL's 1280
+# level (20.7 -> 19.2 us per layer), - 12 % at the 640 level, and nothing on the image (profiles/r05b_*): the 128 x 128 tile it needs
+# covers 160 of the 256 CUs where the 128 x 80 tile of the plain to_q covers all of them
+XATTN = os.environ.get("DIFFUSERS_AMD_XATTN", "0") == "1"
+XATTN_MAX_KEYS = 80                                              # da_gemm_params.xa_skv_alloc limit of the one instantiation
+XATTN_STAGING = L.STAGE_PINGPONG if os.environ.get("DIFFUSERS_AMD_XATTN_STAGE", "pp") == "pp" else L.STAGE_LDS_DIRECT
+XATTN_MIN_TILES = int(os.environ.get("DIFFUSERS_AMD_XATTN_MIN_TILES", "0"))
+
+
+def xattn_eligible(M: int, N: int, seq: int, head_dim: int, skv_alloc: int) -> bool:
+    """The shapes the cross-attention epilogue (da_gemm_params.xa_*) covers: heads of 64 channels, two per 128-column tile; a
+    128-row tile never straddles two batches; at most 80 (padded) text tokens."""
+    return head_dim == 64 and N % 128 == 0 and seq > 0 and seq % 128 == 0 and M % seq == 0 and M > 8 and \
+        0 < skv_alloc <= XATTN_MAX_KEYS and skv_alloc % 8 == 0
+
+
 def linear_qkv(x: torch.Tensor, wqkv: torch.Tensor, col0: int, bias: Optional[torch.Tensor] = None, ln: Optional[tuple] = None):
     """Fused to_q | to_k | to_v (attention_processor.py:2743-2751) in ONE GEMM: returns (qk [M][col0], vt [N - col0][M]) -- the V
     columns leave the epilogue transposed, the layout the flash kernel consumes.  ``ln``: LayerNorm fold (see :func:`linear`)."""
@@ -313,18 +329,23 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            bias_rows: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
            tile: Optional[int] = None, staging: Optional[int] = None, split_k: Optional[int] = None,
            stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None, k_valid: int = 0,
-           prefetch: Optional[torch.Tensor] = None, vt_out: Optional[tuple] = None) -> torch.Tensor:
+           prefetch: Optional[torch.Tensor] = None, vt_out: Optional[tuple] = None,
+           xattn: Optional[dict] = None) -> torch.Tensor:
     """out[M][N] = epilogue(alpha * x[M][K] @ w[N][K]^T).  For act == GEGLU, w/bias are in the packed layout of
     :func:`pack_geglu` and the output has N/2 columns.  ``k_valid`` > 0: columns k >= k_valid of BOTH operands are
     zero padding (da_gemm_params.k_valid): the kernel skips the MFMA steps that would multiply them.
 
     LayerNorm fold: ``stats_out`` (a :class:`RowStats`) makes this launch also write the row statistics of its output;
     ``ln=(RowStats, LNFold)`` makes it compute LN(x) @ w^T from the UN-normalised ``x`` whose statistics another launch
-    wrote (``w`` pre-scaled by :func:`fold_layernorm`)."""
+    wrote (``w`` pre-scaled by :func:`fold_layernorm`).
+
+    ``xattn=dict(k=, vt=, skv=, skv_alloc=, seq=, scale=)`` (da_gemm_params.xa_*): this launch is a cross-attention layer's to_q
+    AND its attention -- the result is softmax(scale * q k^T) v for K / V^T of the text embeddings (layers.CrossKV), see
+    :func:`xattn_eligible`."""
     p, st = _linear_params(x, w, bias, act=act, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch,
                            alpha=alpha, out_scale=out_scale, out=out, out_f32=out_f32, bias_rows=bias_rows, gate=gate,
                            tile=tile, staging=staging, split_k=split_k, stats_out=stats_out, ln=ln, k_valid=k_valid,
-                           prefetch=prefetch, vt_out=vt_out)
+                           prefetch=prefetch, vt_out=vt_out, xattn=xattn)
     if p is None:
         return st     # the skinny-M path ran
     _launch_gemm(p, st, "da_gemm_bf16(linear)")
@@ -367,7 +388,8 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
                    out: Optional[torch.Tensor] = None, out_f32: bool = False, bias_rows: Optional[torch.Tensor] = None,
                    gate: Optional[torch.Tensor] = None, tile: Optional[int] = None, staging: Optional[int] = None,
                    split_k: Optional[int] = None, stats_out: Optional[RowStats] = None, ln: Optional[tuple] = None,
-                   k_valid: int = 0, prefetch: Optional[torch.Tensor] = None, vt_out: Optional[tuple] = None):
+                   k_valid: int = 0, prefetch: Optional[torch.Tensor] = None, vt_out: Optional[tuple] = None,
+                   xattn: Optional[dict] = None):
     """Checks + da_gemm_params of one nn.Linear problem; returns (params, stream), or (None, result) when the skinny-M
     kernel handled it."""
     _req(x, "x"), _req(w, "w")
@@ -425,6 +447,22 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         p.ln_s, p.ln_c, p.ln_eps = fold.s.data_ptr(), fold.c.data_ptr(), fold.eps
     if vt_out is not None:
         p.vt, p.vt_col0, p.ld_vt = vt_out[0].data_ptr(), int(vt_out[1]), vt_out[0].stride(0)
+    if xattn is not None:
+        xk, xvt = xattn["k"], xattn["vt"]
+        _req(xk, "xattn k"), _req(xvt, "xattn vt")
+        if not xattn_eligible(M, N, xattn["seq"], 64, xattn["skv_alloc"]) or xk.shape[1] != N or xvt.shape[0] != N:
+            raise ValueError("linear(xattn=): heads of 64 channels in pairs (N % 128 == 0), row tiles of 128 inside one batch, "
+                             f"<= {XATTN_MAX_KEYS} text tokens")
+        if act != L.ACT_NONE or residual is not None or gate is not None or rowvec is not None or stats_out is not None \
+                or vt_out is not None or out_f32 or out_scale != 1.0 or bias_rows is not None or M <= 8:
+            raise ValueError("linear(xattn=): nothing but bias / the LayerNorm fold combines with the attention epilogue")
+        p.xa_k, p.xa_vt = xk.data_ptr(), xvt.data_ptr()
+        p.xa_skv, p.xa_skv_alloc, p.xa_k_ld, p.xa_vt_ld = int(xattn["skv"]), int(xattn["skv_alloc"]), _rows2d(xk, "xattn k"), _rows2d(xvt, "xattn vt")
+        p.xa_scale = float(xattn["scale"])
+        p.rows_per_batch = int(xattn["seq"])
+        p._keep_xa = (xk, xvt)
+        if tile is None:
+            tile, staging, split_k = L.TILE_K2_128x128, XATTN_STAGING, 1
     tile_given = tile is not None
     if vt_out is not None and tile is None:
         tile, staging = qkv_variant(p, st)       # the transposed column block exists on two tiles of the second family only

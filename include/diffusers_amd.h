@@ -201,6 +201,22 @@ typedef struct da_gemm_params {
   void* vt;
   int vt_col0;
   long long ld_vt;
+  /* Cross-attention in the epilogue (round 5, second kernel family, tile DA_TILE_K2_128x128, nn.Linear): xa_k != NULL makes this
+   * launch attn2.to_q AND the attention it feeds (attention_processor.py:2743-2777 with encoder_hidden_states): C receives
+   * softmax(scale * q k^T) v, [M][N] with heads of 64 channels side by side, where q = the launch's ordinary result (alpha, LayerNorm
+   * fold, bias; rounded to bf16 as the reference's to_q output is).  xa_k = K [batches * xa_skv_alloc][xa_k_ld] (row = key, the
+   * heads' channels side by side as in C), xa_vt = V^T [N][xa_vt_ld] (row = channel, column = batch * xa_skv_alloc + key): the
+   * step-invariant projections of the text embeddings (layers.CrossKV).  Keys >= xa_skv are masked; rows past them up to
+   * xa_skv_alloc must exist (zero rows of K, zero columns of V^T).  Batch of a row = m / rows_per_batch (a multiple of 128 rows).
+   * xa_skv_alloc <= 80 (the 77 CLIP tokens of the SD / SDXL U-Nets), a multiple of 8.  The softmax over so few keys is one exact
+   * pass (no running maximum); probabilities are rounded to bf16 for the P . V product like the flash kernels' (rel. rms vs fp32
+   * within the same tolerance, not bit-identical to da_attention_bf16: another summation order).  Does not combine with residual,
+   * gate, rowvec, activation, statistics, vt. */
+  const void* xa_k;
+  const void* xa_vt;
+  int xa_skv, xa_skv_alloc, xa_k_ld;
+  long long xa_vt_ld;
+  float xa_scale;
 } da_gemm_params;
 
 /* number of stats partials per row the launch *p (tile resolved as da_gemm_bf16 resolves it) writes to stats_out */

@@ -67,7 +67,16 @@ def conv2d_nhwc(x, w, bias=None, *, ksize=3, x2=None, stride=1, up=False, pad=No
 
 def linear(x, w, bias=None, *, act=0, residual=None, rowvec=None, rows_per_batch=0, alpha=1.0, out_scale=1.0, out=None,
            out_f32=False, bias_rows=None, gate=None, tile=None, staging=None, split_k=None, stats_out=None, ln=None,
-           k_valid=0, vt_out=None):
+           k_valid=0, vt_out=None, xattn=None):
+    if xattn is not None:    # da_gemm_params.xa_*: to_q (bf16) -> softmax(scale q k^T) v over the text keys, heads of 64 channels
+        assert act == 0 and residual is None and gate is None and rowvec is None and stats_out is None and vt_out is None and not out_f32
+        q = linear(x, w, bias, ln=ln, alpha=alpha)
+        M, N = q.shape
+        seq, skv, sa = xattn["seq"], xattn["skv"], xattn["skv_alloc"]
+        assert N % 128 == 0 and seq % 128 == 0 and M % seq == 0 and sa <= 80 and sa % 8 == 0
+        return attention(q, xattn["k"], xattn["vt"], B=M // seq, H=N // 64, D=64, Sq=seq, Skv=skv, Skv_alloc=sa, q_row_stride=N,
+                         k_row_stride=xattn["k"].stride(0), q_batch_stride=seq * N, k_batch_stride=sa * xattn["k"].stride(0),
+                         vt_ld=xattn["vt"].stride(0), vt_batch_stride=sa, scale=xattn["scale"], out=out)
     assert x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0, "C ABI: K % 64, N % 4"
     if k_valid:
         assert 0 < k_valid <= x.shape[1] and not x[:, k_valid:].any() and not w[:, k_valid:].any()

@@ -54,3 +54,13 @@ if [[ $WHAT == *prof* ]]; then
   cd $R
   python tools/prof_summary.py $(find $O/prof -name '*kernel_stats.csv' | head -1) "r05 sdxl bench (--steps 1 --warmup 1)" > $O/prof_summary.md 2>> $O/prof.log; head -60 $O/prof_summary.md
 fi
+if [[ $WHAT == *xattn* ]]; then
+  timeout 600 python -m pytest tests/test_xattn_gpu.py tests/test_attention_boundary.py -m gpu -q -s --timeout 300 -x > $O/pytest_xattn.log 2>&1; echo "pytest xattn rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|\[parity\]|\[B3\]" $O/pytest_xattn.log | tail -40
+  timeout 300 python tools/bench_xattn_r5.py $O/xattn_r5.jsonl > $O/xattn_r5.log 2>&1; echo "xattn bench rc=$?"; cat $O/xattn_r5.jsonl | cut -c1-400; tail -3 $O/xattn_r5.log | cut -c1-300
+fi
+if [[ $WHAT == *xab* ]]; then
+  for m in 1 0 1 0; do
+    DIFFUSERS_AMD_XATTN=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_xa$m.json 2> $O/bench_xa$m.err; echo "xattn $m rc=$? $(cut -c1-140 $O/bench_xa$m.json | grep -o '"value": [0-9.]*')"
+  done
+fi
