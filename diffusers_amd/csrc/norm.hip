@@ -183,6 +183,137 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// GroupNorm in ONE launch (round 5) for tensors whose per-(batch, group set) slab is small: the two-kernel form above is bound by
+// its two launches there (~8 us each for the 5 MB tensors of SDXL's 32 x 32 level, 17 us per GroupNorm against ~2 us of traffic;
+// every GroupNorm of the SD1.5 U-Net at 64 x 64 latents is of that kind).  One workgroup owns ALL pixels of one batch for a set of
+// GS whole groups whose channel span CW = GS * (C / G) is a multiple of 8 (cpg 10 -> four groups = 40 channels = five 16-byte
+// chunks): pass 1 streams the slab once (16-byte chunks, chunk index fastest: a pixel's CW channels are contiguous), parks it in
+// LDS when it fits (RES) and accumulates per-thread (sum, sum of squares) per group; the block reduction is a fixed butterfly per
+// wave + an in-order fp64 fold over the waves (deterministic); pass 2 normalises out of LDS (or re-reads the slab -- it is
+// L2-resident -- when it did not fit).  A thread keeps the same chunk position for the whole kernel (T % nch == 0), so its eight
+// channels' group ids, gamma and beta are loop constants.  Same formula and rounding points as gn_apply_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <int GS, bool RES>
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1,
+                                                        const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+                                                        uint16_t* __restrict__ y, int HW, int C, int G, float eps, int act) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  __shared__ float s_part[16][2 * GS];
+  __shared__ float s_a[GS], s_c[GS];                        // mean, rstd per group
+  const int T = (int)blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = T >> 6;
+  const int cpg = C / G, CW = GS * cpg, nch = CW >> 3;
+  const int b = blockIdx.y, g0 = blockIdx.x * GS, c0 = g0 * cpg;
+  const int ch = t % nch;                                   // this thread's 16-byte chunk of every pixel it visits
+  const int cabs = c0 + ch * 8;                             // first of its eight channels
+  const bool second = cabs >= C1;
+  const int Cs = second ? (C - C1) : C1;
+  const uint16_t* xb = (second ? x2 + (size_t)(cabs - C1) : x + (size_t)cabs) + (size_t)b * HW * Cs;
+  int gid[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gid[e] = (ch * 8 + e) / cpg;  // 0 .. GS - 1
+  const int ppr = T / nch;                                  // pixels per round of the whole block
+  const int p_first = t / nch;
+  float s[GS], q[GS];
+#pragma unroll
+  for (int g = 0; g < GS; ++g) s[g] = q[g] = 0.f;
+  uint4* slab = (uint4*)gsm;
+  for (int pix = p_first; pix < HW; pix += 4 * ppr) {       // 4 independent 16-byte loads in flight per lane
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pu = pix + u * ppr;
+      v[u] = (pu < HW) ? *(const uint4*)(xb + (size_t)pu * Cs) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pu = pix + u * ppr;
+      if (pu >= HW) break;
+      if constexpr (RES) slab[(size_t)pu * nch + ch] = v[u];
+      float f[8];
+      unpack8(v[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+          const float m = (GS == 1 || gid[e] == g) ? f[e] : 0.f;
+          s[g] += m;
+          q[g] += m * m;
+        }
+    }
+  }
+  // wave butterfly (fixed pattern), then the waves in index order in fp64
+#pragma unroll
+  for (int g = 0; g < GS; ++g) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s[g] += __shfl_xor(s[g], o, 64);
+      q[g] += __shfl_xor(q[g], o, 64);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int g = 0; g < GS; ++g) s_part[wave][2 * g] = s[g], s_part[wave][2 * g + 1] = q[g];
+  }
+  __syncthreads();
+  if (t < GS) {
+    double ts = 0.0, tq = 0.0;
+    for (int w = 0; w < nw; ++w) {
+      ts += (double)s_part[w][2 * t];
+      tq += (double)s_part[w][2 * t + 1];
+    }
+    const double n = (double)HW * (double)cpg;
+    const double mean = ts / n;
+    double var = tq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_a[t] = (float)mean;
+    s_c[t] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  float a[8], c[8];
+  {
+    float gf[8], bf[8];
+    unpack8(*(const uint4*)(gamma + cabs), gf);
+    unpack8(*(const uint4*)(beta + cabs), bf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float mean = s_a[0], rstd = s_c[0];
+#pragma unroll
+      for (int g = 1; g < GS; ++g)
+        if (gid[e] == g) mean = s_a[g], rstd = s_c[g];
+      a[e] = rstd * gf[e];
+      c[e] = bf[e] - mean * a[e];
+    }
+  }
+  uint16_t* yb = y + (size_t)b * HW * C + cabs;
+  for (int pix = p_first; pix < HW; pix += 4 * ppr) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pu = pix + u * ppr;
+      if constexpr (RES) v[u] = (pu < HW) ? slab[(size_t)pu * nch + ch] : make_uint4(0, 0, 0, 0);   // its own writes: no barrier
+      else v[u] = (pu < HW) ? *(const uint4*)(xb + (size_t)pu * Cs) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pu = pix + u * ppr;
+      if (pu >= HW) break;
+      float f[8];
+      unpack8(v[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float o = f[e] * a[e] + c[e];
+        if (act) {
+          o = bf2f(f2bf(o));  // reference rounds the GroupNorm output to bf16 before SiLU
+          o = silu_f(o);
+        }
+        f[e] = o;
+      }
+      *(uint4*)(yb + (size_t)pu * C) = pack8(f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wave per row, the row lives in registers (NCH chunks of 8 per lane).
 // Optional AdaLN modulation: y = LN(x) * (1 + scale[b]) + shift[b]  (normalization.py:157-170, :194-202, :346-351)
 // ------------------------------------------------------------------------------------------------------------------
@@ -513,6 +644,40 @@ GnPlan gn_plan(int B, int HW, int C) {
 
 }  // namespace
 
+// One-launch plan (gn_fused_kernel): GS = the smallest number of whole groups whose channel span is a multiple of 8, a block size
+// that is a multiple of both 64 and the span's chunk count, and the slab either LDS-resident or small enough to be re-read from
+// L2 by its one workgroup.  Returns GS (0: keep the two-kernel form).  DA_GN_FUSED = 0 switches it off, DA_GN_FUSED_KB pins the
+// largest slab (KiB) that is re-read from L2 instead (default 0: none -- it measured slower), DA_GN_FUSED_MINWG the fewest workgroups
+// worth launching.
+struct GnFused { int gs, threads, resident; size_t lds; };
+GnFused gn_fused_plan(int B, int HW, int C, int C1, int G) {
+  // (read at every call -- a getenv is noise next to a launch: tests and tools/bench_norms_r5.py time both forms in one process)
+  // Measured (profiles/r05c_groupnorm_one_launch.jsonl, chained launches from a HIP graph): LDS-resident slabs win -- 17.4 -> 12.6 us
+  // for SDXL's 14 GroupNorms over (2, 1024 px, 1280 ch), 10.4-14.2 -> 4.1-7.0 us for the 8 x 8 / 16 x 16 levels of the SD1.5 U-Net;
+  // re-reading a larger slab from L2 by its one workgroup LOSES (40-109 us against 15-30): the default reach is the LDS.
+  const int on = gn_knob("DA_GN_FUSED", 1), max_kb = gn_knob("DA_GN_FUSED_KB", 0), min_wg = gn_knob("DA_GN_FUSED_MINWG", 16);
+  GnFused f{0, 0, 0, 0};
+  if (!on) return f;
+  const int cpg = C / G;
+  int gs = 1;
+  while (gs <= 4 && ((gs * cpg) & 7)) ++gs;
+  if (gs > 4 || (G % gs)) return f;
+  const int cw = gs * cpg, nch = cw / 8;
+  // (two sources: C1 is a multiple of 8, so no 16-byte chunk straddles them; a group SET may -- each thread picks its source by
+  // its own chunk)
+  int lcm = 64;
+  while (lcm % nch) lcm += 64;
+  if (lcm > 1024) return f;
+  const int threads = (1024 / lcm) * lcm;
+  const size_t slab = (size_t)HW * cw * 2;
+  const long long wgs = (long long)B * (G / gs);
+  if (wgs < min_wg) return f;
+  const bool res = slab <= 144 * 1024;
+  if (!res && slab > (size_t)max_kb * 1024) return f;
+  f.gs = gs, f.threads = threads, f.resident = res, f.lds = res ? slab : 0;
+  return f;
+}
+
 extern "C" size_t da_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return 0;
   GnPlan g = gn_plan(B, HW, C);
@@ -527,8 +692,32 @@ extern "C" int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
   if (C1 <= 0 || C1 > C || (C1 & 7) || (x2 == nullptr && C1 != C)) return DA_ERR_INVALID;
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7)) return DA_ERR_UNSUPPORTED;
   if (C / 8 > 512) return DA_ERR_UNSUPPORTED;
-  GnPlan g = gn_plan(B, HW, C);
   hipStream_t s = (hipStream_t)stream;
+  const GnFused ff = gn_fused_plan(B, HW, C, C1, G);
+  if (ff.gs) {
+    const dim3 grid(G / ff.gs, B), block(ff.threads);
+#define DA_GNF(GS_, RES_)                                                                                              \
+  do {                                                                                                                 \
+    auto kern = gn_fused_kernel<GS_, RES_>;                                                                            \
+    static bool attr_set = false;                                                                                      \
+    if (RES_ && !attr_set) {                                                                                           \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) \
+        return DA_ERR_LAUNCH;                                                                                          \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    DA_LAUNCH(kern, grid, block, ff.lds, s, (const uint16_t*)x, (const uint16_t*)x2, C1, (const uint16_t*)gamma,       \
+              (const uint16_t*)beta, (uint16_t*)y, HW, C, G, eps, act);                                                \
+  } while (0)
+    if (ff.resident) {
+      if (ff.gs == 1) DA_GNF(1, true); else if (ff.gs == 2) DA_GNF(2, true); else if (ff.gs == 3) DA_GNF(3, true); else DA_GNF(4, true);
+    } else {
+      if (ff.gs == 1) DA_GNF(1, false); else if (ff.gs == 2) DA_GNF(2, false); else if (ff.gs == 3) DA_GNF(3, false); else DA_GNF(4, false);
+    }
+#undef DA_GNF
+    DA_CHECK_LAUNCH();
+    return DA_OK;
+  }
+  GnPlan g = gn_plan(B, HW, C);
   const size_t lds = (size_t)g.krows * C * 2 * sizeof(float);
   if (lds > 64 * 1024) return DA_ERR_UNSUPPORTED;
   DA_LAUNCH(gn_stats_kernel, dim3(g.nblk, B), dim3(g.threads), lds, s, (const uint16_t*)x, (const uint16_t*)x2,

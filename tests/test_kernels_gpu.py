@@ -633,6 +633,37 @@ def test_groupnorm_two_sources():
     assert_close_bf16(y, ref.transpose(1, 2), "groupnorm fused concat", rtol=1.6e-2, atol_rms=8e-3)
 
 
+@pytest.mark.parametrize("B,HW,C1,C2,G", [(2, 1024, 1280, 0, 32), (2, 1024, 1280, 1280, 32), (2, 1024, 1280, 640, 32), (2, 1024, 640, 0, 32),
+                                          (2, 4096, 320, 0, 32), (2, 4096, 640, 0, 32), (2, 4096, 640, 320, 32), (2, 64, 1280, 0, 32),
+                                          (2, 256, 2560, 0, 32), (1, 1000, 128, 0, 32), (3, 77, 256, 0, 32), (2, 4096, 512, 0, 32),
+                                          (1, 100, 960, 0, 32), (2, 1024, 96, 0, 4)])
+def test_groupnorm_one_launch_form_against_the_two_kernel_form(B, HW, C1, C2, G, monkeypatch):
+    """Round 5: tensors whose per-(batch, group set) slab is small run GroupNorm as ONE launch (gn_fused_kernel: slab parked in LDS,
+    or re-read from L2 up to DA_GN_FUSED_KB): against torch in fp32 with the tolerance of the two-kernel form, against that form
+    (DA_GN_FUSED=0) to a bf16 ulp of the normalised value -- the statistics are summed in another order --, deterministic; group
+    sets of 1 / 2 / 4 groups (cpg 40, 80 / 20, 60 / 10, 30), two sources, large means."""
+    ops, L = _ops()
+    C = C1 + C2
+    x1 = rnd((B, HW, C1), 40, scale=2.0) + 3.0
+    x2 = rnd((B, HW, C2), 44, scale=3.0) if C2 else None
+    g, b = rnd((C,), 41) * 0.1 + 1.0, rnd((C,), 42, scale=0.1)
+    full = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.silu(F.group_norm(full.float().transpose(1, 2), G, g.float(), b.float(), 1e-5)).transpose(1, 2)
+    monkeypatch.setenv("DA_GN_FUSED", "0")
+    two = ops.group_norm_nhwc(x1, g, b, G, 1e-5, silu=True, x2=x2)
+    for kb in ("0", "4096"):                       # default reach (LDS-resident slabs); everything the one-launch form can take
+        monkeypatch.setenv("DA_GN_FUSED", "1")
+        monkeypatch.setenv("DA_GN_FUSED_KB", kb)
+        monkeypatch.setenv("DA_GN_FUSED_MINWG", "1")
+        one = ops.group_norm_nhwc(x1, g, b, G, 1e-5, silu=True, x2=x2)
+        what = f"groupnorm one launch B{B} HW{HW} C{C1}+{C2} G{G} reach {kb} KiB"
+        assert_close_bf16(one, ref, what, rtol=1.6e-2, atol_rms=8e-3)
+        d = (one.float() - two.float()).abs()
+        tol = 2.0 ** -6 * two.float().abs() + 1e-3          # (one bf16 ulp of the binade above |value|)
+        assert int((d > tol).sum()) == 0, f"{what}: differs from the two-kernel form by more than a bf16 ulp ({float(d.max()):.3e})"
+        assert torch.equal(one, ops.group_norm_nhwc(x1, g, b, G, 1e-5, silu=True, x2=x2)), "deterministic"
+
+
 @pytest.mark.parametrize("M,C", [(100, 320), (2048, 640), (513, 1280), (64, 3072), (7, 1536), (33, 64)])
 def test_layernorm(M, C):
     ops, L = _ops()

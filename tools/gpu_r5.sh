@@ -64,3 +64,14 @@ if [[ $WHAT == *xab* ]]; then
     DIFFUSERS_AMD_XATTN=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_xa$m.json 2> $O/bench_xa$m.err; echo "xattn $m rc=$? $(cut -c1-140 $O/bench_xa$m.json | grep -o '"value": [0-9.]*')"
   done
 fi
+if [[ $WHAT == *gnfused* ]]; then
+  timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -s --timeout 300 -k "groupnorm" > $O/pytest_gn.log 2>&1; echo "pytest gn rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert" $O/pytest_gn.log | tail -20
+  timeout 300 python tools/bench_norms_r5.py $O/norms_r5.jsonl > $O/norms_r5.log 2>&1; echo "norms bench rc=$?"; cat $O/norms_r5.jsonl | cut -c1-300
+fi
+if [[ $WHAT == *gnab* ]]; then
+  for m in 1 0 1 0; do
+    DA_GN_FUSED=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_gn$m.json 2> $O/bench_gn$m.err; echo "gn fused $m rc=$? $(cut -c1-140 $O/bench_gn$m.json | grep -o '"value": [0-9.]*')"
+    DA_GN_FUSED=$m timeout 600 python bench.py --config sd15 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_sd15_gn$m.json 2> $O/bench_sd15_gn$m.err; echo "sd15 gn fused $m rc=$? $(cut -c1-160 $O/bench_sd15_gn$m.json | grep -o '"value": [0-9.]*')"
+  done
+fi
