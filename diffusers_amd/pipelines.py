@@ -107,9 +107,28 @@ def _capture_step(pipe, step, mode):
             pl, _ = P.record(step)
         return pl
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(pipe), "apply"):
+    cs = _side_stream("capture")
+    from . import tuning
+    if any(len(v) > 3 and v[3] > 1 for v in tuning.table().values()):
+        # split-K launches take their workspace per (device, stream): allocated (and its flags zeroed) for the capture stream BEFORE
+        # the capture, so that neither the allocation lands in the graph's private pool nor the zero-fill becomes a graph node
+        ops.splitk_workspace(pipe.device, cs.cuda_stream)
+    with torch.cuda.graph(g, stream=cs, capture_error_mode=GRAPH_CAPTURE_MODE), ops.weight_prefetch(_pf(pipe), "apply"):
         step()
     return g
+
+
+_side_streams = {}
+
+
+def _side_stream(kind: str) -> "torch.cuda.Stream":
+    """ONE warm-up stream and ONE capture stream per device for every pipeline of the process: per-stream resources (the 64 MiB
+    split-K workspace of ops.splitk_workspace) are then allocated twice, not once per re-capture."""
+    key = (torch.cuda.current_device(), kind)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream()
+    return st
 
 
 def _pf(pipe) -> "ops.WeightPrefetch":
@@ -232,7 +251,7 @@ class _LatentDiffusionBase(_StepCallbacks, PipelineLoadingMixin):
         if self._graph is None or self._graph_key != key:
             # warm-up on a side stream (lazy one-time driver calls must not happen during capture), then capture
             saved = latents.clone()
-            s = torch.cuda.Stream()
+            s = _side_stream("warm")
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 with ops.weight_prefetch(_pf(self), "record"):
@@ -546,7 +565,7 @@ class FluxPipeline(_StepCallbacks, PipelineLoadingMixin):
                id(self.transformer))                        # (a captured step points into THIS model's packed weights)
         if self._graph is None or self._graph_key != key:
             saved = latents.clone()
-            s = torch.cuda.Stream()
+            s = _side_stream("warm")
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 with ops.weight_prefetch(_pf(self), "record"):
@@ -703,7 +722,7 @@ class WanPipeline(_StepCallbacks, PipelineLoadingMixin):
                id(self.transformer))
         if self._graph is None or self._graph_key != key:
             saved = latents.clone()
-            s = torch.cuda.Stream()
+            s = _side_stream("warm")
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 with ops.weight_prefetch(_pf(self), "record"):
@@ -843,7 +862,7 @@ class DDPMPipeline(PipelineLoadingMixin):
             key = (tuple(shape), len(ts), sch.device_table.data_ptr(), use_graph == "plan", id(self.unet))
             if getattr(self, "_graph_key", None) != key:
                 saved = image.clone()
-                s = torch.cuda.Stream()
+                s = _side_stream("warm")
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     with ops.weight_prefetch(_pf(self), "record"):

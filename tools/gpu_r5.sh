@@ -75,3 +75,9 @@ if [[ $WHAT == *gnab* ]]; then
     DA_GN_FUSED=$m timeout 600 python bench.py --config sd15 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_sd15_gn$m.json 2> $O/bench_sd15_gn$m.err; echo "sd15 gn fused $m rc=$? $(cut -c1-160 $O/bench_sd15_gn$m.json | grep -o '"value": [0-9.]*')"
   done
 fi
+if [[ $WHAT == *splitk* ]]; then
+  timeout 900 python tools/bench_splitk_r5.py $O/splitk_r5.jsonl > $O/splitk_r5.log 2>&1; echo "splitk bench rc=$?"; cat $O/splitk_r5.jsonl | cut -c1-700; tail -3 $O/splitk_r5.log | cut -c1-300
+fi
+if [[ $WHAT == *tuneconv* ]]; then
+  DIFFUSERS_AMD_SPLITK=1 DIFFUSERS_AMD_GEMM_FAMILY=all python -c "import json;t=json.load(open('$R/diffusers_amd/tuned/gfx950.json'));t['entries']={k:v for k,v in t['entries'].items() if not k.startswith('conv3:M2048:N1280:C')};json.dump(t,open('$O/table_without_32x32_convs.json','w'))"; DIFFUSERS_AMD_TUNE_DB=$O/table_without_32x32_convs.json timeout 600 python tools/tune_shapes_r5.py > $O/tune_shapes_r5.log 2>&1; echo "tune rc=$?"; cat $O/tune_shapes_r5.log | cut -c1-300 | tail -12
+fi
