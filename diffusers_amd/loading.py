@@ -303,6 +303,10 @@ class PretrainedMixin:
             if tuple(t.shape) != tuple(new[k].shape):
                 raise RuntimeError(f"re-pack changed the shape of {k}")
             t.copy_(new[k])
+        # derived device copies that captured graphs / plans hold by raw pointer follow the edit at once (ops.pad_thin_out: the
+        # 16-channel padded conv_out weight) -- a replayed graph never passes through the Python call that would refresh them
+        from . import ops
+        ops.refresh_thin_out(old.values())
         if hasattr(self, "_cond_cache"):
             self._cond_cache = None
 

@@ -1050,10 +1050,14 @@ _thin_out_cache = {}
 
 
 def pad_thin_out(w: torch.Tensor, bias: Optional[torch.Tensor]):
-    """[Cout][K] (+ bias) zero-padded to THIN_OUT_PAD output channels, cached on the packed weight's identity (models pack once;
-    the padded copy must exist before a HIP-graph capture, which the pipelines' warm-up pass guarantees)."""
-    key = (w.data_ptr(), w._version if not w.is_inference() else -1, tuple(w.shape), bias.data_ptr() if bias is not None else 0,
-           (bias._version if not bias.is_inference() else -1) if bias is not None else 0)
+    """[Cout][K] (+ bias) zero-padded to THIN_OUT_PAD output channels, cached on the packed weight's STORAGE (models pack once;
+    the padded copy must exist before a HIP-graph capture, which the pipelines' warm-up pass guarantees).  An in-place edit of the
+    weight / bias (`fuse_lora` / `unfuse_lora` re-pack in place, loading.py) bumps their `_version`: the padded copies are then
+    REFRESHED IN PLACE -- same addresses -- so that a captured graph or plan, which holds them by raw pointer, replays with the
+    edited weight (round 4 made a new entry per version: the graph kept replaying the old copy and every fuse / unfuse cycle leaked
+    one entry)."""
+    key = (w.data_ptr(), tuple(w.shape), bias.data_ptr() if bias is not None else 0)
+    ver = (w._version if not w.is_inference() else -1, (bias._version if not bias.is_inference() else -1) if bias is not None else 0)
     ent = _thin_out_cache.get(key)
     if ent is None:
         wp = torch.zeros((THIN_OUT_PAD, w.shape[1]), device=w.device, dtype=w.dtype)
@@ -1063,9 +1067,33 @@ def pad_thin_out(w: torch.Tensor, bias: Optional[torch.Tensor]):
             bp = torch.zeros((THIN_OUT_PAD,), device=w.device, dtype=bias.dtype)
             bp[: w.shape[0]] = bias
         # Entries are never evicted: a captured HIP graph references the padded copies by raw pointer only (a few KiB per
-        # thin-output conv, one or two per model).  An in-place edit of the weight / bias (LoRA fuse) makes a new entry.
-        ent = _thin_out_cache[key] = (wp, bp, w, bias)      # keeps `w` / `bias` alive: their addresses are the key
+        # thin-output conv, one or two per model).
+        ent = _thin_out_cache[key] = [wp, bp, w, bias, ver]      # keeps `w` / `bias` alive: their addresses are the key
+    elif ent[4] != ver:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("pad_thin_out: a weight was edited in place since its padded copy was made; run one eager step before "
+                               "capturing (the pipelines' warm-up pass does)")
+        ent[0][: w.shape[0]].copy_(w)
+        if bias is not None:
+            ent[1][: w.shape[0]].copy_(bias)
+        ent[4] = ver
     return ent[0], ent[1]
+
+
+def refresh_thin_out(tensors) -> int:
+    """Refresh (in place) the padded copies of :func:`pad_thin_out` whose weight or bias is one of ``tensors`` -- called after an
+    in-place re-pack (loading._repack_in_place) so that captured graphs see the edit; returns how many were refreshed."""
+    ptrs = {t.data_ptr() for t in tensors}
+    n = 0
+    for ent in _thin_out_cache.values():
+        wp, bp, w, bias, _ = ent
+        if w.data_ptr() in ptrs or (bias is not None and bias.data_ptr() in ptrs):
+            wp[: w.shape[0]].copy_(w)
+            if bias is not None:
+                bp[: w.shape[0]].copy_(bias)
+            ent[4] = (w._version if not w.is_inference() else -1, (bias._version if not bias.is_inference() else -1) if bias is not None else 0)
+            n += 1
+    return n
 
 
 def conv_thin_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, out_f32: bool = False,

@@ -110,7 +110,8 @@ class PipelineLoadingMixin:
                 model = klass(json.loads((sub / "config.json").read_text()))
                 model.load_state_dict(LazyCheckpoint(_weight_files(sub, variant, stem="model")), device=device)
                 return model
-            return getattr(transformers, class_name).from_pretrained(str(sub), torch_dtype=torch.bfloat16).to(device)
+            # (`variant`: a directory that ships only model.fp16.safetensors must load its text encoders too, pipeline_utils.py:1004)
+            return getattr(transformers, class_name).from_pretrained(str(sub), torch_dtype=torch.bfloat16, variant=variant).to(device)
         raise NotImplementedError(f"{slot}: components of library {library!r} are not loaded by the engine; pass `{slot}=`")
 
     # ---- the small surface callers of DiffusionPipeline objects rely on ----------------------------------------------------
@@ -123,7 +124,9 @@ class PipelineLoadingMixin:
     def to(self, *args, **kwargs):
         """``pipe.to("cuda")`` of reference scripts: the engine's models live where they were loaded; a move to their own device /
         dtype is a no-op, anything else is refused (models are re-loaded onto another device, not copied)."""
-        for m in self.components.values():
-            if hasattr(m, "to") and (hasattr(m, "config") or isinstance(m, torch.nn.Module)):
-                m.to(*args, **kwargs)
+        movable = [m for m in self.components.values() if hasattr(m, "to") and (hasattr(m, "config") or isinstance(m, torch.nn.Module))]
+        # the engine components first: they refuse what they cannot honour (another dtype / device) BEFORE a transformers module of the
+        # same pipeline has been converted -- a refused call leaves the pipeline as it was
+        for m in sorted(movable, key=lambda m: isinstance(m, torch.nn.Module)):
+            m.to(*args, **kwargs)
         return self

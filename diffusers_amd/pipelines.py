@@ -72,8 +72,11 @@ def decode_postprocessed(vae, latents: torch.Tensor, output_type: str, **decode_
 
 def _per_prompt(t: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
     """``num_images_per_prompt`` copies of each row of caller-supplied embeddings, the copies of one prompt adjacent -- what the
-    reference's ``encode_prompt`` does to ``prompt_embeds`` it is handed (pipeline_stable_diffusion_xl.py:488-516:
-    ``repeat(1, n, 1).view(bs * n, seq, -1)``; pooled: ``repeat(1, n).view(bs * n, -1)``)."""
+    reference's SD / SDXL ``encode_prompt`` does to ``prompt_embeds`` it is handed (pipeline_stable_diffusion_xl.py:488-516:
+    ``repeat(1, n, 1).view(bs * n, seq, -1)``; pooled: ``repeat(1, n).view(bs * n, -1)``).  The reference's Flux and Wan
+    ``encode_prompt`` return supplied embeddings as they are and only multiply the latent batch (pipeline_flux.py:358-375,
+    pipeline_wan.py:225-262) -- a combination that fails inside their transformer for n > 1; repeating them there as well is an
+    ENGINE EXTENSION of those two pipelines, not reference behaviour."""
     if t is None or n == 1:
         return t
     if n < 1:
@@ -636,6 +639,9 @@ class FluxPipeline(_StepCallbacks, PipelineLoadingMixin):
             gdev = generator.device if generator is not None else torch.device("cpu")
             raw = torch.randn((B, nch, lh, lw), generator=generator, device=gdev, dtype=bf16)
             latents = self._pack_latents(raw, B, nch, lh, lw)
+        if latents.shape[0] != B:
+            # (as in the SD / SDXL pipelines: a stale batch would meet a captured step of another size)
+            raise ValueError(f"`latents` holds {latents.shape[0]} samples, the prompt embeddings (x num_images_per_prompt) {B}")
         latents = latents.to(device=dev, dtype=bf16).contiguous().clone()
         img_ids = self._prepare_latent_image_ids(lh // 2, lw // 2)
         txt_ids = torch.zeros(prompt_embeds.shape[1], 3)

@@ -202,6 +202,8 @@ class EulerDiscreteScheduler(_SchedulerBase):
             raise ValueError("Must pass exactly one of `num_inference_steps` or `timesteps` or `sigmas.")
         if num_inference_steps is not None and (timesteps is not None or sigmas is not None):
             raise ValueError("Can only pass one of `num_inference_steps` or `timesteps` or `sigmas`.")
+        if timesteps is not None and sigmas is not None:          # scheduling_euler_discrete.py:381-382
+            raise ValueError("Only one of `timesteps` or `sigmas` should be set.")
         if timesteps is not None and c.use_karras_sigmas:
             raise ValueError("Cannot set `timesteps` with `config.use_karras_sigmas = True`.")
         if timesteps is not None and c.use_exponential_sigmas:
