@@ -278,9 +278,11 @@ def _run_processor(monkeypatch, dev, cfg, hw, gate, cross_tokens=77):
         a2 = unet(sample.to(bf16), torch.tensor(481.0).to(dev), encoder_hidden_states=ehs_b, return_dict=False,
                   added_cond_kwargs=None if added is None else {k: v.to(bf16) for k, v in added.items()})[0]
         assert len(lin) == n1 - 2 * (n_attn // 2)                                # second call: no K / V^T launches
-        # (whole-model bit equality is not asserted on the GPU: the live variant choice of a first-seen GEMM shape may settle between
-        # two calls, and the reference's own MIOpen convolutions are outside this library; the module-level check below is exact)
-        assert torch.equal(a1, a2) if dev == "cpu" else _rel(a1, a2) < 2e-3
+        # (whole-model equality is asserted on CPU only: on the GPU the reference's OWN convolutions are not reproducible from call to
+        # call -- MIOpen's find mode settles on another solver as its database warms, seen as ~3e-3 rel-rms between two identical
+        # forwards -- so there the module-level check below carries the exactness claim and the model-level one is the fp32 gate)
+        assert torch.equal(a1, a2) if dev == "cpu" else _rel(a1, want) <= gate(rf := _rel(floor, want))
+        repeat_ours = _rel(a1, a2)
         ehs_b.mul_(0.5)                                                          # in-place edit: version bump -> recomputed
         lin.clear()
         a3 = unet(sample.to(bf16), torch.tensor(481.0).to(dev), encoder_hidden_states=ehs_b, return_dict=False,
@@ -301,7 +303,10 @@ def _run_processor(monkeypatch, dev, cfg, hw, gate, cross_tokens=77):
         assert torch.equal(s0, blk.attn1(xs))
         unet.set_attn_processor(importlib.import_module(ref.__name__ + ".models.attention_processor").AttnProcessor2_0())
         back = fwd(bf16)
-        assert torch.equal(back, floor) if dev == "cpu" else _rel(back, floor) < 2e-3
+        back2 = fwd(bf16)
+        print(f"[B3] two identical bf16 forwards: rel-rms {repeat_ours:.3e} with MI355XAttnProcessor, {_rel(back, back2):.3e} with the reference's "
+              f"AttnProcessor2_0 (its convolutions / norms are PyTorch-ROCm's)")
+        assert torch.equal(back, floor) if dev == "cpu" else _rel(back, want) <= 1.2 * _rel(floor, want)
     rf, rg = _rel(floor, want), _rel(got, want)
     print(f"[B3] reference UNet2DConditionModel ({n_attn} attention layers) after set_attn_processor(MI355XAttnProcessor()): rel-rms vs its "
           f"fp32 run {rg:.3e} (AttnProcessor2_0 in bf16: {rf:.3e})")
