@@ -151,10 +151,10 @@ def register_backend(registry=None, name=None, *, slot: Optional[str] = None):
 class _Packed:
     """Packed projection weights of one reference ``Attention`` module, rebuilt when a parameter changes (``_version`` /
     storage): Q|K rows fused for self-attention (one paired launch with the swapped V^T problem, as layers.Attention)."""
-    __slots__ = ("key", "wqk", "bqk", "ehs", "ehs_version", "kv")
+    __slots__ = ("key", "wqk", "bqk", "ehs", "ehs_version", "kv", "pad")
 
     def __init__(self):
-        self.key = self.wqk = self.bqk = self.ehs = self.kv = None
+        self.key = self.wqk = self.bqk = self.ehs = self.kv = self.pad = None
         self.ehs_version = -1
 
 
@@ -179,7 +179,8 @@ class MI355XAttnProcessor:
 
     def _pack(self, attn) -> _Packed:
         pk = self._packs.get(id(attn))
-        key = _param_key(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_q.bias, attn.to_k.bias, attn.to_v.bias)
+        key = _param_key(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_q.bias, attn.to_k.bias, attn.to_v.bias,
+                         attn.to_out[0].weight)
         if pk is None or pk.key != key:
             pk = _Packed()
             pk.key = key
@@ -187,11 +188,26 @@ class MI355XAttnProcessor:
         return pk
 
     @staticmethod
-    def _fused_qk(attn, pk: _Packed):
+    def _proj(attn, pk: _Packed, heads: int, d: int, dp: int):
+        """(wq, wk, wv, bq, bk, bv, wo) of the module; head sizes that are not a kernel size (SD1.5: 40 / 80) are zero-padded to the
+        next one ONCE per module (zero q / k channels add nothing to q . k, zero v channels give zero outputs that meet zero columns
+        of to_out -- layers.pad_head_rows / pad_head_cols, what the engine's own model classes do at load time)."""
+        if d == dp:
+            return (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_q.bias, attn.to_k.bias, attn.to_v.bias,
+                    attn.to_out[0].weight)
+        if pk.pad is None:
+            from .layers import pad_head_cols, pad_head_rows
+            pr = lambda t: None if t is None else pad_head_rows(t.detach(), heads, d, dp)      # noqa: E731
+            pk.pad = (pr(attn.to_q.weight), pr(attn.to_k.weight), pr(attn.to_v.weight), pr(attn.to_q.bias), pr(attn.to_k.bias),
+                      pr(attn.to_v.bias), pad_head_cols(attn.to_out[0].weight.detach(), heads, d, dp))
+        return pk.pad
+
+    @staticmethod
+    def _fused_qk(pk: _Packed, wq, wk, bq, bk):
         if pk.wqk is None:      # built on the first self-attention call of this module
-            pk.wqk = torch.cat([attn.to_q.weight.detach(), attn.to_k.weight.detach()], dim=0).contiguous()
-            if attn.to_q.bias is not None:
-                pk.bqk = torch.cat([attn.to_q.bias.detach(), attn.to_k.bias.detach()]).contiguous()
+            pk.wqk = torch.cat([wq.detach(), wk.detach()], dim=0).contiguous()
+            if bq is not None:
+                pk.bqk = torch.cat([bq.detach(), bk.detach()]).contiguous()
         return pk.wqk, pk.bqk
 
     def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
@@ -213,20 +229,23 @@ class MI355XAttnProcessor:
         if gn is not None:   # nn.GroupNorm over channels of the token tensor == channels-last GroupNorm
             x = ops.group_norm_nhwc(x, gn.weight, gn.bias, gn.num_groups, gn.eps)
         heads = attn.heads
-        inner = attn.to_q.weight.shape[0]
-        D = inner // heads
-        if D not in KERNEL_HEAD_DIMS:
-            raise ValueError(f"MI355XAttnProcessor: head_dim {D} not in {KERNEL_HEAD_DIMS} (the model classes zero-pad 40 / 80)")
+        d_real = attn.to_q.weight.shape[0] // heads
+        from .layers import kernel_head_dim
+        D = kernel_head_dim(d_real)                            # raises beyond the largest flash-kernel head size
+        inner = heads * D
         scale = getattr(attn, "scale", None)
+        if scale is None:
+            scale = d_real ** -0.5
         x2 = x.view(B * S, C)
         pk = self._pack(attn)
+        wq, wk, wv, bq, bk, bv, wo = self._proj(attn, pk, heads, d_real, D)
         if encoder_hidden_states is None:
             if S % 8 != 0:
                 raise ValueError("MI355XAttnProcessor: self-attention needs a token count that is a multiple of 8")
             # [M][2*inner] and V^T [inner][M]: two problems, one launch (no transpose pass; to_v.bias is a ROW bias of V^T)
-            wqk, bqk = self._fused_qk(attn, pk)
+            wqk, bqk = self._fused_qk(pk, wq, wk, bq, bk)
             qk, vt = ops.linear_pair({"x": x2, "w": wqk, "bias": bqk},
-                                     {"x": attn.to_v.weight, "w": x2, "bias_rows": attn.to_v.bias})
+                                     {"x": wv, "w": x2, "bias_rows": bv})
             o = ops.attention(qk, qk[:, inner:], vt, B=B, H=heads, D=D, Sq=S, Skv=S, Skv_alloc=S, q_row_stride=2 * inner,
                               k_row_stride=2 * inner, q_batch_stride=S * 2 * inner, k_batch_stride=S * 2 * inner,
                               vt_ld=B * S, vt_batch_stride=S, scale=scale)
@@ -237,11 +256,11 @@ class MI355XAttnProcessor:
                 if ehs.shape[0] != B:
                     raise ValueError("MI355XAttnProcessor: encoder_hidden_states batch does not match hidden_states")
                 pad, skv, skv_alloc = pad_encoder_states(ehs)      # zero rows up to a multiple of 16 keys (tiny: 77 x 2048)
-                k = ops.linear(pad, attn.to_k.weight, attn.to_k.bias)
-                vt = ops.linear(attn.to_v.weight, pad, bias_rows=attn.to_v.bias)        # [inner][B*skv_alloc] = V^T
+                k = ops.linear(pad, wk, bk)
+                vt = ops.linear(wv, pad, bias_rows=bv)                                  # [inner][B*skv_alloc] = V^T
                 pk.ehs, pk.ehs_version, pk.kv = ehs, ehs._version, (k, vt, skv, skv_alloc)
             k, vt, skv, skv_alloc = pk.kv
-            q = ops.linear(x2, attn.to_q.weight, attn.to_q.bias)
+            q = ops.linear(x2, wq, bq)
             o = ops.attention(q, k, vt, B=B, H=heads, D=D, Sq=S, Skv=skv, Skv_alloc=skv_alloc, q_row_stride=inner,
                               k_row_stride=inner, q_batch_stride=S * inner, k_batch_stride=skv_alloc * inner,
                               vt_ld=B * skv_alloc, vt_batch_stride=skv_alloc, scale=scale)
@@ -249,7 +268,7 @@ class MI355XAttnProcessor:
         fuse_res = input_ndim == 3 and getattr(attn, "residual_connection", False)
         # to_out[0] (+ the residual and 1 / rescale_output_factor in the GEMM epilogue when the tokens are already row-major);
         # to_out[1] is Dropout: identity at inference
-        out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias,
+        out = ops.linear(o, wo, attn.to_out[0].bias,
                          residual=residual.reshape(B * S, -1) if fuse_res else None,
                          out_scale=(1.0 / rs) if (fuse_res and rs != 1.0) else 1.0).view(B, S, -1)
         if fuse_res:

@@ -156,6 +156,46 @@ def test_backend_under_a_full_width_flux_block(monkeypatch):
     _run_flux_backend(monkeypatch, "cuda", cfg, s_img=4096, s_txt=512, gate=lambda f: 1.2 * f)
 
 
+def _run_wan_backend(monkeypatch, dev, gate):
+    """The same binding under a real WanTransformer3DModel (transformer_wan.py:143-155: self-attention over the video tokens and
+    cross-attention over the text tokens both go through dispatch_attention_fn)."""
+    from diffusers_amd import init as dinit
+    from diffusers_amd.attention_backend import BACKEND_NAME, register_backend
+    ref = _load_ref()
+    cnt = _env(monkeypatch, dev)
+    ad = importlib.import_module(ref.__name__ + ".models.attention_dispatch")
+    register_backend()
+    cfg = dinit.TINY_WAN
+    torch.manual_seed(0)
+    model = ref.WanTransformer3DModel(**_as_lists(cfg)).eval().to(dev)
+    g = torch.Generator().manual_seed(2)
+    hs = torch.randn((1, cfg["in_channels"], 3, 16, 16), generator=g).to(dev)            # 3 x 8 x 8 = 192 tokens
+    ehs = torch.randn((1, 16, cfg["text_dim"]), generator=g).to(dev)
+    ts = torch.tensor([500]).to(dev)
+    with torch.no_grad():
+        want = model(hidden_states=hs, timestep=ts, encoder_hidden_states=ehs, return_dict=False)[0]
+        model.to(bf16)
+        floor = model(hidden_states=hs.to(bf16), timestep=ts, encoder_hidden_states=ehs.to(bf16), return_dict=False)[0]
+        assert cnt.n == 0
+        with ad.attention_backend(BACKEND_NAME):
+            got = model(hidden_states=hs.to(bf16), timestep=ts, encoder_hidden_states=ehs.to(bf16), return_dict=False)[0]
+    assert cnt.n == 2 * cfg["num_layers"], f"{cnt.n} flash launches for {cfg['num_layers']} blocks (self + cross each)"
+    assert {s[3] for s in cnt.shapes} == {192, 16}                                         # key counts: video tokens, text tokens
+    rf, rg = _rel(floor, want), _rel(got, want)
+    print(f"[B4] reference WanTransformer3DModel under attention_backend('{BACKEND_NAME}'): rel-rms vs its fp32 run {rg:.3e} (native bf16 floor {rf:.3e})")
+    assert rg <= gate(rf), (rg, rf)
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference sources not present")
+def test_backend_under_the_reference_wan_model_cpu(monkeypatch):
+    _run_wan_backend(monkeypatch, "cpu", gate=lambda f: max(1.5 * f, 2.5e-2))
+
+
+@pytest.mark.gpu
+def test_backend_under_the_reference_wan_model(monkeypatch):
+    _run_wan_backend(monkeypatch, "cuda", gate=lambda f: max(1.2 * f, 1.5e-2))
+
+
 def _run_backend_gates(monkeypatch, dev):
     """What the reference's public API does with the slots: gated slots are refused by register_backend (the API would raise
     before dispatching); an ungated slot can be taken over; unsupported arguments raise from the backend itself."""
@@ -341,3 +381,20 @@ def test_processor_on_the_reference_unet_sdxl_width(monkeypatch):
                use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=256,
                projection_class_embeddings_input_dim=2816)
     _run_processor(monkeypatch, "cuda", cfg, hw=64, gate=lambda f: 1.2 * f)
+
+
+SD15_HEADS_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(320, 640), layers_per_block=1,
+                       cross_attention_dim=768, attention_head_dim=8, down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                       up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D"))
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference sources not present")
+def test_processor_pads_the_sd15_head_sizes_cpu(monkeypatch):
+    """SD1.5's geometry: 8 heads of 40 / 80 channels (`attention_head_dim=8` is the head COUNT there) -- not flash-kernel sizes: the
+    processor zero-pads the projections to 64 / 96 per head once per module, as the engine's own model classes do at load time."""
+    _run_processor(monkeypatch, "cpu", SD15_HEADS_UNET, hw=16, gate=lambda f: max(1.5 * f, 2.5e-2))
+
+
+@pytest.mark.gpu
+def test_processor_pads_the_sd15_head_sizes(monkeypatch):
+    _run_processor(monkeypatch, "cuda", SD15_HEADS_UNET, hw=16, gate=lambda f: max(1.2 * f, 1.5e-2))
