@@ -29,6 +29,8 @@
 // results differ from the previous kernel in the last bits (different shift m, different summation order of l).
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "common.cuh"
 
 namespace da_attn2 {
@@ -67,7 +69,15 @@ __device__ __forceinline__ int k_swz(int row) {
 // P.V k-step accumulates sum_k P^T[k][q] into a 17th / 33rd accumulator tile (every row of it holds the row sums), so the 32 v_add_f32
 // per tile disappear (4 more MFMAs per tile instead).  l is then the sum of the bf16-ROUNDED probabilities -- exactly the weights
 // the second product applies to V -- and it is rescaled with O when the running shift moves.
-template <int D, int NW, int NS, bool AUG, bool RSM>
+// PRIO = 1 (round 5): one s_setprio pair per tile -- priority 1 from the end of the Q.K^T block to the end of the tile's softmax
+// slices (which carry the previous tile's P.V MFMAs), priority 0 for the rescale, the rendezvous, the K-fragment reads, the LDS-DMA
+// issue and the Q.K^T MFMAs.  With three workgroups per CU a SIMD holds three waves of three workgroups; the arbitration then lets a
+// wave that is inside its softmax / P.V phase run ahead of a wave that is starting a tile, which takes the co-resident waves out of
+// step: one wave's transcendental-heavy VALU phase sits beside another's MFMA block instead of beside the same phase of its peers.
+// Measured (profiles/r05f_attention_setprio.jsonl, chained launches): S 1024 24.2 -> 21.6 us, S 4096 121.6 -> 112.7 us at D = 64,
+// nothing at D = 128 (one eight-wave workgroup per CU); eleven other placements (P.V MFMAs alone, VALU slices alone, graded by
+// slice, the memory head raised, static per-workgroup levels) gain less or lose.  Speed only: the same operations in the same order.
+template <int D, int NW, int NS, bool AUG, bool RSM, int PRIO = 0>
 // min waves per SIMD: D = 64 / four waves: three workgroups per CU (<= 168 registers); eight waves: one workgroup = two per SIMD
 __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 1)) void attn2_fwd_kernel(const da_attention_params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -233,6 +243,7 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
 #pragma unroll
       for (int k = 0; k < KB; ++k) kf[k] = kfrag(sb, k);
       if (j + PD < ntiles) issue(j + PD, nxt);
+
       const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if constexpr (AUG) {
         s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, qx, zero16, 0, 0, 0);
@@ -247,6 +258,9 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
         }
       }
     }
+    // PRIO: from here to the end of the tile (softmax slices with tile j - 1's P.V MFMAs riding in them) the wave outranks waves that
+    // are still in their rendezvous / K-fragment / Q.K^T head -- see the template comment
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_sched_barrier(0);
     // ragged last tile: keys past Skv never win the maximum and exponentiate to exactly 0 (wave-uniform branch)
     const int kv0 = j * 64;
@@ -351,6 +365,7 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     pack_p(3);
 #pragma unroll
     for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(pf[u]));
@@ -436,11 +451,11 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int D, int NW, int NS, bool AUG, bool RSM>
-int launch(const da_attention_params& p, hipStream_t s) {
+template <int D, int NW, int NS, bool AUG, bool RSM, int PRIO>
+int launch_prio(const da_attention_params& p, hipStream_t s) {
   using C = Cfg<D>;
   const size_t lds = (size_t)NS * C::STAGE;
-  auto kern = attn2_fwd_kernel<D, NW, NS, AUG, RSM>;
+  auto kern = attn2_fwd_kernel<D, NW, NS, AUG, RSM, PRIO>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DA_ERR_LAUNCH;
@@ -450,6 +465,16 @@ int launch(const da_attention_params& p, hipStream_t s) {
   DA_LAUNCH(kern, dim3(8 * rounds * qtiles), dim3(64 * NW), lds, s, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
+}
+
+// D = 64: the priority pair of the template comment (default on; DA_ATTN2_PRIO=0 switches it off for A/B runs).
+template <int D, int NW, int NS, bool AUG, bool RSM>
+int launch(const da_attention_params& p, hipStream_t s) {
+  if constexpr (D == 64) {
+    static const int prio = [] { const char* v = getenv("DA_ATTN2_PRIO"); return v ? atoi(v) : 1; }();
+    if (prio == 1) return launch_prio<D, NW, NS, AUG, RSM, 1>(p, s);
+  }
+  return launch_prio<D, NW, NS, AUG, RSM, 0>(p, s);
 }
 
 }  // namespace da_attn2

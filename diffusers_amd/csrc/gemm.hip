@@ -27,6 +27,9 @@ namespace da_gemm2 {   // the K2 / K1 family (gemm2_kernel.cuh) compiles in its 
 int dispatch_lin(const da_gemm_params& p, int tile, int staging, hipStream_t s);   // gemm2_lin.hip
 int dispatch_conv(const da_gemm_params& p, int tile, int staging, hipStream_t s);  // gemm2_conv.hip
 }
+namespace da_gemm3 {   // the eight-phase 256 x 256 tile (gemm3.hip), nn.Linear only
+int dispatch_lin(const da_gemm_params& p, int tile, int staging, hipStream_t s);
+}
 
 namespace {
 
@@ -37,9 +40,12 @@ constexpr TileShape kTiles[] = {{0, 0, 0},      {128, 128, 4}, {64, 128, 4},  {1
                                 {256, 128, 8},  {128, 256, 8}, {256, 256, 8}, {128, 128, 8},
                                 // K2 family (gemm2_kernel.cuh)
                                 {128, 128, 8},  {128, 80, 8},  {128, 160, 8}, {80, 128, 8}, {128, 64, 8},
-                                {128, 320, 8},  {256, 128, 8}, {128, 256, 8}, {256, 160, 8}, {256, 256, 8}, {256, 320, 8}};
+                                {128, 320, 8},  {256, 128, 8}, {128, 256, 8}, {256, 160, 8}, {256, 256, 8}, {256, 320, 8},
+                                // K3 (gemm3.hip)
+                                {256, 256, 8}};
 static_assert(sizeof(kTiles) / sizeof(kTiles[0]) == DA_TILE_COUNT, "kTiles / DA_TILE_* mismatch");
-inline bool is_k2(int tile) { return tile >= DA_TILE_K2_128x128; }
+inline bool is_k3(int tile) { return tile == DA_TILE_K3_256x256; }
+inline bool is_k2(int tile) { return tile >= DA_TILE_K2_128x128 && !is_k3(tile); }
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 // Untuned fallback: fewest bytes staged per flop among the tiles that still give every CU a block; output-channel
@@ -103,6 +109,8 @@ int stats_parts(const da_gemm_params& p, int tile) {   // one partial per column
 
 bool tile_ok(const da_gemm_params& p, int tile) {
   if (tile <= 0 || tile >= kNumTiles) return false;
+  if (is_k3(tile))   // nn.Linear, plain or GEGLU epilogue, nothing that needs the other families' extra instantiations
+    return !p.conv && p.split_k <= 1 && !p.stats_out && !p.ln_stats && !p.vt && !p.xa_k;
   if (is_k2(tile)) {
     const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
     const bool geglu_ok = tile == DA_TILE_K2_128x128 || tile == DA_TILE_K1_256x128 || tile == DA_TILE_K1_128x256 ||
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(256) void touch_kernel(const uint4* __restrict__ sr
 }
 
 int run(const da_gemm_params& p, int tile, int staging, hipStream_t s, const da_gemm_params* pb = nullptr) {
+  if (is_k3(tile)) return pb ? DA_ERR_UNSUPPORTED : da_gemm3::dispatch_lin(p, tile, staging, s);
   if (is_k2(tile)) {
     if (pb) return DA_ERR_UNSUPPORTED;
     return p.conv ? da_gemm2::dispatch_conv(p, tile, staging, s) : da_gemm2::dispatch_lin(p, tile, staging, s);
@@ -221,7 +230,8 @@ extern "C" int da_gemm_tune(const da_gemm_params* pp, const da_gemm_params* pair
     const int split = splits[spi];
     p.split_k = split;
     for (int tile = 1; tile < kNumTiles; ++tile) {
-      if ((family == DA_TILE_FAMILY_1 && is_k2(tile)) || (family == DA_TILE_FAMILY_K2 && !is_k2(tile))) continue;
+      // (the K3 tile sums K in the K1 / K2 family's order: it competes wherever that family does)
+      if ((family == DA_TILE_FAMILY_1 && (is_k2(tile) || is_k3(tile))) || (family == DA_TILE_FAMILY_K2 && !is_k2(tile) && !is_k3(tile))) continue;
       if (!tile_ok(p, tile) || (pair && !tile_ok(pb, tile))) continue;
       // a tile more than twice the problem in either dimension only wastes MFMA rows
       if (kTiles[tile].bm >= 2 * p.M + 64 || kTiles[tile].bn >= 2 * p.N + 64) continue;

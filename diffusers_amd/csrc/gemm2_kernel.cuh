@@ -29,18 +29,10 @@
 
 #include "common.cuh"
 #include "diffusers_amd.h"
+#include "gemm2_shared.cuh"
 
 namespace da_gemm2 {
 
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, size_t bytes) {
-  const uint64_t v = (uint64_t)base;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes));
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
-}
-#endif
 
 // Stage timestamps (tools/trace_gemm2.hip builds this header with -DDA_GEMM2_TRACE; the library never does): s_memtime at the
 // marks below, kept in SGPRs and written by lane 0 of every wave after its last output store.
@@ -51,64 +43,7 @@ __device__ unsigned long long* g_da2_trace;
 #define DA2_TRACE(i) ((void)0)
 #endif
 
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
 
-// One 4-channel group of one output row: the fused epilogue of gemm_kernel.cuh (bias, per-row bias, per-batch channel
-// vector, activation, gate, residual, output scale) with the same rounding points.  o[] in, o[] out (fp32).
-// ACT / GATE are compile-time (ACT = -1: decided at run time, the gated launches): the epilogue of a launch is ONE straight
-// line of code per output tile -- with the activation switch inside the unrolled tile loop every tile jumped through its own
-// copy of a 4 KB switch and the epilogue, 650-820 cycles per tile, was bound by instruction fetch
-// (profiles/r03e_gemm_stage_trace.md).  Absent operands are ZERO vectors (adding a bf16 zero / multiplying by 1.0f is exact),
-// so there is no per-tile branch on them either.  FINISH = false stops in front of the residual: the row-contiguous store
-// path adds it (and the output scale) after the values went through LDS -- the same fp32 operations in the same order.
-// GATE: 0 none, 1 bf16 [B][ld_gate], 2 fp32.
-template <int ACT, int GATE, bool FINISH>
-__device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int n, int bidx, float brow, uint2 bv, uint2 rv, uint2 resv) {
-  o[0] += bf_lo(bv.x); o[1] += bf_hi(bv.x); o[2] += bf_lo(bv.y); o[3] += bf_hi(bv.y);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] += brow;
-  o[0] += bf_lo(rv.x); o[1] += bf_hi(rv.x); o[2] += bf_lo(rv.y); o[3] += bf_hi(rv.y);
-  const int act = ACT >= 0 ? ACT : p.act;
-  if (act == DA_ACT_GELU_TANH) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = gelu_tanh_f(bf2f(f2bf(o[e])));
-  } else if (act == DA_ACT_SILU) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = silu_f(bf2f(f2bf(o[e])));
-  } else if (act == DA_ACT_GELU_ERF) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(bf2f(f2bf(o[e])));
-  } else if (act == DA_ACT_QUICK_GELU) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float xv = bf2f(f2bf(o[e]));
-      const float tv = bf2f(f2bf(1.702f * xv));
-      o[e] = xv * bf2f(f2bf(1.0f / (1.0f + __expf(-tv))));
-    }
-  }
-  if constexpr (GATE == 2) {
-    const float4 gv = *(const float4*)((const float*)p.gate + (size_t)bidx * p.ld_gate + n);
-    o[0] = bf2f(f2bf(o[0])) * gv.x; o[1] = bf2f(f2bf(o[1])) * gv.y;
-    o[2] = bf2f(f2bf(o[2])) * gv.z; o[3] = bf2f(f2bf(o[3])) * gv.w;
-  } else if constexpr (GATE == 1) {
-    const uint2 gv = *(const uint2*)((const uint16_t*)p.gate + (size_t)bidx * p.ld_gate + n);
-    o[0] = bf2f(f2bf(bf2f(f2bf(o[0])) * bf_lo(gv.x)));
-    o[1] = bf2f(f2bf(bf2f(f2bf(o[1])) * bf_hi(gv.x)));
-    o[2] = bf2f(f2bf(bf2f(f2bf(o[2])) * bf_lo(gv.y)));
-    o[3] = bf2f(f2bf(bf2f(f2bf(o[3])) * bf_hi(gv.y)));
-  }
-  if constexpr (FINISH) {
-    o[0] += bf_lo(resv.x); o[1] += bf_hi(resv.x); o[2] += bf_lo(resv.y); o[3] += bf_hi(resv.y);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] *= p.out_scale;
-  }
-}
 
 // KG K-groups of WM x WN waves (KG * WM * WN == 8), each wave owns MT x NT tiles of 16 x 16  ->  block tile (16*MT*WM) x (16*NT*WN).
 // KG == 2: the design described above (two groups of four waves on alternate K slices; the ring unit is a slice PAIR).
@@ -1272,35 +1207,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
 }
 
 // ---- host side ----
-inline int choose_xcd_gx2(int tiles_m, int tiles_n, int BM, int BN) {   // as da_gemm::choose_xcd_gx
-  // experiments: DA_XCD_GX = 1 / 2 / 4 / 8 pins the number of XCD columns (1: every XCD owns whole row panels -- it reads rows the
-  // previous launch's same-numbered XCD wrote; 8: whole column panels -- each weight row is fetched by one XCD only)
-  static const int forced = [] { const char* v = getenv("DA_XCD_GX"); return v ? atoi(v) : 0; }();
-  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
-  int best = 1;
-  double best_cost = 1e300;
-  for (int gx = 1; gx <= 8; gx *= 2) {
-    const int gy = 8 / gx;
-    const int tm_per = (tiles_m + gy - 1) / gy, tn_per = (tiles_n + gx - 1) / gx;
-    const double inflation = (double)(8 * tm_per * tn_per) / ((double)tiles_m * tiles_n);
-    const double cost = ((double)tm_per * BM + (double)tn_per * BN) * inflation * inflation;
-    if (cost < best_cost) {
-      best_cost = cost;
-      best = gx;
-    }
-  }
-  return best;
-}
 
-// 31-bit offset budget of the buffer-addressed staging (as da_gemm::buffer_staging_fits, for tiles up to 256 rows)
-inline bool staging_fits(const da_gemm_params& p) {
-  const size_t lim = 0x3fffffffull;
-  if ((size_t)p.ldw * 512 >= lim || (size_t)p.K * 2 >= lim) return false;
-  if (!p.conv) return (size_t)p.lda * 512 < lim;
-  const size_t cmax = (size_t)(p.C1 > p.C2 ? p.C1 : p.C2);
-  const size_t span = (size_t)256 * p.stride * p.stride + (size_t)(6 + 2 * p.stride) * p.Win + 64;
-  return span * cmax * 2 < lim && (size_t)p.M / ((size_t)p.Hout * p.Wout) * p.Hin * p.Win < 0x7fffffffull;
-}
 
 template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false,
           bool LNF = false, int XA = 0>

@@ -1,0 +1,362 @@
+// Third GEMM structure ("K3", round 5): the 256 x 256 tile as an EIGHT-PHASE loop with the two wave rows half a phase apart
+// (the schedule of /opt/skills/guides/cdna_hip_programming.md "The 256^2 8-phase template"; VERDICT r4 "next round" item 4).
+// nn.Linear only: C[M][N] = epilogue(alpha * A[M][K] . W[N][K]^T), the large-M / large-N products of the DiT blocks
+// (transformer_flux.py:383-412 proj_mlp / proj_out, :95-130 to_q/k/v; transformer_wan.py:488-502 ffn) and SDXL's GEGLU projection
+// (activations.py:113-124).
+//
+// Why another structure.  The K1 tiles of gemm2_kernel.cuh run all eight waves through the same K slice at the same time: every
+// wave issues its LDS-DMA and its ds_reads right behind the rendezvous and then every wave multiplies -- the matrix pipe of a SIMD
+// idles while its two waves fetch, and both want it at once afterwards (1000-1050 TFLOP/s steady state, profiles/r04*).  Here the
+// 2 x 4 waves of a workgroup are two GROUPS of four (one wave per SIMD each) that run the same phase sequence ONE BARRIER APART:
+// while group 0 multiplies a 64 x 32 quadrant of its 128 x 64 wave tile (16 MFMAs, s_setprio 1), group 1 -- the other wave of
+// every SIMD -- reads its next fragments from LDS and issues its share of the LDS-DMA; at the next barrier they swap.  A SIMD's
+// matrix pipe then always has exactly one wave feeding it and the other wave's memory work hides under it.
+//
+// Geometry.  Tile 256 x 256, K slices of 64 (128 B per row), 8 waves = 2 (wr) x 4 (wc).  LDS: two K-slice buffers x four 16 KiB
+// HALF-TILES (A0, A1, B0, B1: 128 rows x 128 B each) = 128 KiB.  A half h = tile rows [128 h, 128 h + 128); wave row wr owns rows
+// 64 wr .. 64 wr + 63 of each.  B half h' = the columns 64 q + 32 h' + [0, 32) (q = 0..3) of the tile, wave column wc owns q = wc,
+// i.e. the 64 CONTIGUOUS output columns [64 wc, 64 wc + 64) -- with GEGLU's packed weight rows ([32 value | 32 gate] per 64) half 0
+// is the value and half 1 its gate.  Quadrant (h, h') of a wave = 4 x 2 MFMA tiles of 16 x 16, x 2 k-steps of 32 = 16 MFMAs
+// (v_mfma_f32_16x16x32_bf16, weights as the A operand: a lane ends up with 4 consecutive output channels of one row).
+// LDS image of a half-tile: 1 KiB pieces of 8 rows x 128 B written lane-linear by LDS-DMA, the 16-byte slots XOR-swizzled with
+// (row >> 1) & 7 on the SOURCE side (as gemm2_kernel.cuh: conflict-free for the ds_read_b128 fragment reads).
+//
+// Phases of K slice kt (buffer kt & 1); every wave stages 2 pieces (1/8 of one half-tile) per phase; B half 0 of the slice is already
+// in registers (BX) when its first phase starts, the roles of the two B register sets alternate from slice to slice:
+//   P1 quadrant (0,0): ds_read A0 (8) -> af          stage B0 of slice kt + 2 (this buffer)
+//   P2 quadrant (0,1): ds_read B1 (4) -> BY          stage A0 of slice kt + 2
+//   P3 quadrant (1,1): ds_read A1 (8) -> af          stage B1 of slice kt + 2
+//   P4 quadrant (1,0): ds_read B0 of slice kt + 1 (4, other buffer) -> BY      stage A1 of slice kt + 2
+// each phase = [reads, stage, s_waitcnt vmcnt(12), s_waitcnt lgkmcnt(0)] s_barrier [setprio 1, 16 MFMA, setprio 0] s_barrier.
+// Both waits sit IN FRONT of the phase's first barrier, i.e. inside the segment that runs beside the other group's MFMAs: the
+// multiply starts the moment the barrier opens.
+// Hazards (group 1 runs one barrier late, so "a phase later" for one group is half a phase later for the other; barriers numbered
+// #0, #1, ...: group 0's phase g reads / stages in (#2g-1, #2g) and multiplies in (#2g, #2g+1), group 1's in (#2g, #2g+1) and
+// (#2g+1, #2g+2)):
+//   WAR  the ds_reads of phase g are RETIRED (lgkmcnt(0)) before their wave arrives at the phase's first barrier, so every read of
+//        phase g by either group is complete once barrier #2g+1 has opened, and the staging segment of phase g + 1 starts behind it
+//        for both groups: a half-tile may be restaged ONE phase after its last read.  A0 is read in P1 and restaged in P2, B1:
+//        P2 -> P3, A1: P3 -> P4, B0 (read in P4 of the previous slice) -> P1: every half-tile at the earliest legal phase.
+//   RAW  a wave's counted vmcnt in front of phase w's first barrier retires its own pieces; everybody's are visible once #2w+1 has
+//        opened, i.e. to reads from phase w + 1 on.  vmcnt(12) after the phase's own staging leaves the SIX newest half-tiles in
+//        flight: the half-tile staged in phase s is retired in phase s + 6 and read in phase s + 7 (B0 of slice kt + 2: staged P1 of
+//        kt, read P4 of kt + 1; likewise the other three) -- seven phases, ~3.5 k cycles, between a piece's issue and its use.
+// Slices past the end of K are staged as zeros (bit 31 of the per-lane offset: beyond num_records, the range check writes zeros
+// without touching memory): every phase issues the same loads, the vmcnt immediates are constants and an odd slice count multiplies
+// one slice of zeros.
+//
+// Variants measured on the way (profiles/r05g_*, same-box ratios against k1:256x256 at 8192^3 / Wan's 32760 x 5120 x 13824):
+// the guide's placement (reads 12 / 4 / 8 / 0, lgkmcnt(0) BEHIND the barrier, one vmcnt(6) per slice) 1.12 / 1.09; the reads of a later
+// phase issued behind the MFMAs of the current one (nothing but LDS-DMA in the other segment) 1.04 / 0.99 -- the read issue then
+// sits between the last MFMA and the barrier that lets the other group start, exposed; this form 1.11 / 1.10 and the best absolute
+// rates (1443 TFLOP/s at 8192^3, 1373 at 4096^3, 1434 on the Wan shape; random operands).
+//
+// Numerics: fp32 accumulation, K slices in order, k-step 0 then 1 -- the order of every KG = 1 tile of gemm2_kernel.cuh, and the
+// epilogue is that header's epilogue4: BIT-IDENTICAL to DA_TILE_K1_256x256 (tests/test_gemm_k3_gpu.py asserts equality).
+#include "gemm2_shared.cuh"
+
+namespace da_gemm3 {
+
+using da_gemm2::epilogue4;
+
+constexpr int BM = 256, BN = 256;
+constexpr int HALF = 128 * 128;      // bytes of one half-tile (128 rows x 64 bf16)
+constexpr int KBUF = 4 * HALF;       // one K slice: A0 | A1 | B0 | B1
+constexpr int LDS_BYTES = 2 * KBUF;  // 128 KiB
+
+#define K3_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
+
+template <bool GEGLU>
+__global__ __launch_bounds__(512) void gemm3_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  // ---- XCD-aware tile mapping (as gemm2_kernel.cuh: block b runs on XCD b % 8, each XCD owns a rectangle of tiles) ----
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int gyn = 8 / xcd_gx;
+  const int tm_per = (tiles_m + gyn - 1) / gyn, tn_per = (tiles_n + xcd_gx - 1) / xcd_gx;
+  const int bid = (int)blockIdx.x;
+  const int xcd = bid & 7, kblk = bid >> 3;
+  const int gy = xcd / xcd_gx, gx = xcd - gy * xcd_gx;
+  const int lm = kblk / tn_per, ln = kblk - lm * tn_per;
+  const int tm = gy * tm_per + lm, tn = gx * tn_per + ln;
+  if (tm >= tiles_m || tn >= tiles_n) return;             // ragged rectangle: the whole block leaves before any barrier
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = p.K >> 6;
+
+  const uint16_t* __restrict__ A = (const uint16_t*)p.A;
+  const uint16_t* __restrict__ Wt = (const uint16_t*)p.W;
+  __amdgpu_buffer_rsrc_t rs_a = da_gemm2::uniform_rsrc(A + (size_t)m0 * p.lda, 0x7fffffff);
+  __amdgpu_buffer_rsrc_t rs_w = da_gemm2::uniform_rsrc(Wt + (size_t)n0 * p.ldw, 0x7fffffff);
+
+  // ---- staging: wave w sends pieces w and w + 8 of every half-tile; lane -> row 8 * piece + (lane >> 3), 16-byte slot lane & 7 ----
+  // rows past M / N are clamped to the last valid row (their products land in rows / columns the epilogue never stores)
+  int vo_a[2][2], vo_b[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rho = 8 * (wave + 8 * i) + (lane >> 3);
+      const int sc = (lane & 7) ^ ((rho >> 1) & 7);
+      const int ra = min(h * 128 + rho, p.M - 1 - m0);
+      const int rb = min(64 * (rho >> 5) + 32 * h + (rho & 31), p.N - 1 - n0);
+      vo_a[h][i] = (ra * p.lda + sc * 8) * 2;
+      vo_b[h][i] = (rb * p.ldw + sc * 8) * 2;
+    }
+  // WHICH: 0 = A0, 1 = A1, 2 = B0, 3 = B1 of slice `ks` into buffer BUF
+  auto stage = [&](auto buf_c, auto which_c, int ks) {
+    constexpr int BUF = decltype(buf_c)::value, WHICH = decltype(which_c)::value;
+    const int z = (ks < nk) ? 0 : (int)0x80000000;
+    const int so = min(ks, nk - 1) * 128;
+    unsigned char* dst = smem + BUF * KBUF + WHICH * HALF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (WHICH < 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, K3_LDS(dst + i * 8192), 16, vo_a[WHICH][i] | z, so, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, K3_LDS(dst + i * 8192), 16, vo_b[WHICH - 2][i] | z, so, 0, 0);
+    }
+  };
+  using std::integral_constant;
+  constexpr integral_constant<int, 0> I0{};
+  constexpr integral_constant<int, 1> I1{};
+  constexpr integral_constant<int, 2> I2{};
+  constexpr integral_constant<int, 3> I3{};
+
+  // bias of the wave's four 16-column tiles (zeros without one): requested FIRST, so that the loads are older than every LDS-DMA piece
+  // and the counted vmcnt waits below never see them
+  uint2 bias_v[2][2];
+#pragma unroll
+  for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bias_v[hp][j] = make_uint2(0, 0);
+  if (p.bias) {
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bias_v[hp][j] = *(const uint2*)((const uint16_t*)p.bias + min(n0 + 64 * wc + 32 * hp + 16 * j + 4 * kq, p.N - 4));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- prologue: slices 0 and 1 whole, in the loop's order (B0, A0, B1, A1) ----
+  stage(I0, I2, 0);
+  stage(I0, I0, 0);
+  stage(I0, I3, 0);
+  stage(I0, I1, 0);
+  stage(I1, I2, 1);
+  stage(I1, I0, 1);
+  stage(I1, I3, 1);
+  stage(I1, I1, 1);
+
+  f32x4_t acc[2][2][4][2];   // [A half][B half][row tile][column tile]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[h][hp][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row r16 of a 16-row tile, 16-byte chunk (kq + 4 ks) ^ ((r16 >> 1) & 7); k-step 1 = chunk ^ 4
+  const int fsw = (r16 >> 1) & 7;
+  const int foff0 = r16 * 128 + ((kq ^ fsw) << 4), foff1 = r16 * 128 + (((kq ^ fsw) ^ 4) << 4);
+  const unsigned char* fa[2] = {smem + wr * 8192 + foff0, smem + wr * 8192 + foff1};
+  const unsigned char* fb[2] = {smem + 2 * HALF + wc * 4096 + foff0, smem + 2 * HALF + wc * 4096 + foff1};
+  bf16x8_t af[4][2], bq0[2][2], bq1[2][2];   // [tile][k-step]: the current A half and two B halves (roles alternate per slice)
+
+#define K3_READ_A(BUF, H)                                                                                         \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+      af[i][ks] = *(const bf16x8_t*)(fa[ks] + (BUF) * KBUF + (H) * HALF + i * 2048);                              \
+  } while (0)
+#define K3_READ_B(DST, BUF, HP)                                                                                   \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+      DST[j][ks] = *(const bf16x8_t*)(fb[ks] + (BUF) * KBUF + (HP) * HALF + j * 2048);                            \
+  } while (0)
+#define K3_MFMA(H, HP, BQ)                                                                                        \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+      acc[H][HP][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BQ[j][ks], af[i][ks], acc[H][HP][i][j], 0, 0, 0); \
+  } while (0)
+#define K3_FENCE() __builtin_amdgcn_sched_barrier(0)
+// one phase: [ds_reads of THIS phase's new fragments, LDS-DMA of one half-tile, counted waits] barrier [16 MFMAs] barrier
+#define K3_PHASE(READ_STMT, STAGE_STMT, H, HP, BQ)                                                                \
+  do {                                                                                                            \
+    K3_FENCE();                                                                                                   \
+    READ_STMT;                                                                                                    \
+    K3_FENCE();                                                                                                   \
+    STAGE_STMT;                                                                                                   \
+    K3_FENCE();                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   /* all but the six newest half-tiles have landed */       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* this phase's fragments are in registers */             \
+    K3_FENCE();                                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    K3_FENCE();                                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    K3_MFMA(H, HP, BQ);                                                                                           \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    K3_FENCE();                                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    K3_FENCE();                                                                                                   \
+  } while (0)
+// the four phases of slice KT held in buffer BUF (the other buffer: OTH); BX holds B half 0 of the slice on entry, BY is free
+#define K3_SLICE(BUF, OTH, KT, BX, BY)                                                                            \
+  do {                                                                                                            \
+    K3_PHASE(K3_READ_A(BUF, 0), stage(integral_constant<int, BUF>{}, I2, (KT) + 2), 0, 0, BX);                    \
+    K3_PHASE(K3_READ_B(BY, BUF, 1), stage(integral_constant<int, BUF>{}, I0, (KT) + 2), 0, 1, BY);                \
+    K3_PHASE(K3_READ_A(BUF, 1), stage(integral_constant<int, BUF>{}, I3, (KT) + 2), 1, 1, BY);                    \
+    K3_PHASE(K3_READ_B(BY, OTH, 0), stage(integral_constant<int, BUF>{}, I1, (KT) + 2), 1, 0, BX);                \
+  } while (0)
+
+  // B0 / A0 of slice 0 landed (every wave's own pieces; the barrier makes them everybody's), six half-tiles in flight; B half 0 of
+  // slice 0 is read here and is IN REGISTERS before P1 restages its half-tile
+  K3_FENCE();
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  K3_FENCE();
+  K3_READ_B(bq0, 0, 0);
+  K3_FENCE();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  K3_FENCE();
+  if (wr == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind group 0 from here on
+  K3_FENCE();
+  for (int kt = 0; kt < nk; kt += 2) {
+    K3_SLICE(0, 1, kt, bq0, bq1);
+    K3_SLICE(1, 0, kt + 1, bq1, bq0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the zero-filled stagings of slices past K)
+  K3_FENCE();
+  if (wr == 0) __builtin_amdgcn_s_barrier();              // group 0 meets group 1's last barrier
+  K3_FENCE();
+  __builtin_amdgcn_s_barrier();                           // every wave's LDS-DMA and ds_reads are done: LDS is free for the epilogue
+  K3_FENCE();
+
+  // ---- epilogue: lane holds, for output row r16 of a 16-row tile, channels 4 kq .. 4 kq + 3 of a 16-column tile ----
+  auto row_of = [&](int h, int i) { return m0 + h * 128 + wr * 64 + i * 16 + r16; };
+  auto col_of = [&](int hp, int j) { return n0 + 64 * wc + 32 * hp + 16 * j + 4 * kq; };
+  if constexpr (GEGLU) {
+    // packed weight rows: per 64 = [32 value | 32 gate]: B half 0 is the value, half 1 its gate (activations.py:113-124)
+    auto body = [&](auto tanh_c) __attribute__((always_inline)) {
+      constexpr bool TANH = decltype(tanh_c)::value;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = row_of(h, i);
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (col_of(0, j) >= p.N) continue;
+            const int no = ((n0 + 64 * wc) >> 1) + 16 * j + 4 * kq;
+            const uint2 bh = bias_v[0][j], bg = bias_v[1][j];      // zeros without a bias
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float hv = acc[h][0][i][j][e] * p.alpha, gv = acc[h][1][i][j][e] * p.alpha;
+              hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
+              gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
+              hv = bf2f(f2bf(hv));   // the reference rounds the projection to bf16 before chunk / gelu / mul
+              gv = bf2f(f2bf(gv));
+              o[e] = hv * bf2f(f2bf(TANH ? gelu_tanh_f(gv) : gelu_erf_f(gv)));
+            }
+            uint2 pk;
+            pk.x = pack_bf2(o[0], o[1]);
+            pk.y = pack_bf2(o[2], o[3]);
+            *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + no) = pk;
+          }
+        }
+    };
+    if (p.act == DA_ACT_GEGLU) body(std::false_type{});
+    else body(std::true_type{});
+  } else {
+    const uint16_t* __restrict__ bias_rows = (const uint16_t*)p.bias_rows;
+    const bool has_rowvec = p.rowvec != nullptr, has_res = p.residual != nullptr;
+    auto body = [&](auto act_c, auto gate_c) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_c)::value, GATE = decltype(gate_c)::value;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = row_of(h, i);
+          if (m >= p.M) continue;
+          const int bidx = (GATE != 0 || has_rowvec) ? (m / p.rows_per_batch) : 0;
+          const float brow = bias_rows ? bf2f(bias_rows[m]) : 0.f;
+#pragma unroll
+          for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int n = col_of(hp, j);
+              if (n >= p.N) continue;
+              float o[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = acc[h][hp][i][j][e] * p.alpha;
+              uint2 rvv = make_uint2(0, 0), rsv = make_uint2(0, 0);
+              if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
+              if (has_res) rsv = *(const uint2*)((const uint16_t*)p.residual + (size_t)m * p.ldr + n);
+              epilogue4<ACT, GATE, true>(p, o, n, bidx, brow, bias_v[hp][j], rvv, rsv);
+              if (p.out_f32) {
+                *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+              } else {
+                uint2 pk;
+                pk.x = pack_bf2(o[0], o[1]);
+                pk.y = pack_bf2(o[2], o[3]);
+                *(uint2*)((uint16_t*)p.C + (size_t)m * p.ldc + n) = pk;
+              }
+            }
+        }
+    };
+    constexpr integral_constant<int, -1> RT{};
+    constexpr integral_constant<int, 0> G0{};
+    if (p.gate && p.gate_f32) body(RT, integral_constant<int, 2>{});
+    else if (p.gate) body(RT, integral_constant<int, 1>{});
+    else if (p.act == DA_ACT_NONE) body(integral_constant<int, DA_ACT_NONE>{}, G0);
+    else if (p.act == DA_ACT_GELU_TANH) body(integral_constant<int, DA_ACT_GELU_TANH>{}, G0);
+    else body(RT, G0);
+  }
+#undef K3_READ_A
+#undef K3_READ_B
+#undef K3_MFMA
+#undef K3_FENCE
+#undef K3_PHASE
+#undef K3_SLICE
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <bool GEGLU>
+int launch(const da_gemm_params& p, hipStream_t s) {
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int gx = da_gemm2::choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
+  const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
+  auto kern = gemm3_bf16_kernel<GEGLU>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return DA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  DA_LAUNCH(kern, dim3(grid), dim3(512), LDS_BYTES, s, p, gx);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// nn.Linear, one ring form (DA_STAGE_LDS_DIRECT), no split-K / LayerNorm fold / transposed block / cross-attention epilogue
+int dispatch_lin(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
+  if (tile != DA_TILE_K3_256x256 || staging != DA_STAGE_LDS_DIRECT) return DA_ERR_UNSUPPORTED;
+  if (p.conv || p.split_k > 1 || p.stats_out || p.ln_stats || p.vt || p.xa_k || !da_gemm2::staging_fits(p)) return DA_ERR_UNSUPPORTED;
+  const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
+  return geglu ? launch<true>(p, s) : launch<false>(p, s);
+}
+
+}  // namespace da_gemm3

@@ -67,7 +67,12 @@ extern "C" {
 #define DA_TILE_K1_256x160 17 /* 4 x 2 waves of 64 x 80 */
 #define DA_TILE_K1_256x256 18 /* 2 x 4 waves of 128 x 64 */
 #define DA_TILE_K1_256x320 19 /* 4 x 2 waves of 64 x 160, W fragments streamed (nn.Linear; GEGLU with interleaved tile ownership) */
-#define DA_TILE_COUNT 20
+/* Third structure (K3, gemm3.hip; round 5): the 256 x 256 tile as an eight-phase loop, the two wave rows of the workgroup half a
+ * phase apart (one multiplies while the other reads LDS and issues LDS-DMA).  nn.Linear only, staging DA_STAGE_LDS_DIRECT only; no
+ * split_k / LayerNorm fold / transposed block / cross-attention epilogue.  Bit-identical to the K1 tiles above (same K order, same
+ * epilogue). */
+#define DA_TILE_K3_256x256 20 /* 2 x 4 waves of 128 x 64 (64 contiguous columns per wave: GEGLU pairs inside the wave) */
+#define DA_TILE_COUNT 21
 /* da_gemm_tune only: which variants compete, given in da_gemm_params.tile (DA_TILE_AUTO = all of them).  Within one family
  * every variant is bit-identical to every other; the two families differ in the fp32 summation order. */
 #define DA_TILE_FAMILY_1 (-1)

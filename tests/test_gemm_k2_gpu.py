@@ -52,7 +52,7 @@ def run_all(fn, L, what, conv=False, geglu=False, min_ok=5):
             assert "DA_ERR_UNSUPPORTED" in str(e), f"{what} {L.TILE_NAMES[t]}/{st}: {e}"
             continue
         n_ok += 1
-        fam = L.TILE_NAMES[t][:2]
+        fam = L.TILE_NAMES[t][:2].replace("k3", "k1")   # the eight-phase tile (gemm3.hip) sums K in the k1 order
         if fam not in base:
             base[fam] = y.clone()
         else:

@@ -1,0 +1,124 @@
+"""GPU tests of the eight-phase 256 x 256 tile (csrc/gemm3.hip, DA_TILE_K3_256x256): two wave rows half a phase apart, one
+multiplying while the other reads LDS and issues LDS-DMA (nn.Linear: transformer_flux.py:383-412, transformer_wan.py:488-502,
+activations.py:113-124).
+
+What must hold: (1) BIT-identical to DA_TILE_K1_256x256 of gemm2_kernel.cuh -- the same K order (slices in order, k-step 0 then 1),
+the same MFMA, the same epilogue -- on every shape, ragged edges, odd slice counts and every fused epilogue; since the two kernels
+share nothing but that arithmetic, one wrong or stale LDS byte anywhere shows as an inequality; (2) right against a plain PyTorch
+fp32 reference; (3) the same bits launch after launch (the schedule places every ds_read by counted vmcnt + barrier: a read that
+could overtake its LDS-DMA would come and go with timing) at 256 / 512 / 4096-sized problems; (4) refusals by name."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close_bf16
+
+pytestmark = pytest.mark.gpu
+bf16 = torch.bfloat16
+DEV = "cuda"
+
+
+def _ops():
+    from diffusers_amd import _lib as L
+    from diffusers_amd import ops
+    return ops, L
+
+
+def rnd(shape, seed, scale=1.0, dtype=bf16):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def k3(ops, L, x, w, *a, **kw):
+    return ops.linear(x, w, *a, tile=L.TILE_K3_256x256, staging=L.STAGE_LDS_DIRECT, **kw)
+
+
+def k1(ops, L, x, w, *a, **kw):
+    return ops.linear(x, w, *a, tile=L.TILE_K1_256x256, staging=L.STAGE_LDS_DIRECT, **kw)
+
+
+# Flux / Wan / SDXL projections (reduced where the fp32 reference would dominate the run time), one tile, one slice (K = 64), odd slice
+# counts (K = 192, 320, 1088), ragged M / N edges, fewer rows / columns than a tile
+@pytest.mark.parametrize("M,N,K", [(4608, 3072, 3072), (2048, 10240, 1280), (8192, 1280, 640), (256, 256, 64), (256, 256, 128),
+                                   (512, 512, 192), (300, 320, 320), (777, 644, 1152), (130, 1284, 1088), (4096, 4096, 256),
+                                   (32760 // 8, 5120, 512)])
+def test_k3_bit_identical_to_k1(M, N, K):
+    ops, L = _ops()
+    x, w, b, r = rnd((M, K), 31), rnd((N, K), 32, K ** -0.5), rnd((N,), 33), rnd((M, N), 34)
+    y = k3(ops, L, x, w, b, residual=r)
+    want = k1(ops, L, x, w, b, residual=r)
+    assert torch.equal(y, want), f"k3 {M}x{N}x{K}: {int((y != want).sum())} outputs differ from k1:256x256"
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    assert_close_bf16(y, ref, f"k3 gemm {M}x{N}x{K}", rtol=8e-3, atol_rms=4e-3)
+
+
+@pytest.mark.parametrize("n", [256, 512, 4096])
+def test_k3_race_screen(n):
+    """The same bits on every one of 25 launches, with other traffic between them (a 64 MiB fill moves the LDS-DMA's arrival times)."""
+    ops, L = _ops()
+    x, w = rnd((n, n), 41), rnd((n, n), 42, n ** -0.5)
+    want = k1(ops, L, x, w)
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    for it in range(25):
+        if it % 3 == 1:
+            noise.fill_(it)
+        y = k3(ops, L, x, w)
+        assert torch.equal(y, want), f"k3 {n}^3 launch {it}: {int((y != want).sum())} outputs differ"
+
+
+@pytest.mark.parametrize("act", ["none", "gelu_tanh", "silu"])
+def test_k3_epilogues(act):
+    ops, L = _ops()
+    A = {"none": L.ACT_NONE, "silu": L.ACT_SILU, "gelu_tanh": L.ACT_GELU_TANH}[act]
+    M, N, K, B = 1536, 640, 448, 3
+    x, w, b = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5), rnd((N,), 3)
+    rv, res, br = rnd((B, N), 4), rnd((M, N), 5), rnd((M,), 6)
+    gate_b, gate_f = rnd((B, N), 7), rnd((B, N), 8, dtype=torch.float32)
+    cases = {
+        "bias+rowvec+act+res+scale": dict(bias=b, rowvec=rv, rows_per_batch=M // B, act=A, residual=res, out_scale=0.5),
+        "bias_rows+alpha": dict(bias_rows=br, alpha=0.125, act=A),
+        "gate bf16 + res": dict(bias=b, gate=gate_b, rows_per_batch=M // B, residual=res, act=A),
+        "gate fp32 + res": dict(bias=b, gate=gate_f, rows_per_batch=M // B, residual=res, act=A),
+        "fp32 out": dict(bias=b, out_f32=True, alpha=0.25, act=A),
+    }
+    for name, kw in cases.items():
+        got, want = k3(ops, L, x, w, **kw), k1(ops, L, x, w, **kw)
+        assert got.dtype == want.dtype and torch.equal(got, want), f"k3 epilogue {act} / {name} differs from k1:256x256"
+
+
+def test_k3_strided_operands_and_outputs():
+    ops, L = _ops()
+    M, N, K = 1024, 640, 640
+    xx, ww = rnd((M, 2 * K), 1), rnd((N, 2 * K), 2, K ** -0.5)
+    out = torch.zeros((M, 2 * N), device=DEV, dtype=bf16)
+    res = rnd((M, 2 * N), 3)
+    x, w, r = xx[:, K:], ww[:, :K], res[:, N:]
+    k3(ops, L, x, w, residual=r, out=out[:, :N])
+    assert_close_bf16(out[:, :N], x.float() @ w.float().t() + r.float(), "k3 strided", rtol=8e-3, atol_rms=4e-3)
+    assert float(out[:, N:].abs().max()) == 0.0, "wrote outside its column block"
+
+
+@pytest.mark.parametrize("M,N2,K", [(2048, 10240, 1280), (300, 256, 192), (8192, 5120, 640)])
+def test_k3_geglu(M, N2, K):
+    ops, L = _ops()
+    x, w, b = rnd((M, K), 1), rnd((N2, K), 2, K ** -0.5), rnd((N2,), 3)
+    wp, bp = ops.pack_geglu(w, b)
+    h = (x.float() @ w.float().t() + b.float()).to(bf16).float()
+    ref = h[:, : N2 // 2] * F.gelu(h[:, N2 // 2:]).to(bf16).float()
+    y = k3(ops, L, x, wp, bias=bp, act=L.ACT_GEGLU)
+    assert y.shape == (M, N2 // 2)
+    assert torch.equal(y, k1(ops, L, x, wp, bias=bp, act=L.ACT_GEGLU)), "k3 GEGLU differs from k1:256x256"
+    assert_close_bf16(y, ref, f"k3 geglu {M}x{N2}x{K}", rtol=1.6e-2, atol_rms=6e-3)
+
+
+def test_k3_refuses_what_it_does_not_implement():
+    ops, L = _ops()
+    x, w = rnd((512, 256), 1), rnd((512, 256), 2)
+    for st in (L.STAGE_LDS_DIRECT3, L.STAGE_PINGPONG, L.STAGE_REGISTER):
+        with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+            ops.linear(x, w, tile=L.TILE_K3_256x256, staging=st)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        ops.linear(x, w, tile=L.TILE_K3_256x256, staging=L.STAGE_LDS_DIRECT, split_k=2)
+    xc, wc = rnd((1, 16, 16, 64), 3), rnd((64, 9 * 64), 4)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        ops.conv2d_nhwc(xc, wc, None, ksize=3, tile=L.TILE_K3_256x256, staging=L.STAGE_LDS_DIRECT)

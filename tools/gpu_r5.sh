@@ -81,3 +81,32 @@ fi
 if [[ $WHAT == *tuneconv* ]]; then
   DIFFUSERS_AMD_SPLITK=1 DIFFUSERS_AMD_GEMM_FAMILY=all python -c "import json;t=json.load(open('$R/diffusers_amd/tuned/gfx950.json'));t['entries']={k:v for k,v in t['entries'].items() if not k.startswith('conv3:M2048:N1280:C')};json.dump(t,open('$O/table_without_32x32_convs.json','w'))"; DIFFUSERS_AMD_TUNE_DB=$O/table_without_32x32_convs.json timeout 600 python tools/tune_shapes_r5.py > $O/tune_shapes_r5.log 2>&1; echo "tune rc=$?"; cat $O/tune_shapes_r5.log | cut -c1-300 | tail -12
 fi
+if [[ $WHAT == *attnprio* ]]; then
+  rm -f $O/attn_r5.jsonl
+  for pr in ${PRIOS:-0 1 2 3 4 5 0}; do DA_ATTN2_PRIO=$pr timeout 200 python tools/bench_attn_r5.py $O/attn_r5.jsonl > $O/attn_r5.log 2>&1; done
+  cat $O/attn_r5.jsonl | cut -c1-200
+fi
+if [[ $WHAT == *prioab* ]]; then
+  for m in 1 0 1 0; do
+    DA_ATTN2_PRIO=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_prio$m.json 2> $O/bench_prio$m.err; echo "attn prio $m rc=$? $(cut -c1-140 $O/bench_prio$m.json | grep -o '"value": [0-9.]*')"
+  done
+  timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --timeout 300 -k "attention" 2>&1 | tail -2
+fi
+if [[ $WHAT == *k3test* ]]; then
+  timeout 600 python -m pytest tests/test_gemm_k3_gpu.py -m gpu -q -x --timeout 300 > $O/pytest_k3.log 2>&1; echo "pytest k3 rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|differ" $O/pytest_k3.log | tail -20
+fi
+if [[ $WHAT == *k3bench* ]]; then
+  rm -f $O/k3_r5.jsonl
+  timeout 600 python tools/bench_k3.py $O/k3_r5.jsonl "${K3_ONLY:-}" > $O/k3_r5.log 2>&1; echo "k3 bench rc=$?"
+  cat $O/k3_r5.jsonl | cut -c1-600; tail -3 $O/k3_r5.log | cut -c1-300
+fi
+if [[ $WHAT == *attnab* ]]; then
+  rm -f $O/attn_r5.jsonl
+  for pr in 0 1 0 1; do DA_ATTN2_PRIO=$pr timeout 200 python tools/bench_attn_r5.py $O/attn_r5.jsonl > $O/attn_r5.log 2>&1; done
+  cat $O/attn_r5.jsonl | cut -c1-200
+fi
+if [[ $WHAT == *k3retune* ]]; then
+  timeout 900 python tools/retune_k3.py $O/k3_retune.jsonl $O/table_k3.json > $O/k3_retune.log 2>&1; echo "k3 retune rc=$?"
+  cut -c1-330 $O/k3_retune.log | tail -40
+fi
