@@ -74,7 +74,8 @@ __device__ __forceinline__ int k_swz(int row) {
 // issue and the Q.K^T MFMAs.  With three workgroups per CU a SIMD holds three waves of three workgroups; the arbitration then lets a
 // wave that is inside its softmax / P.V phase run ahead of a wave that is starting a tile, which takes the co-resident waves out of
 // step: one wave's transcendental-heavy VALU phase sits beside another's MFMA block instead of beside the same phase of its peers.
-// Measured (profiles/r05f_attention_setprio.jsonl, chained launches): S 1024 24.2 -> 21.6 us, S 4096 121.6 -> 112.7 us at D = 64,
+// Measured (profiles/r05f_attention_setprio.jsonl, chained launches, off / on / off / on on one box): S 1024 24.6 -> 22.1 us, S 4096
+// 126.4 -> 118.4 us at D = 64 (another box: 24.2 -> 21.6, 121.6 -> 112.7),
 // nothing at D = 128 (one eight-wave workgroup per CU); eleven other placements (P.V MFMAs alone, VALU slices alone, graded by
 // slice, the memory head raised, static per-workgroup levels) gain less or lose.  Speed only: the same operations in the same order.
 template <int D, int NW, int NS, bool AUG, bool RSM, int PRIO = 0>

@@ -110,3 +110,15 @@ if [[ $WHAT == *k3retune* ]]; then
   timeout 900 python tools/retune_k3.py $O/k3_retune.jsonl $O/table_k3.json > $O/k3_retune.log 2>&1; echo "k3 retune rc=$?"
   cut -c1-330 $O/k3_retune.log | tail -40
 fi
+if [[ $WHAT == *k3ab* ]]; then
+  # other configs before / after the table moved entries to k3 (same box): flux 4 steps, wan 6 steps (UniPC + decode), sdxl fast
+  for tb in old new old new; do
+    if [[ $tb == new ]]; then export DIFFUSERS_AMD_TUNE_DB=$O/table_k3.json; else unset DIFFUSERS_AMD_TUNE_DB; fi
+    timeout 600 python bench.py --config flux --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/bench_flux_$tb.json 2> $O/bench_flux_$tb.err; echo "flux $tb rc=$? $(grep -o '"value": [0-9.]*' $O/bench_flux_$tb.json | head -1)"
+  done
+  for tb in old new; do
+    if [[ $tb == new ]]; then export DIFFUSERS_AMD_TUNE_DB=$O/table_k3.json; else unset DIFFUSERS_AMD_TUNE_DB; fi
+    timeout 600 python bench.py --config wan --steps 1 --warmup 1 --denoise-steps 6 --no-cpu-baseline --no-roofline > $O/bench_wan_$tb.json 2> $O/bench_wan_$tb.err; echo "wan $tb rc=$? $(grep -o '"value": [0-9.]*' $O/bench_wan_$tb.json | head -1) $(grep -o '"ms_per_step": [0-9.]*' $O/bench_wan_$tb.json | head -1)"
+  done
+  unset DIFFUSERS_AMD_TUNE_DB
+fi
