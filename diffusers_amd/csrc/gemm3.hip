@@ -62,7 +62,7 @@ using da_gemm2::epilogue4;
 constexpr int BM = 256, BN = 256;
 constexpr int HALF = 128 * 128;      // bytes of one half-tile (128 rows x 64 bf16)
 constexpr int KBUF = 4 * HALF;       // one K slice: A0 | A1 | B0 | B1
-constexpr int LDS_BYTES = 2 * KBUF;  // 128 KiB
+constexpr int LDS_BYTES = 2 * KBUF;  // 128 KiB ring (+ 1 KiB behind it: the tile's bias)
 
 #define K3_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
 
@@ -127,19 +127,15 @@ __global__ __launch_bounds__(512) void gemm3_bf16_kernel(const da_gemm_params p,
   constexpr integral_constant<int, 2> I2{};
   constexpr integral_constant<int, 3> I3{};
 
-  // bias of the wave's four 16-column tiles (zeros without one): requested FIRST, so that the loads are older than every LDS-DMA piece
-  // and the counted vmcnt waits below never see them
-  uint2 bias_v[2][2];
-#pragma unroll
-  for (int hp = 0; hp < 2; ++hp)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bias_v[hp][j] = make_uint2(0, 0);
-  if (p.bias) {
-#pragma unroll
-    for (int hp = 0; hp < 2; ++hp)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bias_v[hp][j] = *(const uint2*)((const uint16_t*)p.bias + min(n0 + 64 * wc + 32 * hp + 16 * j + 4 * kq, p.N - 4));
+  // bias of the tile's 256 columns: ONE LDS-DMA piece (wave 0, lanes 0 .. 31 x 16 bytes; everything past N or without a bias is out of
+  // the descriptor's range and arrives as zeros) into the KiB behind the ring -- issued first, so it is older than every staged
+  // half-tile and retired by the first counted wait; the epilogue reads it back.  (Held in registers through the loop it cost the
+  // eight VGPRs that made the wide epilogue spill.)
+  if (wave == 0) {
+    const int ncols = min(BN, p.N - n0);
+    __amdgpu_buffer_rsrc_t rs_bias = da_gemm2::uniform_rsrc(p.bias ? (const void*)((const uint16_t*)p.bias + n0) : (const void*)Wt,
+                                                            p.bias ? (size_t)ncols * 2 : 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bias, K3_LDS(smem + LDS_BYTES), 16, lane * 16, 0, 0, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -244,6 +240,12 @@ __global__ __launch_bounds__(512) void gemm3_bf16_kernel(const da_gemm_params p,
   K3_FENCE();
 
   // ---- epilogue: lane holds, for output row r16 of a 16-row tile, channels 4 kq .. 4 kq + 3 of a 16-column tile ----
+  uint2 bias_v[2][2];                                       // the wave's four 16-column tiles, this lane's 4 channels of each
+#pragma unroll
+  for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bias_v[hp][j] = *(const uint2*)(smem + LDS_BYTES + (64 * wc + 32 * hp + 16 * j + 4 * kq) * 2);
+  K3_FENCE();                                               // (read before the wide epilogue's scratch traffic is issued)
   auto row_of = [&](int h, int i) { return m0 + h * 128 + wr * 64 + i * 16 + r16; };
   auto col_of = [&](int hp, int j) { return n0 + 64 * wc + 32 * hp + 16 * j + 4 * kq; };
   if constexpr (GEGLU) {
@@ -317,13 +319,94 @@ __global__ __launch_bounds__(512) void gemm3_bf16_kernel(const da_gemm_params p,
             }
         }
     };
+    // Row-contiguous output: a wave's 16 x 64 band of finished values goes through LDS once (wave-private scratch: the ring is free, and
+    // a wave's LDS operations execute in order, so no barrier) so that every lane stores -- and, for the residual, loads -- 16
+    // contiguous bytes of ONE row: 128 contiguous bytes per row and instruction, a whole line, instead of four separate 32-byte
+    // segments by four instructions.  The 8-byte path's store tail (32 global_store_dwordx2 per lane, 16 partial lines each) is
+    // issue-bound (MI355X_MICROARCH.md, "epilogue store tail") and cost the short-K Wan shapes more than the loop gained.  Values
+    // cross LDS in fp32 and meet the residual / output scale behind it (the same fp32 operations in the same order as the 8-byte
+    // path: bit-identical), or already packed to bf16 when there is neither.  Needs 16-byte aligned rows.
+    const bool wide = !p.out_f32 && !(p.ldc & 7) && !((size_t)p.C & 15) && !(p.N & 7) &&
+                      (!p.residual || (!(p.ldr & 7) && !((size_t)p.residual & 15)));
+    constexpr int ROWB = 4 * 64 + 32;                       // bytes per staged fp32 row (ROWB / 2: the packed rows)
+    unsigned char* stg = smem + wave * 16384;               // two alternating bands of 16 rows
+    auto wide_body = [&](auto act_c, auto gate_c, auto packed_c) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_c)::value, GATE = decltype(gate_c)::value;
+      constexpr bool PACKED = decltype(packed_c)::value;
+      const uint16_t* __restrict__ resid = (const uint16_t*)p.residual;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned char* sb = stg + (i & 1) * (16 * ROWB);
+          const int mc = min(row_of(h, i), p.M - 1);
+          const int bidx = (GATE != 0 || has_rowvec) ? (mc / p.rows_per_batch) : 0;
+          const float brow = bias_rows ? bf2f(bias_rows[mc]) : 0.f;
+#pragma unroll
+          for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int c = 32 * hp + 16 * j + 4 * kq;      // column inside the wave's 64-column band
+              const int n = min(n0 + 64 * wc + c, p.N - 4);
+              float o[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = acc[h][hp][i][j][e] * p.alpha;
+              uint2 rvv = make_uint2(0, 0);
+              if (has_rowvec) rvv = *(const uint2*)((const uint16_t*)p.rowvec + (size_t)bidx * p.ld_rowvec + n);
+              epilogue4<ACT, GATE, false>(p, o, n, bidx, brow, bias_v[hp][j], rvv, make_uint2(0, 0));
+              if constexpr (PACKED) {
+                uint2 pk;
+                pk.x = pack_bf2(o[0], o[1]);
+                pk.y = pack_bf2(o[2], o[3]);
+                *(uint2*)(sb + r16 * (ROWB / 2) + c * 2) = pk;
+              } else {
+                *(float4*)(sb + r16 * ROWB + c * 4) = make_float4(o[0], o[1], o[2], o[3]);
+              }
+            }
+          // ... and back: piece q = lane + 64 t of the band -> row q / 8, 8-channel slot q % 8
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) {
+            const int q = lane + 64 * t2;
+            const int row = q >> 3, c8 = q & 7;
+            const int mo = m0 + h * 128 + wr * 64 + i * 16 + row, no = n0 + 64 * wc + c8 * 8;
+            const bool inside = mo < p.M && no < p.N;
+            uint4 pk;
+            if constexpr (PACKED) {
+              pk = *(const uint4*)(sb + row * (ROWB / 2) + c8 * 16);
+            } else {
+              const float4 lo = *(const float4*)(sb + row * ROWB + c8 * 32), hi = *(const float4*)(sb + row * ROWB + c8 * 32 + 16);
+              float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+              uint4 rw = make_uint4(0, 0, 0, 0);
+              if (has_res && inside) rw = *(const uint4*)(resid + (size_t)mo * p.ldr + no);
+              o[0] += bf_lo(rw.x); o[1] += bf_hi(rw.x); o[2] += bf_lo(rw.y); o[3] += bf_hi(rw.y);
+              o[4] += bf_lo(rw.z); o[5] += bf_hi(rw.z); o[6] += bf_lo(rw.w); o[7] += bf_hi(rw.w);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] *= p.out_scale;
+              pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]); pk.z = pack_bf2(o[4], o[5]); pk.w = pack_bf2(o[6], o[7]);
+            }
+            if (inside) *(uint4*)((uint16_t*)p.C + (size_t)mo * p.ldc + no) = pk;
+          }
+        }
+    };
     constexpr integral_constant<int, -1> RT{};
     constexpr integral_constant<int, 0> G0{};
-    if (p.gate && p.gate_f32) body(RT, integral_constant<int, 2>{});
-    else if (p.gate) body(RT, integral_constant<int, 1>{});
-    else if (p.act == DA_ACT_NONE) body(integral_constant<int, DA_ACT_NONE>{}, G0);
-    else if (p.act == DA_ACT_GELU_TANH) body(integral_constant<int, DA_ACT_GELU_TANH>{}, G0);
-    else body(RT, G0);
+    if (wide) {
+      const bool packed = !has_res && p.out_scale == 1.0f;
+      if (p.gate && p.gate_f32) wide_body(RT, integral_constant<int, 2>{}, std::false_type{});
+      else if (p.gate) wide_body(RT, integral_constant<int, 1>{}, std::false_type{});
+      else if (packed) {
+        if (p.act == DA_ACT_NONE) wide_body(integral_constant<int, DA_ACT_NONE>{}, G0, std::true_type{});
+        else if (p.act == DA_ACT_GELU_TANH) wide_body(integral_constant<int, DA_ACT_GELU_TANH>{}, G0, std::true_type{});
+        else wide_body(RT, G0, std::true_type{});
+      } else {
+        if (p.act == DA_ACT_NONE) wide_body(integral_constant<int, DA_ACT_NONE>{}, G0, std::false_type{});
+        else wide_body(RT, G0, std::false_type{});
+      }
+    } else {   // fp32 output, rows that are not 16-byte aligned: the 8-byte path, one run-time-switched copy per gate form
+      if (p.gate && p.gate_f32) body(RT, integral_constant<int, 2>{});
+      else if (p.gate) body(RT, integral_constant<int, 1>{});
+      else body(RT, G0);
+    }
   }
 #undef K3_READ_A
 #undef K3_READ_B
@@ -342,11 +425,11 @@ int launch(const da_gemm_params& p, hipStream_t s) {
   auto kern = gemm3_bf16_kernel<GEGLU>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 1024) != hipSuccess)
       return DA_ERR_LAUNCH;
     attr_set = true;
   }
-  DA_LAUNCH(kern, dim3(grid), dim3(512), LDS_BYTES, s, p, gx);
+  DA_LAUNCH(kern, dim3(grid), dim3(512), LDS_BYTES + 1024, s, p, gx);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

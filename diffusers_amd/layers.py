@@ -220,10 +220,11 @@ class Upsample2D:
 class CrossKV:
     """Step-invariant cross-attention keys / transposed values of one attention layer (hoisted out of the loop)."""
 
-    __slots__ = ("k", "vt", "skv", "skv_alloc", "batch", "bias")
+    __slots__ = ("k", "vt", "skv", "skv_alloc", "batch", "bias", "buf")
 
-    def __init__(self, k, vt, skv, skv_alloc, batch, bias=None):
+    def __init__(self, k, vt, skv, skv_alloc, batch, bias=None, buf=None):
         self.k, self.vt, self.skv, self.skv_alloc, self.batch = k, vt, skv, skv_alloc, batch
+        self.buf = buf     # the ONE allocation that holds k then vt (a prefetch hint covers both), or None
         self.bias = bias   # [batch][1][1][ceil64(skv)] additive key mask (encoder_attention_mask), or None
 
 
@@ -290,9 +291,11 @@ class Attention:
         if bias is not None and self.kdim != 64:
             raise ValueError(f"encoder_attention_mask: the masked attention kernel exists for head sizes <= 64 "
                              f"(this layer: {self.head_dim})")
-        k = ops.linear(ehs_pad, self.wk)
-        vt = ops.linear(self.wv, ehs_pad)  # [inner][batch*skv_alloc] = V^T
-        return CrossKV(k, vt, skv, skv_alloc, batch, bias)
+        rows, inner = ehs_pad.shape[0], self.wk.shape[0]
+        buf = torch.empty(2 * rows * inner, device=ehs_pad.device, dtype=ehs_pad.dtype)
+        k = ops.linear(ehs_pad, self.wk, out=buf[: rows * inner].view(rows, inner))
+        vt = ops.linear(self.wv, ehs_pad, out=buf[rows * inner:].view(inner, rows))  # [inner][batch*skv_alloc] = V^T
+        return CrossKV(k, vt, skv, skv_alloc, batch, bias, buf)
 
     def fold_norm(self, norm: "LayerNorm") -> None:
         """Cross-attention only: fold the LayerNorm in front of the block (attention.py:1030) into to_q."""
@@ -319,7 +322,8 @@ class Attention:
             xa = {"k": kv.k, "vt": kv.vt, "skv": kv.skv, "skv_alloc": kv.skv_alloc, "seq": seq, "scale": self.scale}
             o = ops.linear(x, self.wq_ln, ln=(stats, self.fold), xattn=xa) if stats is not None else ops.linear(x, self.wq, xattn=xa)
         elif self.cross:
-            q = ops.linear(x, self.wq_ln, ln=(stats, self.fold)) if stats is not None else ops.linear(x, self.wq)
+            pfk = {"prefetch": kv.buf} if (getattr(ops, "KV_PREFETCH", False) and kv.buf is not None) else {}
+            q = ops.linear(x, self.wq_ln, ln=(stats, self.fold), **pfk) if stats is not None else ops.linear(x, self.wq, **pfk)
             o = ops.attention(q, kv.k, kv.vt, B=batch, H=Hh, D=D, Sq=seq, Skv=kv.skv, Skv_alloc=kv.skv_alloc,
                               q_row_stride=self.inner, k_row_stride=self.inner,
                               q_batch_stride=seq * self.inner, k_batch_stride=kv.skv_alloc * self.inner,

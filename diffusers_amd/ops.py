@@ -302,6 +302,10 @@ def qkv_variant(p: "L.GemmParams", stream: int):
 # level (20.7 -> 19.2 us per layer), - 12 % at the 640 level, and nothing on the image (profiles/r05b_*): the 128 x 128 tile it needs
 # covers 160 of the 256 CUs where the 128 x 80 tile of the plain to_q covers all of them
 XATTN = os.environ.get("DIFFUSERS_AMD_XATTN", "0") == "1"
+# Cross-attention: attn2.to_q pulls the layer's step-invariant K / V^T (one buffer, layers.CrossKV.buf) towards the memory-side cache
+# behind its K loop instead of the next GEMM's weight -- the 77-key attention launch that follows otherwise meets them cold
+# (5 GB of weights went through the 256 MB cache since the last step touched them).  A/B knob, round 5.
+KV_PREFETCH = os.environ.get("DIFFUSERS_AMD_KV_PREFETCH", "0") == "1"
 XATTN_MAX_KEYS = 80                                              # da_gemm_params.xa_skv_alloc limit of the one instantiation
 XATTN_STAGING = L.STAGE_PINGPONG if os.environ.get("DIFFUSERS_AMD_XATTN_STAGE", "pp") == "pp" else L.STAGE_LDS_DIRECT
 XATTN_MIN_TILES = int(os.environ.get("DIFFUSERS_AMD_XATTN_MIN_TILES", "0"))
@@ -420,10 +424,9 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     p.ld_rowvec = _rows2d(rowvec, "rowvec") if rowvec is not None else 0
     p.bias_rows, p.gate = _ptr(bias_rows), _ptr(gate)
     p.ld_gate = _rows2d(gate, "gate") if gate is not None else 0
-    if prefetch is not None:      # a later launch's weight: read towards the memory-side cache behind this launch's K loop
+    _prefetch_hook(p, x, w)       # (always: the recorded launch sequence must stay in step)
+    if prefetch is not None:      # the caller knows better what is met cold next (cross-attention: the layer's K / V^T)
         p.prefetch, p.prefetch_bytes = prefetch.data_ptr(), (prefetch.numel() * prefetch.element_size()) & ~15
-    else:
-        _prefetch_hook(p, x, w)
     if gate is not None:
         if gate.dtype not in (bf16, torch.float32):
             raise TypeError("linear: gate must be bf16 (Flux rounding) or float32 (Wan rounding)")

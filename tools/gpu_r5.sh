@@ -122,3 +122,16 @@ if [[ $WHAT == *k3ab* ]]; then
   done
   unset DIFFUSERS_AMD_TUNE_DB
 fi
+if [[ $WHAT == *kvpfab* ]]; then
+  for m in 1 0 1 0; do
+    DIFFUSERS_AMD_KV_PREFETCH=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_kvpf$m.json 2> $O/bench_kvpf$m.err; echo "kv prefetch $m rc=$? $(cut -c1-140 $O/bench_kvpf$m.json | grep -o '"value": [0-9.]*')"
+  done
+fi
+if [[ $WHAT == *gemmtests* ]]; then
+  timeout 900 python -m pytest tests/test_gemm_k2_gpu.py tests/test_gemm_k3_gpu.py -m gpu -q --timeout 600 > $O/pytest_gemm.log 2>&1; echo "pytest gemm rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|differ" $O/pytest_gemm.log | tail -20
+fi
+if [[ $WHAT == *otherbench* ]]; then
+  timeout 600 python bench.py --config flux --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_flux.json 2> $O/bench_flux.err; echo "flux rc=$? $(grep -o '"value": [0-9.]*' $O/bench_flux.json | head -1)"
+  timeout 600 python bench.py --config wan --steps 1 --warmup 1 --denoise-steps 6 --no-cpu-baseline > $O/bench_wan6.json 2> $O/bench_wan6.err; echo "wan rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/bench_wan6.json | head -1)"
+fi
