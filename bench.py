@@ -12,7 +12,7 @@ launcher re-executes itself under ``torch.distributed.run`` with N ranks (the re
 same way, docs/source/en/training/distributed_inference.md:62-108).  Rank 0 prints ONE JSON line.
 
 Besides the contract keys the line carries, all measured OUTSIDE the timed region on rank 0 at N = 1:
-  roofline            dominant kernel family (igemm_bf16_kernel + igemm2_bf16_kernel) over the launches of one eager denoising step,
+  roofline            dominant kernel family (igemm_bf16_kernel + igemm2_bf16_kernel + gemm3_bf16_kernel) over the launches of one eager denoising step,
                       timed with HIP events ATTACHED to every launch (da_set_launch_events: the dispatch's own begin / end, the
                       duration rocprofv3 reports; `timing` says which method ran, `host_event_pairs` carries the host-recorded
                       pairs of the same launches -- the method of rounds 1-3 -- as a cross-check); `kernels`: one entry per family
@@ -290,7 +290,7 @@ def build_fingerprint() -> str:
 
 
 def roofline_leg(pipe, mine, world, images_per_s):
-    """Dominant kernel = the implicit-GEMM family (igemm_bf16_kernel + igemm2_bf16_kernel: all Linear + Conv2d 3x3 / 1x1, paired
+    """Dominant kernel = the implicit-GEMM family (igemm_bf16_kernel + igemm2_bf16_kernel + gemm3_bf16_kernel: all Linear + Conv2d 3x3 / 1x1, paired
     launches included): MFMA-bound.  `kernels` carries the other families of the denoising step and the VAE decode.  The
     conditioning is built here (not taken from the graph's static inputs), so the leg also works after --no-graph."""
     sch = pipe.scheduler
@@ -327,7 +327,7 @@ def roofline_leg(pipe, mine, world, images_per_s):
                         f"this library is {fp}; re-run tools/gpu_r4.sh traffic")
         except (ValueError, KeyError) as e:
             note = f"unreadable {TRAFFIC_FILE.name}: {e}"
-    kernels = [_kernel_entry("igemm", "igemm_bf16_kernel + igemm2_bf16_kernel (Linear, Conv2d, paired Q|K + V^T)", "mfma", fam["igemm"])]
+    kernels = [_kernel_entry("igemm", "igemm_bf16_kernel + igemm2_bf16_kernel + gemm3_bf16_kernel (Linear, Conv2d, paired Q|K + V^T)", "mfma", fam["igemm"])]
     if "attention" in fam:
         kernels.append(_kernel_entry("attention", "attn_fwd_kernel (flash attention forward)", "mfma", fam["attention"]))
     if "groupnorm" in fam:
@@ -363,7 +363,7 @@ def roofline_leg(pipe, mine, world, images_per_s):
     return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / MFMA_PEAK_TFLOPS, "timing": timing, "host_event_pairs": host_pair,
             "traffic": traffic, "traffic_source": note, "build_fingerprint": fp,
-            "kernel": "igemm_bf16_kernel + igemm2_bf16_kernel (Linear + Conv2d implicit GEMM, paired launches included)",
+            "kernel": "igemm_bf16_kernel + igemm2_bf16_kernel + gemm3_bf16_kernel (Linear + Conv2d implicit GEMM, paired launches included)",
             "launches_per_denoise_step": n, "avg_launch_us": 1000.0 * ms / max(n, 1),
             "algorithmic_tflop_per_denoise_step": fl / 1e12,
             "algorithmic_bytes_per_launch": nbytes / max(n, 1),
@@ -664,7 +664,7 @@ def _other_kernels(unit):
     run()                                   # untimed warm pass (variant lookup)
     fam, timing, _ = measured_families(run)
     kernels = []
-    for name, kern, bound in (("igemm", "igemm_bf16_kernel + igemm2_bf16_kernel (Linear, Conv2d, paired launches)", "mfma"),
+    for name, kern, bound in (("igemm", "igemm_bf16_kernel + igemm2_bf16_kernel + gemm3_bf16_kernel (Linear, Conv2d, paired launches)", "mfma"),
                               ("attention", "attn2_fwd_kernel / attn_fwd_kernel (flash attention forward)", "mfma"),
                               ("groupnorm", "gn_stats_kernel + gn_apply_kernel", "hbm"), ("layernorm", "layernorm_kernel", "hbm")):
         if name in fam:

@@ -66,7 +66,7 @@ constexpr int LDS_BYTES = 2 * KBUF;  // 128 KiB ring (+ 1 KiB behind it: the til
 
 #define K3_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
 
-template <bool GEGLU>
+template <bool GEGLU, int PRIO = 1>
 __global__ __launch_bounds__(512) void gemm3_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -199,9 +199,9 @@ __global__ __launch_bounds__(512) void gemm3_bf16_kernel(const da_gemm_params p,
     K3_FENCE();                                                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                 \
     K3_FENCE();                                                                                                   \
-    __builtin_amdgcn_s_setprio(1);                                                                                \
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                       \
     K3_MFMA(H, HP, BQ);                                                                                           \
-    __builtin_amdgcn_s_setprio(0);                                                                                \
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                       \
     K3_FENCE();                                                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                 \
     K3_FENCE();                                                                                                   \
@@ -227,6 +227,9 @@ __global__ __launch_bounds__(512) void gemm3_bf16_kernel(const da_gemm_params p,
   __builtin_amdgcn_s_barrier();
   K3_FENCE();
   if (wr == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind group 0 from here on
+  if constexpr (PRIO == 2) {                              // static priority for the second-dispatched half, no flips (see launch())
+    if (wr == 1) __builtin_amdgcn_s_setprio(1);
+  }
   K3_FENCE();
   for (int kt = 0; kt < nk; kt += 2) {
     K3_SLICE(0, 1, kt, bq0, bq1);
@@ -417,12 +420,12 @@ __global__ __launch_bounds__(512) void gemm3_bf16_kernel(const da_gemm_params p,
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <bool GEGLU>
-int launch(const da_gemm_params& p, hipStream_t s) {
+template <bool GEGLU, int PRIO>
+int launch_prio(const da_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int gx = da_gemm2::choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
-  auto kern = gemm3_bf16_kernel<GEGLU>;
+  auto kern = gemm3_bf16_kernel<GEGLU, PRIO>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 1024) != hipSuccess)
@@ -432,6 +435,19 @@ int launch(const da_gemm_params& p, hipStream_t s) {
   DA_LAUNCH(kern, dim3(grid), dim3(512), LDS_BYTES + 1024, s, p, gx);
   DA_CHECK_LAUNCH();
   return DA_OK;
+}
+
+// Priority form (speed only; DA_K3_PRIO = 0 / 1 / 2 for A/B runs): 1 = the guide's per-phase pair (s_setprio 1 around the 16 MFMAs),
+// 0 = none, 2 = ONE s_setprio 1 for the second-dispatched wave row before the loop and no flips (MI355X_MICROARCH.md, "static priority
+// for the younger half": waves 4-7 otherwise lose the arbitration at the head of every phase).  Measured, chained launches on random
+// operands, 1 / 0 / 2 / 1 / 0 / 2 in one call (profiles/r05k_k3_priority_forms.txt): 8192^3 1484 / 1509 / 1507 / 1486 / 1480 / 1505 TFLOP/s,
+// 4096^3 1355 / 1339 / 1387 / 1355 / 1350 / 1350: the static form is the only one that is never behind; default.
+template <bool GEGLU>
+int launch(const da_gemm_params& p, hipStream_t s) {
+  static const int prio = [] { const char* v = getenv("DA_K3_PRIO"); return v ? atoi(v) : 2; }();
+  if (prio == 0) return launch_prio<GEGLU, 0>(p, s);
+  if (prio == 1) return launch_prio<GEGLU, 1>(p, s);
+  return launch_prio<GEGLU, 2>(p, s);
 }
 
 // nn.Linear, one ring form (DA_STAGE_LDS_DIRECT), no split-K / LayerNorm fold / transposed block / cross-attention epilogue

@@ -135,3 +135,15 @@ if [[ $WHAT == *otherbench* ]]; then
   timeout 600 python bench.py --config flux --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_flux.json 2> $O/bench_flux.err; echo "flux rc=$? $(grep -o '"value": [0-9.]*' $O/bench_flux.json | head -1)"
   timeout 600 python bench.py --config wan --steps 1 --warmup 1 --denoise-steps 6 --no-cpu-baseline > $O/bench_wan6.json 2> $O/bench_wan6.err; echo "wan rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/bench_wan6.json | head -1)"
 fi
+if [[ $WHAT == *k3prio* ]]; then
+  rm -f $O/k3_prio.jsonl
+  for pr in 1 0 2 1 0 2; do echo "{\"DA_K3_PRIO\": $pr}" >> $O/k3_prio.jsonl; DA_K3_PRIO=$pr timeout 300 python tools/bench_k3.py $O/k3_prio.jsonl "${K3_ONLY:-square}" > $O/k3_prio.log 2>&1; done
+  python - <<PY
+import json
+pr=None
+for l in open("$O/k3_prio.jsonl"):
+    d=json.loads(l)
+    if "DA_K3_PRIO" in d: pr=d["DA_K3_PRIO"]; continue
+    print(pr, d["name"], d.get("k3:256x256"), d.get("k1:256x256"))
+PY
+fi

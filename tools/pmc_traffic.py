@@ -17,7 +17,7 @@ from pathlib import Path
 
 def family(name: str) -> str:
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    if "igemm2_bf16_kernel" in name:          # the K2 / K1 family counts with the implicit-GEMM family (one roofline entry)
+    if "igemm2_bf16_kernel" in name or "gemm3_bf16_kernel" in name:   # K2 / K1 / K3 count with the implicit-GEMM family (one roofline entry)
         return "igemm_bf16_kernel"
     for key in ("igemm_bf16_kernel", "attn2_fwd_kernel", "attn_fwd_kernel", "layernorm_kernel", "gn_apply_kernel", "gn_stats_kernel",
                 "linear_small_m_kernel", "conv_thin_in_kernel", "conv_thin_out_kernel", "softmax_rows_kernel",
