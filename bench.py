@@ -114,6 +114,42 @@ def box_mfma_probe(target_ms: float = 50.0):
             "v_mfma_f32_32x32x16_bf16, registers only"}
 
 
+def box_memory_probe():
+    """`config.box_hbm_copy_gbps` / `config.box_cold_gemm_us` (round 5): the pool's boxes come in two kinds with the SAME register-only
+    MFMA rate (2450-2466 TFLOP/s) whose SDXL lines differ by 15 % (profiles/r05j_*, r05m_*: every weight-streaming GEMM 12-28 % slower,
+    flash attention unchanged) -- the difference is on the memory side, which the MFMA probe cannot see.  Two more normalisers, never
+    peaks: (1) a 1 GiB device copy (bytes read + written per second); (2) SDXL's 2048 x 1280 x 1280 projection with its weight rotated
+    over 128 different tensors (420 MB: every launch streams its weight from HBM, as inside a denoising step), mean us per launch."""
+    from diffusers_amd import ops
+    bf16 = torch.bfloat16
+    out = {}
+    src = torch.empty(1 << 29, dtype=bf16, device="cuda")
+    src.fill_(1.0)
+    dst = torch.empty_like(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(src)
+    e0.record()
+    for _ in range(4):
+        dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    out["hbm_copy_gbps"] = 4 * 2 * src.numel() * 2 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    x = torch.randn(2048, 1280, device="cuda").to(bf16)
+    ws = (torch.randn(128, 1280, 1280, device="cuda") * 1280 ** -0.5).to(bf16)
+    for i in range(8):
+        ops.linear(x, ws[i])
+    e0.record()
+    for i in range(128):
+        ops.linear(x, ws[i])
+    e1.record()
+    e1.synchronize()
+    out["cold_gemm_us"] = e0.elapsed_time(e1) * 1e3 / 128
+    out["what"] = ("1 GiB torch copy (read + written bytes / s); da_gemm_bf16 2048 x 1280 x 1280 with 128 rotating weights (420 MB), "
+                   "mean per launch, back to back")
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -899,6 +935,12 @@ def main(argv=None):
             log(f"box normaliser: {box['tflops']:.0f} TFLOP/s on the register-only MFMA loop ({box['ms']:.1f} ms)")
         except Exception as e:  # a diagnostic must not cost the line
             box = {"tflops": None, "error": f"{type(e).__name__}: {e}"}
+        try:
+            box["memory"] = box_memory_probe()
+            log(f"box normaliser: {box['memory']['hbm_copy_gbps']:.0f} GB/s device copy, "
+                f"{box['memory']['cold_gemm_us']:.1f} us per cold-weight 2048 x 1280 x 1280 projection")
+        except Exception as e:
+            box["memory"] = {"hbm_copy_gbps": None, "cold_gemm_us": None, "error": f"{type(e).__name__}: {e}"}
     log("warm-up (tunes GEMM variants for unseen shapes, captures the denoising-step HIP graph)")
     img = None
     for _ in range(args.warmup):
@@ -955,6 +997,8 @@ def main(argv=None):
                    "process_group": D.backend_name(),     # "nccl" = RCCL; None: a lone process without a launcher (no collectives)
                    "tuned_live": _tuned_live(),
                    "box_mfma_tflops": box["tflops"] if box else None, "box_mfma_probe": box,
+                   "box_hbm_copy_gbps": (box or {}).get("memory", {}).get("hbm_copy_gbps"),
+                   "box_cold_gemm_us": (box or {}).get("memory", {}).get("cold_gemm_us"),
                    "images_per_s_per_rank": per_rank},
     }
 

@@ -18,11 +18,11 @@ ACT_NONE, ACT_GEGLU, ACT_GELU_TANH, ACT_SILU, ACT_GELU_ERF, ACT_QUICK_GELU, ACT_
 (TILE_AUTO, TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64, TILE_256x128, TILE_128x256, TILE_256x256,
  TILE_128x128_W8, TILE_K2_128x128, TILE_K2_128x80, TILE_K2_128x160, TILE_K2_80x128, TILE_K2_128x64,
  TILE_K1_128x320, TILE_K1_256x128, TILE_K1_128x256, TILE_K1_256x160, TILE_K1_256x256, TILE_K1_256x320,
- TILE_K3_256x256) = range(21)
+ TILE_K3_256x256, TILE_K3_256x320) = range(22)
 TILE_NAMES = ("auto", "128x128", "64x128", "128x64", "64x64", "256x128", "128x256", "256x256", "128x128w8",
               "k2:128x128", "k2:128x80", "k2:128x160", "k2:80x128", "k2:128x64",
               "k1:128x320", "k1:256x128", "k1:128x256", "k1:256x160", "k1:256x256", "k1:256x320",
-              "k3:256x256")   # k3 = csrc/gemm3.hip (eight-phase loop; sums K in the k1 order: bit-identical to the k1 tiles)
+              "k3:256x256", "k3:256x320")   # k3 = csrc/gemm3.hip (eight-phase loop; sums K in the k1 order: bit-identical to the k1 tiles)
 FIRST_K2_TILE = TILE_K2_128x128   # tiles >= this run csrc/gemm2_kernel.cuh (2 K-groups x 4 waves, 16x16x32 MFMA)
 STAGE_REGISTER, STAGE_LDS_DIRECT, STAGE_LDS_DIRECT3, STAGE_LDS_DIRECT4, STAGE_LDS_DIRECT6, STAGE_LDS_DIRECT8 = range(6)
 STAGE_PINGPONG, STAGE_PINGPONG3 = 6, 7   # K2 tiles: 2- / 3-pair ring with the two K-groups half an iteration apart

@@ -42,9 +42,9 @@ constexpr TileShape kTiles[] = {{0, 0, 0},      {128, 128, 4}, {64, 128, 4},  {1
                                 {128, 128, 8},  {128, 80, 8},  {128, 160, 8}, {80, 128, 8}, {128, 64, 8},
                                 {128, 320, 8},  {256, 128, 8}, {128, 256, 8}, {256, 160, 8}, {256, 256, 8}, {256, 320, 8},
                                 // K3 (gemm3.hip)
-                                {256, 256, 8}};
+                                {256, 256, 8},  {256, 320, 8}};
 static_assert(sizeof(kTiles) / sizeof(kTiles[0]) == DA_TILE_COUNT, "kTiles / DA_TILE_* mismatch");
-inline bool is_k3(int tile) { return tile == DA_TILE_K3_256x256; }
+inline bool is_k3(int tile) { return tile == DA_TILE_K3_256x256 || tile == DA_TILE_K3_256x320; }
 inline bool is_k2(int tile) { return tile >= DA_TILE_K2_128x128 && !is_k3(tile); }
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -109,8 +109,13 @@ int stats_parts(const da_gemm_params& p, int tile) {   // one partial per column
 
 bool tile_ok(const da_gemm_params& p, int tile) {
   if (tile <= 0 || tile >= kNumTiles) return false;
-  if (is_k3(tile))   // nn.Linear, plain or GEGLU epilogue, nothing that needs the other families' extra instantiations
-    return !p.conv && p.split_k <= 1 && !p.stats_out && !p.ln_stats && !p.vt && !p.xa_k;
+  if (is_k3(tile)) {  // nn.Linear, plain or GEGLU epilogue, nothing that needs the other families' extra instantiations
+    if (p.conv || p.split_k > 1 || p.stats_out || p.ln_stats || p.vt || p.xa_k) return false;
+    if (tile == DA_TILE_K3_256x320)   // the GEGLU projection's tile: whole tiles, aligned output rows
+      return (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) && (p.M % 256) == 0 && (p.N % 320) == 0 && !(p.ldc & 7) &&
+             !((size_t)p.C & 15);
+    return true;
+  }
   if (is_k2(tile)) {
     const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
     const bool geglu_ok = tile == DA_TILE_K2_128x128 || tile == DA_TILE_K1_256x128 || tile == DA_TILE_K1_128x256 ||

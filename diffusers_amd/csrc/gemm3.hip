@@ -437,6 +437,316 @@ int launch_prio(const da_gemm_params& p, hipStream_t s) {
   return DA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The GEGLU projection's own eight-phase tile: 256 x 320 (DA_TILE_K3_256x320).  SDXL's ff.net.0.proj (activations.py:113-124) is
+// M 2048 x N 10240 (packed [32 value | 32 gate] rows) x K 1280 at the 32 x 32 level and 8192 x 5120 x 640 at the 64 x 64 level: 320
+// and 640 tiles of 256 x 256 (1.25 / 2.5 rounds of the 256 CUs), but exactly 256 and 512 tiles of 256 x 320 -- ONE and TWO rounds.  It
+// is the largest single launch population of an SDXL step (60 launches, 3.5 ms of 20.9).
+//
+// Same structure as the kernel above (two wave groups one barrier apart, phases of [reads, one half-tile of LDS-DMA, counted waits]
+// barrier [MFMAs] barrier, six half-tiles in flight, every half-tile restaged one phase after its last read) with the roles of the
+// operands exchanged, because the wave tile is 64 x 160:
+//   8 waves = 4 rows (wr) x 2 columns (wc = the group); A half h = tile rows 64 wr' + 32 h + [0, 32): a wave owns 2 row tiles of each
+//   half; B half 0 = the ten VALUE tiles of the 320 packed columns, half 1 their GATE tiles (LDS row 16 T + r of half h' = packed row
+//   64 (T / 2) + 32 h' + 16 (T % 2) + r): a wave owns value tiles 5 wc .. 5 wc + 4 and their gates, i.e. 80 contiguous OUTPUT columns.
+//   Quadrant (h, h') = 2 x 5 tiles x 2 k-steps = 20 MFMAs; quadrant order (0,0) (1,0) (1,1) (0,1): ONE B fragment set (40 registers:
+//   B0 for P1 / P2, B1 for P3 / P4) and TWO A sets (16 each: A0 lives P1 .. P4, A1 P2 .. P3; the next slice's A0 is read in P4 into
+//   the set A1 left, the sets swap roles every slice).  160 accumulator + 72 fragment registers.
+//   P1: read B0 (10)         stage A0 of slice kt + 2        P2: read A1 (4)              stage B0 of slice kt + 2
+//   P3: read B1 (10)         stage A1 of slice kt + 2        P4: read A0 of kt + 1 (4)    stage B1 of slice kt + 2
+//   LDS: 2 x (16 + 16 + 20 + 20) KiB + 1 KiB dump (the four waves without a third B piece issue theirs out of range into it; the weight
+//   prefetch lands there too) + 1 KiB bias = 146 KiB.  A wave issues 2 (A) or 3 (B) pieces per phase: the six newest half-tiles are
+//   always 15 loads -- vmcnt(15).
+// Restrictions (tile_ok): GEGLU epilogue only, M % 256 == 0, N % 320 == 0 (no clamped rows: the half-tile origin rides in the scalar
+// offset and five per-lane offsets serve all four half-tiles), 16-byte aligned output rows.
+// Numerics: K slices in order, k-step 0 then 1, the GEGLU arithmetic of the other tiles: bit-identical to k1:128x320.
+constexpr int G_BM = 256, G_BN = 320;
+constexpr int G_AH = 128 * 128, G_BH = 160 * 128;          // bytes of an A / B half-tile
+constexpr int G_KBUF = 2 * G_AH + 2 * G_BH;                // 72 KiB per slice
+constexpr int G_DUMP = 2 * G_KBUF, G_BIAS = G_DUMP + 1024, G_LDS = G_BIAS + 1024;
+
+template <int PRIO>
+__global__ __launch_bounds__(512) void gemm3_geglu_kernel(const da_gemm_params p, const int xcd_gx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wc = wave >> 2, wr = wave & 3;                 // wc = the group (one wave per SIMD each)
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  const int tiles_n = p.N / G_BN, tiles_m = p.M / G_BM;
+  const int gyn = 8 / xcd_gx;
+  const int tm_per = (tiles_m + gyn - 1) / gyn, tn_per = (tiles_n + xcd_gx - 1) / xcd_gx;
+  const int bid = (int)blockIdx.x;
+  const int xcd = bid & 7, kblk = bid >> 3;
+  const int gy = xcd / xcd_gx, gx = xcd - gy * xcd_gx;
+  const int lm = kblk / tn_per, ln = kblk - lm * tn_per;
+  const int tm = gy * tm_per + lm, tn = gx * tn_per + ln;
+  if (tm >= tiles_m || tn >= tiles_n) return;
+  const int m0 = tm * G_BM, n0 = tn * G_BN;
+  const int nk = p.K >> 6;
+
+  const uint16_t* __restrict__ A = (const uint16_t*)p.A;
+  const uint16_t* __restrict__ Wt = (const uint16_t*)p.W;
+  __amdgpu_buffer_rsrc_t rs_a = da_gemm2::uniform_rsrc(A + (size_t)m0 * p.lda, 0x7fffffff);
+  __amdgpu_buffer_rsrc_t rs_w = da_gemm2::uniform_rsrc(Wt + (size_t)n0 * p.ldw, 0x7fffffff);
+
+  // ---- staging: wave w sends pieces w, w + 8 (A) / w, w + 8, w + 16 (B; the third exists for w < 4) of every half-tile.  Offsets are
+  // those of half 0; half 1 adds 32 rows through the scalar offset ----
+  // (piece w + 8 i is 64 LDS rows = 128 tile rows further on for both operands: uniform, so ONE per-lane offset per operand serves every
+  // piece and half -- the rest rides in the scalar offset)
+  int vo_a, vo_b;
+  {
+    const int rho = 8 * wave + (lane >> 3);               // piece `wave`: LDS rows 0 .. 63
+    const int sc = (lane & 7) ^ ((rho >> 1) & 7);
+    const int T = rho >> 4;
+    vo_a = ((64 * (rho >> 5) + (rho & 31)) * p.lda + sc * 8) * 2;
+    vo_b = ((64 * (T >> 1) + 16 * (T & 1) + (rho & 15)) * p.ldw + sc * 8) * 2;
+  }
+  const int half_a = 32 * p.lda * 2, half_b = 32 * p.ldw * 2, piece_a = 128 * p.lda * 2, piece_b = 128 * p.ldw * 2;
+  const int dead3 = wave < 4 ? 0 : (int)0x80000000;       // the third B piece exists for waves 0 .. 3 (LDS rows 128 .. 159)
+  // WHICH: 0 = A0, 1 = A1, 2 = B0, 3 = B1 of slice `ks` into buffer BUF
+  auto stage = [&](auto buf_c, auto which_c, int ks) {
+    constexpr int BUF = decltype(buf_c)::value, WHICH = decltype(which_c)::value;
+    const int z = (ks < nk) ? 0 : (int)0x80000000;
+    const int so = min(ks, nk - 1) * 128;
+    if constexpr (WHICH < 2) {
+      unsigned char* dst = smem + BUF * G_KBUF + WHICH * G_AH + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, K3_LDS(dst + i * 8192), 16, vo_a | z, so + WHICH * half_a + i * piece_a, 0, 0);
+    } else {
+      unsigned char* dst = smem + BUF * G_KBUF + 2 * G_AH + (WHICH - 2) * G_BH + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, K3_LDS(dst + i * 8192), 16, vo_b | z, so + (WHICH - 2) * half_b + i * piece_b, 0, 0);
+      // third piece (waves 0 .. 3); the others issue theirs out of range (zeros, no memory traffic) into the dump KiB
+      unsigned char* dst3 = wave < 4 ? dst + 16384 : smem + G_DUMP;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, K3_LDS(dst3), 16, vo_b | z | dead3, so + (WHICH - 2) * half_b + 2 * piece_b, 0, 0);
+    }
+  };
+  using std::integral_constant;
+  constexpr integral_constant<int, 0> I0{};
+  constexpr integral_constant<int, 1> I1{};
+  constexpr integral_constant<int, 2> I2{};
+  constexpr integral_constant<int, 3> I3{};
+
+  // bias of the tile's 320 packed columns: one LDS-DMA piece (wave 0, lanes 0 .. 39 x 16 bytes; zeros without a bias), issued first
+  if (wave == 0) {
+    __amdgpu_buffer_rsrc_t rs_bias = da_gemm2::uniform_rsrc(p.bias ? (const void*)((const uint16_t*)p.bias + n0) : (const void*)Wt,
+                                                            p.bias ? (size_t)G_BN * 2 : 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bias, K3_LDS(smem + G_BIAS), 16, lane * 16, 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- prologue: slice 0 whole, then B0 / A1 / B1 of slice 1 (its A0 leaves in P1 of slice 0: the loop's order) ----
+  stage(I0, I0, 0);
+  stage(I0, I2, 0);
+  stage(I0, I1, 0);
+  stage(I0, I3, 0);
+  stage(I1, I2, 1);
+  stage(I1, I1, 1);
+  stage(I1, I3, 1);
+
+  f32x4_t acc[2][2][2][5];   // [A half][B half: value / gate][row tile][column tile]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[h][hp][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fsw = (r16 >> 1) & 7;
+  const int foff0 = r16 * 128 + ((kq ^ fsw) << 4), foff1 = r16 * 128 + (((kq ^ fsw) ^ 4) << 4);
+  // Fragment base addresses of the CURRENT buffer (32-bit LDS addresses), toggled between the two buffers by an opaque add: written as
+  // compile-time buffer offsets the second buffer's 72 KiB origin does not fit the 16-bit ds_read offset and the compiler keeps a
+  // second set of bases -- the registers that made this kernel spill.  pa moves in front of P4 (whose read is the NEXT slice's A0),
+  // pb behind it.
+  unsigned pa0 = (unsigned)(size_t)(smem + wr * 4096 + foff0), pa1 = (unsigned)(size_t)(smem + wr * 4096 + foff1);
+  unsigned pb0 = (unsigned)(size_t)(smem + 2 * G_AH + wc * 10240 + foff0), pb1 = (unsigned)(size_t)(smem + 2 * G_AH + wc * 10240 + foff1);
+  int dbuf = G_KBUF;                                       // + 72 KiB, then - 72 KiB, ...
+  bf16x8_t af[2][2], bq[5][2];   // [tile][k-step]: the current A half, the current B half
+#define G3_LDSP(addr) ((const __attribute__((address_space(3))) bf16x8_t*)(size_t)(addr))
+#define G3_TOGGLE(P0, P1)                                                                                         \
+  do {                                                                                                            \
+    asm volatile("v_add_u32 %0, %0, %2\n\tv_add_u32 %1, %1, %2" : "+v"(P0), "+v"(P1) : "s"(dbuf));               \
+  } while (0)
+#define G3_READ_A(H)                                                                                              \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
+      af[i][0] = *G3_LDSP(pa0 + (H) * G_AH + i * 2048);                                                           \
+      af[i][1] = *G3_LDSP(pa1 + (H) * G_AH + i * 2048);                                                           \
+    }                                                                                                             \
+  } while (0)
+#define G3_READ_B(HP)                                                                                             \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                               \
+      bq[j][0] = *G3_LDSP(pb0 + (HP) * G_BH + j * 2048);                                                          \
+      bq[j][1] = *G3_LDSP(pb1 + (HP) * G_BH + j * 2048);                                                          \
+    }                                                                                                             \
+  } while (0)
+#define G3_MFMA(H, HP)                                                                                            \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 5; ++j)                                                                 \
+      acc[H][HP][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j][ks], af[i][ks], acc[H][HP][i][j], 0, 0, 0); \
+  } while (0)
+#define G3_FENCE() __builtin_amdgcn_sched_barrier(0)
+// WAIT_STMT: the slice's ONE counted vmcnt (P4), nothing elsewhere
+#define G3_PHASE(READ_STMT, STAGE_STMT, WAIT_STMT, H, HP)                                                         \
+  do {                                                                                                            \
+    G3_FENCE();                                                                                                   \
+    READ_STMT;                                                                                                    \
+    G3_FENCE();                                                                                                   \
+    STAGE_STMT;                                                                                                   \
+    G3_FENCE();                                                                                                   \
+    WAIT_STMT;                                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+    G3_FENCE();                                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    G3_FENCE();                                                                                                   \
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                       \
+    G3_MFMA(H, HP);                                                                                               \
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                       \
+    G3_FENCE();                                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    G3_FENCE();                                                                                                   \
+  } while (0)
+#define G3_READ_A0B0() do { G3_READ_A(0); G3_FENCE(); G3_READ_B(0); } while (0)
+#define G3_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")   /* all but the three newest half-tiles (B0, A1, B1: 3 + 2 + 3 loads) */
+// the four phases of slice KT in buffer BUF (the other buffer: OTH)
+#define G3_SLICE(BUF, OTH, KT)                                                                                    \
+  do {                                                                                                            \
+    G3_PHASE(G3_READ_A0B0(), stage(integral_constant<int, OTH>{}, I0, (KT) + 1), (void)0, 0, 0);                  \
+    G3_PHASE(G3_READ_A(1), stage(integral_constant<int, BUF>{}, I2, (KT) + 2), (void)0, 1, 0);                    \
+    G3_PHASE(G3_READ_B(1), stage(integral_constant<int, BUF>{}, I1, (KT) + 2), (void)0, 1, 1);                    \
+    G3_PHASE(G3_READ_A(0), stage(integral_constant<int, BUF>{}, I3, (KT) + 2), G3_VMCNT8(), 0, 1);                \
+    G3_TOGGLE(pa0, pa1);                                                                                          \
+    G3_TOGGLE(pb0, pb1);                                                                                          \
+    dbuf = -dbuf;                                                                                                 \
+  } while (0)
+
+  // slice 0 landed (every wave's own pieces; the barrier makes them everybody's), B0 / A1 / B1 of slice 1 in flight
+  G3_FENCE();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  G3_FENCE();
+  if (wc == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind group 0 from here on
+  if constexpr (PRIO == 2) {
+    if (wc == 1) __builtin_amdgcn_s_setprio(1);
+  }
+  G3_FENCE();
+  for (int kt = 0; kt < nk; kt += 2) {
+    G3_SLICE(0, 1, kt);
+    G3_SLICE(1, 0, kt + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G3_FENCE();
+  if (wc == 0) __builtin_amdgcn_s_barrier();              // group 0 meets group 1's last barrier
+  G3_FENCE();
+  __builtin_amdgcn_s_barrier();                           // LDS is free for the epilogue
+  G3_FENCE();
+
+  // optional: pull a later launch's weight towards the memory-side cache (da_gemm_params.prefetch, as gemm2_kernel.cuh: up to 16 KiB per
+  // wave of this workgroup's share into the dump KiB; nothing waits for it)
+  if (p.prefetch) {
+    const int nchunk = (int)min((long long)0x7fffffff >> 10, p.prefetch_bytes >> 10);
+    __amdgpu_buffer_rsrc_t rs_pf = da_gemm2::uniform_rsrc(p.prefetch, (size_t)nchunk << 10);
+    const int stride = (int)gridDim.x * 8;
+    int c = bid * 8 + wave;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (c < nchunk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pf, K3_LDS(smem + G_DUMP), 16, lane * 16, c << 10, 0, 0);
+      c += stride;
+    }
+  }
+
+  // ---- epilogue: value * gelu(gate) of the wave's 64 rows x 80 output columns, whole rows from wave-private LDS (16 bytes per lane) ----
+  // (its lane-dependent values are formed from an OPAQUE copy of the thread index: computed from `lane` the compiler hoists them above
+  // the loop and they cost the loop registers it does not have)
+  int tl = t;
+  asm volatile("" : "+v"(tl));
+  const int lane_e = tl & 63, r16_e = tl & 15, kq_e = (tl >> 4) & 3;
+  uint2 bias_v[2][5];
+#pragma unroll
+  for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int T = 5 * wc + j;
+      bias_v[hp][j] = *(const uint2*)(smem + G_BIAS + (64 * (T >> 1) + 32 * hp + 16 * (T & 1) + 4 * kq_e) * 2);
+    }
+  G3_FENCE();
+  constexpr int OROW = 160 + 16;                            // bytes per staged output row (80 bf16 + pad)
+  unsigned char* stg = smem + wave * 8192;                  // two alternating bands of 16 rows
+  auto body = [&](auto tanh_c) __attribute__((always_inline)) {
+    constexpr bool TANH = decltype(tanh_c)::value;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        unsigned char* sb = stg + (i & 1) * (16 * OROW);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const uint2 bh = bias_v[0][j], bg = bias_v[1][j];      // zeros without a bias
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float hv = acc[h][0][i][j][e] * p.alpha, gv = acc[h][1][i][j][e] * p.alpha;
+            hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
+            gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
+            hv = bf2f(f2bf(hv));   // the reference rounds the projection to bf16 before chunk / gelu / mul
+            gv = bf2f(f2bf(gv));
+            o[e] = hv * bf2f(f2bf(TANH ? gelu_tanh_f(gv) : gelu_erf_f(gv)));
+          }
+          uint2 pk;
+          pk.x = pack_bf2(o[0], o[1]);
+          pk.y = pack_bf2(o[2], o[3]);
+          *(uint2*)(sb + r16_e * OROW + (16 * j + 4 * kq_e) * 2) = pk;
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 3; ++t2) {
+          const int q = lane_e + 64 * t2;
+          if (q >= 160) continue;
+          const int row = q / 10, c8 = q - row * 10;
+          const int mo = m0 + 64 * wr + 32 * h + 16 * i + row, no = (n0 >> 1) + 80 * wc + c8 * 8;
+          *(uint4*)((uint16_t*)p.C + (size_t)mo * p.ldc + no) = *(const uint4*)(sb + row * OROW + c8 * 16);
+        }
+      }
+  };
+  if (p.act == DA_ACT_GEGLU) body(std::false_type{});
+  else body(std::true_type{});
+#undef G3_READ_A
+#undef G3_LDSP
+#undef G3_TOGGLE
+#undef G3_READ_B
+#undef G3_MFMA
+#undef G3_FENCE
+#undef G3_PHASE
+#undef G3_READ_A0B0
+#undef G3_VMCNT8
+#undef G3_SLICE
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int PRIO>
+int launch_geglu_prio(const da_gemm_params& p, hipStream_t s) {
+  const int tiles_m = p.M / G_BM, tiles_n = p.N / G_BN;
+  const int gx = da_gemm2::choose_xcd_gx2(tiles_m, tiles_n, G_BM, G_BN), gy = 8 / gx;
+  const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
+  auto kern = gemm3_geglu_kernel<PRIO>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess) return DA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  DA_LAUNCH(kern, dim3(grid), dim3(512), G_LDS, s, p, gx);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
 // Priority form (speed only; DA_K3_PRIO = 0 / 1 / 2 for A/B runs): 1 = the guide's per-phase pair (s_setprio 1 around the 16 MFMAs),
 // 0 = none, 2 = ONE s_setprio 1 for the second-dispatched wave row before the loop and no flips (MI355X_MICROARCH.md, "static priority
 // for the younger half": waves 4-7 otherwise lose the arbitration at the head of every phase).  Measured, chained launches on random
@@ -452,9 +762,16 @@ int launch(const da_gemm_params& p, hipStream_t s) {
 
 // nn.Linear, one ring form (DA_STAGE_LDS_DIRECT), no split-K / LayerNorm fold / transposed block / cross-attention epilogue
 int dispatch_lin(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
-  if (tile != DA_TILE_K3_256x256 || staging != DA_STAGE_LDS_DIRECT) return DA_ERR_UNSUPPORTED;
+  if ((tile != DA_TILE_K3_256x256 && tile != DA_TILE_K3_256x320) || staging != DA_STAGE_LDS_DIRECT) return DA_ERR_UNSUPPORTED;
   if (p.conv || p.split_k > 1 || p.stats_out || p.ln_stats || p.vt || p.xa_k || !da_gemm2::staging_fits(p)) return DA_ERR_UNSUPPORTED;
   const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
+  if (tile == DA_TILE_K3_256x320) {   // the GEGLU projection's tile: whole tiles only, 16-byte aligned output rows
+    if (!geglu || (p.M % G_BM) || (p.N % G_BN) || (p.ldc & 7) || ((size_t)p.C & 15)) return DA_ERR_UNSUPPORTED;
+    static const int prio = [] { const char* v = getenv("DA_K3_PRIO"); return v ? atoi(v) : 2; }();
+    if (prio == 0) return launch_geglu_prio<0>(p, s);
+    if (prio == 1) return launch_geglu_prio<1>(p, s);
+    return launch_geglu_prio<2>(p, s);
+  }
   return geglu ? launch<true>(p, s) : launch<false>(p, s);
 }
 

@@ -72,7 +72,9 @@ extern "C" {
  * split_k / LayerNorm fold / transposed block / cross-attention epilogue.  Bit-identical to the K1 tiles above (same K order, same
  * epilogue). */
 #define DA_TILE_K3_256x256 20 /* 2 x 4 waves of 128 x 64 (64 contiguous columns per wave: GEGLU pairs inside the wave) */
-#define DA_TILE_COUNT 21
+#define DA_TILE_K3_256x320 21 /* 4 x 2 waves of 64 x 160, GEGLU epilogue ONLY (a wave owns five value tiles and their gate tiles), M % 256
+                                 == 0, N % 320 == 0, 16-byte aligned output rows: M 2048 x N 10240 = exactly 256 tiles (SDXL's ff.net.0.proj) */
+#define DA_TILE_COUNT 22
 /* da_gemm_tune only: which variants compete, given in da_gemm_params.tile (DA_TILE_AUTO = all of them).  Within one family
  * every variant is bit-identical to every other; the two families differ in the fp32 summation order. */
 #define DA_TILE_FAMILY_1 (-1)

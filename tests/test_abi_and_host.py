@@ -442,7 +442,7 @@ def test_tuning_keys_bucket_giant_row_counts_only():
         # summation order; the split variants serve the small-M, deep-K convs of the SD1.5 / DDPM U-Nets)
         assert split == [] or (len(split) == 1 and 2 <= split[0] <= 8 and tile < L.FIRST_K2_TILE and key not in sdxl), key
         # the eight-phase tile (csrc/gemm3.hip): nn.Linear only, one ring form, unsplit
-        if tile == L.TILE_K3_256x256:
+        if tile in (L.TILE_K3_256x256, L.TILE_K3_256x320):
             assert key.startswith("lin:") and staging == L.STAGE_LDS_DIRECT and split == [], key
     n_k3 = sum(1 for v in table["entries"].values() if v[0] == L.TILE_K3_256x256)
     assert n_k3 >= 20, "the round-5 retune moved the large Flux / Wan / VAE nn.Linear entries to k3:256x256"
@@ -450,6 +450,7 @@ def test_tuning_keys_bucket_giant_row_counts_only():
     import re
     assert int(re.search(r"#define DA_TILE_COUNT (\d+)", header).group(1)) == len(L.TILE_NAMES)
     assert int(re.search(r"#define DA_TILE_K3_256x256 (\d+)", header).group(1)) == L.TILE_K3_256x256
+    assert int(re.search(r"#define DA_TILE_K3_256x320 (\d+)", header).group(1)) == L.TILE_K3_256x320
 
 
 def test_torch_library_ops_are_registered_with_fake_kernels():

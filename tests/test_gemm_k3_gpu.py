@@ -122,3 +122,57 @@ def test_k3_refuses_what_it_does_not_implement():
     xc, wc = rnd((1, 16, 16, 64), 3), rnd((64, 9 * 64), 4)
     with pytest.raises(RuntimeError, match="UNSUPPORTED"):
         ops.conv2d_nhwc(xc, wc, None, ksize=3, tile=L.TILE_K3_256x256, staging=L.STAGE_LDS_DIRECT)
+
+
+# ---- the GEGLU projection's own eight-phase tile (DA_TILE_K3_256x320: 4 x 2 waves of 64 x 160, value / gate tiles paired in a wave) ----
+def k3g(ops, L, x, w, *a, **kw):
+    return ops.linear(x, w, *a, tile=L.TILE_K3_256x320, staging=L.STAGE_LDS_DIRECT, **kw)
+
+
+# SDXL's two GEGLU projections, one tile / one slice, odd slice counts (K = 192, 320), several tiles in both directions
+# (N2 = packed value + gate columns: whole 320-column tiles AND whole 64-column [32 value | 32 gate] groups -> multiples of 640)
+@pytest.mark.parametrize("M,N2,K", [(2048, 10240, 1280), (8192, 5120, 640), (256, 640, 64), (256, 640, 192), (512, 1280, 320),
+                                    (1024, 1280, 2560), (768, 1920, 128)])
+@pytest.mark.parametrize("tanh", [False, True])
+def test_k3_geglu_tile_bit_identical_to_k1(M, N2, K, tanh):
+    ops, L = _ops()
+    act = L.ACT_GEGLU_TANH if tanh else L.ACT_GEGLU
+    x, w, b = rnd((M, K), 51), rnd((N2, K), 52, K ** -0.5), rnd((N2,), 53)
+    wp, bp = ops.pack_geglu(w, b)
+    y = k3g(ops, L, x, wp, bias=bp, act=act)
+    want = ops.linear(x, wp, bias=bp, act=act, tile=L.TILE_K1_128x320, staging=L.STAGE_LDS_DIRECT)
+    assert y.shape == (M, N2 // 2)
+    assert torch.equal(y, want), f"k3:256x320 {M}x{N2}x{K}: {int((y != want).sum())} outputs differ from k1:128x320"
+    h = (x.float() @ w.float().t() + b.float()).to(bf16).float()
+    ref = h[:, : N2 // 2] * F.gelu(h[:, N2 // 2:], approximate="tanh" if tanh else "none").to(bf16).float()
+    assert_close_bf16(y, ref, f"k3:256x320 geglu {M}x{N2}x{K}", rtol=1.6e-2, atol_rms=6e-3)
+    # no bias, alpha, a strided output block
+    out = torch.zeros((M, N2), device=DEV, dtype=bf16)
+    k3g(ops, L, x, wp, act=act, alpha=0.5, out=out[:, : N2 // 2])
+    assert torch.equal(out[:, : N2 // 2], ops.linear(x, wp, act=act, alpha=0.5, tile=L.TILE_K1_128x320, staging=L.STAGE_LDS_DIRECT))
+    assert float(out[:, N2 // 2:].abs().max()) == 0.0, "wrote outside its column block"
+
+
+def test_k3_geglu_tile_race_screen():
+    ops, L = _ops()
+    M, N2, K = 2048, 10240, 1280
+    x, w, b = rnd((M, K), 61), rnd((N2, K), 62, K ** -0.5), rnd((N2,), 63)
+    wp, bp = ops.pack_geglu(w, b)
+    want = ops.linear(x, wp, bias=bp, act=L.ACT_GEGLU, tile=L.TILE_K1_128x320, staging=L.STAGE_LDS_DIRECT)
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    for it in range(25):
+        if it % 3 == 1:
+            noise.fill_(it)
+        y = k3g(ops, L, x, wp, bias=bp, act=L.ACT_GEGLU)
+        assert torch.equal(y, want), f"k3:256x320 launch {it}: {int((y != want).sum())} outputs differ"
+
+
+def test_k3_geglu_tile_refusals():
+    ops, L = _ops()
+    x, w = rnd((256, 128), 1), rnd((640, 128), 2)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        k3g(ops, L, x, w)                                               # not a GEGLU epilogue
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        k3g(ops, L, rnd((300, 128), 3), w, act=L.ACT_GEGLU)             # M is not whole tiles
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        k3g(ops, L, x, rnd((256, 128), 4), act=L.ACT_GEGLU)             # N is not whole tiles

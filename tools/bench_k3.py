@@ -76,7 +76,7 @@ def main():
         fl = 2.0 * M * N * K
         rec = {"op": "linear", "name": name, "M": M, "N": N, "K": K, "gflop": round(fl * 1e-9, 1)}
         ref = ops.linear(x, w, b, act=act, residual=r, tile=L.TILE_K1_256x256, staging=L.STAGE_LDS_DIRECT)
-        cands = [("table", None, None), ("k3:256x256", L.TILE_K3_256x256, L.STAGE_LDS_DIRECT), ("k1:256x256", L.TILE_K1_256x256, L.STAGE_LDS_DIRECT),
+        cands = [("table", None, None), ("k3:256x256", L.TILE_K3_256x256, L.STAGE_LDS_DIRECT), ("k3:256x320", L.TILE_K3_256x320, L.STAGE_LDS_DIRECT), ("k1:256x256", L.TILE_K1_256x256, L.STAGE_LDS_DIRECT),
                  ("k1:256x128/3", L.TILE_K1_256x128, L.STAGE_LDS_DIRECT3), ("k1:128x256/3", L.TILE_K1_128x256, L.STAGE_LDS_DIRECT3),
                  ("k1:128x320", L.TILE_K1_128x320, L.STAGE_LDS_DIRECT), ("k1:256x320", L.TILE_K1_256x320, L.STAGE_LDS_DIRECT)]
         for label, t, st in cands:

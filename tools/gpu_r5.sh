@@ -93,7 +93,7 @@ if [[ $WHAT == *prioab* ]]; then
   timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --timeout 300 -k "attention" 2>&1 | tail -2
 fi
 if [[ $WHAT == *k3test* ]]; then
-  timeout 600 python -m pytest tests/test_gemm_k3_gpu.py -m gpu -q -x --timeout 300 > $O/pytest_k3.log 2>&1; echo "pytest k3 rc=$?"
+  timeout 600 python -m pytest tests/test_gemm_k3_gpu.py -m gpu -q --timeout 300 > $O/pytest_k3.log 2>&1; echo "pytest k3 rc=$?"
   grep -E "passed|failed|FAILED|Error|assert|differ" $O/pytest_k3.log | tail -20
 fi
 if [[ $WHAT == *k3bench* ]]; then
@@ -146,4 +146,12 @@ for l in open("$O/k3_prio.jsonl"):
     if "DA_K3_PRIO" in d: pr=d["DA_K3_PRIO"]; continue
     print(pr, d["name"], d.get("k3:256x256"), d.get("k1:256x256"))
 PY
+fi
+if [[ $WHAT == *gegluab* ]]; then
+  for tb in new old new old; do
+    if [[ $tb == old ]]; then export DIFFUSERS_AMD_TUNE_DB=$R/profiles/r05n_table_before_geglu_tile.json; else unset DIFFUSERS_AMD_TUNE_DB; fi
+    timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_geglu_$tb.json 2> $O/bench_geglu_$tb.err; echo "sdxl table $tb rc=$? $(cut -c1-140 $O/bench_geglu_$tb.json | grep -o '"value": [0-9.]*')"
+    timeout 600 python bench.py --config sd15 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/bench_sd15_$tb.json 2> $O/bench_sd15_$tb.err; echo "sd15 table $tb rc=$? $(cut -c1-160 $O/bench_sd15_$tb.json | grep -o '"value": [0-9.]*')"
+  done
+  unset DIFFUSERS_AMD_TUNE_DB
 fi
