@@ -28,7 +28,7 @@ if [[ $WHAT == *fulltest* ]]; then
   grep -E "passed|failed|FAILED|Error" $O/pytest_gpu.log | tail -20
   grep -E "\[parity\] (SDXL|FLUX|Wan|SD1.5|full|Auto)|\[drop-in\]|\[B3\]|\[B4\]|\[rccl\]" $O/pytest_gpu.log | tail -60
 fi
-if [[ $WHAT == *benchfull* ]]; then
+if [[ $WHAT == *benchfull* && $WHAT != *trafficfirst* ]]; then
   timeout 1500 python bench.py --steps 3 --warmup 1 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"
   cut -c1-300 $O/bench_full.json; grep "^\[bench" $O/bench_full.err | tail -40
 fi
@@ -154,4 +154,8 @@ if [[ $WHAT == *gegluab* ]]; then
     timeout 600 python bench.py --config sd15 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/bench_sd15_$tb.json 2> $O/bench_sd15_$tb.err; echo "sd15 table $tb rc=$? $(cut -c1-160 $O/bench_sd15_$tb.json | grep -o '"value": [0-9.]*')"
   done
   unset DIFFUSERS_AMD_TUNE_DB
+fi
+if [[ $WHAT == *trafficfirst* ]]; then   # (the stages above run in file order: this one runs the full bench AFTER the traffic stage)
+  timeout 1500 python bench.py --steps 3 --warmup 1 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"
+  cut -c1-300 $O/bench_full.json; grep "^\[bench" $O/bench_full.err | tail -40
 fi
