@@ -159,3 +159,6 @@ if [[ $WHAT == *trafficfirst* ]]; then   # (the stages above run in file order: 
   timeout 1500 python bench.py --steps 3 --warmup 1 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"
   cut -c1-300 $O/bench_full.json; grep "^\[bench" $O/bench_full.err | tail -40
 fi
+if [[ $WHAT == *wanfull* ]]; then
+  timeout 900 python bench.py --config wan --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_wan_full.json 2> $O/bench_wan_full.err; echo "wan full rc=$? $(grep -o '"value": [0-9.]*' $O/bench_wan_full.json | head -1) $(grep -o '"ms_per_step": [0-9.]*' $O/bench_wan_full.json | head -1)"
+fi
