@@ -110,7 +110,7 @@ if [[ $WHAT == *k3retune* ]]; then
   timeout 900 python tools/retune_k3.py $O/k3_retune.jsonl $O/table_k3.json > $O/k3_retune.log 2>&1; echo "k3 retune rc=$?"
   cut -c1-330 $O/k3_retune.log | tail -40
 fi
-if [[ $WHAT == *k3ab* ]]; then
+if [[ $WHAT == *k3tabab* ]]; then
   # other configs before / after the table moved entries to k3 (same box): flux 4 steps, wan 6 steps (UniPC + decode), sdxl fast
   for tb in old new old new; do
     if [[ $tb == new ]]; then export DIFFUSERS_AMD_TUNE_DB=$O/table_k3.json; else unset DIFFUSERS_AMD_TUNE_DB; fi
@@ -161,4 +161,15 @@ if [[ $WHAT == *trafficfirst* ]]; then   # (the stages above run in file order: 
 fi
 if [[ $WHAT == *wanfull* ]]; then
   timeout 900 python bench.py --config wan --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_wan_full.json 2> $O/bench_wan_full.err; echo "wan full rc=$? $(grep -o '"value": [0-9.]*' $O/bench_wan_full.json | head -1) $(grep -o '"ms_per_step": [0-9.]*' $O/bench_wan_full.json | head -1)"
+fi
+if [[ $WHAT == *forcedk3ab* ]]; then
+  for tb in new old new old; do
+    if [[ $tb == new ]]; then export DIFFUSERS_AMD_TUNE_DB=$R/profiles/r05q_table_forced_k3_candidates.json; else unset DIFFUSERS_AMD_TUNE_DB; fi
+    timeout 600 python bench.py --config flux --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/bench_flux_f$tb.json 2> $O/bench_flux_f$tb.err; echo "flux forced-k3 $tb rc=$? $(grep -o '"value": [0-9.]*' $O/bench_flux_f$tb.json | head -1)"
+  done
+  for tb in new old; do
+    if [[ $tb == new ]]; then export DIFFUSERS_AMD_TUNE_DB=$R/profiles/r05q_table_forced_k3_candidates.json; else unset DIFFUSERS_AMD_TUNE_DB; fi
+    timeout 600 python bench.py --config wan --steps 1 --warmup 1 --denoise-steps 6 --no-cpu-baseline --no-roofline > $O/bench_wan_f$tb.json 2> $O/bench_wan_f$tb.err; echo "wan forced-k3 $tb rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/bench_wan_f$tb.json | head -1)"
+  done
+  unset DIFFUSERS_AMD_TUNE_DB
 fi
