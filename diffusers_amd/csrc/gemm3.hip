@@ -8,7 +8,7 @@
 // wave issues its LDS-DMA and its ds_reads right behind the rendezvous and then every wave multiplies -- the matrix pipe of a SIMD
 // idles while its two waves fetch, and both want it at once afterwards (1000-1050 TFLOP/s steady state, profiles/r04*).  Here the
 // 2 x 4 waves of a workgroup are two GROUPS of four (one wave per SIMD each) that run the same phase sequence ONE BARRIER APART:
-// while group 0 multiplies a 64 x 32 quadrant of its 128 x 64 wave tile (16 MFMAs, s_setprio 1), group 1 -- the other wave of
+// while group 0 multiplies a 64 x 32 quadrant of its 128 x 64 wave tile (16 MFMAs), group 1 -- the other wave of
 // every SIMD -- reads its next fragments from LDS and issues its share of the LDS-DMA; at the next barrier they swap.  A SIMD's
 // matrix pipe then always has exactly one wave feeding it and the other wave's memory work hides under it.
 //
@@ -27,7 +27,7 @@
 //   P2 quadrant (0,1): ds_read B1 (4) -> BY          stage A0 of slice kt + 2
 //   P3 quadrant (1,1): ds_read A1 (8) -> af          stage B1 of slice kt + 2
 //   P4 quadrant (1,0): ds_read B0 of slice kt + 1 (4, other buffer) -> BY      stage A1 of slice kt + 2
-// each phase = [reads, stage, s_waitcnt vmcnt(12), s_waitcnt lgkmcnt(0)] s_barrier [setprio 1, 16 MFMA, setprio 0] s_barrier.
+// each phase = [reads, stage, s_waitcnt vmcnt(12), s_waitcnt lgkmcnt(0)] s_barrier [16 MFMA] s_barrier (priority forms: launch()).
 // Both waits sit IN FRONT of the phase's first barrier, i.e. inside the segment that runs beside the other group's MFMAs: the
 // multiply starts the moment the barrier opens.
 // Hazards (group 1 runs one barrier late, so "a phase later" for one group is half a phase later for the other; barriers numbered
@@ -49,7 +49,8 @@
 // the guide's placement (reads 12 / 4 / 8 / 0, lgkmcnt(0) BEHIND the barrier, one vmcnt(6) per slice) 1.12 / 1.09; the reads of a later
 // phase issued behind the MFMAs of the current one (nothing but LDS-DMA in the other segment) 1.04 / 0.99 -- the read issue then
 // sits between the last MFMA and the barrier that lets the other group start, exposed; this form 1.11 / 1.10 and the best absolute
-// rates (1443 TFLOP/s at 8192^3, 1373 at 4096^3, 1434 on the Wan shape; random operands).
+// rates (1443 TFLOP/s at 8192^3, 1373 at 4096^3, 1434 on the Wan shape; random operands) -- 1484-1509 / 1339-1387 with the 16-byte
+// epilogue and the static priority form (launch(), profiles/r05k_*).
 //
 // Numerics: fp32 accumulation, K slices in order, k-step 0 then 1 -- the order of every KG = 1 tile of gemm2_kernel.cuh, and the
 // epilogue is that header's epilogue4: BIT-IDENTICAL to DA_TILE_K1_256x256 (tests/test_gemm_k3_gpu.py asserts equality).
@@ -441,25 +442,35 @@ int launch_prio(const da_gemm_params& p, hipStream_t s) {
 // The GEGLU projection's own eight-phase tile: 256 x 320 (DA_TILE_K3_256x320).  SDXL's ff.net.0.proj (activations.py:113-124) is
 // M 2048 x N 10240 (packed [32 value | 32 gate] rows) x K 1280 at the 32 x 32 level and 8192 x 5120 x 640 at the 64 x 64 level: 320
 // and 640 tiles of 256 x 256 (1.25 / 2.5 rounds of the 256 CUs), but exactly 256 and 512 tiles of 256 x 320 -- ONE and TWO rounds.  It
-// is the largest single launch population of an SDXL step (60 launches, 3.5 ms of 20.9).
+// is the largest single launch population of an SDXL step (70 launches, 4.1 ms of 20.9).
 //
-// Same structure as the kernel above (two wave groups one barrier apart, phases of [reads, one half-tile of LDS-DMA, counted waits]
-// barrier [MFMAs] barrier, six half-tiles in flight, every half-tile restaged one phase after its last read) with the roles of the
-// operands exchanged, because the wave tile is 64 x 160:
+// Same structure as the kernel above (two wave groups one barrier apart, phases of [reads, one half-tile of LDS-DMA, waits] barrier
+// [MFMAs] barrier, every half-tile restaged one phase after its last read) with the roles of the operands exchanged, because the wave
+// tile is 64 x 160:
 //   8 waves = 4 rows (wr) x 2 columns (wc = the group); A half h = tile rows 64 wr' + 32 h + [0, 32): a wave owns 2 row tiles of each
 //   half; B half 0 = the ten VALUE tiles of the 320 packed columns, half 1 their GATE tiles (LDS row 16 T + r of half h' = packed row
 //   64 (T / 2) + 32 h' + 16 (T % 2) + r): a wave owns value tiles 5 wc .. 5 wc + 4 and their gates, i.e. 80 contiguous OUTPUT columns.
-//   Quadrant (h, h') = 2 x 5 tiles x 2 k-steps = 20 MFMAs; quadrant order (0,0) (1,0) (1,1) (0,1): ONE B fragment set (40 registers:
-//   B0 for P1 / P2, B1 for P3 / P4) and TWO A sets (16 each: A0 lives P1 .. P4, A1 P2 .. P3; the next slice's A0 is read in P4 into
-//   the set A1 left, the sets swap roles every slice).  160 accumulator + 72 fragment registers.
-//   P1: read B0 (10)         stage A0 of slice kt + 2        P2: read A1 (4)              stage B0 of slice kt + 2
-//   P3: read B1 (10)         stage A1 of slice kt + 2        P4: read A0 of kt + 1 (4)    stage B1 of slice kt + 2
+//   Quadrant (h, h') = 2 x 5 tiles x 2 k-steps = 20 MFMAs; quadrant order (0,0) (1,0) (1,1) (0,1) with ONE B fragment set (40
+//   registers: B0 for P1 / P2, B1 for P3 / P4) and ONE A set (16: A0, A1, A1, A0 again -- A half 0 is read twice per slice) next to 160
+//   accumulator registers: 240 VGPRs, no scratch.  (Two A sets -- A0 kept from P1 to P4, the next slice's A0 read in P4, six half-tiles
+//   in flight as in the 256 x 256 kernel -- compiled to 256 registers plus spills INSIDE the loop, whose scratch traffic also counts in
+//   vmcnt: discarded at the compiler output.)
+//   P1: read A0 (4) + B0 (10)   stage A0 of slice kt + 1 (other buffer)     P2: read A1 (4)    stage B0 of slice kt + 2
+//   P3: read B1 (10)            stage A1 of slice kt + 2                    P4: read A0 (4)    stage B1 of slice kt + 2, vmcnt(8)
+//   ONE counted wait per slice: P4's vmcnt(8) leaves the three newest half-tiles (B0, A1, B1 of slice kt + 2: 3 + 2 + 3 loads) in
+//   flight and retires everything older, i.e. all of slice kt + 1 -- read from P1 of kt + 1 on, one phase after the wait (RAW rule of
+//   the kernel above).  Latency budgets in phases of ~680 cycles: B0 6, A1 5, B1 4 (the weight, met cold) and 3 for A0 (the
+//   activation, written by the kernel in front: warm).  WAR: A0 is last read in P4 and restaged in P1 of the next slice, B0: P1 -> P2,
+//   A1: P2 -> P3, B1: P3 -> P4 -- each one phase after its last read, whose lgkmcnt(0) sits in front of that phase's barrier.
 //   LDS: 2 x (16 + 16 + 20 + 20) KiB + 1 KiB dump (the four waves without a third B piece issue theirs out of range into it; the weight
-//   prefetch lands there too) + 1 KiB bias = 146 KiB.  A wave issues 2 (A) or 3 (B) pieces per phase: the six newest half-tiles are
-//   always 15 loads -- vmcnt(15).
-// Restrictions (tile_ok): GEGLU epilogue only, M % 256 == 0, N % 320 == 0 (no clamped rows: the half-tile origin rides in the scalar
-// offset and five per-lane offsets serve all four half-tiles), 16-byte aligned output rows.
+//   prefetch lands there too) + 1 KiB bias = 146 KiB.  The fragment bases toggle between the two buffers by an opaque add (as
+//   compile-time offsets the second buffer's 72 KiB origin does not fit ds_read's 16-bit offset field and the compiler keeps a
+//   second set of bases).
+// Restrictions (tile_ok): GEGLU epilogue only, M % 256 == 0, N % 320 == 0 (no clamped rows: pieces and halves ride in the scalar
+// offset, ONE per-lane offset per operand serves all of them), 16-byte aligned output rows.
 // Numerics: K slices in order, k-step 0 then 1, the GEGLU arithmetic of the other tiles: bit-identical to k1:128x320.
+// Measured (profiles/r05n_*): chains 58.2 -> 51.6 us at 2048 x 10240 x 1280 and 72 -> 59.5 us at 8192 x 5120 x 640, in situ 58.7 -> 48.5 us,
+// same-box SDXL image + 3.9 %.
 constexpr int G_BM = 256, G_BN = 320;
 constexpr int G_AH = 128 * 128, G_BH = 160 * 128;          // bytes of an A / B half-tile
 constexpr int G_KBUF = 2 * G_AH + 2 * G_BH;                // 72 KiB per slice
