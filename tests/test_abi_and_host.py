@@ -453,6 +453,34 @@ def test_tuning_keys_bucket_giant_row_counts_only():
     assert int(re.search(r"#define DA_TILE_K3_256x320 (\d+)", header).group(1)) == L.TILE_K3_256x320
 
 
+def test_eight_phase_tiles_refuse_before_any_launch():
+    """DA_TILE_K3_256x256 / DA_TILE_K3_256x320 (csrc/gemm3.hip): what the tiles do not implement is refused by name in the host part of
+    da_gemm_bf16 (tile_ok / dispatch) -- no launch is attempted, so this runs without a GPU.  nn.Linear only, one ring form, unsplit;
+    the 256 x 320 tile: GEGLU epilogue, whole tiles, 16-byte aligned output rows."""
+    import ctypes as C
+    from diffusers_amd import _lib as L
+    lib = L.load()
+    buf = (C.c_char * 4096)()
+    addr = C.addressof(buf)
+
+    def params(**kw):
+        p = L.GemmParams()
+        p.A = p.W = p.C = addr
+        p.M, p.N, p.K, p.lda, p.ldw, p.ldc = 256, 640, 128, 128, 128, 320
+        p.act, p.tile, p.staging = L.ACT_GEGLU, L.TILE_K3_256x320, L.STAGE_LDS_DIRECT
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+    UNSUP = 3
+    assert L.ERRORS[UNSUP] == "DA_ERR_UNSUPPORTED"
+    for kw in (dict(act=L.ACT_NONE), dict(M=300), dict(N=768), dict(ldc=324), dict(C=addr + 8), dict(split_k=2),
+               dict(staging=L.STAGE_LDS_DIRECT3), dict(staging=L.STAGE_PINGPONG),
+               dict(tile=L.TILE_K3_256x256, split_k=2), dict(tile=L.TILE_K3_256x256, staging=L.STAGE_PINGPONG),
+               dict(tile=L.TILE_K3_256x256, stats_out=addr, stats_ld=64, act=L.ACT_NONE),
+               dict(tile=L.TILE_K3_256x256, vt=addr, vt_col0=320, ld_vt=256, act=L.ACT_NONE)):
+        assert lib.da_gemm_bf16(C.byref(params(**kw)), None) == UNSUP, kw
+
+
 def test_torch_library_ops_are_registered_with_fake_kernels():
     """torch.ops.mi355x.* (diffusers_amd/torch_ops.py): the reference's binding pattern for native kernels
     (attention_dispatch.py:746-816, custom_op + register_fake).  On a host without a GPU the REAL kernels are unreachable
