@@ -173,3 +173,9 @@ if [[ $WHAT == *forcedk3ab* ]]; then
   done
   unset DIFFUSERS_AMD_TUNE_DB
 fi
+if [[ $WHAT == *prioinsitu* ]]; then
+  for pr in 2 0 1 2 0 1; do
+    DA_K3_PRIO=$pr timeout 300 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/b_sdxl_p$pr.json 2> $O/b_sdxl_p$pr.err; echo "sdxl DA_K3_PRIO=$pr $(cut -c1-140 $O/b_sdxl_p$pr.json | grep -o '"value": [0-9.]*')"
+    DA_K3_PRIO=$pr timeout 300 python bench.py --config flux --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/b_flux_p$pr.json 2> $O/b_flux_p$pr.err; echo "flux DA_K3_PRIO=$pr $(grep -o '"value": [0-9.]*' $O/b_flux_p$pr.json | head -1)"
+  done
+fi
