@@ -304,7 +304,8 @@ def qkv_variant(p: "L.GemmParams", stream: int):
 XATTN = os.environ.get("DIFFUSERS_AMD_XATTN", "0") == "1"
 # Cross-attention: attn2.to_q pulls the layer's step-invariant K / V^T (one buffer, layers.CrossKV.buf) towards the memory-side cache
 # behind its K loop instead of the next GEMM's weight -- the 77-key attention launch that follows otherwise meets them cold
-# (5 GB of weights went through the 256 MB cache since the last step touched them).  A/B knob, round 5.
+# (5 GB of weights went through the 256 MB cache since the last step touched them).  A/B knob, round 5: measured - 0.5 % on the image on
+# two boxes (profiles/r05j_kv_prefetch_same_box_ab.txt: the hint displaces the to_out weight's prefetch and buys less than that): off.
 KV_PREFETCH = os.environ.get("DIFFUSERS_AMD_KV_PREFETCH", "0") == "1"
 XATTN_MAX_KEYS = 80                                              # da_gemm_params.xa_skv_alloc limit of the one instantiation
 XATTN_STAGING = L.STAGE_PINGPONG if os.environ.get("DIFFUSERS_AMD_XATTN_STAGE", "pp") == "pp" else L.STAGE_LDS_DIRECT
