@@ -46,6 +46,8 @@ def graph_us(fn, n=20):
 
 SHAPES = [  # name, M, N, K, act, residual
     ("flux proj_mlp", 4608, 12288, 3072, L.ACT_GELU_TANH, False),
+    ("flux proj_mlp shape, plain epilogue", 4608, 12288, 3072, L.ACT_NONE, False),
+    ("flux proj_mlp shape, 4 exact rounds (M 5120), plain epilogue", 5120, 12800, 3072, L.ACT_NONE, False),
     ("flux qk", 4608, 6144, 3072, L.ACT_NONE, False),
     ("flux to_out", 4608, 3072, 3072, L.ACT_NONE, True),
     ("flux proj_out", 4608, 3072, 15360, L.ACT_NONE, True),
