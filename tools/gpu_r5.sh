@@ -1,5 +1,10 @@
 #!/bin/bash
-# Round-5 gpurun stages.  usage: gpu_r5.sh "boundary benchfast ..."
+# Round-5 gpurun stages.  usage: gpu_r5.sh "boundary benchfast ..." -- stages run in FILE order, selected by substring (keep stage names
+# free of each other as substrings).  Stages of the eight-phase GEMM work: k3test (tests/test_gemm_k3_gpu.py), k3bench (tools/bench_k3.py,
+# K3_ONLY=<name filter>), k3retune (tools/retune_k3.py -> gpurun_out/table_k3.json), k3prio (priority forms in chains), prioinsitu
+# (the same in situ), gegluab (new / old table on one box), forcedk3ab, attnab (flash attention priority pair), kvpfab (K / V^T prefetch),
+# gemmtests, otherbench, wanfull; the round's record: fulltest, then "traffic prof trafficfirst" (PMC traffic, rocprofv3 stats, full
+# default bench line reading the fresh traffic file).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
