@@ -433,6 +433,7 @@ def test_tuning_keys_bucket_giant_row_counts_only():
     k81 = tuning.key_of(p)
     p.M = 79 * 480 * 832
     assert tuning.key_of(p) == k81
+    import re
     table = json.loads((Path(tuning.__file__).parent / "tuned" / "gfx950.json").read_text())
     assert table["arch"] == "gfx950" and len(table["entries"]) >= 250
     sdxl = set(json.loads((Path(__file__).parent / "golden" / "sdxl_gemm_shape_keys.json").read_text())["keys"])
@@ -444,6 +445,9 @@ def test_tuning_keys_bucket_giant_row_counts_only():
         # the eight-phase tile (csrc/gemm3.hip): nn.Linear only, one ring form, unsplit
         if tile in (L.TILE_K3_256x256, L.TILE_K3_256x320):
             assert key.startswith("lin:") and staging == L.STAGE_LDS_DIRECT and split == [], key
+        if tile == L.TILE_K3_256x320:   # the GEGLU projection's tile: GEGLU epilogue, whole tiles (what tile_ok admits)
+            m, n, act = (int(re.search(p, key).group(1)) for p in (r":M(\d+)", r":N(\d+)", r":a(\d+)"))
+            assert act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH) and m % 256 == 0 and n % 320 == 0, key
     n_k3 = sum(1 for v in table["entries"].values() if v[0] == L.TILE_K3_256x256)
     assert n_k3 >= 20, "the round-5 retune moved the large Flux / Wan / VAE nn.Linear entries to k3:256x256"
     header = (Path(__file__).parent.parent / "include" / "diffusers_amd.h").read_text()
