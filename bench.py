@@ -922,7 +922,9 @@ def main(argv=None):
 
     state = {"graph": not args.no_graph}
 
-    def one_image(output_type="raw"):
+    def one_image(output_type="pt"):
+        # the timed call returns [0, 1] images, SURVEY.md 8d's protocol (output_type="pt"); the postprocess is fused into the
+        # decoder's last pass.  The parity legs below ask for "raw" ([-1, 1]) / "latent" explicitly, outside the timed region.
         return pipe(prompt_embeds=mine["prompt_embeds"], negative_prompt_embeds=mine["negative_prompt_embeds"],
                     pooled_prompt_embeds=mine["pooled"], negative_pooled_prompt_embeds=mine["negative_pooled"],
                     latents=mine["latents"].clone(), num_inference_steps=args.denoise_steps, guidance_scale=GUIDANCE,
@@ -957,6 +959,10 @@ def main(argv=None):
             pipe._graph = None
             img = one_image()
     _sync()
+    if _pg() and torch.distributed.get_world_size() != int(os.environ.get("WORLD_SIZE", world)):
+        # the line's `n_gpus` and `value` assume every launched rank is inside the group that brackets the timed region
+        raise SystemExit(f"process group has {torch.distributed.get_world_size()} ranks, the launcher started "
+                         f"{os.environ.get('WORLD_SIZE')}: refusing to time a partial job")
     log("timed region")
     if _pg():
         torch.distributed.barrier()
@@ -976,6 +982,16 @@ def main(argv=None):
         gathered = [torch.zeros_like(tt) for _ in range(world)]
         torch.distributed.all_gather(gathered, tt)
         per_rank = [float(g.item()) for g in gathered]
+    # per-rank box normalisers on the line: a replica on a slow-kind box (or starved of host cores) is visible next to its rate
+    cold = (box or {}).get("memory", {}).get("cold_gemm_us")
+    per_rank_cold = [cold]
+    per_rank_cpus = [len(os.sched_getaffinity(0))]
+    if _pg():
+        tt = torch.tensor([cold if cold is not None else -1.0, float(per_rank_cpus[0])], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        torch.distributed.all_gather(gathered, tt)
+        per_rank_cold = [(float(g[0]) if float(g[0]) >= 0 else None) for g in gathered]
+        per_rank_cpus = [int(g[1]) for g in gathered]
     finite = bool(torch.isfinite(img.float()).all())
     log(f"timed region done: {elapsed:.3f} s for {args.steps} image(s) per GPU")
     if args.save_tuning and rank == 0:
@@ -992,14 +1008,17 @@ def main(argv=None):
                                "128x128 latents + AutoencoderKL decode to 1024x1024; 1 prompt per GPU"
                                if not args.tiny else "TINY plumbing config (not a benchmark)",
                    "global_batch": world, "parallelism": f"dp{world} (independent prompts, replicas)",
-                   "denoise_steps": args.denoise_steps, "hip_graph": state["graph"], "output_finite": finite,
+                   "denoise_steps": args.denoise_steps, "output_type": "pt", "hip_graph": state["graph"], "output_finite": finite,
                    "rccl_ranks": torch.distributed.get_world_size() if _pg() else 1,
                    "process_group": D.backend_name(),     # "nccl" = RCCL; None: a lone process without a launcher (no collectives)
                    "tuned_live": _tuned_live(),
                    "box_mfma_tflops": box["tflops"] if box else None, "box_mfma_probe": box,
                    "box_hbm_copy_gbps": (box or {}).get("memory", {}).get("hbm_copy_gbps"),
                    "box_cold_gemm_us": (box or {}).get("memory", {}).get("cold_gemm_us"),
-                   "images_per_s_per_rank": per_rank},
+                   "images_per_s_per_rank": per_rank, "box_cold_gemm_us_per_rank": per_rank_cold,
+                   "host_cores_per_rank": per_rank_cpus,
+                   "cpu_binding": ("per-rank NUMA-local core share (distributed.bind_rank_to_cpus)" if world > 1 and
+                                   os.environ.get("DIFFUSERS_AMD_BIND", "1") != "0" else "none")},
     }
 
     if rank == 0 and not args.tiny:

@@ -69,7 +69,11 @@ class AttentionParams(C.Structure):
         ("bias", C.c_void_p), ("bias_batch_stride", C.c_longlong), ("bias_head_stride", C.c_longlong),
         ("bias_row_stride", C.c_int), ("bias_f32", C.c_int), ("causal", C.c_int), ("q_block", C.c_int), ("pv_delay", C.c_int),
         ("algo", C.c_int),
+        ("split_ws", C.c_void_p), ("split_ws_bytes", C.c_longlong), ("kv_split", C.c_int),
     ]
+
+
+ATTN_SPLIT_COUNTER_BYTES = 16384      # DA_ATTN_SPLIT_COUNTER_BYTES
 
 
 # ---- launch plans (include/diffusers_amd.h "launch plans"; csrc/plan.hip) ----
@@ -105,6 +109,7 @@ SIGNATURES = {
     "da_gemm_tune": (_i, [C.POINTER(GemmParams), C.POINTER(GemmParams), _vp, _i, _vp, C.c_size_t, C.POINTER(C.c_int),
                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "da_attention_bf16": (_i, [C.POINTER(AttentionParams), _vp]),
+    "da_attention_split_plan": (_ll, [C.POINTER(AttentionParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "da_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "da_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "da_rmsnorm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -145,7 +150,7 @@ SIGNATURES = {
     "da_plan_arg_kinds": (C.c_char_p, [_i]),
 }
 
-ABI_VERSION = 5              # include/diffusers_amd.h DA_ABI_VERSION
+ABI_VERSION = 6              # include/diffusers_amd.h DA_ABI_VERSION
 _lib = None
 _tls = threading.local()     # .recorder: the plan recorder of this thread (diffusers_amd/plan.py), if one is active
 

@@ -16,6 +16,7 @@ Both raise for arguments the kernels do not implement (masks, dropout, causal, G
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -108,15 +109,36 @@ _SUPPORTED_ARGS = {"query", "key", "value", "attn_mask", "dropout_p", "is_causal
 
 def _extend_enum(enum_cls, member_name: str, value: str):
     """Add ``member_name = value`` to a ``(str, Enum)`` class at run time -- what the one-line patch
-    ``MI355X = "mi355x"`` in ``AttentionBackendName`` (attention_dispatch.py:212-257) does at import time."""
-    if value in enum_cls._value2member_map_:
-        return enum_cls._value2member_map_[value]
-    m = str.__new__(enum_cls, value)
-    m._name_, m._value_ = member_name, value
-    enum_cls._member_map_[member_name] = m
-    enum_cls._member_names_.append(member_name)
-    enum_cls._value2member_map_[value] = m
-    return m
+    ``MI355X = "mi355x"`` in ``AttentionBackendName`` (attention_dispatch.py:212-257) does at import time.
+    The Enum is closed in the source, so this writes the class's private tables (`_member_map_`, `_member_names_`,
+    `_value2member_map_`) -- CPython internals that may move.  :func:`_enum_member_is_whole` checks every public view of the
+    result (lookup by value, by name, attribute access, iteration, ``__members__``); a caller that gets ``None`` back must not
+    use the member (register_backend then falls back to an ungated slot of the reference with a warning)."""
+    try:
+        if value in enum_cls._value2member_map_:
+            return enum_cls._value2member_map_[value]
+        m = str.__new__(enum_cls, value)
+        m._name_, m._value_ = member_name, value
+        enum_cls._member_map_[member_name] = m
+        enum_cls._member_names_.append(member_name)
+        enum_cls._value2member_map_[value] = m
+        # Python >= 3.12 resolves `Cls.NAME` through the class dict (EnumType.__getattr__ is gone): put the member there too
+        type.__setattr__(enum_cls, member_name, m)
+    except Exception:
+        return None
+    return m if _enum_member_is_whole(enum_cls, member_name, value) else None
+
+
+def _enum_member_is_whole(enum_cls, member_name: str, value: str) -> bool:
+    """True when every public view of ``enum_cls`` sees the run-time member: by value, by name, as an attribute, in iteration and
+    in ``__members__`` -- and they are all the same object."""
+    try:
+        m = enum_cls(value)
+        return (enum_cls[member_name] is m and getattr(enum_cls, member_name) is m and m in list(enum_cls)
+                and enum_cls.__members__.get(member_name) is m and m.value == value and m.name == member_name
+                and isinstance(m, enum_cls))
+    except Exception:
+        return False
 
 
 def register_backend(registry=None, name=None, *, slot: Optional[str] = None):
@@ -140,6 +162,12 @@ def register_backend(registry=None, name=None, *, slot: Optional[str] = None):
             name = AttentionBackendName(slot)
         elif name is None:
             name = _extend_enum(AttentionBackendName, "MI355X", BACKEND_NAME)
+            if name is None:      # the interpreter's enum internals are not the ones this shim knows: use a slot the reference ships
+                import warnings
+                name = AttentionBackendName(UNGATED_SLOTS[0])
+                warnings.warn(f"diffusers_amd: could not add AttentionBackendName.MI355X to the reference's Enum on this Python; "
+                              f"the HIP kernel is registered under the ungated slot {name.value!r} instead -- select it with "
+                              f"attention_backend({name.value!r})", RuntimeWarning, stacklevel=2)
     elif name is None:
         raise ValueError("register_backend: a custom registry needs an explicit name")
     registry._backends[name] = mi355x_flash_attention
@@ -158,8 +186,14 @@ class _Packed:
         self.ehs_version = -1
 
 
+def _version_of(t) -> int:
+    """A tensor's in-place edit counter; inference tensors (`torch.inference_mode()`) do not track one and cannot be edited in
+    place outside inference mode either, so identity alone keys them (ops.pad_thin_out guards the same case)."""
+    return -1 if t.is_inference() else t._version
+
+
 def _param_key(*params):
-    return tuple((p.data_ptr(), p._version) if p is not None else None for p in params)
+    return tuple((p.data_ptr(), _version_of(p)) if p is not None else None for p in params)
 
 
 class MI355XAttnProcessor:
@@ -175,16 +209,18 @@ class MI355XAttnProcessor:
     pipeline_stable_diffusion_xl.py:1193-1215)."""
 
     def __init__(self):
-        self._packs = {}
+        # keyed by a weak reference to the module: an entry dies with its module, so a freed module's `id()` being reused by
+        # another one cannot hand that one a stale pack (and the cache does not grow with every module ever seen)
+        self._packs = weakref.WeakKeyDictionary()
 
     def _pack(self, attn) -> _Packed:
-        pk = self._packs.get(id(attn))
+        pk = self._packs.get(attn)
         key = _param_key(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_q.bias, attn.to_k.bias, attn.to_v.bias,
                          attn.to_out[0].weight)
         if pk is None or pk.key != key:
             pk = _Packed()
             pk.key = key
-            self._packs[id(attn)] = pk
+            self._packs[attn] = pk
         return pk
 
     @staticmethod
@@ -241,7 +277,14 @@ class MI355XAttnProcessor:
         wq, wk, wv, bq, bk, bv, wo = self._proj(attn, pk, heads, d_real, D)
         if encoder_hidden_states is None:
             if S % 8 != 0:
-                raise ValueError("MI355XAttnProcessor: self-attention needs a token count that is a multiple of 8")
+                # the strided form reads K / V^T in 16-byte chunks of whole rows; odd latent sizes take the padded-key path of
+                # the backend function (one copy of K, one transpose of V), as before round 5
+                q = ops.linear(x2, wq, bq).view(B, S, heads, D)
+                k = ops.linear(x2, wk, bk).view(B, S, heads, D)
+                v = ops.linear(x2, wv, bv).view(B, S, heads, D)
+                o = mi355x_flash_attention(q, k, v, scale=scale).reshape(B * S, inner)
+                return self._finish(attn, o, wo, residual, input_ndim, B, S,
+                                    (Bn, Cn, Hn, Wn) if input_ndim == 4 else None)
             # [M][2*inner] and V^T [inner][M]: two problems, one launch (no transpose pass; to_v.bias is a ROW bias of V^T)
             wqk, bqk = self._fused_qk(pk, wq, wk, bq, bk)
             qk, vt = ops.linear_pair({"x": x2, "w": wqk, "bias": bqk},
@@ -251,19 +294,23 @@ class MI355XAttnProcessor:
                               vt_ld=B * S, vt_batch_stride=S, scale=scale)
         else:
             ehs = encoder_hidden_states
-            if pk.ehs is not ehs or pk.ehs_version != ehs._version:
+            if ehs.shape[0] != B:          # on every call: a cached K / V^T was laid out for ITS batch count
+                raise ValueError("MI355XAttnProcessor: encoder_hidden_states batch does not match hidden_states")
+            if pk.ehs is not ehs or pk.ehs_version != _version_of(ehs):
                 from .layers import pad_encoder_states
-                if ehs.shape[0] != B:
-                    raise ValueError("MI355XAttnProcessor: encoder_hidden_states batch does not match hidden_states")
                 pad, skv, skv_alloc = pad_encoder_states(ehs)      # zero rows up to a multiple of 16 keys (tiny: 77 x 2048)
                 k = ops.linear(pad, wk, bk)
                 vt = ops.linear(wv, pad, bias_rows=bv)                                  # [inner][B*skv_alloc] = V^T
-                pk.ehs, pk.ehs_version, pk.kv = ehs, ehs._version, (k, vt, skv, skv_alloc)
+                pk.ehs, pk.ehs_version, pk.kv = ehs, _version_of(ehs), (k, vt, skv, skv_alloc)
             k, vt, skv, skv_alloc = pk.kv
             q = ops.linear(x2, wq, bq)
             o = ops.attention(q, k, vt, B=B, H=heads, D=D, Sq=S, Skv=skv, Skv_alloc=skv_alloc, q_row_stride=inner,
                               k_row_stride=inner, q_batch_stride=S * inner, k_batch_stride=skv_alloc * inner,
                               vt_ld=B * skv_alloc, vt_batch_stride=skv_alloc, scale=scale)
+        return self._finish(attn, o, wo, residual, input_ndim, B, S, (Bn, Cn, Hn, Wn) if input_ndim == 4 else None)
+
+    @staticmethod
+    def _finish(attn, o, wo, residual, input_ndim, B, S, nchw):
         rs = getattr(attn, "rescale_output_factor", 1.0)
         fuse_res = input_ndim == 3 and getattr(attn, "residual_connection", False)
         # to_out[0] (+ the residual and 1 / rescale_output_factor in the GEMM epilogue when the tokens are already row-major);
@@ -274,7 +321,7 @@ class MI355XAttnProcessor:
         if fuse_res:
             return out
         if input_ndim == 4:
-            out = out.transpose(-1, -2).reshape(Bn, Cn, Hn, Wn)
+            out = out.transpose(-1, -2).reshape(*nchw)
         if getattr(attn, "residual_connection", False):
             out = out + residual
         if rs != 1.0:

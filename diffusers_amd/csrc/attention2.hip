@@ -47,6 +47,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base,
 
 constexpr float kDeferLog2 = 8.0f;   // THR: P stays <= 2^8 between rescales
 
+// Block -> (batch, head, query tile) mapping and the key-split tail (round 6; include/diffusers_amd.h da_attention_params.split_ws).
+// nb8 > 0 ("balanced" mapping; nb = B * H * qtiles is a multiple of 8): the grid is exactly nb blocks (+ the split units), the
+// LOGICAL blocks are numbered pair-major (pair * qtiles + query tile) and XCD x (= physical block id & 7) owns the contiguous run
+// [x * nb8, (x + 1) * nb8): every XCD gets the same number of blocks and sees at most nb8 / qtiles + 2 different (batch, head)
+// pairs' K / V^T in its L2.  (The legacy mapping, nb8 == 0, gives every XCD whole pairs: with 20 pairs -- SDXL's 64 x 64 level -- four
+// XCDs run three pairs and four run two, and a fifth of the grid's blocks exit at once.)
+// Key split: physical blocks [0, full) are whole logical blocks (slot b >> 3 of XCD b & 7); behind them come `s` UNITS for each
+// of the `tail` remaining logical blocks, unit si of a block walking key tiles [si * tps, min(ntiles, (si + 1) * tps)).  Unit
+// u = blockIdx.x - full sits on XCD u & 7, the XCD that owns the logical block it belongs to.  s == 1: no split.
+struct SplitPlan {
+  int full, tail, s, tps, nb8;
+};
+constexpr int kSplitCounterBytes = DA_ATTN_SPLIT_COUNTER_BYTES;
+template <int D, int NW>
+constexpr int split_unit_bytes() { return NW * (D * 128 + 512); }   // per wave: 32 queries x D fp32 of O, then (m, l) per lane
+
 template <int D>
 struct Cfg {
   static constexpr int CPR = D / 8;              // 16-byte chunks per K row
@@ -80,7 +96,7 @@ __device__ __forceinline__ int k_swz(int row) {
 // slice, the memory head raised, static per-workgroup levels) gain less or lose.  Speed only: the same operations in the same order.
 template <int D, int NW, int NS, bool AUG, bool RSM, int PRIO = 0>
 // min waves per SIMD: D = 64 / four waves: three workgroups per CU (<= 168 registers); eight waves: one workgroup = two per SIMD
-__global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 1)) void attn2_fwd_kernel(const da_attention_params p) {
+__global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 1)) void attn2_fwd_kernel(const da_attention_params p, const SplitPlan sp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using C = Cfg<D>;
   static_assert(D == 64 || D == 128, "head sizes of the v2 kernel");
@@ -100,20 +116,39 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
 
-  // XCD-aware mapping (speed only): all query tiles of one (batch, head) pair go to ONE XCD (attention.hip)
   const int qtiles = (p.Sq + QT - 1) / QT;
-  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
-  const int pair = (slot_id / qtiles) * 8 + xcd;
-  if (pair >= p.B * p.H) return;
+  const int ntiles = (p.Skv + 63) >> 6;
+  // which logical block, which key tiles (all wave-uniform scalars)
+  int t_begin = 0, t_end = ntiles, unit = -1, rblk = 0, pair, qt;
+  if (sp.nb8 > 0) {
+    int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    if (sp.s > 1 && bid >= sp.full) {
+      const int u = bid - sp.full, v = u >> 3, vb = v / sp.s, si = v - vb * sp.s;
+      xcd = u & 7;
+      rblk = (vb << 3) | xcd;
+      unit = rblk * sp.s + si;
+      slot = (sp.full >> 3) + vb;
+      t_begin = si * sp.tps;
+      t_end = min(ntiles, t_begin + sp.tps);
+    }
+    const int lb = xcd * sp.nb8 + slot;
+    pair = lb / qtiles;
+    qt = lb - pair * qtiles;
+  } else {
+    // legacy mapping: all query tiles of one (batch, head) pair go to ONE XCD (attention.hip)
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    pair = (slot_id / qtiles) * 8 + xcd;
+    qt = slot_id % qtiles;
+    if (pair >= p.B * p.H) return;
+  }
   const int b = pair / p.H, h = pair - b * p.H;
-  const int q0 = (slot_id % qtiles) * QT + wave * 32;
+  const int q0 = qt * QT + wave * 32;
 
   const uint16_t* __restrict__ Q = (const uint16_t*)p.q + (size_t)b * p.q_batch_stride + (size_t)h * D;
   const uint16_t* __restrict__ K = (const uint16_t*)p.k + (size_t)b * p.k_batch_stride + (size_t)h * D;
   const uint16_t* __restrict__ VT = (const uint16_t*)p.vt + (size_t)h * D * p.vt_ld + (size_t)b * p.vt_batch_stride;
   uint16_t* __restrict__ O = (uint16_t*)p.out + (size_t)b * p.o_batch_stride + (size_t)h * D;
   const float sl2 = p.scale * 1.4426950408889634f;
-  const int ntiles = (p.Skv + 63) >> 6;
 
   // ---- staging: buffer-addressed LDS-DMA, one 1 KiB piece (64 lanes x 16 B) per wave instruction ----
   // piece pi = i * NW + wave; K: chunk pch = 64 pi + lane -> (row = pch / CPR, slot = pch % CPR), source chunk slot ^ k_swz(row);
@@ -166,7 +201,7 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
   // ---- prologue: tiles 0 .. PD - 1 in flight before anything else ----
 #pragma unroll
   for (int t0 = 0; t0 < PD; ++t0)
-    if (t0 < ntiles) issue(t0, t0 * C::STAGE);
+    if (t_begin + t0 < t_end) issue(t_begin + t0, t0 * C::STAGE);
 
   // ---- Q fragments (MFMA B operand): lane (q = l31, hi) holds Q[q][16 ks + 8 hi + 0..7] ----
   bf16x8_t qf[D / 16];
@@ -228,8 +263,8 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
   // One iteration: [rendezvous, DMA of tile j + PD, Q.K^T(j), softmax(j) in eight slices with P.V(j - 1) riding in them].
   auto iter = [&](int j, auto has_prev_c) __attribute__((always_inline)) {
     constexpr bool HAS_PREV = decltype(has_prev_c)::value;
-    // issued so far: tiles 0 .. min(ntiles, j + PD) - 1; tile j must have landed, the later ones may stay in flight
-    if (PD >= 2 && j + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
+    // issued so far: tiles t_begin .. min(t_end, j + PD) - 1; tile j must have landed, the later ones may stay in flight
+    if (PD >= 2 && j + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -243,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
       bf16x8_t kf[KB];
 #pragma unroll
       for (int k = 0; k < KB; ++k) kf[k] = kfrag(sb, k);
-      if (j + PD < ntiles) issue(j + PD, nxt);
+      if (j + PD < t_end) issue(j + PD, nxt);
 
       const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if constexpr (AUG) {
@@ -389,8 +424,8 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
-  iter(0, F_{});
-  for (int j = 1; j < ntiles; ++j) iter(j, T_{});
+  iter(t_begin, F_{});
+  for (int j = t_begin + 1; j < t_end; ++j) iter(j, T_{});
   {                                                               // the last tile's product (its slot was not refilled)
     const unsigned char* sbl = smem + prv;
 #pragma unroll
@@ -409,10 +444,78 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     l_tot = __uint_as_float(r[0]) + __uint_as_float(r[1]);
   }
-  const float inv = 1.0f / l_tot;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                   // every wave is out of the ring
   asm volatile("" ::: "memory");
+  if (unit >= 0) {
+    // ---- key-split tail: publish this unit's (O, m, l), draw a ticket, the last arriver of the block combines all s units ----
+    // Hand-off R1 of cdna_hip_programming.md Guideline 16: write-through (sc1) payload stores, every storing wave drains its stores,
+    // workgroup barrier, ONE relaxed agent-scope ticket; the combiner reads with sc1 loads.  No polling: a unit that is not last
+    // leaves.  The combine runs over the units in index order whichever arrives last (its own partial is re-read like the others),
+    // so the block's result is a fixed function of the inputs.
+    constexpr int WAVE_BYTES = D * 128 + 512, UNIT_BYTES = NW * WAVE_BYTES;
+    static_assert(UNIT_BYTES == split_unit_bytes<D, NW>(), "unit size");
+    unsigned char* data = (unsigned char*)p.split_ws + kSplitCounterBytes;
+    int* cnt = (int*)p.split_ws;
+    {
+      const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(data + (size_t)unit * UNIT_BYTES + wave * WAVE_BYTES, WAVE_BYTES);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x4_t v;
+          v.x = __float_as_uint(o[dt][4 * g + 0]); v.y = __float_as_uint(o[dt][4 * g + 1]);
+          v.z = __float_as_uint(o[dt][4 * g + 2]); v.w = __float_as_uint(o[dt][4 * g + 3]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((dt * 4 + g) * 64 + lane) * 16, 0, 16);   // lane-linear KiB pieces, sc1
+        }
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+      u32x2_t ml;
+      ml.x = __float_as_uint(m_run); ml.y = __float_as_uint(l_tot);
+      __builtin_amdgcn_raw_buffer_store_b64(ml, rs, D * 128 + lane * 8, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // EVERY storing wave drains before the ticket
+    __syncthreads();
+    int* tick = (int*)smem;
+    if (t == 0) *tick = __hip_atomic_fetch_add(cnt + rblk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(*tick);
+    if (ticket != sp.s - 1) return;
+    if (t == 0) __hip_atomic_store(cnt + rblk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+    __syncthreads();                                               // `tick` is read; the ring is staging space again
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+    const unsigned char* blk = data + (size_t)(rblk * sp.s) * UNIT_BYTES + wave * WAVE_BYTES;
+    float m_all = -3.0e38f;
+    for (int i = 0; i < sp.s; ++i) {
+      const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(blk + (size_t)i * UNIT_BYTES, WAVE_BYTES);
+      const u32x2_t ml = __builtin_amdgcn_raw_buffer_load_b64(rs, D * 128 + lane * 8, 0, 16);
+      m_all = fmaxf(m_all, __uint_as_float(ml.x));
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    l_tot = 0.f;
+    for (int i = 0; i < sp.s; ++i) {
+      const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(blk + (size_t)i * UNIT_BYTES, WAVE_BYTES);
+      const u32x2_t ml = __builtin_amdgcn_raw_buffer_load_b64(rs, D * 128 + lane * 8, 0, 16);
+      const float w = __builtin_amdgcn_exp2f(__uint_as_float(ml.x) - m_all);
+      l_tot = __builtin_fmaf(w, __uint_as_float(ml.y), l_tot);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        u32x4_t v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((dt * 4 + g) * 64 + lane) * 16, 0, 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          o[dt][4 * g + 0] = __builtin_fmaf(w, __uint_as_float(v[g].x), o[dt][4 * g + 0]);
+          o[dt][4 * g + 1] = __builtin_fmaf(w, __uint_as_float(v[g].y), o[dt][4 * g + 1]);
+          o[dt][4 * g + 2] = __builtin_fmaf(w, __uint_as_float(v[g].z), o[dt][4 * g + 2]);
+          o[dt][4 * g + 3] = __builtin_fmaf(w, __uint_as_float(v[g].w), o[dt][4 * g + 3]);
+        }
+      }
+    }
+  }
+  const float inv = 1.0f / l_tot;
   constexpr int OROW = 2 * D + 16;                                // bytes per staged row (pad: the 8-byte writes spread over the banks)
   unsigned char* stg = smem + wave * (32 * OROW);
   if ((p.o_row_stride & 7) == 0 && ((size_t)p.out & 15) == 0 && (p.o_batch_stride & 7) == 0) {
@@ -452,6 +555,51 @@ __global__ __launch_bounds__(64 * NW, (D == 64 && NW == 4) ? 3 : (NW == 8 ? 2 : 
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// The key-split plan of a launch with QT queries per workgroup and `unit_bytes` of workspace per unit: how many blocks run whole,
+// how many are split and how.  Cost model in key tiles per CU: the whole blocks take (full / CUs) * ntiles everywhere; the tail adds
+// ceil(tail * s / CUs) rounds of ceil(ntiles / s) tiles, plus OVH tiles once for a split (prologue, publish, combine).  s = 1 is the
+// unsplit launch (its tail costs a whole extra round of ntiles).  Units are whole tiles, at least four of them, and none is empty.
+inline int cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+inline SplitPlan split_plan(const da_attention_params& p, int QT, int unit_bytes, long long* ws_bytes) {
+  if (ws_bytes) *ws_bytes = 0;
+  const int npairs = p.B * p.H, qtiles = (p.Sq + QT - 1) / QT, ntiles = (p.Skv + 63) >> 6;
+  const long long nbl = (long long)npairs * qtiles;
+  if ((nbl & 7) || nbl > 0x3fffffff) return SplitPlan{0, 0, 1, 0, 0};         // legacy mapping, whole blocks
+  const int nb = (int)nbl;
+  const SplitPlan none = {nb, 0, 1, 0, nb >> 3};                              // balanced mapping, whole blocks
+  if (p.kv_split == 1 || ntiles < 8) return none;
+  const int cus = cu_count();
+  const int tail = nb % cus, full = nb - tail;
+  if (tail == 0 || (cus & 7) || (size_t)tail * 4 > (size_t)kSplitCounterBytes) return none;
+  auto valid = [&](int s) { const int tps = (ntiles + s - 1) / s; return s >= 2 && s <= 8 && tps >= 4 && (s - 1) * tps < ntiles; };   // units of >= 256 keys
+  int best = 1;
+  if (p.kv_split >= 2) {
+    if (!valid(p.kv_split)) return none;
+    best = p.kv_split;
+  } else {
+    const double OVH = 2.0;
+    double best_cost = (double)ntiles;                      // s = 1: one more round of whole blocks
+    for (int s = 2; s <= 8; ++s) {
+      if (!valid(s)) continue;
+      const int tps = (ntiles + s - 1) / s, rounds = (tail * s + cus - 1) / cus;
+      const double cost = (double)rounds * tps + OVH;
+      if (cost < best_cost - 0.5) best_cost = cost, best = s;
+    }
+    if (best == 1) return none;
+  }
+  const long long need = (long long)kSplitCounterBytes + (long long)tail * best * unit_bytes;
+  if (ws_bytes) *ws_bytes = need;
+  if (!p.split_ws || p.split_ws_bytes < need) return none;
+  return SplitPlan{full, tail, best, (ntiles + best - 1) / best, nb >> 3};
+}
+
 template <int D, int NW, int NS, bool AUG, bool RSM, int PRIO>
 int launch_prio(const da_attention_params& p, hipStream_t s) {
   using C = Cfg<D>;
@@ -463,7 +611,9 @@ int launch_prio(const da_attention_params& p, hipStream_t s) {
     attr_set = true;
   }
   const int qtiles = (p.Sq + 32 * NW - 1) / (32 * NW), rounds = (p.B * p.H + 7) / 8;
-  DA_LAUNCH(kern, dim3(8 * rounds * qtiles), dim3(64 * NW), lds, s, p);
+  const SplitPlan sp = split_plan(p, 32 * NW, split_unit_bytes<D, NW>(), nullptr);
+  const int grid = sp.nb8 > 0 ? sp.full + sp.tail * sp.s : 8 * rounds * qtiles;
+  DA_LAUNCH(kern, dim3(grid), dim3(64 * NW), lds, s, p, sp);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -490,6 +640,7 @@ int da_attn2_dispatch(const da_attention_params& p, hipStream_t s) {
   // 31-bit byte offsets of the buffer-addressed staging
   if ((size_t)p.Skv_alloc * (size_t)p.k_row_stride * 2 + 64ull * p.k_row_stride * 2 >= 0x7fffffffull) return DA_ERR_UNSUPPORTED;
   if ((size_t)p.D * (size_t)p.vt_ld * 2 + (size_t)p.Skv_alloc * 2 >= 0x7fffffffull) return DA_ERR_UNSUPPORTED;
+  if (p.kv_split < 0 || p.kv_split > 8) return DA_ERR_INVALID;
   const int ns = p.ring_slots ? p.ring_slots : 3;
   // Queries per workgroup, measured (profiles/r04a_attention_v2.md).  D = 128 (one workgroup per CU either way): eight waves put two
   // waves on every SIMD and halve the K / V^T stream per flop -- 1.35x over four (Flux 332 -> 245 us, Wan 9.3 -> 7.8 ms) whenever
@@ -516,4 +667,32 @@ int da_attn2_dispatch(const da_attention_params& p, hipStream_t s) {
   DA_A2(128, 4);
 #undef DA_A2V
 #undef DA_A2
+}
+
+// include/diffusers_amd.h: the split a launch would take (for sizing the workspace and for tests)
+extern "C" long long da_attention_split_plan(const da_attention_params* pp, int* full_blocks, int* tail_blocks, int* units_per_tail_block) {
+  if (full_blocks) *full_blocks = 0;
+  if (tail_blocks) *tail_blocks = 0;
+  if (units_per_tail_block) *units_per_tail_block = 1;
+  if (!pp || pp->bias || pp->causal || (pp->D != 64 && pp->D != 128) || pp->B <= 0 || pp->H <= 0 || pp->Sq <= 0 || pp->Skv <= 0) return 0;
+  da_attention_params p = *pp;
+  int qb = p.q_block;
+  if (qb == 0) {
+    const long long blocks256 = (long long)p.B * p.H * ((p.Sq + 255) / 256);
+    qb = (p.D == 128 && blocks256 >= 192) ? 256 : 128;
+  }
+  if (qb != 128 && qb != 256) return 0;
+  const int nw = qb / 32;
+  const int unit = nw * (p.D * 128 + 512);
+  // size query: plan as if a large enough workspace were there
+  static int dummy;
+  p.split_ws = &dummy;
+  p.split_ws_bytes = (long long)1 << 60;
+  long long need = 0;
+  const da_attn2::SplitPlan sp = da_attn2::split_plan(p, qb, unit, &need);
+  if (sp.s <= 1) return 0;
+  if (full_blocks) *full_blocks = sp.full;
+  if (tail_blocks) *tail_blocks = sp.tail;
+  if (units_per_tail_block) *units_per_tail_block = sp.s;
+  return need;
 }

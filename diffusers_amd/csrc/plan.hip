@@ -98,7 +98,7 @@ void for_each_device_pointer(da_plan* plan, F&& f) {
     { void* q = g->stats_out; f(q); g->stats_out = (float*)q; }
     cf(g->ln_stats), cf(g->ln_s), cf(g->ln_c), cv(g->prefetch), f(g->vt), cv(g->xa_k), cv(g->xa_vt);
   }
-  for (auto& t : plan->attn) cv(t->q), cv(t->k), cv(t->vt), f(t->out), cv(t->bias);
+  for (auto& t : plan->attn) cv(t->q), cv(t->k), cv(t->vt), f(t->out), cv(t->bias), f(t->split_ws);
   for (auto& v : plan->ptrs)
     for (const void*& p : *v) cv(p);
 }

@@ -133,6 +133,27 @@ def splitk_workspace(device: torch.device, stream: int):
     return ent
 
 
+# Key-split tail of the flash kernel (include/diffusers_amd.h da_attention_params.split_ws, csrc/attention2.hip): a launch whose
+# query blocks do not fill the chip's CUs in whole rounds (SDXL S = 1024: 320 blocks on 256 CUs) splits the keys of its LAST
+# partial round over several workgroups.  DIFFUSERS_AMD_ATTN_SPLIT=0 turns it off (every block whole: the round-5 launches).
+ATTN_SPLIT = os.environ.get("DIFFUSERS_AMD_ATTN_SPLIT", "1") == "1"
+ATTN_SPLIT_WS_BYTES = 128 << 20
+_attn_split_ws = {}
+
+
+def attn_split_workspace(device: torch.device, stream: int) -> torch.Tensor:
+    """The flash kernel's key-split workspace, one per (device, stream) like the split-K one: ticket counters (zeroed ONCE here,
+    re-armed by the kernel) followed by scratch for the (O, m, l) partials.  Allocated on first use and kept (a HIP graph may have
+    captured its address); pipelines allocate the capture stream's before they capture."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream)
+    ws = _attn_split_ws.get(key)
+    if ws is None:
+        ws = torch.empty(ATTN_SPLIT_WS_BYTES, dtype=torch.uint8, device=device)
+        ws[:L.ATTN_SPLIT_COUNTER_BYTES].zero_()
+        _attn_split_ws[key] = ws
+    return ws
+
+
 def splitk_error(device=None) -> bool:
     """True if any split-K reducer ever gave up waiting for a producer on this device (diagnostics / tests)."""
     return any(bool(f[L.SPLITK_ERR_SLOT].item()) for (d, _), (_, f) in _splitk_ws.items()
@@ -478,7 +499,8 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         # launch takes that (tile, staging); otherwise the first family's fixed choices (profiles/r02d_layernorm_fold.md).
         geglu_ = act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH)
         ent = tuning.table().get(tuning.key_of(p)) if TUNING else None
-        if geglu_ and ent is not None and ent[0] in (L.TILE_K1_256x256, L.TILE_K1_128x256, L.TILE_K1_256x128, L.TILE_K1_256x320):
+        if geglu_ and ent is not None and ent[0] in (L.TILE_K1_256x256, L.TILE_K1_128x256, L.TILE_K1_256x128, L.TILE_K1_256x320,
+                                                     L.TILE_K3_256x256, L.TILE_K3_256x320):
             ent = (L.TILE_K1_128x320, L.STAGE_LDS_DIRECT) + tuple(ent[2:])     # the GEGLU tile of that family that carries the fold
         k2_ok = (ent is not None and ent[0] in ((L.TILE_K1_128x320,) if geglu_ else (L.TILE_K2_128x80, L.TILE_K2_128x160))
                  and not out_f32 and p.ldc % 8 == 0 and out.data_ptr() % 16 == 0 and N % 16 == 0 and gate is None
@@ -619,10 +641,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: 
               Skv_alloc: int, q_row_stride: int, k_row_stride: int, q_batch_stride: int, k_batch_stride: int,
               vt_ld: int, vt_batch_stride: int, scale: Optional[float] = None,
               out: Optional[torch.Tensor] = None, ring_slots: int = 0, causal: bool = False,
-              bias: Optional[torch.Tensor] = None, q_block: int = 0, pv_delay: int = 0, algo: int = 0) -> torch.Tensor:
+              bias: Optional[torch.Tensor] = None, q_block: int = 0, pv_delay: int = 0, algo: int = 0,
+              kv_split: int = 0) -> torch.Tensor:
     """Flash attention over strided views; returns out [B*Sq][H*D].  ``causal`` / ``bias`` (D = 64 only): the masked
     variant for the text encoders -- ``bias`` is [B or 1][H or 1][Sq][>= ceil64(Skv)] (bf16 or fp32), added to
-    scale * q.k^T; entries <= -1e29 mask a key."""
+    scale * q.k^T; entries <= -1e29 mask a key.  ``kv_split``: 0 = the library decides whether the launch's last partial round of
+    query blocks is split over the keys (module flag ATTN_SPLIT), 1 = never, 2..8 = pinned (tests)."""
     _req(q, "q"), _req(k, "k"), _req(vt, "vt")
     if out is None:
         out = torch.empty((B * Sq, H * D), device=q.device, dtype=bf16)
@@ -639,6 +663,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, H: 
     p.pv_delay = pv_delay
     p.algo = algo
     p.causal = int(causal)
+    p.kv_split = kv_split if ATTN_SPLIT or kv_split > 1 else 1
+    # the workspace rides along only where a split can pay: long key sequences and at least a quarter of the chip's CUs in blocks
+    # (small launches -- tiny models, text encoders -- keep a struct without it: their plans stay free of the 128 MiB region)
+    if p.kv_split != 1 and bias is None and not causal and D in (64, 128) and Skv >= 256 and B * H * ((Sq + 127) // 128) >= 64:
+        ws = attn_split_workspace(q.device, _stream())
+        p.split_ws, p.split_ws_bytes = ws.data_ptr(), ws.numel()
     if bias is not None:
         _req(bias, "bias", None)
         if bias.dtype not in (bf16, torch.float32) or bias.dim() != 4 or bias.stride(3) != 1 or \

@@ -106,12 +106,16 @@ def _capture_step(pipe, step, mode):
             # split-K launches take their workspace per (device, stream); the warm-up ran on a side stream, and allocating (and
             # zeroing) this stream's inside the recording would be a torch operator the plan cannot replay
             ops.splitk_workspace(pipe.device, torch.cuda.current_stream().cuda_stream)
+        if ops.ATTN_SPLIT:
+            ops.attn_split_workspace(pipe.device, torch.cuda.current_stream().cuda_stream)
         with ops.weight_prefetch(_pf(pipe), "apply"):
             pl, _ = P.record(step)
         return pl
     g = torch.cuda.CUDAGraph()
     cs = _side_stream("capture")
     from . import tuning
+    if ops.ATTN_SPLIT:     # the flash kernel's key-split workspace of the capture stream: allocated (counters zeroed) BEFORE the capture
+        ops.attn_split_workspace(pipe.device, cs.cuda_stream)
     if any(len(v) > 3 and v[3] > 1 for v in tuning.table().values()):
         # split-K launches take their workspace per (device, stream): allocated (and its flags zeroed) for the capture stream BEFORE
         # the capture, so that neither the allocation lands in the graph's private pool nor the zero-fill becomes a graph node

@@ -98,8 +98,8 @@ extern "C" {
  * structs by hand (ctypes, JNI, cgo), `da_sizeof_*()` against their own sizeof -- because the structs carry no size field: a host
  * built against an older header would pass shorter structs and the library would read garbage for the new members
  * (da_gemm_params.vt is a STORE address).  History: 1 = rounds 1-3; 4 = round 4 (da_gemm_params.vt / vt_col0 / ld_vt,
- * da_attention_params.algo); 5 = round 5 (this header). */
-#define DA_ABI_VERSION 5
+ * da_attention_params.algo); 5 = round 5; 6 = round 6 (this header: da_attention_params.split_ws / split_ws_bytes / kv_split). */
+#define DA_ABI_VERSION 6
 int da_version(void);
 size_t da_sizeof_gemm_params(void);
 size_t da_sizeof_attention_params(void);
@@ -308,7 +308,24 @@ typedef struct da_attention_params {
                bf16-rounded probabilities); 5 = both.
                The generations agree to bf16 rounding of the output, not bit for bit (different shift, different order of
                the row sum); within the second generation q_block 128 / 256 and ring_slots 3 / 4 are bit-identical. */
+  /* ---- key-split tail (round 6; second generation only; speed only up to fp32 summation order) ----
+   * A launch has nb = B * H * ceil(Sq / q_block) query blocks for a chip of 256 CUs; nb = 320 (SDXL, S = 1024) leaves 64 CUs with two
+   * blocks and 192 with one, nb = 432 (Flux) runs two rounds of which the second is 69 % full.  With a workspace the library runs the
+   * first nb - nb % CUs blocks whole and splits the keys of each of the remaining nb % CUs blocks over `s` workgroups (s chosen so
+   * that the split units cover the chip once more with short units); the units of a block publish (O, m, l) partials in fp32 with
+   * write-through stores, draw a ticket from a per-block counter, and the LAST arriver combines the partials of all s units in
+   * unit order (a fixed order: the result does not depend on which unit arrives last) and writes the block's rows.
+   * split_ws: device workspace, or NULL = never split.  Its first DA_ATTN_SPLIT_COUNTER_BYTES hold the ticket counters: the
+   *   caller zeroes them ONCE (the kernel re-arms them); the rest is scratch.  One workspace per stream (launches on a stream are
+   *   ordered).  A workspace that is too small for a launch's plan just disables the split for that launch.
+   * kv_split: 0 = the library's choice, 1 = off, 2..8 = that many units per tail block (tests). */
+  void* split_ws;
+  long long split_ws_bytes;
+  int kv_split;
 } da_attention_params;
+#define DA_ATTN_SPLIT_COUNTER_BYTES 16384
+/* bytes of split_ws this launch would use (0: it would not split), and the split it would choose; for tests / sizing */
+long long da_attention_split_plan(const da_attention_params* p, int* full_blocks, int* tail_blocks, int* units_per_tail_block);
 
 int da_attention_bf16(const da_attention_params* p, void* stream);
 

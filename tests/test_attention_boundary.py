@@ -398,3 +398,116 @@ def test_processor_pads_the_sd15_head_sizes_cpu(monkeypatch):
 @pytest.mark.gpu
 def test_processor_pads_the_sd15_head_sizes(monkeypatch):
     _run_processor(monkeypatch, "cuda", SD15_HEADS_UNET, hw=16, gate=lambda f: max(1.2 * f, 1.5e-2))
+
+
+# ---- hardening of the two binding shims ------------------------------------------------------------
+@pytest.mark.skipif(not REF.exists(), reason="reference sources not present")
+def test_run_time_enum_member_is_visible_through_every_public_view(monkeypatch):
+    """`_extend_enum` writes CPython's private Enum tables; every PUBLIC view must then agree: lookup by value and by name, attribute
+    access (the documented `AttentionBackendName.MI355X`; Python >= 3.12 resolves it through the class dict), iteration and
+    `__members__`."""
+    from diffusers_amd.attention_backend import BACKEND_NAME, _enum_member_is_whole, register_backend
+    ref = _load_ref()
+    ad = importlib.import_module(ref.__name__ + ".models.attention_dispatch")
+    name = register_backend()
+    E = ad.AttentionBackendName
+    assert name is E(BACKEND_NAME) is E["MI355X"] is E.MI355X
+    assert name in list(E) and E.__members__["MI355X"] is name and isinstance(name, E) and name.value == BACKEND_NAME
+    assert _enum_member_is_whole(E, "MI355X", BACKEND_NAME)
+    assert register_backend() is name                              # idempotent
+
+
+def test_enum_shim_falls_back_to_an_ungated_slot_when_the_internals_moved():
+    """An Enum whose private tables are not the ones the shim knows (simulated: `_member_names_` is not a list any more) must not
+    be half-extended silently: `_extend_enum` returns None and `register_backend` registers under an ungated slot with a warning."""
+    import enum
+    from diffusers_amd import attention_backend as ab
+
+    class Name(str, enum.Enum):
+        NATIVE = "native"
+        _NATIVE_FLASH = "_native_flash"
+
+    class Broken(str, enum.Enum):
+        NATIVE = "native"
+    Broken._member_names_ = tuple(Broken._member_names_)          # .append() raises: the shim must notice, not half-register
+    assert ab._extend_enum(Broken, "MI355X", "mi355x") is None
+    m = ab._extend_enum(Name, "MI355X", "mi355x")
+    assert m is not None and Name("mi355x") is m and Name.MI355X is m and m in list(Name)
+
+    class Registry:
+        _backends, _constraints, _supported_arg_names = {}, {}, {}
+    import types
+    fake = types.ModuleType("diffusers.models.attention_dispatch")
+    fake.AttentionBackendName, fake._AttentionBackendRegistry = Name, Registry
+    saved = {k: sys.modules.get(k) for k in ("diffusers", "diffusers.models", "diffusers.models.attention_dispatch")}
+    pkg, models = types.ModuleType("diffusers"), types.ModuleType("diffusers.models")
+    pkg.models, models.attention_dispatch = models, fake
+    sys.modules.update({"diffusers": pkg, "diffusers.models": models, "diffusers.models.attention_dispatch": fake})
+    orig = ab._extend_enum
+    try:
+        ab._extend_enum = lambda *a, **k: None
+        with pytest.warns(RuntimeWarning, match="ungated slot"):
+            name = ab.register_backend()
+        assert name is Name(ab.UNGATED_SLOTS[0]) and Registry._backends[name] is ab.mi355x_flash_attention
+    finally:
+        ab._extend_enum = orig
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def _attn_module(ref, dev, dim=64, heads=2, cross=None):
+    ap = importlib.import_module(ref.__name__ + ".models.attention_processor")
+    torch.manual_seed(3)
+    return ap.Attention(query_dim=dim, cross_attention_dim=cross, heads=heads, dim_head=dim // heads, bias=False).eval().to(dev).to(bf16)
+
+
+def _run_processor_cache_rules(monkeypatch, dev):
+    """(1) the pack cache is keyed by a weak reference: it empties when the module dies; (2) tensors made under
+    `torch.inference_mode()` (no version counter) work and are cached by identity; (3) a cached K / V^T is never used with another
+    batch count -- the batch check runs on every call; (4) a self-attention token count that is not a multiple of 8 takes the
+    padded-key path instead of raising."""
+    import gc
+    from diffusers_amd.attention_backend import MI355XAttnProcessor
+    ref = _load_ref()
+    _env(monkeypatch, dev)
+    proc = MI355XAttnProcessor()
+    a = _attn_module(ref, dev, cross=64)
+    a.set_processor(proc)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((2, 16, 64), generator=g).to(bf16).to(dev)
+    e = torch.randn((2, 8, 64), generator=g).to(bf16).to(dev)
+    with torch.no_grad():
+        y = a(x, encoder_hidden_states=e)
+        assert len(proc._packs) == 1
+        with pytest.raises(ValueError, match="batch does not match"):       # cache HIT on `e`, other batch count
+            a(x[:1], encoder_hidden_states=e)
+    with torch.inference_mode():
+        xi, ei = x.clone(), e.clone()
+        assert ei.is_inference()
+        yi = a(xi, encoder_hidden_states=ei)
+        yi2 = a(xi, encoder_hidden_states=ei)
+    assert torch.equal(yi, yi2) and torch.equal(yi.clone(), y)
+    del a
+    gc.collect()
+    assert len(proc._packs) == 0, "the pack of a freed module is still cached"
+    s = _attn_module(ref, dev)
+    native = _attn_module(ref, dev)
+    native.load_state_dict(s.state_dict())
+    s.set_processor(proc)
+    xo = torch.randn((2, 13, 64), generator=g).to(bf16).to(dev)              # 13 tokens: not a multiple of 8
+    with torch.no_grad():
+        got, want = s(xo), native(xo)
+    assert got.shape == want.shape and _rel(got, want) < 2e-2
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference sources not present")
+def test_processor_cache_rules_cpu(monkeypatch):
+    _run_processor_cache_rules(monkeypatch, "cpu")
+
+
+@pytest.mark.gpu
+def test_processor_cache_rules(monkeypatch):
+    _run_processor_cache_rules(monkeypatch, "cuda")

@@ -30,8 +30,12 @@ def _worker(rank, world, port, n_prompts, q):
                       MASTER_PORT=str(port))
     from diffusers_amd import distributed as D
     try:
+        before = sorted(os.sched_getaffinity(0))
         r, w, _ = D.init_from_env(backend="gloo")
         assert (r, w) == (rank, world)
+        # every rank pinned itself to ITS share of the host's cores (no GPU here: the equal contiguous split)
+        after = sorted(os.sched_getaffinity(0))
+        assert after == D.cpu_share(rank, world, before, [-1] * world, {}), (before, after)
         g = torch.Generator().manual_seed(1234)
         full = {"prompt_embeds": torch.randn((n_prompts, 7, 16), generator=g),
                 "pooled": torch.randn((n_prompts, 8), generator=g)}
@@ -234,3 +238,70 @@ def test_bench_main_one_launched_rank_runs_the_collectives(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["rccl_ranks"] == 1 and rec["config"]["process_group"] == "gloo"
     assert len(rec["config"]["images_per_s_per_rank"]) == 1 and rec["config"]["tuned_live"] == 0
+
+
+def test_cpu_share_policy():
+    """distributed.cpu_share: ranks on the cores of their GPU's NUMA node, peers of a node split it in rank order, every rank
+    computes the same disjoint partition on its own; unknown topology -> equal contiguous runs of the allowed cores."""
+    from diffusers_amd import distributed as D
+    allowed = list(range(128))
+    node_cpus = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    gpu_nodes = [0, 0, 0, 0, 1, 1, 1, 1]                                   # the usual 8-GPU node: four GPUs per socket
+    shares = [D.cpu_share(r, 8, allowed, gpu_nodes, node_cpus) for r in range(8)]
+    assert shares[0] == list(range(0, 16)) and shares[3] == list(range(48, 64)) and shares[4] == list(range(64, 80))
+    assert sorted(c for sh in shares for c in sh) == allowed              # disjoint, nothing left over
+    # a cpuset that hides half of socket 1 (container limits): its ranks split what is left
+    lim = [c for c in allowed if c < 96]
+    sh = [D.cpu_share(r, 8, lim, gpu_nodes, node_cpus) for r in range(8)]
+    assert sh[4] == list(range(64, 72)) and sh[7] == list(range(88, 96)) and all(set(x) <= set(lim) for x in sh)
+    # unknown topology
+    flat = [D.cpu_share(r, 8, allowed, [-1] * 8, {}) for r in range(8)]
+    assert flat[2] == list(range(32, 48)) and sorted(c for x in flat for c in x) == allowed
+    # one GPU's node unknown: that rank takes its flat run, the others their node's
+    mixed = D.cpu_share(1, 8, allowed, [0, -1, 0, 0, 1, 1, 1, 1], node_cpus)
+    assert mixed == list(range(16, 32))
+    # fewer cores than ranks: ranks share, never an empty set
+    assert all(len(D.cpu_share(r, 8, [0, 1, 2], [-1] * 8, {})) == 1 for r in range(8))
+    with pytest.raises(ValueError):
+        D.cpu_share(8, 8, allowed, gpu_nodes, node_cpus)
+    assert D._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def _solo(port_env, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.pop("MASTER_PORT", None)
+    if port_env:
+        os.environ["MASTER_PORT"] = str(port_env)
+    from diffusers_amd import distributed as D
+    try:
+        D.init_from_env(backend="gloo")
+        q.put(("ok", int(os.environ["MASTER_PORT"]), D.max_over_ranks(3.0, torch.device("cpu"))))
+        import time
+        time.sleep(2.0)          # hold the store while the sibling job starts
+    except Exception as e:
+        q.put((f"fail: {e!r}", None, None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_independent_single_rank_jobs_do_not_collide():
+    """SLURM / k8s export RANK=0 WORLD_SIZE=1 without a MASTER_PORT; two such jobs on one host must both come up (each
+    one-rank group rendezvouses on a free port of its own, not on the shared default 29500); a launcher-provided port is kept."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_solo, args=(None, q)) for _ in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[0] == "ok" and r[2] == 3.0 for r in res), res
+    assert res[0][1] != res[1][1] and 29500 not in (res[0][1], res[1][1])
+    port = _free_port()
+    p = ctx.Process(target=_solo, args=(port, q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(timeout=60)
+    assert got[0] == "ok" and got[1] == port

@@ -484,3 +484,115 @@ def test_wan_vae_full_resolution_decode_vs_the_reference_class():
     _gate_image(ps, pf, "AutoencoderKLWan.decode")
     del vae, sd
     torch.cuda.empty_cache()
+
+
+def _psnr_unit(a, b):
+    """PSNR of two [0, 1] image / video tensors (or arrays)."""
+    a = torch.as_tensor(a).float().cpu()
+    b = torch.as_tensor(b).float().cpu()
+    return 10 * np.log10(1.0 / max(float((a - b).pow(2).mean()), 1e-12))
+
+
+def test_ddpm_cat_256_full_size_50_step_image_vs_the_reference_pipeline():
+    """BASELINE config 1 at size: google/ddpm-cat-256's UNet2DModel (114 M parameters, 256 x 256, attention at
+    the 16 x 16 level) + DDPMScheduler, 50 ancestral steps, batch 1, the reference's seeded random stream -- the engine DDPMPipeline
+    against the REAL `DDPMPipeline.__call__` (pipelines/ddpm/pipeline_ddpm.py:104-121 over models/unets/unet_2d.py:249-353 and
+    schedulers/scheduling_ddpm.py:461-567) in fp32 on this GPU.  The reference config is fp32; the engine computes it in bf16
+    (DESIGN section 7), so the reference's own bf16 run is printed as the floor that arithmetic costs and the gate is the one of
+    every other image here: >= 40 dB and no more than 1 dB under that floor."""
+    refpkg = _reference()
+    if refpkg is None:
+        pytest.skip("reference archive oracle/_ref/diffusers_ref.zip did not ship")
+    from diffusers_amd import factory, init as dinit
+    from diffusers_amd.pipelines import DDPMPipeline
+    from diffusers_amd.schedulers import DDPMScheduler
+    from oracle import ref_runtime as RR
+    unet, sd = factory.build_unet2d(dinit.DDPM_CAT, seed=0, device=DEV, init_device=DEV)
+    pipe = DDPMPipeline(unet=unet, scheduler=DDPMScheduler(**dinit.DDPM_SCHEDULER))
+    img = pipe(batch_size=1, generator=torch.Generator().manual_seed(0), num_inference_steps=50, output_type="np").images
+    img_eager = pipe(batch_size=1, generator=torch.Generator().manual_seed(0), num_inference_steps=50, output_type="np",
+                     use_graph=False).images
+    assert np.array_equal(img, img_eager), "HIP-graph replay and eager launches differ at full size"
+
+    def run(dtype):
+        m = RR.build_model(refpkg, "UNet2DModel", dinit.DDPM_CAT, sd, DEV, dtype)
+        rp = refpkg.DDPMPipeline(unet=m, scheduler=refpkg.DDPMScheduler(**dinit.DDPM_SCHEDULER))
+        rp.set_progress_bar_config(disable=True)
+        with torch.no_grad():
+            out = rp(batch_size=1, generator=torch.Generator().manual_seed(0), num_inference_steps=50, output_type="np").images
+        del rp, m
+        torch.cuda.empty_cache()
+        return out
+    ref, floor = run(torch.float32), run(bf16)
+    ps, pf = _psnr_unit(img, ref), _psnr_unit(floor, ref)
+    print(f"[parity] ddpm-cat-256 (UNet2DModel 256 x 256, 50 DDPM steps, seeded stream) vs the reference DDPMPipeline in fp32: image PSNR "
+          f"engine = {ps:.1f} dB, reference bf16 (noise floor) = {pf:.1f} dB, engine vs reference bf16 = {_psnr_unit(img, floor):.1f} dB; "
+          f"image std {float(np.std(ref)):.3f}")
+    assert img.shape == ref.shape == (1, 256, 256, 3) and np.isfinite(img).all()
+    assert float(np.std(ref)) > 1e-3, "the reference image is constant: the comparison would be vacuous"
+    _gate_image(ps, pf, "ddpm-cat-256 50-step image")
+    del pipe, unet, sd
+    torch.cuda.empty_cache()
+
+
+def test_wan13_full_size_3_step_pipeline_vs_the_reference_pipeline():
+    """BASELINE config 5's loop at size: Wan2.1-T2V-1.3B, 832 x 480 x 81 frames (latents 16 x 21 x 60 x 104 = 32 760
+    tokens), 3 UniPC steps (flow, order 2: first-order start, corrector + second-order predictor from step 2 on), CFG 5, fp32
+    latents, latent de-normalisation, AutoencoderKLWan.decode of all 21 latent frames, video post-processing -- the engine WanPipeline
+    against the REAL `WanPipeline.__call__` (pipelines/wan/pipeline_wan.py:560-661 over WanTransformer3DModel, UniPCMultistepScheduler
+    and AutoencoderKLWan from the archive) in fp32 on this GPU, with its own bf16 run as the floor."""
+    refpkg = _reference()
+    if refpkg is None:
+        pytest.skip("reference archive oracle/_ref/diffusers_ref.zip did not ship")
+    from diffusers_amd import factory, init as dinit
+    from diffusers_amd.pipelines import WanPipeline
+    from diffusers_amd.schedulers import UniPCMultistepScheduler
+    from oracle import ref_runtime as RR
+    sched_kw = dict(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=3.0)
+    g = torch.Generator("cpu").manual_seed(1234)
+    lat = torch.randn((1, 16, 21, 60, 104), generator=g)
+    pe = torch.randn((1, 512, 4096), generator=g).to(bf16)
+    ne = torch.randn((1, 512, 4096), generator=g).to(bf16)
+    kw = dict(num_inference_steps=3, guidance_scale=5.0, height=480, width=832, num_frames=81, output_type="pt")
+    tr, tsd = factory.build_wan_transformer(dinit.WAN_1_3B, seed=9, device=DEV, init_device=DEV)
+    vae, vsd = factory.build_wan_vae(dinit.WAN_VAE, seed=21, device=DEV, init_device=DEV)
+    pipe = WanPipeline(scheduler=UniPCMultistepScheduler(**sched_kw), transformer=tr, vae=vae)
+    got = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.clone(), **kw).images.float().cpu()
+    lat_e = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.clone(), **dict(kw, output_type="latent")
+                 ).images.float().cpu()
+    del pipe, tr, vae
+    torch.cuda.empty_cache()
+
+    def run(dtype):
+        rtr = RR.build_model(refpkg, "WanTransformer3DModel", dinit.WAN_1_3B, tsd, DEV, dtype,
+                             keep_fp32=("time_embedder", "scale_shift_table", "norm1", "norm2", "norm3"))
+        rvae = refpkg.AutoencoderKLWan(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in dinit.WAN_VAE.items()}).to(DEV)
+        rvae.load_state_dict({k: v.to(DEV, torch.float32) for k, v in vsd.items()}, strict=False)          # decoder half: the path
+        rvae = rvae.to(dtype).eval()
+        rp = refpkg.WanPipeline(tokenizer=None, text_encoder=None, vae=rvae, scheduler=refpkg.UniPCMultistepScheduler(**sched_kw),
+                                transformer=rtr)
+        rp.set_progress_bar_config(disable=True)
+        last = {}
+
+        def grab(p, i, t, cb):
+            last["latents"] = cb["latents"]
+            return {}
+        with torch.no_grad():
+            out = rp(prompt_embeds=pe.to(DEV, dtype), negative_prompt_embeds=ne.to(DEV, dtype), latents=lat.clone().to(DEV),
+                     callback_on_step_end=grab, callback_on_step_end_tensor_inputs=["latents"], **kw).frames.float().cpu()
+        lt = last["latents"].float().cpu()
+        del rp, rtr, rvae, last
+        torch.cuda.empty_cache()
+        return out, lt
+    floor, lat_b = run(bf16)
+    want, lat_f = run(torch.float32)
+    ps, pf = _psnr_unit(got, want), _psnr_unit(floor, want)
+    rl, rlf = rel_rms(lat_e, lat_f), rel_rms(lat_b, lat_f)
+    print(f"[parity] Wan2.1-T2V-1.3B 832 x 480 x 81, 3 UniPC steps, CFG 5 + AutoencoderKLWan.decode vs the reference WanPipeline in fp32: "
+          f"video PSNR engine = {ps:.1f} dB, reference bf16 (noise floor) = {pf:.1f} dB, engine vs reference bf16 = "
+          f"{_psnr_unit(got, floor):.1f} dB; final latents rel_rms engine {rl:.3e}, reference bf16 {rlf:.3e}")
+    assert got.shape == want.shape == (1, 81, 3, 480, 832) and torch.isfinite(got).all()
+    _gate_image(ps, pf, "Wan 3-step video")
+    assert rl < 5e-2 and rl <= 1.25 * rlf, (rl, rlf)
+    del tsd, vsd
+    torch.cuda.empty_cache()

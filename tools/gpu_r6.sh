@@ -1,0 +1,69 @@
+#!/bin/bash
+# Round-6 gpurun stages.  usage: gpu_r6.sh "stage stage ..." -- stages run in FILE order, selected by substring.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+WHAT=${1:-attnsplit}
+if [[ $WHAT == *attnsplit* ]]; then
+  timeout 900 python -m pytest tests/test_attention_split.py -q -s --timeout 600 > $O/pytest_attnsplit.log 2>&1; echo "pytest attnsplit rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|\[split\]" $O/pytest_attnsplit.log | tail -40
+  timeout 600 python tools/bench_attn_r6.py $O/r06_attention.jsonl > $O/attn_r6.log 2>&1; echo "attn bench rc=$?"; cat $O/attn_r6.log | cut -c1-300 | tail -40
+fi
+if [[ $WHAT == *attntests* ]]; then
+  timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_attention_boundary.py -m gpu -q --timeout 600 -k "attention or attn or backend or processor" > $O/pytest_attn.log 2>&1; echo "pytest attn rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert" $O/pytest_attn.log | tail -20
+fi
+if [[ $WHAT == *newparity* ]]; then
+  timeout 2400 python -m pytest tests/test_full_size_gpu.py -m gpu -q -s --timeout 1800 -k "ddpm_cat or 3_step" > $O/pytest_newparity.log 2>&1; echo "pytest newparity rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|\[parity\]" $O/pytest_newparity.log | tail -20
+fi
+if [[ $WHAT == *splitab* ]]; then
+  for m in 0 1 0 1; do
+    DIFFUSERS_AMD_ATTN_SPLIT=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_split$m.json 2> $O/bench_split$m.err; echo "attn split $m rc=$? $(cut -c1-140 $O/bench_split$m.json | grep -o '"value": [0-9.]*')"
+  done
+fi
+if [[ $WHAT == *benchfast* ]]; then
+  timeout 900 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-other-configs > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+  cut -c1-1400 $O/bench.json; grep "^\[bench" $O/bench.err | tail -20
+fi
+if [[ $WHAT == *fulltest* ]]; then
+  timeout 3600 python -m pytest tests -m gpu -q -s --timeout 1800 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
+  grep -E "passed|failed|FAILED|Error" $O/pytest_gpu.log | tail -20
+  grep -E "\[parity\] (SDXL|FLUX|Wan|SD1.5|full|Auto|ddpm)|\[drop-in\]|\[B3\]|\[B4\]|\[rccl\]|\[split\]" $O/pytest_gpu.log | tail -70
+fi
+if [[ $WHAT == *benchfull* && $WHAT != *trafficfirst* ]]; then
+  timeout 1500 python bench.py --steps 3 --warmup 1 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"
+  cut -c1-300 $O/bench_full.json; grep "^\[bench" $O/bench_full.err | tail -40
+fi
+if [[ $WHAT == *traffic* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc_traffic; mkdir -p $O/pmc_traffic
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_traffic/fetch -o sdxl -- python $R/tools/pmc_one_step.py 2 $O/pmc_traffic/launch_log.json > $O/pmc_traffic/fetch.log 2>&1; echo "pmc fetch rc=$?"
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_traffic/write -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_traffic/write.log 2>&1; echo "pmc write rc=$?"
+  cd $R
+  ALGO=$(python -c "import json;print(json.load(open('$O/bench_full.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null || python -c "import json;print(json.load(open('$R/profiles/r05r_bench_line_full.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null)
+  python tools/pmc_traffic.py $O/pmc_traffic/fetch $O/pmc_traffic/write $O/r06_sdxl_traffic.md $O/sdxl_traffic.json "$ALGO" 140 $O/pmc_traffic/launch_log.json 2
+  cp $O/sdxl_traffic.json $R/profiles/sdxl_traffic.json   # a later `benchfull` stage of this call reads it (roofline.traffic)
+  find $O/pmc_traffic -name '*kernel_trace*' -delete
+  find $O/pmc_traffic -name '*counter_collection.csv' -size +8M -delete
+  tail -4 $O/pmc_traffic/fetch.log | cut -c1-200
+fi
+if [[ $WHAT == *prof* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/prof
+  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o sdxl -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-reference --no-other-configs > $O/prof.log 2>&1; echo "prof rc=$?"
+  grep '"metric"' $O/prof.log | cut -c1-200
+  find $O/prof -name '*kernel_trace*' -size +30M -delete
+  cd $R
+  python tools/prof_summary.py $(find $O/prof -name '*kernel_stats.csv' | head -1) "r06 sdxl bench (--steps 1 --warmup 1)" > $O/prof_summary.md 2>> $O/prof.log; head -60 $O/prof_summary.md
+fi
+if [[ $WHAT == *trafficfirst* && $WHAT == *benchfull* ]]; then
+  timeout 1500 python bench.py --steps 3 --warmup 1 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"
+  cut -c1-300 $O/bench_full.json; grep "^\[bench" $O/bench_full.err | tail -40
+fi
+if [[ $WHAT == *otherbench* ]]; then
+  for c in sd15 flux ddpm; do
+    timeout 900 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc=$? $(cut -c1-200 $O/bench_$c.json)"
+  done
+fi

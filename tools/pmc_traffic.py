@@ -58,10 +58,54 @@ def collect(root: Path, counter: str, skip_igemm: int = 0):
     return acc
 
 
+def is_igemm(name: str) -> bool:
+    return any(k in name for k in ("igemm_bf16_kernel", "igemm2_bf16_kernel", "gemm3_bf16_kernel", "gemm3_geglu_kernel"))
+
+
+def short_kernel(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    cut = name.find("(")
+    name = name if cut < 0 else name[:cut]
+    for ns in ("da_gemm2::", "da_gemm3::", "da_gemm::"):
+        name = name.replace(ns, "")
+    return name.replace(" ", "")
+
+
+def per_population(root_f: Path, root_w: Path, log_path: Path, skip: int):
+    """Round 6: one row per launch POPULATION.  The PMC rows carry kernel names only; tools/pmc_one_step.py logs
+    every implicit-GEMM launch of the steps in issue order (population label, algorithmic bytes); the i-th implicit-GEMM dispatch
+    behind the `skip` hoisted ones IS the i-th logged launch (one process, one stream, eager).  Returns None when the two
+    sequences do not have the same length in both passes (then only the per-family table is written)."""
+    log = json.loads(log_path.read_text())
+
+    def seq(root, counter):
+        rows = []
+        for f in root.rglob("*counter_collection.csv"):
+            with open(f, newline="") as fh:
+                rows += [r for r in csv.DictReader(fh) if r["Counter_Name"] == counter and is_igemm(r["Kernel_Name"])]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        return rows[skip:]
+    fe, wr = seq(root_f, "FETCH_SIZE"), seq(root_w, "WRITE_SIZE")
+    if len(fe) != len(log) or len(wr) != len(log):
+        print(f"per-population table skipped: {len(log)} logged launches, {len(fe)} / {len(wr)} implicit-GEMM dispatches in the passes")
+        return None
+    pops = {}
+    for ent, rf, rw in zip(log, fe, wr):
+        a = pops.setdefault((ent["pop"], short_kernel(rf["Kernel_Name"])), [0, 0.0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += 2.0 * float(rf["Counter_Value"]) * 1024.0
+        a[2] += float(rw["Counter_Value"]) * 1024.0
+        a[3] += ent["bytes"]
+        a[4] += ent["flop"]
+    return pops
+
+
 def main():
     fetch_dir, write_dir, out_md, out_json = (Path(p) for p in sys.argv[1:5])
     algo = float(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] else None
     skip = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    log_path = Path(sys.argv[7]) if len(sys.argv) > 7 else None
+    steps = int(sys.argv[8]) if len(sys.argv) > 8 else 2
     fe, wr = collect(fetch_dir, "FETCH_SIZE", skip), collect(write_dir, "WRITE_SIZE", skip)
     fams = sorted(set(fe) | set(wr), key=lambda k: -(2 * fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1]))
     lines = ["# HBM-side traffic per launch, SDXL denoising step (eager launches, rocprofv3 --pmc; FETCH and WRITE in separate passes)",
@@ -99,6 +143,32 @@ def main():
                      f"launches of a denoising step): ratio {tot / algo:.2f}x" if algo else "")]
         if algo:
             out["igemm_algorithmic_bytes_per_launch"] = algo
+    pops = per_population(fetch_dir, write_dir, log_path, skip) if log_path is not None and log_path.exists() else None
+    if pops:
+        lines += ["", "## Implicit-GEMM launches by population (shape x role x kernel instantiation)", "",
+                  "fetched / written as above; algorithmic = each operand and the output (and the residual, where fused) once.  "
+                  "`floor x8` = what eight non-coherent L2s must fetch at least for this launch's XCD tile rectangles is NOT computed here; "
+                  "the ratio column is total / algorithmic.", "",
+                  "| population | kernel | launches / step | fetched MB | written MB | total MB | algorithmic MB | ratio | GFLOP |",
+                  "|---|---|---:|---:|---:|---:|---:|---:|---:|"]
+        fam_tot = {}
+        for (pop, kern), (n, fb, wb, ab, fl) in sorted(pops.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+            lines.append(f"| {pop} | `{kern}` | {n / steps:.1f} | {fb / n / 1e6:.2f} | {wb / n / 1e6:.2f} | {(fb + wb) / n / 1e6:.2f} | "
+                         f"{ab / n / 1e6:.2f} | {(fb + wb) / ab:.2f} | {fl / n / 1e9:.1f} |")
+            fam = kern.split("<")[0]
+            t = fam_tot.setdefault(fam, [0, 0.0, 0.0])
+            t[0] += n
+            t[1] += fb + wb
+            t[2] += ab
+        lines += ["", "| kernel family | launches / step | total MB / launch | algorithmic MB / launch | ratio |", "|---|---:|---:|---:|---:|"]
+        for fam, (n, tb, ab) in sorted(fam_tot.items(), key=lambda kv: -kv[1][1]):
+            lines.append(f"| `{fam}` | {n / steps:.1f} | {tb / n / 1e6:.2f} | {ab / n / 1e6:.2f} | {tb / ab:.2f} |")
+        out["igemm_family_ratios"] = {fam: {"launches_per_step": n / steps, "traffic_bytes_per_launch": tb / n,
+                                            "algorithmic_bytes_per_launch": ab / n, "ratio": tb / ab} for fam, (n, tb, ab) in fam_tot.items()}
+        allt = [sum(v[i] for v in fam_tot.values()) for i in range(3)]
+        out["igemm_ratio_by_logged_algorithmic_bytes"] = allt[1] / allt[2]
+        lines += ["", f"all implicit-GEMM launches of the steps: {allt[1] / allt[0] / 1e6:.2f} MB per launch against {allt[2] / allt[0] / 1e6:.2f} MB "
+                  f"algorithmic = {allt[1] / allt[2]:.2f}x"]
     out_md.write_text("\n".join(lines) + "\n")
     out_json.write_text(json.dumps(out, indent=1) + "\n")
     print("\n".join(lines[-3:]))
