@@ -212,15 +212,28 @@ class MI355XAttnProcessor:
         # keyed by a weak reference to the module: an entry dies with its module, so a freed module's `id()` being reused by
         # another one cannot hand that one a stale pack (and the cache does not grow with every module ever seen)
         self._packs = weakref.WeakKeyDictionary()
+        self._strong = {}      # objects that cannot be weakly referenced (duck-typed stand-ins): id -> (object, pack); the entry
+        #                        holds the object, so its id cannot be handed to another one while the pack is cached
 
     def _pack(self, attn) -> _Packed:
-        pk = self._packs.get(attn)
         key = _param_key(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_q.bias, attn.to_k.bias, attn.to_v.bias,
                          attn.to_out[0].weight)
+        try:
+            pk = self._packs.get(attn)
+            weak = True
+        except TypeError:
+            ent = self._strong.get(id(attn))
+            pk, weak = (ent[1] if ent is not None and ent[0] is attn else None), False
         if pk is None or pk.key != key:
             pk = _Packed()
             pk.key = key
-            self._packs[attn] = pk
+            if weak:
+                try:
+                    self._packs[attn] = pk
+                except TypeError:
+                    weak = False
+            if not weak:
+                self._strong[id(attn)] = (attn, pk)
         return pk
 
     @staticmethod

@@ -583,6 +583,11 @@ inline SplitPlan split_plan(const da_attention_params& p, int QT, int unit_bytes
   if (p.kv_split >= 2) {
     if (!valid(p.kv_split)) return none;
     best = p.kv_split;
+  } else if (p.D != 64) {
+    // D = 128 (eight-wave workgroups, one per CU, 135 KB of partials per unit): measured on Flux's joint attention (432 blocks: 256 + 176)
+    // every split factor that fits the workspace LOSES -- 251-255 us whole, 278 / 284 / 269 us at 2 / 3 / 4 units
+    // (profiles/r06_attention.jsonl): the partials' round trip costs more than the shorter last round saves.  Pinned splits only.
+    return none;
   } else {
     const double OVH = 2.0;
     double best_cost = (double)ntiles;                      // s = 1: one more round of whole blocks

@@ -37,7 +37,8 @@ def test_split_plan_of_the_baseline_shapes():
     cb = L.ATTN_SPLIT_COUNTER_BYTES
     assert _plan(2, 20, 1024, 1024, 64) == (cb + 64 * 4 * 4 * (64 * 128 + 512), 256, 64, 4)
     assert _plan(2, 10, 4096, 4096, 64) == (cb + 128 * 2 * 4 * (64 * 128 + 512), 512, 128, 2)
-    assert _plan(1, 24, 4608, 4608, 128) == (cb + 176 * 4 * 8 * (128 * 128 + 512), 256, 176, 4)
+    assert _plan(1, 24, 4608, 4608, 128)[3] == 1                   # D = 128 never splits on its own (measured: a loss) ...
+    assert _plan(1, 24, 4608, 4608, 128, kv_split=4) == (cb + 176 * 4 * 8 * (128 * 128 + 512), 256, 176, 4)      # ... only pinned
     assert _plan(2, 12, 32760, 32760, 128)[3] == 1 and _plan(2, 12, 32760, 32760, 128)[0] == 0
     assert _plan(2, 20, 1024, 77, 64)[3] == 1                      # cross-attention: two key tiles, nothing to split
     assert _plan(2, 20, 1024, 1024, 64, kv_split=1)[3] == 1        # switched off
@@ -85,18 +86,23 @@ def _run(ops, q, kp, vt, B, H, D, Sq, Skv, sa, **kw):
 def test_split_launch_vs_unsplit_and_fp32(B, H, D, Sq, Skv):
     from diffusers_amd import ops
     q, k, v, kp, vt, sa = _case(B, H, D, Sq, Skv, seed=Sq + Skv)
-    need, full, tail, s = _plan(B, H, Sq, Skv, D)
+    # D = 64: the library's own choice; D = 128 does not split on its own (measured: a loss, profiles/r06_attention.jsonl): pinned
+    pin0 = 0 if D == 64 else 4
+    need, full, tail, s = _plan(B, H, Sq, Skv, D, kv_split=pin0)
     assert s > 1, "the case is meant to split"
     ref = _sdpa(q, k, v, B, H, D, Sq, Skv)
     whole = _run(ops, q, kp, vt, B, H, D, Sq, Skv, sa, kv_split=1)
-    auto = _run(ops, q, kp, vt, B, H, D, Sq, Skv, sa)
+    auto = _run(ops, q, kp, vt, B, H, D, Sq, Skv, sa, kv_split=pin0)
     r_whole, r_auto, r_between = rel_rms(whole, ref), rel_rms(auto, ref), rel_rms(auto, whole)
     same = float((auto == whole).float().mean())
     print(f"[split] B{B} H{H} D{D} Sq{Sq} Skv{Skv}: {full} whole blocks + {tail} x {s} units; rel-rms vs fp32 SDPA: whole {r_whole:.3e}, "
           f"split {r_auto:.3e}; split vs whole {r_between:.3e}, {100 * same:.2f} % of the outputs bit-equal")
     assert torch.isfinite(auto.float()).all()
     assert r_auto < 4e-3 and r_auto <= 1.05 * r_whole + 1e-5          # the same kernel's accuracy (fp32 partials, one more fp32 combine)
-    assert r_between < 1.5e-3 and same > 0.95
+    # (split and whole blocks round P = 2^(s - m) to bf16 under DIFFERENT running shifts m, so a tail block's outputs differ from the
+    # unsplit launch's in the last bf16 bit about as often as not -- as two flash kernels with different tile sizes do; the bound is
+    # the rel-rms between the two, a fraction of either one's distance to fp32)
+    assert r_between < 1.5e-3
     # whole blocks are untouched by the split: their rows are the unsplit launch's bits
     QT = 256 if (D == 128 and B * H * ((Sq + 255) // 256) >= 192) else 128
     qtiles = (Sq + QT - 1) // QT
@@ -128,13 +134,15 @@ def test_split_launch_is_run_to_run_bit_identical_under_other_traffic():
     a = torch.randn(2048, 2048, device=DEV).to(bf16)
     for (B, H, D, Sq) in ((2, 20, 64, 1024), (1, 24, 128, 4608)):
         q, k, v, kp, vt, sa = _case(B, H, D, Sq, Sq, seed=3)
-        first = _run(ops, q, kp, vt, B, H, D, Sq, Sq, sa).clone()
+        pin = 0 if D == 64 else 4
+        assert _plan(B, H, Sq, Sq, D, kv_split=pin)[3] > 1
+        first = _run(ops, q, kp, vt, B, H, D, Sq, Sq, sa, kv_split=pin).clone()
         for i in range(25):
             if i % 3 == 0:
                 junk.mul_(1.0001)
             if i % 2 == 0:
                 a @ a
-            o = _run(ops, q, kp, vt, B, H, D, Sq, Sq, sa)
+            o = _run(ops, q, kp, vt, B, H, D, Sq, Sq, sa, kv_split=pin)
             assert torch.equal(o, first), f"launch {i} of B{B} H{H} D{D} S{Sq} differs"
 
 

@@ -518,8 +518,21 @@ def test_ddpm_cat_256_full_size_50_step_image_vs_the_reference_pipeline():
         m = RR.build_model(refpkg, "UNet2DModel", dinit.DDPM_CAT, sd, DEV, dtype)
         rp = refpkg.DDPMPipeline(unet=m, scheduler=refpkg.DDPMScheduler(**dinit.DDPM_SCHEDULER))
         rp.set_progress_bar_config(disable=True)
+        gen = torch.Generator().manual_seed(0)
         with torch.no_grad():
-            out = rp(batch_size=1, generator=torch.Generator().manual_seed(0), num_inference_steps=50, output_type="np").images
+            if dtype == torch.float32:
+                out = rp(batch_size=1, generator=gen, num_inference_steps=50, output_type="np").images
+            else:
+                # the reference pipeline cannot emit a bf16 run (pipeline_ddpm.py:132 calls .numpy() on the model-dtype tensor:
+                # "Got unsupported ScalarType BFloat16"), so the floor is ITS loop (:113-129) over ITS modules with the one cast added:
+                # randn_tensor in the model dtype from the same generator, unet, scheduler.step with the generator, (x / 2 + 0.5).clamp
+                from oracle.ref_runtime import load_reference
+                randn_tensor = __import__(load_reference().__name__ + ".utils.torch_utils", fromlist=["randn_tensor"]).randn_tensor
+                image = randn_tensor((1, 3, 256, 256), generator=gen, device=torch.device(DEV), dtype=dtype)
+                rp.scheduler.set_timesteps(50)
+                for t in rp.scheduler.timesteps:
+                    image = rp.scheduler.step(m(image, t).sample, t, image, generator=gen).prev_sample
+                out = (image / 2 + 0.5).clamp(0, 1).float().cpu().permute(0, 2, 3, 1).numpy()
         del rp, m
         torch.cuda.empty_cache()
         return out
