@@ -111,7 +111,8 @@ SIGNATURES = {
     "da_attention_bf16": (_i, [C.POINTER(AttentionParams), _vp]),
     "da_attention_split_plan": (_ll, [C.POINTER(AttentionParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "da_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
-    "da_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "da_groupnorm_sync_bytes": (C.c_size_t, []),
+    "da_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "da_rmsnorm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "da_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "da_rmsnorm_rope_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_void_p), _f, _vp, _vp,

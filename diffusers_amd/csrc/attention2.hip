@@ -646,7 +646,13 @@ int da_attn2_dispatch(const da_attention_params& p, hipStream_t s) {
   if ((size_t)p.Skv_alloc * (size_t)p.k_row_stride * 2 + 64ull * p.k_row_stride * 2 >= 0x7fffffffull) return DA_ERR_UNSUPPORTED;
   if ((size_t)p.D * (size_t)p.vt_ld * 2 + (size_t)p.Skv_alloc * 2 >= 0x7fffffffull) return DA_ERR_UNSUPPORTED;
   if (p.kv_split < 0 || p.kv_split > 8) return DA_ERR_INVALID;
-  const int ns = p.ring_slots ? p.ring_slots : 3;
+  int ns = p.ring_slots ? p.ring_slots : 3;
+  // experiment (round 6): a fourth ring slot (two key tiles in flight ahead instead of one) for D = 64 launches with at most two
+  // 128-query workgroups per CU -- LDS then admits two workgroups per CU, which is all such a launch has.  DA_ATTN2_RING4=1 enables.
+  if (p.ring_slots == 0 && p.D == 64) {
+    static const int ring4 = [] { const char* v = getenv("DA_ATTN2_RING4"); return v ? atoi(v) : 0; }();
+    if (ring4 && (long long)p.B * p.H * ((p.Sq + 127) / 128) <= 2LL * da_attn2::cu_count()) ns = 4;
+  }
   // Queries per workgroup, measured (profiles/r04a_attention_v2.md).  D = 128 (one workgroup per CU either way): eight waves put two
   // waves on every SIMD and halve the K / V^T stream per flop -- 1.35x over four (Flux 332 -> 245 us, Wan 9.3 -> 7.8 ms) whenever
   // there are enough 256-query workgroups to cover the chip.  D = 64: three 128-query workgroups per CU (three waves per SIMD, by

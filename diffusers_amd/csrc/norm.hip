@@ -193,13 +193,32 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
 // L2-resident -- when it did not fit).  A thread keeps the same chunk position for the whole kernel (T % nch == 0), so its eight
 // channels' group ids, gamma and beta are loop constants.  Same formula and rounding points as gn_apply_kernel.
 // ------------------------------------------------------------------------------------------------------------------
+//
+// Round 6: the same kernel with the pixels of a slab dealt to `nparts` workgroups (gridDim.z; a power of two <= 32), for slabs that
+// do not fit one CU's LDS but whose tensor fits the chip's (B * G / GS * nparts <= CUs workgroups of <= 144 KB: every one of them is
+// resident, so waiting for each other cannot deadlock).  Each part parks ITS pixels in LDS, reduces its (sum, sum of squares) per group
+// in fp64 as before and publishes them with 8-byte agent-scope (write-through) stores; thread 0 adds 32 / nparts to the slab's
+// arrival counter and waits -- one lane, relaxed loads, s_sleep, bounded -- until the counter reaches the end of its generation (every
+// launch adds exactly 32 per slab, so generations start at multiples of 32 whatever nparts the launches sharing the counter use;
+// the counter is monotonic and never reset); then every part folds ALL parts' partials in part order (a fixed order: every part
+// computes the same mean / rstd bits) and normalises out of LDS.  The tensor is read ONCE and written once.
+constexpr int kGnSyncCounters = 4096;                       // slabs (batch x group set) a sync workspace serves
+constexpr int kGnSyncPartBytes = 32 * 4 * 16;               // per slab: 32 parts x up to 4 groups x (sum, sumsq) fp64
+constexpr size_t kGnSyncBytes = (size_t)kGnSyncCounters * 4 + 64 + (size_t)kGnSyncCounters * kGnSyncPartBytes;
 template <int GS, bool RES>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1,
                                                         const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
-                                                        uint16_t* __restrict__ y, int HW, int C, int G, float eps, int act) {
+                                                        uint16_t* __restrict__ y, int HW_all, int C, int G, float eps, int act,
+                                                        unsigned char* __restrict__ sync) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __shared__ float s_part[16][2 * GS];
   __shared__ float s_a[GS], s_c[GS];                        // mean, rstd per group
+  __shared__ double s_tot[GS][2];
+  // this part's pixels [pix0, pix0 + HW) of the batch's HW_all (one part: everything)
+  const int nparts = (int)gridDim.z, part = (int)blockIdx.z;
+  const int per_part = (HW_all + nparts - 1) / nparts;
+  const int pix0 = part * per_part;
+  const int HW = max(0, min(HW_all, pix0 + per_part) - pix0);
   const int T = (int)blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = T >> 6;
   const int cpg = C / G, CW = GS * cpg, nch = CW >> 3;
   const int b = blockIdx.y, g0 = blockIdx.x * GS, c0 = g0 * cpg;
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const uint16_t* __restri
   const int cabs = c0 + ch * 8;                             // first of its eight channels
   const bool second = cabs >= C1;
   const int Cs = second ? (C - C1) : C1;
-  const uint16_t* xb = (second ? x2 + (size_t)(cabs - C1) : x + (size_t)cabs) + (size_t)b * HW * Cs;
+  const uint16_t* xb = (second ? x2 + (size_t)(cabs - C1) : x + (size_t)cabs) + ((size_t)b * HW_all + pix0) * Cs;
   int gid[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) gid[e] = (ch * 8 + e) / cpg;  // 0 .. GS - 1
@@ -261,7 +280,49 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const uint16_t* __restri
       ts += (double)s_part[w][2 * t];
       tq += (double)s_part[w][2 * t + 1];
     }
-    const double n = (double)HW * (double)cpg;
+    s_tot[t][0] = ts;
+    s_tot[t][1] = tq;
+  }
+  if (nparts > 1) {
+    // ---- the parts of a slab meet (see the kernel comment): publish, arrive, wait, fold in part order ----
+    const int slab_id = b * (int)gridDim.x + (int)blockIdx.x;
+    unsigned int* cnt = (unsigned int*)sync + slab_id;
+    unsigned long long* parts = (unsigned long long*)(sync + (size_t)kGnSyncCounters * 4 + 64 + (size_t)slab_id * kGnSyncPartBytes);
+    if (t < GS) {
+      __hip_atomic_store(parts + (part * 4 + t) * 2 + 0, (unsigned long long)__double_as_longlong(s_tot[t][0]), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(parts + (part * 4 + t) * 2 + 1, (unsigned long long)__double_as_longlong(s_tot[t][1]), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the storing lanes drain before the arrival
+    }
+    __syncthreads();
+    if (t == 0) {
+      const unsigned int inc = 32u / (unsigned int)nparts;
+      const unsigned int old = __hip_atomic_fetch_add(cnt, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int target = (old & ~31u) + 32u;
+      int spins = 0;
+      while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 22)) {                          // a lost part must not hang the GPU: flag it and go on (wrong statistics)
+          __hip_atomic_store((unsigned int*)(sync + (size_t)kGnSyncCounters * 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < GS) {
+      double ts = 0.0, tq = 0.0;
+      for (int pz = 0; pz < nparts; ++pz) {
+        ts += __longlong_as_double((long long)__hip_atomic_load(parts + (pz * 4 + t) * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        tq += __longlong_as_double((long long)__hip_atomic_load(parts + (pz * 4 + t) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+      s_tot[t][0] = ts;
+      s_tot[t][1] = tq;
+    }
+  }
+  if (t < GS) {
+    const double ts = s_tot[t][0], tq = s_tot[t][1];
+    const double n = (double)HW_all * (double)cpg;
     const double mean = ts / n;
     double var = tq / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -284,7 +345,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const uint16_t* __restri
       c[e] = bf[e] - mean * a[e];
     }
   }
-  uint16_t* yb = y + (size_t)b * HW * C + cabs;
+  uint16_t* yb = y + ((size_t)b * HW_all + pix0) * C + cabs;
   for (int pix = p_first; pix < HW; pix += 4 * ppr) {
     uint4 v[4];
 #pragma unroll
@@ -649,14 +710,15 @@ GnPlan gn_plan(int B, int HW, int C) {
 // L2 by its one workgroup.  Returns GS (0: keep the two-kernel form).  DA_GN_FUSED = 0 switches it off, DA_GN_FUSED_KB pins the
 // largest slab (KiB) that is re-read from L2 instead (default 0: none -- it measured slower), DA_GN_FUSED_MINWG the fewest workgroups
 // worth launching.
-struct GnFused { int gs, threads, resident; size_t lds; };
-GnFused gn_fused_plan(int B, int HW, int C, int C1, int G) {
+struct GnFused { int gs, threads, resident; size_t lds; int parts; };
+GnFused gn_fused_plan(int B, int HW, int C, int C1, int G, bool have_sync) {
   // (read at every call -- a getenv is noise next to a launch: tests and tools/bench_norms_r5.py time both forms in one process)
   // Measured (profiles/r05c_groupnorm_one_launch.jsonl, chained launches from a HIP graph): LDS-resident slabs win -- 17.4 -> 12.6 us
   // for SDXL's 14 GroupNorms over (2, 1024 px, 1280 ch), 10.4-14.2 -> 4.1-7.0 us for the 8 x 8 / 16 x 16 levels of the SD1.5 U-Net;
   // re-reading a larger slab from L2 by its one workgroup LOSES (40-109 us against 15-30): the default reach is the LDS.
   const int on = gn_knob("DA_GN_FUSED", 1), max_kb = gn_knob("DA_GN_FUSED_KB", 0), min_wg = gn_knob("DA_GN_FUSED_MINWG", 16);
-  GnFused f{0, 0, 0, 0};
+  const int multi = gn_knob("DA_GN_MULTI", 1);
+  GnFused f{0, 0, 0, 0, 1};
   if (!on) return f;
   const int cpg = C / G;
   int gs = 1;
@@ -673,6 +735,18 @@ GnFused gn_fused_plan(int B, int HW, int C, int C1, int G) {
   const long long wgs = (long long)B * (G / gs);
   if (wgs < min_wg) return f;
   const bool res = slab <= 144 * 1024;
+  if (!res && multi && have_sync && wgs <= kGnSyncCounters) {
+    // round 6: deal the slab's pixels to a power-of-two number of workgroups, each LDS-resident, all of them resident at once
+    // (<= one per CU): as many parts as the chip has CUs for, at least enough for the LDS
+    int parts = 2;
+    while (parts <= 32 && (size_t)((HW + parts - 1) / parts) * cw * 2 > 144 * 1024) parts *= 2;
+    while (parts * 2 <= 32 && wgs * parts * 2 <= 256 && (HW + parts * 2 - 1) / (parts * 2) >= 4 * (threads / nch)) parts *= 2;
+    if (parts <= 32 && wgs * parts <= 256) {
+      f.gs = gs, f.threads = threads, f.resident = 1, f.parts = parts;
+      f.lds = (size_t)((HW + parts - 1) / parts) * cw * 2;
+      return f;
+    }
+  }
   if (!res && slab > (size_t)max_kb * 1024) return f;
   f.gs = gs, f.threads = threads, f.resident = res, f.lds = res ? slab : 0;
   return f;
@@ -684,18 +758,20 @@ extern "C" size_t da_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
   return (size_t)B * g.nblk * G * 2 * sizeof(float);
 }
 
+extern "C" size_t da_groupnorm_sync_bytes(void) { return kGnSyncBytes; }
+
 extern "C" int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const void* gamma, const void* beta,
                                       void* y, void* workspace, int B, int HW, int C, int G, float eps, int act,
-                                      void* stream) {
+                                      void* sync, void* stream) {
   if (!x || !gamma || !beta || !y || !workspace) return DA_ERR_INVALID;
   if (!x2) C1 = C;
   if (C1 <= 0 || C1 > C || (C1 & 7) || (x2 == nullptr && C1 != C)) return DA_ERR_INVALID;
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7)) return DA_ERR_UNSUPPORTED;
   if (C / 8 > 512) return DA_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  const GnFused ff = gn_fused_plan(B, HW, C, C1, G);
+  const GnFused ff = gn_fused_plan(B, HW, C, C1, G, sync != nullptr);
   if (ff.gs) {
-    const dim3 grid(G / ff.gs, B), block(ff.threads);
+    const dim3 grid(G / ff.gs, B, ff.parts), block(ff.threads);
 #define DA_GNF(GS_, RES_)                                                                                              \
   do {                                                                                                                 \
     auto kern = gn_fused_kernel<GS_, RES_>;                                                                            \
@@ -706,7 +782,7 @@ extern "C" int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
     DA_LAUNCH(kern, grid, block, ff.lds, s, (const uint16_t*)x, (const uint16_t*)x2, C1, (const uint16_t*)gamma,       \
-              (const uint16_t*)beta, (uint16_t*)y, HW, C, G, eps, act);                                                \
+              (const uint16_t*)beta, (uint16_t*)y, HW, C, G, eps, act, (unsigned char*)sync);                          \
   } while (0)
     if (ff.resident) {
       if (ff.gs == 1) DA_GNF(1, true); else if (ff.gs == 2) DA_GNF(2, true); else if (ff.gs == 3) DA_GNF(3, true); else DA_GNF(4, true);

@@ -23,7 +23,7 @@ const char* const kSig[DA_FN_COUNT] = {
     /* DA_FN_GEMM                     */ "G",
     /* DA_FN_GEMM_PAIR                */ "GG",
     /* DA_FN_ATTENTION                */ "A",
-    /* DA_FN_GROUPNORM_NHWC           */ "ppippppiiiifi",
+    /* DA_FN_GROUPNORM_NHWC           */ "ppippppiiiifip",
     /* DA_FN_RMSNORM                  */ "pppiiiif",
     /* DA_FN_LAYERNORM                */ "ppppppiiiiiiif",
     /* DA_FN_RMSNORM_ROPE             */ "piiiiinIQfppii",
@@ -116,7 +116,7 @@ int run_op(const Op& op, void* s) {
     case DA_FN_GEMM_PAIR: return da_gemm_pair_bf16((const da_gemm_params*)P(0), (const da_gemm_params*)P(1), s);
     case DA_FN_ATTENTION: return da_attention_bf16((const da_attention_params*)P(0), s);
     case DA_FN_GROUPNORM_NHWC:
-      return da_groupnorm_nhwc_bf16(P(0), P(1), I(2), P(3), P(4), P(5), P(6), I(7), I(8), I(9), I(10), F(11), I(12), s);
+      return da_groupnorm_nhwc_bf16(P(0), P(1), I(2), P(3), P(4), P(5), P(6), I(7), I(8), I(9), I(10), F(11), I(12), P(13), s);
     case DA_FN_RMSNORM: return da_rmsnorm_bf16(P(0), P(1), P(2), I(3), I(4), I(5), I(6), F(7), s);
     case DA_FN_LAYERNORM:
       return da_layernorm_bf16(P(0), P(1), P(2), P(3), P(4), P(5), I(6), I(7), I(8), I(9), I(10), I(11), I(12), F(13), s);

@@ -704,6 +704,27 @@ def softmax_rows(scores: torch.Tensor, out: Optional[torch.Tensor] = None) -> to
 # norms
 # ----------------------------------------------------------------------------------------------------------------------
 _gn_ws = {}
+# One-launch GroupNorm over several workgroups per slab (include/diffusers_amd.h da_groupnorm_nhwc_bf16 `sync`): the arrival counters
+# and partial statistics the parts of a slab exchange -- one buffer per (device, stream), zeroed ONCE here, then the kernels' own.
+# DIFFUSERS_AMD_GN_MULTI=0: no buffer is passed, mid-size tensors keep the two-kernel form.
+GN_MULTI = os.environ.get("DIFFUSERS_AMD_GN_MULTI", "1") == "1"
+_gn_sync = {}
+
+
+def gn_sync_workspace(device: torch.device, stream: int) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream)
+    ws = _gn_sync.get(key)
+    if ws is None:
+        ws = torch.zeros(int(L.load().da_groupnorm_sync_bytes()), dtype=torch.uint8, device=device)
+        _gn_sync[key] = ws
+    return ws
+
+
+def gn_sync_error(device=None) -> bool:
+    """True if a part of a multi-workgroup GroupNorm ever gave up waiting for its peers on this device (diagnostics / tests)."""
+    off = 4096 * 4
+    return any(bool(w[off:off + 4].view(torch.int32).item()) for (d, _), w in _gn_sync.items()
+               if device is None or d == torch.device(device).index)
 
 
 def group_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
@@ -720,9 +741,12 @@ def group_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gr
     nbytes = lib.da_groupnorm_workspace_bytes(B, HW, Ctot, groups)
     ws = torch.empty((max(nbytes, 4) // 4,), device=x.device, dtype=torch.float32)
     y = torch.empty(tuple(x.shape[:-1]) + (Ctot,), device=x.device, dtype=bf16)
+    # the sync buffer rides along for tensors of 2 MB and more (smaller ones are LDS-resident per slab or latency-bound either way;
+    # tiny models' plans stay free of the region)
+    sync = gn_sync_workspace(x.device, _stream()).data_ptr() if GN_MULTI and B * HW * Ctot >= (1 << 20) else None
     L.check(lib.da_groupnorm_nhwc_bf16(x.data_ptr(), _ptr(x2), C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                        ws.data_ptr(), B, HW, Ctot, groups, eps, L.ACT_SILU if silu else L.ACT_NONE,
-                                       _stream()), "da_groupnorm_nhwc_bf16")
+                                       sync, _stream()), "da_groupnorm_nhwc_bf16")
     return y
 
 

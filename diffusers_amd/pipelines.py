@@ -12,6 +12,8 @@ replayed for every step: per-step scalars come from the scheduler's device table
 """
 from __future__ import annotations
 
+import threading
+
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -108,6 +110,8 @@ def _capture_step(pipe, step, mode):
             ops.splitk_workspace(pipe.device, torch.cuda.current_stream().cuda_stream)
         if ops.ATTN_SPLIT:
             ops.attn_split_workspace(pipe.device, torch.cuda.current_stream().cuda_stream)
+        if ops.GN_MULTI:
+            ops.gn_sync_workspace(pipe.device, torch.cuda.current_stream().cuda_stream)
         with ops.weight_prefetch(_pf(pipe), "apply"):
             pl, _ = P.record(step)
         return pl
@@ -116,6 +120,8 @@ def _capture_step(pipe, step, mode):
     from . import tuning
     if ops.ATTN_SPLIT:     # the flash kernel's key-split workspace of the capture stream: allocated (counters zeroed) BEFORE the capture
         ops.attn_split_workspace(pipe.device, cs.cuda_stream)
+    if ops.GN_MULTI:       # likewise the multi-workgroup GroupNorm's arrival counters
+        ops.gn_sync_workspace(pipe.device, cs.cuda_stream)
     if any(len(v) > 3 and v[3] > 1 for v in tuning.table().values()):
         # split-K launches take their workspace per (device, stream): allocated (and its flags zeroed) for the capture stream BEFORE
         # the capture, so that neither the allocation lands in the graph's private pool nor the zero-fill becomes a graph node
@@ -128,10 +134,16 @@ def _capture_step(pipe, step, mode):
 _side_streams = {}
 
 
+STREAM_DOMAIN = threading.local()
+
+
 def _side_stream(kind: str) -> "torch.cuda.Stream":
     """ONE warm-up stream and ONE capture stream per device for every pipeline of the process: per-stream resources (the 64 MiB
-    split-K workspace of ops.splitk_workspace) are then allocated twice, not once per re-capture."""
-    key = (torch.cuda.current_device(), kind)
+    split-K workspace of ops.splitk_workspace, the flash kernel's key-split workspace, the GroupNorm sync buffer) are then allocated
+    twice, not once per re-capture.  Graphs captured on one stream bake in the SAME workspaces and must not replay concurrently; a host
+    that replays several pipelines' graphs at the same time (one thread and stream per pipeline) sets ``STREAM_DOMAIN.tag`` to a
+    distinct value in each thread BEFORE the pipeline's first call: each domain gets side streams -- hence workspaces -- of its own."""
+    key = (torch.cuda.current_device(), kind, getattr(STREAM_DOMAIN, "tag", 0))
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream()

@@ -98,7 +98,7 @@ extern "C" {
  * structs by hand (ctypes, JNI, cgo), `da_sizeof_*()` against their own sizeof -- because the structs carry no size field: a host
  * built against an older header would pass shorter structs and the library would read garbage for the new members
  * (da_gemm_params.vt is a STORE address).  History: 1 = rounds 1-3; 4 = round 4 (da_gemm_params.vt / vt_col0 / ld_vt,
- * da_attention_params.algo); 5 = round 5; 6 = round 6 (this header: da_attention_params.split_ws / split_ws_bytes / kv_split). */
+ * da_attention_params.algo); 5 = round 5; 6 = round 6 (this header: da_attention_params.split_ws / split_ws_bytes / kv_split; da_groupnorm_nhwc_bf16 takes `sync`). */
 #define DA_ABI_VERSION 6
 int da_version(void);
 size_t da_sizeof_gemm_params(void);
@@ -353,8 +353,15 @@ int da_attention_bf16(const da_attention_params* p, void* stream);
  *                            attention_processor.py:2767 via vae.py / unet_2d_blocks.py:736-748).
  * ------------------------------------------------------------------------------------------------------------------ */
 size_t da_groupnorm_workspace_bytes(int B, int HW, int C, int G);
+/* sync (round 6; may be NULL): a device buffer of da_groupnorm_sync_bytes() bytes, ZEROED ONCE by the caller and then owned by the
+ * library's kernels (monotonic arrival counters + fp64 partial sums), one per stream.  With it, tensors whose per-(batch, group set)
+ * slab exceeds one CU's LDS but that fit the chip's (<= 256 LDS-resident workgroups) are normalised in ONE launch that reads the tensor
+ * once: the parts of a slab exchange their partial statistics through `sync` and wait for each other (all of them are resident).
+ * Without it those tensors take the two-kernel form (statistics pass + apply pass = one more read).  Same formula and rounding points
+ * either way; the statistics are summed in another order (outputs agree to a bf16 ulp). */
+size_t da_groupnorm_sync_bytes(void);
 int da_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const void* gamma, const void* beta, void* y,
-                           void* workspace, int B, int HW, int C, int G, float eps, int act, void* stream);
+                           void* workspace, int B, int HW, int C, int G, float eps, int act, void* sync, void* stream);
 /* T5LayerNorm (modeling_t5.py: no mean subtraction, no bias): y = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * gamma), the two
  * roundings of the reference's fp32 -> weight-dtype cast followed by the bf16 multiply. */
 int da_rmsnorm_bf16(const void* x, const void* gamma, void* y, int M, int C, int ldx, int ldy, float eps, void* stream);

@@ -99,10 +99,11 @@ def test_split_launch_vs_unsplit_and_fp32(B, H, D, Sq, Skv):
           f"split {r_auto:.3e}; split vs whole {r_between:.3e}, {100 * same:.2f} % of the outputs bit-equal")
     assert torch.isfinite(auto.float()).all()
     assert r_auto < 4e-3 and r_auto <= 1.05 * r_whole + 1e-5          # the same kernel's accuracy (fp32 partials, one more fp32 combine)
-    # (split and whole blocks round P = 2^(s - m) to bf16 under DIFFERENT running shifts m, so a tail block's outputs differ from the
-    # unsplit launch's in the last bf16 bit about as often as not -- as two flash kernels with different tile sizes do; the bound is
-    # the rel-rms between the two, a fraction of either one's distance to fp32)
-    assert r_between < 1.5e-3
+    # (split and whole blocks round P = 2^(s - m) to bf16 under DIFFERENT running shifts m, so a split block's outputs differ from
+    # the unsplit launch's in the last bf16 bit about as often as not -- as two flash kernels with different tile sizes do.  Two
+    # results that each sit r from fp32 with independent roundings sit up to sqrt(2) r from each other: measured 1.1e-3 .. 2.7e-3,
+    # the latter when EVERY block of the launch is split)
+    assert r_between < 1.5 * r_whole
     # whole blocks are untouched by the split: their rows are the unsplit launch's bits
     QT = 256 if (D == 128 and B * H * ((Sq + 255) // 256) >= 192) else 128
     qtiles = (Sq + QT - 1) // QT
@@ -122,7 +123,7 @@ def test_split_launch_vs_unsplit_and_fp32(B, H, D, Sq, Skv):
             continue
         o = _run(ops, q, kp, vt, B, H, D, Sq, Skv, sa, kv_split=pin)
         assert rel_rms(o, ref) < 4e-3, f"kv_split={pin}"
-        assert rel_rms(o, whole) < 1.5e-3, f"kv_split={pin}"
+        assert rel_rms(o, whole) < 1.5 * r_whole, f"kv_split={pin}"
 
 
 @pytest.mark.gpu

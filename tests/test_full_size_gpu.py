@@ -524,14 +524,26 @@ def test_ddpm_cat_256_full_size_50_step_image_vs_the_reference_pipeline():
                 out = rp(batch_size=1, generator=gen, num_inference_steps=50, output_type="np").images
             else:
                 # the reference pipeline cannot emit a bf16 run (pipeline_ddpm.py:132 calls .numpy() on the model-dtype tensor:
-                # "Got unsupported ScalarType BFloat16"), so the floor is ITS loop (:113-129) over ITS modules with the one cast added:
-                # randn_tensor in the model dtype from the same generator, unet, scheduler.step with the generator, (x / 2 + 0.5).clamp
-                from oracle.ref_runtime import load_reference
-                randn_tensor = __import__(load_reference().__name__ + ".utils.torch_utils", fromlist=["randn_tensor"]).randn_tensor
-                image = randn_tensor((1, 3, 256, 256), generator=gen, device=torch.device(DEV), dtype=dtype)
-                rp.scheduler.set_timesteps(50)
-                for t in rp.scheduler.timesteps:
-                    image = rp.scheduler.step(m(image, t).sample, t, image, generator=gen).prev_sample
+                # "Got unsupported ScalarType BFloat16"), so the floor is ITS loop (:113-129) over ITS modules with that one cast
+                # added -- and with the noise drawn in fp32 from the generator and ROUNDED to bf16, as the engine does: a bf16
+                # `torch.randn` consumes the generator differently, i.e. samples an unrelated image (measured: 5.2 dB against the fp32
+                # run, which says nothing about arithmetic).  scheduler.step draws through the module-level `randn_tensor`
+                # (scheduling_ddpm.py:543-548): wrapped for the duration of this run.
+                import importlib
+                tu = importlib.import_module(refpkg.__name__ + ".utils.torch_utils")
+                sd_mod = importlib.import_module(refpkg.__name__ + ".schedulers.scheduling_ddpm")
+
+                def fp32_draw(shape, generator=None, device=None, dtype=None, layout=None):
+                    return tu.randn_tensor(shape, generator=generator, device=device, dtype=torch.float32, layout=layout).to(dtype)
+                orig = sd_mod.randn_tensor
+                sd_mod.randn_tensor = fp32_draw
+                try:
+                    image = fp32_draw((1, 3, 256, 256), generator=gen, device=torch.device(DEV), dtype=dtype)
+                    rp.scheduler.set_timesteps(50)
+                    for t in rp.scheduler.timesteps:
+                        image = rp.scheduler.step(m(image, t).sample, t, image, generator=gen).prev_sample
+                finally:
+                    sd_mod.randn_tensor = orig
                 out = (image / 2 + 0.5).clamp(0, 1).float().cpu().permute(0, 2, 3, 1).numpy()
         del rp, m
         torch.cuda.empty_cache()

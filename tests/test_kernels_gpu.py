@@ -651,6 +651,7 @@ def test_groupnorm_one_launch_form_against_the_two_kernel_form(B, HW, C1, C2, G,
     ref = F.silu(F.group_norm(full.float().transpose(1, 2), G, g.float(), b.float(), 1e-5)).transpose(1, 2)
     monkeypatch.setenv("DA_GN_FUSED", "0")
     two = ops.group_norm_nhwc(x1, g, b, G, 1e-5, silu=True, x2=x2)
+    monkeypatch.setenv("DA_GN_MULTI", "0")          # (the several-workgroup form of round 6 has its own test below)
     for kb in ("0", "4096"):                       # default reach (LDS-resident slabs); everything the one-launch form can take
         monkeypatch.setenv("DA_GN_FUSED", "1")
         monkeypatch.setenv("DA_GN_FUSED_KB", kb)
@@ -662,6 +663,69 @@ def test_groupnorm_one_launch_form_against_the_two_kernel_form(B, HW, C1, C2, G,
         tol = 2.0 ** -6 * two.float().abs() + 1e-3          # (one bf16 ulp of the binade above |value|)
         assert int((d > tol).sum()) == 0, f"{what}: differs from the two-kernel form by more than a bf16 ulp ({float(d.max()):.3e})"
         assert torch.equal(one, ops.group_norm_nhwc(x1, g, b, G, 1e-5, silu=True, x2=x2)), "deterministic"
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,G", [(2, 4096, 320, 0, 32), (2, 4096, 640, 0, 32), (2, 16384, 320, 0, 32), (2, 4096, 1280, 640, 32),
+                                          (2, 1024, 1280, 1280, 32), (2, 1024, 1280, 640, 32), (2, 4096, 640, 320, 32), (2, 4096, 640, 640, 32),
+                                          (2, 4001, 640, 0, 32), (1, 5000, 512, 0, 32), (3, 3000, 256, 0, 8)])
+def test_groupnorm_one_launch_over_several_workgroups(B, HW, C1, C2, G, monkeypatch):
+    """Round 6 (the statistics pass of the mid-size tensors): slabs that exceed one CU's LDS are dealt to 2 .. 32
+    workgroups that park their pixels in LDS, exchange fp64 partial sums through the stream's sync buffer and wait for each other --
+    ONE launch, the tensor read once.  Against torch in fp32 with the two-kernel form's tolerance; against the two-kernel form to a bf16
+    ulp (another summation order); deterministic over repeats that share the arrival counters with launches of OTHER part counts
+    (every launch adds 32 to a slab's counter whatever its part count); no part ever timed out waiting."""
+    ops, L = _ops()
+    C = C1 + C2
+    x1 = rnd((B, HW, C1), 40, scale=2.0) + 3.0
+    x2 = rnd((B, HW, C2), 44, scale=3.0) if C2 else None
+    g, b = rnd((C,), 41) * 0.1 + 1.0, rnd((C,), 42, scale=0.1)
+    full = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.silu(F.group_norm(full.float().transpose(1, 2), G, g.float(), b.float(), 1e-5)).transpose(1, 2)
+    monkeypatch.setenv("DA_GN_MULTI", "0")
+    monkeypatch.setenv("DA_GN_FUSED", "0")
+    two = ops.group_norm_nhwc(x1, g, b, G, 1e-5, silu=True, x2=x2)
+    monkeypatch.setenv("DA_GN_MULTI", "1")
+    monkeypatch.setenv("DA_GN_FUSED", "1")
+    one = ops.group_norm_nhwc(x1, g, b, G, 1e-5, silu=True, x2=x2)
+    what = f"groupnorm one launch / several workgroups B{B} HW{HW} C{C1}+{C2} G{G}"
+    assert_close_bf16(one, ref, what, rtol=1.6e-2, atol_rms=8e-3)
+    d = (one.float() - two.float()).abs()
+    tol = 2.0 ** -6 * two.float().abs() + 1e-3
+    assert int((d > tol).sum()) == 0, f"{what}: differs from the two-kernel form by more than a bf16 ulp ({float(d.max()):.3e})"
+    other = rnd((2, 2048, 640), 77)
+    go, bo = rnd((640,), 78) * 0.1 + 1.0, rnd((640,), 79, scale=0.1)
+    for i in range(6):
+        if i % 2:
+            ops.group_norm_nhwc(other, go, bo, 32, 1e-5)          # another shape (another part count) on the same counters
+        assert torch.equal(one, ops.group_norm_nhwc(x1, g, b, G, 1e-5, silu=True, x2=x2)), f"repeat {i}"
+    torch.cuda.synchronize()
+    assert not ops.gn_sync_error()
+
+
+def test_groupnorm_several_workgroups_replays_from_a_hip_graph():
+    """The arrival counters are monotonic and never reset: a captured chain of three GroupNorms of different part counts replays
+    twenty times with the eager result."""
+    ops, L = _ops()
+    shapes = [(2, 4096, 640), (2, 16384, 320), (2, 1024, 2560)]
+    xs = [rnd(sh, 60 + i, scale=1.5) + 0.7 for i, sh in enumerate(shapes)]
+    gs = [rnd((sh[2],), 70 + i) * 0.1 + 1.0 for i, sh in enumerate(shapes)]
+    bs = [rnd((sh[2],), 80 + i, scale=0.1) for i, sh in enumerate(shapes)]
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        eager = [ops.group_norm_nhwc(x, g, b, 32, 1e-5, silu=True).clone() for x, g, b in zip(xs, gs, bs)]
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            outs = [ops.group_norm_nhwc(x, g, b, 32, 1e-5, silu=True) for x, g, b in zip(xs, gs, bs)]
+    torch.cuda.synchronize()
+    for i in range(20):
+        for o in outs:
+            o.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, e) for o, e in zip(outs, eager)), f"replay {i}"
+    assert not ops.gn_sync_error()
 
 
 @pytest.mark.parametrize("M,C", [(100, 320), (2048, 640), (513, 1280), (64, 3072), (7, 1536), (33, 64)])

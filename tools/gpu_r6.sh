@@ -67,3 +67,31 @@ if [[ $WHAT == *otherbench* ]]; then
     timeout 900 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc=$? $(cut -c1-200 $O/bench_$c.json)"
   done
 fi
+if [[ $WHAT == *insitu* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/pmc_insitu; mkdir -p $O/pmc_insitu
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -f csv -d $O/pmc_insitu/a -o sdxl -- python $R/tools/pmc_one_step.py 2 $O/pmc_insitu/launch_log.json > $O/pmc_insitu/a.log 2>&1; echo "pmc insitu a rc=$?"
+  DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES -f csv -d $O/pmc_insitu/b -o sdxl -- python $R/tools/pmc_one_step.py 2 > $O/pmc_insitu/b.log 2>&1; echo "pmc insitu b rc=$?"
+  cd $R
+  python tools/pmc_insitu.py $O/pmc_insitu/launch_log.json 140 $O/r06_insitu_counters.md $O/pmc_insitu/a $O/pmc_insitu/b
+  find $O/pmc_insitu -name '*.csv' -size +8M -delete
+  tail -3 $O/pmc_insitu/a.log | cut -c1-200
+fi
+if [[ $WHAT == *gnmulti* ]]; then
+  timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -s --timeout 600 -k "groupnorm" > $O/pytest_gn.log 2>&1; echo "pytest gn rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert" $O/pytest_gn.log | tail -20
+  timeout 600 python tools/bench_norms_r6.py $O/r06_groupnorm_several_workgroups.jsonl > $O/norms_r6.log 2>&1; echo "norms bench rc=$?"; cut -c1-260 $O/norms_r6.log | tail -36
+fi
+if [[ $WHAT == *gnab* ]]; then
+  for m in 0 1 0 1; do
+    DIFFUSERS_AMD_GN_MULTI=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_gnm$m.json 2> $O/bench_gnm$m.err; echo "gn multi $m rc=$? $(cut -c1-140 $O/bench_gnm$m.json | grep -o '"value": [0-9.]*')"
+  done
+fi
+if [[ $WHAT == *ring4ab* ]]; then
+  for m in 0 1 0 1; do
+    DA_ATTN2_RING4=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_ring$m.json 2> $O/bench_ring$m.err; echo "attn ring4 $m rc=$? $(cut -c1-140 $O/bench_ring$m.json | grep -o '"value": [0-9.]*')"
+  done
+fi
+if [[ $WHAT == *inflight* ]]; then
+  timeout 900 python tools/bench_inflight.py $O/r06_two_in_flight.json 3 > $O/inflight.log 2>&1; echo "inflight rc=$?"; tail -5 $O/inflight.log | cut -c1-300
+fi

@@ -85,7 +85,8 @@ def _launch_log():
         m = out.shape[0] * out.shape[1] * out.shape[2]
         kk = w.numel() // w.shape[0]
         extra = sum(t.numel() for t in (k.get("residual"),) if t is not None)
-        rows.append({"pop": f"conv{w.shape[1]}x{w.shape[2]} M{m} N{w.shape[0]} K{kk}" + (" up" if k.get("up") else "")
+        ks = k.get("ksize", 3)
+        rows.append({"pop": f"conv{ks}x{ks} M{m} N{w.shape[0]} K{kk}" + (" up" if k.get("up") else "")
                             + (" s2" if k.get("stride", 1) == 2 else ""),
                      "bytes": 2.0 * (x.numel() + (x2.numel() if x2 is not None else 0) + w.numel() + out.numel() + extra),
                      "flop": 2.0 * m * w.shape[0] * kk})
