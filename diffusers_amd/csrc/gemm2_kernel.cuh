@@ -80,8 +80,9 @@ __device__ unsigned long long* g_da2_trace;
 //          softmax(q k^T) v instead of q: one launch where there were two (to_q, flash attention) and no q round trip.
 template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP = false, bool STREAMW = false, bool GIL = false,
           bool LNF = false, int XA = 0>
-__global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p, const int xcd_gx) {
+__global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p, const int xcd_gx_chunk) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  const int xcd_gx = xcd_gx_chunk & 255;                  // XCD columns; bits 8.. : conv channel-chunk size in 64-wide slices (0: whole)
   static_assert((KG == 1 || KG == 2) && KG * WM * WN == 8, "eight waves: one or two K-groups");
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int PX = BM / 8, PW = BN / 8;                 // 1 KiB pieces (8 rows x 128 B) per slice
@@ -224,7 +225,15 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   // parity are recomputed only when its tap changes.  Pairs are staged strictly in order, so the state below always
   // describes the NEXT pair to stage (`st_pr`); it is advanced right after a pair's loads were issued, i.e. the address
   // arithmetic of pair n + 1 runs under the MFMAs that follow the issue of pair n and the issue itself is straight-line.
+  // Round 6 -- K order of a k x k conv: CHUNKED.  The weight rows are [tap][channel] and rounds 1-5 walked K in that order: all
+  // channels of tap 0, then all channels of tap 1 ...  The nine taps read the SAME activation pixels shifted by one, but a tap's sweep
+  // over C channels is (CUs of an XCD) x (tile rows) x C x 2 B -- 5 MB per XCD at C = 640 on 128-row tiles -- more than the XCD's
+  // 4 MB L2, so every tap re-fetched the activations through the fabric: 404 MB fetched for a conv with 67 MB of operands
+  // (profiles/r06_sdxl_traffic.md, 6.4x).  Now: for each chunk of `cchunk` channels, all taps, then the next chunk -- the taps of a
+  // chunk re-read 1-2 MB per XCD, which stays in L2.  Same slices, another order of summation; cchunk >= C is the old order.
+  const int cchunk = CONV ? (((xcd_gx_chunk >> 8) > 0 && p.conv > 1) ? min((xcd_gx_chunk >> 8) * 64, Ctot) : Ctot) : 0;
   int c_kh[2] = {0, 0}, c_kw[2] = {0, 0}, c_c0[2] = {0, 0};
+  int c_beg[2] = {0, 0}, c_end[2] = {cchunk, cchunk};     // channel range of the chunk each parity's cursor is in
   int st_pr = 0;                                          // next pair to stage
   int st_s[2] = {PP ? min(g, nk - 1) : 0, nk > 1 ? 1 : 0};   // slice (clamped to nk - 1) each parity stages next
   // a slice of the next pair that lies past K is staged as zeros (bit 31 of the per-lane offset: beyond num_records)
@@ -244,14 +253,20 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   };
   auto cursor_step = [&](int h) {                         // advance parity h's cursor by one slice (wave-uniform)
     c_c0[h] += 64;
-    if (c_c0[h] >= Ctot) {
-      c_c0[h] = 0;
+    if (c_c0[h] >= c_end[h]) {                            // this tap has seen the chunk's channels: next tap, same chunk
       if (++c_kw[h] >= p.conv) {
         c_kw[h] = 0;
-        ++c_kh[h];
+        if (++c_kh[h] >= p.conv && c_end[h] < Ctot) {     // all taps of the chunk done: first tap of the next chunk
+          c_kh[h] = 0;
+          c_beg[h] = c_end[h];
+          c_end[h] = min(c_end[h] + cchunk, Ctot);
+        }
       }
+      c_c0[h] = c_beg[h];
     }
   };
+  // byte offset of the cursor's K slice inside a weight row ([tap][channel]: in the old order this was slice index * 128)
+  auto w_off = [&](int h) { return ((c_kh[h] * p.conv + c_kw[h]) * Ctot + c_c0[h]) * 2; };
   if constexpr (CONV) {
     if (PP) {
       if (g == 1 && nk > 1) cursor_step(0);               // group 1 starts on slice 1
@@ -261,6 +276,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
     tap_offsets(0);
     if (KG == 2 && !PP) tap_offsets(1);
   }
+  int st_woff[2] = {CONV ? w_off(0) : 0, CONV ? w_off(1) : 0};   // conv: weight-row byte offset of the slice each parity stages next
 
 #define DA2_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
   // Issue the LDS-DMA of the next slice pair into ring slot `slot` (straight-line code).  A slice past the end of K (odd
@@ -293,7 +309,10 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
       const int h = w_h[i];
       const int z = w_ok[i] ? (h ? st_zero[1] : st_zero[0]) : (int)0x80000000;
       unsigned char* dst = w_ok[i] ? base + own_half + h * SLICE + XBYTES + w_r[i] * 1024 : smem + NSLOT * PAIR;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DA2_LDS(dst), 16, vo_w[i] | z, (h ? st_s[1] : st_s[0]) * 128, 0, 0);
+      if constexpr (CONV)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DA2_LDS(dst), 16, vo_w[i] | z, h ? st_woff[1] : st_woff[0], 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DA2_LDS(dst), 16, vo_w[i] | z, (h ? st_s[1] : st_s[0]) * 128, 0, 0);
     };
     if constexpr (WHICH >= 0) {                           // weights (the HBM-cold operand) first
       if constexpr (WHICH < WI) issue_w(std::integral_constant<int, WHICH < WI ? WHICH : 0>{});
@@ -318,6 +337,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
           ++st_s[h];
         }
         if (c_kh[h] != kh0 || c_kw[h] != kw0) tap_offsets(h);
+        st_woff[h] = w_off(h);
       } else {
         st_s[h] = want;
       }
@@ -1224,7 +1244,7 @@ int launch(const da_gemm_params& p, hipStream_t s) {
       return DA_ERR_LAUNCH;
     attr_set = true;
   }
-  DA_LAUNCH(kern, dim3(grid), dim3(512), lds, s, p, gx);
+  DA_LAUNCH(kern, dim3(grid), dim3(512), lds, s, p, gx | (CONV ? conv_chunk_slices(p) << 8 : 0));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

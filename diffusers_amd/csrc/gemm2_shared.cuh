@@ -100,6 +100,16 @@ inline int choose_xcd_gx2(int tiles_m, int tiles_n, int BM, int BN) {   // as da
   return best;
 }
 
+// Channel chunk of a k x k conv's K order, in 64-wide slices (gemm2_kernel.cuh "K order of a k x k conv: CHUNKED"): two slices
+// (128 channels) -- the nine taps of a chunk then re-read at most CUs-per-XCD x tile rows x 256 B = 1-2 MB per XCD.
+// DA_CONV_CHUNK = 0 restores the tap-major order of rounds 1-5 (A/B runs), n > 0 pins n channels (multiples of 64).
+inline int conv_chunk_slices(const da_gemm_params& p) {
+  static const int forced = [] { const char* v = getenv("DA_CONV_CHUNK"); return v ? atoi(v) : -1; }();
+  if (p.conv <= 1) return 0;
+  if (forced >= 0) return forced / 64;
+  return 2;
+}
+
 // 31-bit offset budget of the buffer-addressed staging (as da_gemm::buffer_staging_fits, for tiles up to 256 rows)
 inline bool staging_fits(const da_gemm_params& p) {
   const size_t lim = 0x3fffffffull;

@@ -735,7 +735,9 @@ GnFused gn_fused_plan(int B, int HW, int C, int C1, int G, bool have_sync) {
   const long long wgs = (long long)B * (G / gs);
   if (wgs < min_wg) return f;
   const bool res = slab <= 144 * 1024;
-  if (!res && multi && have_sync && wgs <= kGnSyncCounters) {
+  // (group sets of 3 / 4 groups -- 10 or 30 channels per group -- LOSE in this form: the masked per-group accumulation is 4x the VALU
+  //  work per chunk, measured 15.1 -> 18.4 us at (2, 4096 px, 320 ch), profiles/r06_groupnorm_several_workgroups.jsonl)
+  if (!res && multi && have_sync && gs <= 2 && wgs <= kGnSyncCounters) {
     // round 6: deal the slab's pixels to a power-of-two number of workgroups, each LDS-resident, all of them resident at once
     // (<= one per CU): as many parts as the chip has CUs for, at least enough for the LDS
     int parts = 2;

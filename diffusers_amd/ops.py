@@ -706,8 +706,11 @@ def softmax_rows(scores: torch.Tensor, out: Optional[torch.Tensor] = None) -> to
 _gn_ws = {}
 # One-launch GroupNorm over several workgroups per slab (include/diffusers_amd.h da_groupnorm_nhwc_bf16 `sync`): the arrival counters
 # and partial statistics the parts of a slab exchange -- one buffer per (device, stream), zeroed ONCE here, then the kernels' own.
-# DIFFUSERS_AMD_GN_MULTI=0: no buffer is passed, mid-size tensors keep the two-kernel form.
-GN_MULTI = os.environ.get("DIFFUSERS_AMD_GN_MULTI", "1") == "1"
+# OFF by default (DIFFUSERS_AMD_GN_MULTI=1 turns it on): measured on the GroupNorm shapes of an SDXL step it wins 2.6-3.5 us on five
+# launches of a step and is a wash or a loss elsewhere -- 703 -> 696 us over the step's 37 GroupNorms, + 0.4 % on the image (inside the
+# pair-to-pair spread), profiles/r06_groupnorm_several_workgroups.jsonl -- and its parts WAIT for each other, which is only safe
+# while every part is resident: two such launches from two concurrent streams can starve each other until the bounded wait gives up.
+GN_MULTI = os.environ.get("DIFFUSERS_AMD_GN_MULTI", "0") == "1"
 _gn_sync = {}
 
 

@@ -675,6 +675,7 @@ def test_groupnorm_one_launch_over_several_workgroups(B, HW, C1, C2, G, monkeypa
     ulp (another summation order); deterministic over repeats that share the arrival counters with launches of OTHER part counts
     (every launch adds 32 to a slab's counter whatever its part count); no part ever timed out waiting."""
     ops, L = _ops()
+    monkeypatch.setattr(ops, "GN_MULTI", True)        # (opt-in: the host passes the sync buffer only when the module flag is set)
     C = C1 + C2
     x1 = rnd((B, HW, C1), 40, scale=2.0) + 3.0
     x2 = rnd((B, HW, C2), 44, scale=3.0) if C2 else None
@@ -702,11 +703,12 @@ def test_groupnorm_one_launch_over_several_workgroups(B, HW, C1, C2, G, monkeypa
     assert not ops.gn_sync_error()
 
 
-def test_groupnorm_several_workgroups_replays_from_a_hip_graph():
+def test_groupnorm_several_workgroups_replays_from_a_hip_graph(monkeypatch):
     """The arrival counters are monotonic and never reset: a captured chain of three GroupNorms of different part counts replays
     twenty times with the eager result."""
     ops, L = _ops()
-    shapes = [(2, 4096, 640), (2, 16384, 320), (2, 1024, 2560)]
+    monkeypatch.setattr(ops, "GN_MULTI", True)
+    shapes = [(2, 4096, 640), (2, 4096, 1280), (2, 1024, 2560)]
     xs = [rnd(sh, 60 + i, scale=1.5) + 0.7 for i, sh in enumerate(shapes)]
     gs = [rnd((sh[2],), 70 + i) * 0.1 + 1.0 for i, sh in enumerate(shapes)]
     bs = [rnd((sh[2],), 80 + i, scale=0.1) for i, sh in enumerate(shapes)]

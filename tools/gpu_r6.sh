@@ -95,3 +95,10 @@ fi
 if [[ $WHAT == *inflight* ]]; then
   timeout 900 python tools/bench_inflight.py $O/r06_two_in_flight.json 3 > $O/inflight.log 2>&1; echo "inflight rc=$?"; tail -5 $O/inflight.log | cut -c1-300
 fi
+if [[ $WHAT == *convchunk* ]]; then
+  timeout 1200 python -m pytest tests/test_gemm_k2_gpu.py tests/test_kernels_gpu.py tests/test_models_gpu.py -m gpu -q --timeout 900 -k "conv or unet or vae or k2 or resnet" > $O/pytest_conv.log 2>&1; echo "pytest conv rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert" $O/pytest_conv.log | tail -20
+  for m in 0 128 256 0 128 512; do
+    DA_CONV_CHUNK=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_cc$m.json 2> $O/bench_cc$m.err; echo "conv chunk $m rc=$? $(cut -c1-140 $O/bench_cc$m.json | grep -o '"value": [0-9.]*')"
+  done
+fi
