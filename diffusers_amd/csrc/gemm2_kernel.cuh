@@ -225,12 +225,13 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   // parity are recomputed only when its tap changes.  Pairs are staged strictly in order, so the state below always
   // describes the NEXT pair to stage (`st_pr`); it is advanced right after a pair's loads were issued, i.e. the address
   // arithmetic of pair n + 1 runs under the MFMAs that follow the issue of pair n and the issue itself is straight-line.
-  // Round 6 -- K order of a k x k conv: CHUNKED.  The weight rows are [tap][channel] and rounds 1-5 walked K in that order: all
-  // channels of tap 0, then all channels of tap 1 ...  The nine taps read the SAME activation pixels shifted by one, but a tap's sweep
-  // over C channels is (CUs of an XCD) x (tile rows) x C x 2 B -- 5 MB per XCD at C = 640 on 128-row tiles -- more than the XCD's
-  // 4 MB L2, so every tap re-fetched the activations through the fabric: 404 MB fetched for a conv with 67 MB of operands
-  // (profiles/r06_sdxl_traffic.md, 6.4x).  Now: for each chunk of `cchunk` channels, all taps, then the next chunk -- the taps of a
-  // chunk re-read 1-2 MB per XCD, which stays in L2.  Same slices, another order of summation; cchunk >= C is the old order.
+  // Round 6 -- K order of a k x k conv, optionally CHUNKED (off by default: gemm2_shared.cuh conv_chunk_slices has the measurement).
+  // The weight rows are [tap][channel] and K is walked in that order: all channels of tap 0, then all channels of tap 1 ...  The nine
+  // taps read the SAME activation pixels shifted by one, but a tap's sweep over C channels is (CUs of an XCD) x (tile rows) x C x 2 B
+  // -- 5 MB per XCD at C = 640 on 128-row tiles -- more than the XCD's 4 MB L2, so every tap re-fetches the activations through the
+  // fabric: 404 MB fetched for a conv with 67 MB of operands (profiles/r06_sdxl_traffic.md, 6.4x).  Chunked: for each chunk of
+  // `cchunk` channels, all taps, then the next chunk -- the taps of a chunk re-read 1-2 MB per XCD, which stays in L2.  Same slices,
+  // another order of summation; cchunk >= C (the default) is the tap-major order.
   const int cchunk = CONV ? (((xcd_gx_chunk >> 8) > 0 && p.conv > 1) ? min((xcd_gx_chunk >> 8) * 64, Ctot) : Ctot) : 0;
   int c_kh[2] = {0, 0}, c_kw[2] = {0, 0}, c_c0[2] = {0, 0};
   int c_beg[2] = {0, 0}, c_end[2] = {cchunk, cchunk};     // channel range of the chunk each parity's cursor is in

@@ -100,14 +100,16 @@ inline int choose_xcd_gx2(int tiles_m, int tiles_n, int BM, int BN) {   // as da
   return best;
 }
 
-// Channel chunk of a k x k conv's K order, in 64-wide slices (gemm2_kernel.cuh "K order of a k x k conv: CHUNKED"): two slices
-// (128 channels) -- the nine taps of a chunk then re-read at most CUs-per-XCD x tile rows x 256 B = 1-2 MB per XCD.
-// DA_CONV_CHUNK = 0 restores the tap-major order of rounds 1-5 (A/B runs), n > 0 pins n channels (multiples of 64).
+// Channel chunk of a k x k conv's K order, in 64-wide slices (gemm2_kernel.cuh "K order of a k x k conv: CHUNKED").  DEFAULT 0 = the
+// tap-major order of rounds 1-5; DA_CONV_CHUNK = n pins chunks of n channels (multiples of 64).  Measured (round 6, same box, SDXL
+// image, images/s): tap-major 0.9869 / 0.9923, chunks of 128 channels 0.9689 / 0.9710, 256: 0.9802, 512: 0.9885 -- the chunked order
+// cuts the fetched bytes of the deep-K convs by up to 5.5x (profiles/r06_sdxl_traffic_conv_chunk128.md: 404 -> 74 MB at
+// M 32768 x N 320 x K 5760) and LOSES 2 % of the image, because a tap change recomputes the per-lane gather offsets (now every slice
+// pair instead of every C / 64 slices) and these launches were not bound by the fabric in the first place.  Kept as a knob.
 inline int conv_chunk_slices(const da_gemm_params& p) {
-  static const int forced = [] { const char* v = getenv("DA_CONV_CHUNK"); return v ? atoi(v) : -1; }();
+  static const int forced = [] { const char* v = getenv("DA_CONV_CHUNK"); return v ? atoi(v) : 0; }();
   if (p.conv <= 1) return 0;
-  if (forced >= 0) return forced / 64;
-  return 2;
+  return forced > 0 ? forced / 64 : 0;
 }
 
 // 31-bit offset budget of the buffer-addressed staging (as da_gemm::buffer_staging_fits, for tiles up to 256 rows)

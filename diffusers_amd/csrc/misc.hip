@@ -8,6 +8,8 @@
 //   time_emb_proj                models/resnet.py:345-349         (Linear(SiLU(temb)))
 //   conv_in / conv_out           models/unets/unet_2d_condition.py:1108,:1230 ; models/autoencoders/vae.py:286,:309
 //   post_quant_conv              models/autoencoders/autoencoder_kl.py:204
+#include <cstdlib>
+
 #include "common.cuh"
 
 namespace {
@@ -135,6 +137,89 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const uint16_t* __res
       }
     }
     *(uint4*)(y + pix * Cout + co0 + cg * 8) = pack8(acc);
+  }
+}
+
+// Round 6: the same conv with FOUR consecutive output pixels of a row per thread (3 x 3, Cin <= 4: U-Net conv_in 4 -> 320, the DDPM
+// U-Net's 3 -> 128).  The kernel above reads the two 16-byte weight vectors of every (tap, input channel) from LDS and ONE input
+// value from memory per 8 multiply-adds; here the weight vectors feed 32 multiply-adds (four pixels) and a kernel row's six input
+// columns are loaded once for the four pixels that share them.  Per output element the operations and their order are the ones of
+// the kernel above (bias, then taps in (kh, kw, c) order, the same input conversions): bit-identical.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_thin_in4_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                            const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int B, int H,
+                                                            int W, int Cout, int in_nchw, float in_div, float in_add, int coc) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [9 * CIN][coc]
+  constexpr int kk = 9 * CIN;
+  const int co0 = blockIdx.y * coc;
+  const int ncoc = min(coc, Cout - co0);
+  for (int i = threadIdx.x; i < ncoc * kk; i += blockDim.x) {
+    const int co = i / kk, k = i - co * kk;
+    wsm[k * coc + co] = bf2f(w[(size_t)(co0 + co) * kk + k]);
+  }
+  __syncthreads();
+  const int cgroups = ncoc >> 3;
+  const int wq = (W + 3) >> 2;                                 // pixel quads per row
+  const size_t total = (size_t)B * H * wq * cgroups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cgroups);
+    const size_t quad = idx / cgroups;
+    const int x0 = (int)(quad % wq) * 4;
+    const int yh = (int)((quad / wq) % H);
+    const int b = (int)(quad / ((size_t)wq * H));
+    float acc[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float bv = bias ? bf2f(bias[co0 + cg * 8 + e]) : 0.f;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) acc[px][e] = bv;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = yh + kh - 1;
+      const bool row_ok = (unsigned)iy < (unsigned)H;          // (a padded row adds nothing: skipped in the kernel above as well)
+      float xin[6][CIN];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int ix = x0 + j - 1;
+        const bool ok = row_ok && (unsigned)ix < (unsigned)W;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          float xv = 0.f;
+          if (ok) {
+            const size_t off = in_nchw ? (((size_t)b * CIN + c) * H + iy) * W + ix : (((size_t)b * H + iy) * W + ix) * CIN + c;
+            xv = bf2f(x[off]);
+            if (in_div != 1.0f) xv = bf2f(f2bf(__fdiv_rn(xv, in_div)));
+            if (in_add != 0.0f) xv = bf2f(f2bf(__fadd_rn(xv, in_add)));
+          }
+          xin[j][c] = xv;
+        }
+      }
+      if (!row_ok) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const float* wp = wsm + (size_t)((kh * 3 + kw) * CIN + c) * coc + cg * 8;
+          const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            // a tap that falls into the left / right padding is SKIPPED above (not multiplied by zero): keep that -- x * w with
+            // x = 0 is exact, but skipping and adding + 0.0f can differ in the sign of a zero sum; the predicate keeps the bits
+            const int ix = x0 + px + kw - 1;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const float xv = xin[px + kw][c];
+            acc[px][0] += xv * w0.x; acc[px][1] += xv * w0.y; acc[px][2] += xv * w0.z; acc[px][3] += xv * w0.w;
+            acc[px][4] += xv * w1.x; acc[px][5] += xv * w1.y; acc[px][6] += xv * w1.z; acc[px][7] += xv * w1.w;
+          }
+        }
+    }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      if (x0 + px >= W) break;
+      const size_t pix = ((size_t)b * H + yh) * W + x0 + px;
+      *(uint4*)(y + pix * Cout + co0 + cg * 8) = pack8(acc[px]);
+    }
   }
 }
 
@@ -462,6 +547,20 @@ extern "C" int da_conv_thin_in_bf16(const void* x, const void* w, const void* bi
   // of output).  Three blocks per CU (what 46-64 KiB of LDS each admits), grid-stride over the pixels.
   const size_t cap = 768 / nchunk > 0 ? 768 / nchunk : 1;
   if (blocks > cap) blocks = cap;
+  const char* quad_env = getenv("DA_CONV_IN_QUAD");             // (read per call: tests compare the two kernels in one process)
+  const int quad = quad_env ? atoi(quad_env) : 1;
+  if (quad && ksize == 3 && (Cin == 3 || Cin == 4)) {          // four pixels per thread (round 6; bit-identical)
+    size_t qblocks = ((size_t)B * H * ((W + 3) / 4) * (coc / 8) + 255) / 256;
+    if (qblocks > cap) qblocks = cap;
+    if (Cin == 4)
+      DA_LAUNCH(conv_thin_in4_kernel<4>, dim3((unsigned)qblocks, (unsigned)nchunk), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x,
+                (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)y, B, H, W, Cout, in_nchw, in_div, in_add, coc);
+    else
+      DA_LAUNCH(conv_thin_in4_kernel<3>, dim3((unsigned)qblocks, (unsigned)nchunk), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x,
+                (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)y, B, H, W, Cout, in_nchw, in_div, in_add, coc);
+    DA_CHECK_LAUNCH();
+    return DA_OK;
+  }
   DA_LAUNCH(conv_thin_in_kernel, dim3((unsigned)blocks, (unsigned)nchunk), dim3(256), lds, (hipStream_t)stream,
             (const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)y, B, H, W, Cin, Cout, ksize,
             in_nchw, in_div, in_add, coc);

@@ -1035,6 +1035,27 @@ def test_linear_small_m(M, N, K):
     assert_close_bf16(y, F.silu(x.float() @ w.float().t() + b.float()) + res.float(), "small-M silu-out+res", rtol=1.6e-2, atol_rms=8e-3)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,nchw", [(2, 4, 128, 128, 320, True), (1, 3, 64, 64, 128, True), (2, 4, 17, 30, 64, True),
+                                                 (1, 4, 9, 5, 16, False), (1, 3, 8, 3, 8, True)])
+def test_conv_thin_in_four_pixels_per_thread_is_bit_identical(B, Cin, H, W, Cout, nchw, monkeypatch):
+    """Round 6: U-Net conv_in (4 -> 320 at 128 x 128) / the DDPM U-Net's (3 -> 128) with four output pixels of a row per thread:
+    the same operations in the same order per output element as the one-pixel kernel -- equal bits, also on ragged widths (W % 4 != 0),
+    image borders, channels-last input and with the latent scaling / shift conversions."""
+    ops, L = _ops()
+    x = rnd((B, Cin, H, W), 90) if nchw else rnd((B, H, W, Cin), 90)
+    w, b = rnd((Cout, Cin, 3, 3), 91, scale=0.2), rnd((Cout,), 92)
+    wp = ops.pack_conv_weight(w)
+    for kw in (dict(), dict(in_div=0.13025), dict(in_div=0.3611, in_add=0.1159)):
+        monkeypatch.setenv("DA_CONV_IN_QUAD", "0")
+        one = ops.conv_thin_in(x, wp, b, ksize=3, in_nchw=nchw, **kw)
+        monkeypatch.setenv("DA_CONV_IN_QUAD", "1")
+        four = ops.conv_thin_in(x, wp, b, ksize=3, in_nchw=nchw, **kw)
+        assert torch.equal(one, four), f"conv_thin_in quad differs {kw}"
+    xr = x.float() if nchw else x.float().permute(0, 3, 1, 2)
+    ref = F.conv2d(xr, w.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    assert_close_bf16(four if not kw else ops.conv_thin_in(x, wp, b, ksize=3, in_nchw=nchw), ref, "conv_thin_in quad vs torch", rtol=8e-3, atol_rms=4e-3)
+
+
 def test_conv_thin_in_out():
     ops, L = _ops()
     B, Cin, H, W, Cout = 2, 4, 16, 16, 64

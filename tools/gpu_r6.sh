@@ -102,3 +102,10 @@ if [[ $WHAT == *convchunk* ]]; then
     DA_CONV_CHUNK=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_cc$m.json 2> $O/bench_cc$m.err; echo "conv chunk $m rc=$? $(cut -c1-140 $O/bench_cc$m.json | grep -o '"value": [0-9.]*')"
   done
 fi
+if [[ $WHAT == *convin* ]]; then
+  timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --timeout 300 -k "conv_thin" > $O/pytest_convin.log 2>&1; echo "pytest conv_thin rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert" $O/pytest_convin.log | tail -8
+  for m in 0 1 0 1; do
+    DA_CONV_IN_QUAD=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_ci$m.json 2> $O/bench_ci$m.err; echo "conv_in quad $m rc=$? $(cut -c1-140 $O/bench_ci$m.json | grep -o '"value": [0-9.]*')"
+  done
+fi
