@@ -56,9 +56,48 @@ def postprocess_images(img: torch.Tensor, output_type: str):
     raise ValueError(f"output_type={output_type!r}: use 'pil', 'np', 'pt', 'raw' or 'latent'")
 
 
+_DECODE_LOCK = threading.Lock()
+
+
+class _exclusive_decode:
+    """Round 6, several pipelines in flight on one GPU (``STREAM_DOMAIN``).  The step graphs of several pipelines replay concurrently on
+    several streams without touching each other (final latents bit-identical over every round tried, tools/debug_inflight.py --latent).
+    Two EAGER VAE decodes running at the same time on two streams do NOT reproduce their one-at-a-time bits (tools/debug_decode_concurrent.py:
+    most concurrent decodes differ, the first differing launch usually a conv / nn.Linear of the 1024 x 1024 level).  What was ruled out,
+    each by its own run under tools/: out-of-bounds writes (64 KiB canaries around every allocation of a decode and of a U-Net step:
+    intact), the caching allocator (per-thread bump arenas: same result), a host-side launch race (a lock around every C-ABI call: same),
+    split-K / one-launch GroupNorm / prefetch hints / the four-pixel conv_in (switched off: same), any single op looped next to a
+    decode (the decode stays intact); one hardware queue (GPU_MAX_HW_QUEUES=1) makes the difference disappear, and decodes replayed
+    from their own HIP graphs reproduce their bits (48 of 48) -- but a graph-captured decode next to another pipeline's step graphs
+    made things worse, not better.  The cause is NOT isolated.  Mitigation: a thread that set ``STREAM_DOMAIN.tag`` takes this lock around
+    its decode and holds it until its stream has drained, so two decodes never overlap; with it 5 of 6 concurrent images reproduce their
+    bits and the sixth differs by <= 2e-2 (a decode overlapping the OTHER pipeline's step replays).  Running several pipelines
+    concurrently is therefore a MEASUREMENT in this repository (bench.py's informational `serving_two_in_flight` leg says whether its
+    images were bit-identical), not a supported mode.  The default single-domain path takes no lock and no synchronisation."""
+
+    def __enter__(self):
+        self.on = getattr(STREAM_DOMAIN, "tag", 0) != 0
+        if self.on:
+            _DECODE_LOCK.acquire()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            try:
+                torch.cuda.current_stream().synchronize()
+            finally:
+                _DECODE_LOCK.release()
+        return False
+
+
 def decode_postprocessed(vae, latents: torch.Tensor, output_type: str, **decode_kw):
     """``vae.decode(latents / scaling_factor).sample`` followed by ``image_processor.postprocess(..., output_type)``
     (pipeline_stable_diffusion_xl.py:1283-1299) with the postprocess fused into the decoder's last pass."""
+    with _exclusive_decode():
+        return _decode_postprocessed(vae, latents, output_type, **decode_kw)
+
+
+def _decode_postprocessed(vae, latents: torch.Tensor, output_type: str, **decode_kw):
     mode = {"pt": "pt", "np": "np", "pil": "uint8"}.get(output_type)
     if mode is None:
         return postprocess_images(vae.decode(latents, return_dict=False, **decode_kw)[0], output_type)
@@ -827,7 +866,8 @@ class WanPipeline(_StepCallbacks, PipelineLoadingMixin):
         cond = self.transformer.precompute_conditioning(pe.contiguous())
         latents = self._denoise(latents, cond, len(self.scheduler.timesteps), guidance_scale, do_cfg, use_graph)
         if output_type != "latent":
-            video = self.vae.decode(latents, return_dict=False, denormalize=True)[0]            # [B][3][F][H][W]
+            with _exclusive_decode():
+                video = self.vae.decode(latents, return_dict=False, denormalize=True)[0]        # [B][3][F][H][W]
             # VideoProcessor.postprocess_video (video_processor.py): "np" [B][F][H][W][C], "pt" [B][F][C][H][W], in [0, 1]
             latents = postprocess_images(video, output_type)
             if output_type == "pt":

@@ -109,3 +109,51 @@ if [[ $WHAT == *convin* ]]; then
     DA_CONV_IN_QUAD=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_ci$m.json 2> $O/bench_ci$m.err; echo "conv_in quad $m rc=$? $(cut -c1-140 $O/bench_ci$m.json | grep -o '"value": [0-9.]*')"
   done
 fi
+if [[ $WHAT == *dbginflight* ]]; then
+  timeout 600 python tools/debug_inflight.py > $O/dbg_inflight_a.log 2>&1; echo "dbg a rc=$?"; grep -E "sequential|concurrent|Error" $O/dbg_inflight_a.log | cut -c1-200
+  timeout 600 python tools/debug_inflight.py --headline-first > $O/dbg_inflight_b.log 2>&1; echo "dbg b rc=$?"; grep -E "sequential|concurrent|Error" $O/dbg_inflight_b.log | cut -c1-200
+  DIFFUSERS_AMD_ATTN_SPLIT=0 timeout 600 python tools/debug_inflight.py --headline-first > $O/dbg_inflight_c.log 2>&1; echo "dbg c (no attn split) rc=$?"; grep -E "sequential|concurrent|Error" $O/dbg_inflight_c.log | cut -c1-200
+  timeout 600 python tools/debug_inflight.py --headline-first --latent > $O/dbg_inflight_d.log 2>&1; echo "dbg d (latents) rc=$?"; grep -E "sequential|concurrent|Error" $O/dbg_inflight_d.log | cut -c1-200
+fi
+if [[ $WHAT == *dbgdecode* ]]; then
+  timeout 300 python tools/debug_decode_concurrent.py 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+  timeout 300 python tools/debug_decode_concurrent.py --nosplitk 2>&1 | grep -E "RESULT|Error|switched" | cut -c1-300
+  DA_GN_FUSED=0 timeout 300 python tools/debug_decode_concurrent.py 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+  DIFFUSERS_AMD_PREFETCH=0 timeout 300 python tools/debug_decode_concurrent.py 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+  DA_CONV_IN_QUAD=0 timeout 300 python tools/debug_decode_concurrent.py --raw 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+fi
+if [[ $WHAT == *dbgops* ]]; then
+  timeout 600 python tools/debug_ops_concurrent.py 2>&1 | grep -E "RESULT|Error|splitk" | cut -c1-200
+fi
+if [[ $WHAT == *dbgalloc* ]]; then
+  PYTORCH_NO_CUDA_MEMORY_CACHING=1 timeout 600 python tools/debug_decode_concurrent.py 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+  PYTORCH_NO_HIP_MEMORY_CACHING=1 timeout 600 python tools/debug_decode_concurrent.py 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+  AMD_SERIALIZE_KERNEL=3 timeout 600 python tools/debug_decode_concurrent.py 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+  GPU_MAX_HW_QUEUES=1 timeout 600 python tools/debug_decode_concurrent.py 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+fi
+if [[ $WHAT == *dbgtrace* ]]; then
+  timeout 600 python tools/debug_decode_trace.py 2>&1 | grep -E "RESULT|Error" | cut -c1-260
+fi
+if [[ $WHAT == *dbgvs* ]]; then
+  timeout 900 python tools/debug_decode_vs_op.py 2>&1 | grep -E "RESULT B|Error" | cut -c1-260
+fi
+if [[ $WHAT == *dbglock* ]]; then
+  timeout 600 python tools/debug_inflight.py --headline-first > $O/dbg_inflight_lock.log 2>&1; echo "dbg lock rc=$?"; grep -E "sequential|concurrent|Error" $O/dbg_inflight_lock.log | cut -c1-200
+  timeout 600 python tools/debug_inflight.py > $O/dbg_inflight_lock2.log 2>&1; echo "dbg lock2 rc=$?"; grep -E "sequential|concurrent|Error" $O/dbg_inflight_lock2.log | cut -c1-200
+  timeout 900 python tools/bench_inflight.py $O/r06_two_in_flight.json 3 > $O/inflight.log 2>&1; echo "inflight rc=$?"; tail -3 $O/inflight.log | cut -c1-300
+fi
+if [[ $WHAT == *dbggraph* ]]; then
+  timeout 600 python tools/debug_decode_graph_concurrent.py 2>&1 | grep -E "RESULT|round|sequential|Error" | cut -c1-200
+fi
+if [[ $WHAT == *dbgoob* ]]; then
+  timeout 900 python tools/debug_oob.py 2>&1 | grep -E "RESULT|OOB|alloc |Error|decode alloc" | cut -c1-260 | head -60
+  timeout 900 python tools/debug_oob.py --unet --gb 64 2>&1 | grep -E "RESULT|OOB|alloc |Error" | cut -c1-260 | head -60
+fi
+if [[ $WHAT == *dbglaunch* ]]; then
+  timeout 300 python tools/debug_decode_concurrent.py --launchlock 2>&1 | grep -E "RESULT|Error|installed" | cut -c1-300
+  HIP_FORCE_DEV_KERNARG=0 timeout 300 python tools/debug_decode_concurrent.py 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+  HIP_FORCE_DEV_KERNARG=1 timeout 300 python tools/debug_decode_concurrent.py 2>&1 | grep -E "RESULT|Error" | cut -c1-300
+fi
+if [[ $WHAT == *dbgarena* ]]; then
+  timeout 300 python tools/debug_decode_concurrent.py --arena 2>&1 | grep -E "RESULT|Error|installed" | cut -c1-300
+fi

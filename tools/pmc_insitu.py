@@ -5,9 +5,10 @@ XCD's L2 as in the real loop), from rocprofv3 counter passes over tools/pmc_one_
 usage: pmc_insitu.py <launch_log.json> <skip> <out.md> <pass_dir> [<pass_dir> ...]
 Each pass directory holds one `--kernel-trace --pmc ...` run (counter_collection.csv + kernel_trace.csv).  Per population (shape x role
 x kernel) the report gives the launch duration from the trace of that pass and the mean of every counter; derived columns:
-  clock GHz     = GRBM_GUI_ACTIVE / duration (MI355X_MICROARCH.md "DVFS give-back": effective clock)
+  GUI GHz       = GRBM_GUI_ACTIVE / 8 XCDs / duration: the effective clock (MI355X_MICROARCH.md "DVFS give-back") for long launches; an
+                  UPPER bound for short ones (GUI-active also counts the dispatch ramp outside the kernel's begin / end timestamps)
   L2 hit        = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
-  mfma busy     = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE)     [cycles the matrix pipes were busy]
+  mfma busy     = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of the GUI-active cycles the matrix pipes were busy
   parked / stall / active = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES
 Profiled runs clock lower than unprofiled ones (guide: never compare a profiled arm with an unprofiled one): ratios only."""
 import csv
@@ -62,17 +63,17 @@ def main():
                 p["us"] += us
                 p["usn"] += 1
     lines = ["# Implicit-GEMM launch populations in situ: counters per launch (rocprofv3 --pmc over an eager SDXL step; profiled clocks)", "",
-             "| population | kernel | us (profiled) | TFLOP/s | clock GHz | L2 hit | mfma busy | parked | stalled | issuing |",
+             "| population | kernel | us (profiled) | TFLOP/s | GUI GHz | L2 hit | mfma busy | parked | stalled | issuing |",
              "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
     rec = {}
     for (pop, kern), p in sorted(pops.items(), key=lambda kv: -kv[1]["us"]):
         m = {k: p["c"][k] / p["cn"][k] for k in p["c"]}
         us = p["us"] / max(p["usn"], 1)
         gui = m.get("GRBM_GUI_ACTIVE")
-        clock = gui / (us * 1e3) if gui and us else None
+        clock = gui / 8.0 / (us * 1e3) if gui and us else None
         hit = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]) if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m else None
         wc = m.get("SQ_WAVE_CYCLES")
-        busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui) if gui and "SQ_VALU_MFMA_BUSY_CYCLES" in m else None
+        busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * gui) if gui and "SQ_VALU_MFMA_BUSY_CYCLES" in m else None
         f = lambda v, fmt="{:.2f}": fmt.format(v) if v is not None else "-"   # noqa: E731
         frac = lambda k: (m[k] / wc if wc and k in m else None)             # noqa: E731
         lines.append(f"| {pop} | `{kern}` | {us:.1f} | {p['flop'] / us / 1e6 if us else 0:.0f} | {f(clock)} | {f(hit)} | {f(busy)} | "
