@@ -206,3 +206,60 @@ def test_split_units_with_spiked_keys_and_score_offsets(algo):
     print(f"[split] spiked / drifting keys, algo {algo}: rel-rms vs fp32 whole {rw:.3e}, split x4 {rs:.3e}")
     assert torch.isfinite(split.float()).all()
     assert rs <= 1.1 * rw + 2e-4 and rs < 3e-2
+
+
+# ---- CPU model of the kernel's block decode (attention2.hip, "which logical block, which key tiles") -------------------------------
+def _decode_block(bid, qtiles, ntiles, plan):
+    """Python restatement of the kernel's scalar block decode for the balanced mapping: -> (pair, query tile, first key tile, end key
+    tile, unit id or -1, tail-block id, XCD the block runs on = physical id & 7)."""
+    full, tail, s, nb8 = plan
+    tps = (ntiles + s - 1) // s if s > 1 else ntiles
+    xcd, slot = bid & 7, bid >> 3
+    t0, t1, unit, rblk = 0, ntiles, -1, 0
+    if s > 1 and bid >= full:
+        u = bid - full
+        v, xcd = u >> 3, u & 7
+        vb, si = v // s, v % s
+        rblk = (vb << 3) | xcd
+        unit = rblk * s + si
+        slot = (full >> 3) + vb
+        t0, t1 = si * tps, min(ntiles, si * tps + tps)
+    lb = xcd * nb8 + slot
+    return lb // qtiles, lb % qtiles, t0, t1, unit, rblk, (bid & 7)
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,D,pin", [(2, 20, 1024, 1024, 64, 0), (2, 10, 4096, 4096, 64, 0), (1, 24, 4608, 4608, 128, 4),
+                                             (2, 8, 1280, 700, 64, 0), (1, 16, 2560, 1100, 128, 4), (1, 3, 1000, 1024, 64, 0),
+                                             (2, 20, 1024, 1000, 64, 3), (2, 5, 2048, 2048, 64, 0), (2, 12, 32760, 32760, 128, 0),
+                                             (4, 10, 4096, 520, 64, 2), (2, 20, 1024, 77, 64, 0)])
+def test_every_query_block_and_key_tile_is_covered_exactly_once(B, H, Sq, Skv, D, pin):
+    """The grid the library launches (whole blocks, then `s` units per tail block) walks every (batch, head, query tile, key tile)
+    exactly once; the units of one tail block have distinct unit ids, share its tail-block id (their ticket counter) and run on the
+    XCD that owns the block; every XCD owns the same number of logical blocks."""
+    need, full, tail, s = _plan(B, H, Sq, Skv, D, kv_split=pin)
+    QT = 256 if (D == 128 and B * H * ((Sq + 255) // 256) >= 192) else 128
+    qtiles, ntiles = (Sq + QT - 1) // QT, (Skv + 63) // 64
+    nb = B * H * qtiles
+    if nb % 8:
+        pytest.skip("legacy mapping (block count not a multiple of the XCD count): whole blocks only")
+    if s <= 1:
+        full, tail, s = nb, 0, 1
+    plan = (full, tail, s, nb // 8)
+    seen, per_xcd, units_of, xcd_of = {}, [0] * 8, {}, {}
+    for bid in range(full + tail * s):
+        pair, qt, t0, t1, unit, rblk, xcd = _decode_block(bid, qtiles, ntiles, plan)
+        assert 0 <= pair < B * H and 0 <= qt < qtiles and 0 <= t0 < t1 <= ntiles, (bid, pair, qt, t0, t1)
+        for t in range(t0, t1):
+            assert (pair, qt, t) not in seen, f"key tile {t} of block ({pair}, {qt}) walked twice (blocks {seen[(pair, qt, t)]} and {bid})"
+            seen[(pair, qt, t)] = bid
+        if unit < 0:
+            per_xcd[xcd] += 1
+        else:
+            units_of.setdefault(rblk, []).append(unit)
+            assert xcd_of.setdefault((pair, qt), xcd) == xcd, "the units of one block run on different XCDs"
+            assert unit // s == rblk
+    assert len(seen) == B * H * qtiles * ntiles
+    assert len(set(per_xcd)) == 1, per_xcd                       # whole blocks: the same count on every XCD
+    assert len(units_of) == tail and all(sorted(u) == list(range(r * s, r * s + s)) for r, u in units_of.items())
+    if tail:
+        assert max(units_of) < 4096                              # ticket counters: DA_ATTN_SPLIT_COUNTER_BYTES / 4

@@ -678,3 +678,29 @@ def test_latents_batch_must_match_the_embeddings(golden):
         pipe(prompt_embeds=_t(g, "prompt_embeds"), negative_prompt_embeds=_t(g, "negative_prompt_embeds"), pooled_prompt_embeds=_t(g, "pooled"),
              negative_pooled_prompt_embeds=_t(g, "negative_pooled"), latents=_t(g, "latents"), num_images_per_prompt=2, num_inference_steps=2,
              height=128, width=128, use_graph=False)
+
+
+def test_groupnorm_arrival_counter_generations():
+    """norm.hip gn_fused_kernel, several workgroups per slab: every launch adds exactly 32 to a slab's monotonic counter (each of its
+    `nparts` parts adds 32 / nparts) and a part waits until the counter reaches the end of the generation its own add fell into.  A
+    model of that arithmetic over launches of DIFFERENT part counts sharing one counter, with the arrivals of a launch in any order:
+    no part's target is reachable before the last part of ITS launch has arrived, every target is reached once it has, and the 32-bit
+    wrap is harmless."""
+    import itertools
+    import random
+    rng = random.Random(0)
+    for start in (0, 32 * 7, (1 << 32) - 64, (1 << 32) - 32):
+        cnt = start
+        for _ in range(200):
+            nparts = rng.choice((2, 4, 8, 16, 32))
+            inc = 32 // nparts
+            targets = []
+            for k in range(nparts):                               # arrivals of ONE launch (launches of a stream are serialised)
+                old = cnt
+                cnt = (cnt + inc) & 0xFFFFFFFF
+                target = ((old & ~31) + 32) & 0xFFFFFFFF
+                targets.append(target)
+                reached = ((cnt - target) & 0xFFFFFFFF) < (1 << 31)           # the kernel's (int)(load - target) >= 0
+                assert reached == (k == nparts - 1), (start, nparts, k, old, cnt, target)
+            assert len(set(targets)) == 1 and cnt == targets[0]   # all parts wait for the same value: the generation's end
+    assert all(32 % n == 0 for n in (2, 4, 8, 16, 32)) and list(itertools.accumulate([8] * 4))[-1] == 32
