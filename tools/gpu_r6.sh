@@ -157,3 +157,16 @@ fi
 if [[ $WHAT == *dbgarena* ]]; then
   timeout 300 python tools/debug_decode_concurrent.py --arena 2>&1 | grep -E "RESULT|Error|installed" | cut -c1-300
 fi
+if [[ $WHAT == *r05ab* ]]; then
+  # the round-5 library (git edaa4bd, built in the worktree _r05_ab/) against this round's, alternating, one box
+  for m in r05 r06 r05 r06; do
+    if [[ $m == r05 ]]; then D=$R/_r05_ab; else D=$R; fi
+    (cd $D && timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-other-configs > $O/bench_ab_$m.json 2> $O/bench_ab_$m.err); echo "library $m rc=$? $(cut -c1-140 $O/bench_ab_$m.json | grep -o '"value": [0-9.]*') $(python -c "import json;d=json.load(open('$O/bench_ab_$m.json'));r=d['roofline'];print('igemm',round(r['frac'],3),'attention',round([k for k in r['kernels'] if k['name']=='attention'][0]['frac'],3), 'attn_ms', round([k for k in r['kernels'] if k['name']=='attention'][0]['ms'],3))" 2>/dev/null)"
+  done
+  for c in sd15 flux; do
+    for m in r05 r06; do
+      if [[ $m == r05 ]]; then D=$R/_r05_ab; else D=$R; fi
+      (cd $D && timeout 600 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_ab_${c}_$m.json 2> $O/bench_ab_${c}_$m.err); echo "$c library $m rc=$? $(cut -c1-160 $O/bench_ab_${c}_$m.json | grep -o '"value": [0-9.]*')"
+    done
+  done
+fi
