@@ -63,6 +63,9 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic: do not run the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) in subprocesses; replay "
+                         "profiles/sdxl_traffic.json instead (what a multi-rank run and a box without rocprofv3 do anyway)")
     ap.add_argument("--no-reference", action="store_true", help="skip the parity / torch_rocm_baseline / dropin legs")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs leg (sd15, flux, ddpm, wan) of the default run")
     ap.add_argument("--save-tuning", default=None, help="write the GEMM variant table measured during warm-up here")
@@ -325,7 +328,48 @@ def build_fingerprint() -> str:
     return stamp.read_text().strip()[:16] if stamp.exists() else "unknown"
 
 
-def roofline_leg(pipe, mine, world, images_per_s):
+def live_traffic(algo_bytes_per_launch: float, timeout_s: int = 240):
+    """roofline.traffic MEASURED IN THIS RUN: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE -- separate --pmc passes with
+    --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes) over tools/pmc_one_step.py in SUBPROCESSES (one eager SDXL
+    denoising step at the bench configuration: same library, same tuned table, same launches as the timed graph; this process cannot
+    be profiled from inside), reduced by tools/pmc_traffic.py (gfx950's 2 x FETCH_SIZE correction, the 140 hoisted K / V^T launches
+    set aside).  Returns (record, note) or (None, why not); never raises -- the caller then replays the committed measurement."""
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    tmp = Path(tempfile.mkdtemp(prefix="da_pmc_", dir="/tmp"))
+    env = dict(os.environ, DIFFUSERS_AMD_TUNE="0", TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for name, counter, extra in (("fetch", "FETCH_SIZE", [str(tmp / "launch_log.json")]), ("write", "WRITE_SIZE", [])):
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", str(tmp / name), "-o", "sdxl", "--",
+                   sys.executable, str(ROOT / "tools" / "pmc_one_step.py"), "1", *extra]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0 or "pmc_one_step: done" not in r.stdout + r.stderr:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]!r}"
+        r = subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_traffic.py"), str(tmp / "fetch"), str(tmp / "write"),
+                            str(tmp / "traffic.md"), str(tmp / "traffic.json"), repr(float(algo_bytes_per_launch)), "140",
+                            str(tmp / "launch_log.json"), "1"], capture_output=True, text=True, timeout=120)
+        if r.returncode != 0:
+            return None, f"tools/pmc_traffic.py failed: {r.stderr[-200:]!r}"
+        tr = json.loads((tmp / "traffic.json").read_text())
+        if "igemm_bytes_per_launch" not in tr:
+            return None, "no implicit-GEMM rows in the counter files"
+        return tr, ("MEASURED IN THIS RUN: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, 2x FETCH_SIZE "
+                    "correction for gfx950's wide streams, WRITE_SIZE as reported) over one eager SDXL denoising step of this library in a "
+                    "subprocess (tools/pmc_one_step.py; same tuned table and launches as the timed graph), bytes / implicit-GEMM launches "
+                    "of the step (tools/pmc_traffic.py; the 140 hoisted K / V^T projections set aside)")
+    except Exception as e:  # a diagnostic leg never costs the line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def roofline_leg(pipe, mine, world, images_per_s, live=True):
     """Dominant kernel = the implicit-GEMM family (igemm_bf16_kernel + igemm2_bf16_kernel + gemm3_bf16_kernel: all Linear + Conv2d 3x3 / 1x1, paired
     launches included): MFMA-bound.  `kernels` carries the other families of the denoising step and the VAE decode.  The
     conditioning is built here (not taken from the graph's static inputs), so the leg also works after --no-graph."""
@@ -350,8 +394,20 @@ def roofline_leg(pipe, mine, world, images_per_s):
     n, ms, fl, nbytes = fam["igemm"]
     ach = fl / (ms * 1e-3) / 1e12
     fp = build_fingerprint()
-    traffic, note = None, "no committed PMC measurement (profiles/sdxl_traffic.json)"
-    if TRAFFIC_FILE.exists():
+    traffic, note, family_ratios = None, "no committed PMC measurement (profiles/sdxl_traffic.json)", None
+    if live and world == 1:
+        log("roofline leg: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eager step (subprocesses)")
+        t0 = time.perf_counter()
+        tr, why = live_traffic(nbytes / max(n, 1))
+        if tr is not None:
+            traffic, note = tr["igemm_bytes_per_launch"], why
+            family_ratios = {k: round(v["ratio"], 3) for k, v in tr.get("igemm_family_ratios", {}).items()}
+            log(f"roofline leg: traffic {traffic / 1e6:.1f} MB per implicit-GEMM launch, measured in {time.perf_counter() - t0:.0f} s")
+        else:
+            log(f"roofline leg: live traffic measurement unavailable ({why}); replaying {TRAFFIC_FILE.name}")
+            note = f"live measurement unavailable ({why}); "
+    if traffic is None and TRAFFIC_FILE.exists():
+        live_note, note = (note if note.startswith("live measurement") else ""), ""
         try:
             tr = json.loads(TRAFFIC_FILE.read_text())
             if tr.get("build_fingerprint") == fp:
@@ -363,6 +419,7 @@ def roofline_leg(pipe, mine, world, images_per_s):
                         f"this library is {fp}; re-run tools/gpu_r4.sh traffic")
         except (ValueError, KeyError) as e:
             note = f"unreadable {TRAFFIC_FILE.name}: {e}"
+        note = live_note + note
     kernels = [_kernel_entry("igemm", "igemm_bf16_kernel + igemm2_bf16_kernel + gemm3_bf16_kernel (Linear, Conv2d, paired Q|K + V^T)", "mfma", fam["igemm"])]
     if "attention" in fam:
         kernels.append(_kernel_entry("attention", "attn_fwd_kernel (flash attention forward)", "mfma", fam["attention"]))
@@ -398,7 +455,7 @@ def roofline_leg(pipe, mine, world, images_per_s):
                             if k in ("igemm", "attention") else {})} for k, v in fam_host.items()}
     return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / MFMA_PEAK_TFLOPS, "timing": timing, "host_event_pairs": host_pair,
-            "traffic": traffic, "traffic_source": note, "build_fingerprint": fp,
+            "traffic": traffic, "traffic_source": note, "traffic_ratio_by_kernel_family": family_ratios, "build_fingerprint": fp,
             "kernel": "igemm_bf16_kernel + igemm2_bf16_kernel + gemm3_bf16_kernel (Linear + Conv2d implicit GEMM, paired launches included)",
             "launches_per_denoise_step": n, "avg_launch_us": 1000.0 * ms / max(n, 1),
             "algorithmic_tflop_per_denoise_step": fl / 1e12,
@@ -1091,7 +1148,7 @@ def main(argv=None):
         if not args.no_roofline:
             log("roofline leg: one eager denoising step with HIP events around every igemm launch")
             try:
-                result["roofline"] = roofline_leg(pipe, mine, world, value)
+                result["roofline"] = roofline_leg(pipe, mine, world, value, live=not args.no_live_traffic)
             except Exception as e:  # never lose the measured line to a diagnostic leg
                 result["roofline"] = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": None, "traffic": None, "error": f"{type(e).__name__}: {e}"}

@@ -102,6 +102,7 @@ SIGNATURES = {
     "da_sizeof_attention_params": (C.c_size_t, []),
     "da_last_error": (C.c_char_p, []),
     "da_set_launch_events": (_i, [_vp, _vp]),
+    "da_set_launch_flags": (_i, [C.c_uint]),
     "da_mfma_probe": (_i, [_i, _i, _vp, C.POINTER(C.c_double), _vp]),
     "da_gemm_bf16": (_i, [C.POINTER(GemmParams), _vp]),
     "da_gemm_pair_bf16": (_i, [C.POINTER(GemmParams), C.POINTER(GemmParams), _vp]),

@@ -18,18 +18,21 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 // da_set_launch_events() (version.hip): a caller may arm a start / stop event pair for this thread's next launches; such a launch
 // goes through hipExtLaunchKernelGGL, which stamps the events with the dispatch's OWN begin / end (what rocprofv3 reports as the
 // kernel's duration) instead of the completion of separate marker packets either side of it.  One thread-local load otherwise.
-extern "C" int da_take_launch_events(hipEvent_t* start, hipEvent_t* stop);
+// da_set_launch_flags() (version.hip, experiments only): the flags word of hipExtLaunchKernelGGL for this thread's launches
+// (hipExtAnyOrderLaunch = the dispatch packet without its barrier bit); da_take_launch_events() reports it through *flags.
+extern "C" int da_take_launch_events(hipEvent_t* start, hipEvent_t* stop, unsigned* flags);
 template <typename F, typename... Args>
-inline void da_launch_with_events(hipEvent_t start, hipEvent_t stop, F kernel, const dim3& grid, const dim3& block, uint32_t shmem,
-                                  hipStream_t stream, Args... args) {
-  hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, start, stop, 0, args...);
+inline void da_launch_with_events(hipEvent_t start, hipEvent_t stop, unsigned flags, F kernel, const dim3& grid, const dim3& block,
+                                  uint32_t shmem, hipStream_t stream, Args... args) {
+  hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, start, stop, flags, args...);
 }
 #define DA_LAUNCH(...)                                      \
   do {                                                      \
     (void)hipGetLastError();                                \
     hipEvent_t es__ = nullptr, ee__ = nullptr;              \
-    if (__builtin_expect(da_take_launch_events(&es__, &ee__), 0)) \
-      da_launch_with_events(es__, ee__, __VA_ARGS__);       \
+    unsigned fl__ = 0;                                      \
+    if (__builtin_expect(da_take_launch_events(&es__, &ee__, &fl__), 0)) \
+      da_launch_with_events(es__, ee__, fl__, __VA_ARGS__); \
     else                                                    \
       hipLaunchKernelGGL(__VA_ARGS__);                      \
   } while (0)

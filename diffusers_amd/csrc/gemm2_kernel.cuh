@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void igemm2_bf16_kernel(const da_gemm_params p
   // parity are recomputed only when its tap changes.  Pairs are staged strictly in order, so the state below always
   // describes the NEXT pair to stage (`st_pr`); it is advanced right after a pair's loads were issued, i.e. the address
   // arithmetic of pair n + 1 runs under the MFMAs that follow the issue of pair n and the issue itself is straight-line.
-  // Round 6 -- K order of a k x k conv, optionally CHUNKED (off by default: gemm2_shared.cuh conv_chunk_slices has the measurement).
+  // Round 6 -- K order of a k x k conv, optionally CHUNKED (per launch, where a tap sweep outgrows the L2: gemm2_shared.cuh conv_chunk_slices has the rule and the measurements).
   // The weight rows are [tap][channel] and K is walked in that order: all channels of tap 0, then all channels of tap 1 ...  The nine
   // taps read the SAME activation pixels shifted by one, but a tap's sweep over C channels is (CUs of an XCD) x (tile rows) x C x 2 B
   // -- 5 MB per XCD at C = 640 on 128-row tiles -- more than the XCD's 4 MB L2, so every tap re-fetches the activations through the
@@ -1235,8 +1235,10 @@ template <int KG, int WM, int WN, int MT, int NT, int NSLOT, bool CONV, bool PP 
 int launch(const da_gemm_params& p, hipStream_t s) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int gx = choose_xcd_gx2(tiles_m, tiles_n, BM, BN), gy = 8 / gx;
-  const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
+  const int gx = choose_xcd_gx2(tiles_m, tiles_n, BM, BN, CONV ? xcd_conv_weighting(p) : 1, CONV ? (long long)(p.C1 + p.C2) * 2 : 0), gy = 8 / gx;
+  const int tm_per = (tiles_m + gy - 1) / gy, tn_per = (tiles_n + gx - 1) / gx;
+  const int grid = 8 * tm_per * tn_per;
+  const long long rows_xcd = (long long)BM * (tm_per < (32 + tn_per - 1) / tn_per ? tm_per : (32 + tn_per - 1) / tn_per);
   constexpr size_t lds = (size_t)NSLOT * KG * (BM + BN) * 128 + 1024 + (LNF ? 2 * BN * 4 : 0);   // ring + the scratch KiB (ragged pieces, prefetch) + s / c
   auto kern = igemm2_bf16_kernel<KG, WM, WN, MT, NT, NSLOT, CONV, PP, STREAMW, GIL, LNF, XA>;
   static bool attr_set = false;  // per instantiation
@@ -1245,7 +1247,7 @@ int launch(const da_gemm_params& p, hipStream_t s) {
       return DA_ERR_LAUNCH;
     attr_set = true;
   }
-  DA_LAUNCH(kern, dim3(grid), dim3(512), lds, s, p, gx | (CONV ? conv_chunk_slices(p) << 8 : 0));
+  DA_LAUNCH(kern, dim3(grid), dim3(512), lds, s, p, gx | (CONV ? conv_chunk_slices(p, rows_xcd) << 8 : 0));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

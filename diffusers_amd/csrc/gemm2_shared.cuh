@@ -80,7 +80,10 @@ __device__ __forceinline__ void epilogue4(const da_gemm_params& p, float* o, int
 }
 
 // ---- host side ----
-inline int choose_xcd_gx2(int tiles_m, int tiles_n, int BM, int BN) {   // as da_gemm::choose_xcd_gx
+// `wrow`: bytes of one weight row relative to one activation row (1 for nn.Linear; a k x k conv's weight row is k * k activation rows
+// long, and the taps' re-reads of the activations are L2 hits as long as the XCD's rows of a tap sweep stay resident: the rectangle's
+// weight rows are weighed by it -- fewer XCDs then fetch each weight row of a deep-K conv; xcd_conv_weighting() below).
+inline int choose_xcd_gx2(int tiles_m, int tiles_n, int BM, int BN, int wrow = 1, long long arow_bytes = 0) {   // as da_gemm::choose_xcd_gx
   // experiments: DA_XCD_GX = 1 / 2 / 4 / 8 pins the number of XCD columns (1: every XCD owns whole row panels -- it reads rows the
   // previous launch's same-numbered XCD wrote; 8: whole column panels -- each weight row is fetched by one XCD only)
   static const int forced = [] { const char* v = getenv("DA_XCD_GX"); return v ? atoi(v) : 0; }();
@@ -91,7 +94,9 @@ inline int choose_xcd_gx2(int tiles_m, int tiles_n, int BM, int BN) {   // as da
     const int gy = 8 / gx;
     const int tm_per = (tiles_m + gy - 1) / gy, tn_per = (tiles_n + gx - 1) / gx;
     const double inflation = (double)(8 * tm_per * tn_per) / ((double)tiles_m * tiles_n);
-    const double cost = ((double)tm_per * BM + (double)tn_per * BN) * inflation * inflation;
+    double cost = ((double)tm_per * BM + (double)tn_per * BN * wrow) * inflation * inflation;
+    // weighted form only: a rectangle whose activation rows (all channels) do not stay in the 4 MiB L2 pays them once per tap
+    if (wrow > 1 && (double)tm_per * BM * (double)arow_bytes > 2.75 * 1048576.0) cost = ((double)tm_per * BM + (double)tn_per * BN) * wrow * inflation * inflation;
     if (cost < best_cost) {
       best_cost = cost;
       best = gx;
@@ -100,16 +105,37 @@ inline int choose_xcd_gx2(int tiles_m, int tiles_n, int BM, int BN) {   // as da
   return best;
 }
 
-// Channel chunk of a k x k conv's K order, in 64-wide slices (gemm2_kernel.cuh "K order of a k x k conv: CHUNKED").  DEFAULT 0 = the
-// tap-major order of rounds 1-5; DA_CONV_CHUNK = n pins chunks of n channels (multiples of 64).  Measured (round 6, same box, SDXL
+// Channel chunk of a k x k conv's K order, in 64-wide slices (gemm2_kernel.cuh "K order of a k x k conv: CHUNKED").  First form: ONE
+// chunk size for every k x k conv, DA_CONV_CHUNK = n channels (multiples of 64).  Measured (round 6, same box, SDXL
 // image, images/s): tap-major 0.9869 / 0.9923, chunks of 128 channels 0.9689 / 0.9710, 256: 0.9802, 512: 0.9885 -- the chunked order
 // cuts the fetched bytes of the deep-K convs by up to 5.5x (profiles/r06_sdxl_traffic_conv_chunk128.md: 404 -> 74 MB at
 // M 32768 x N 320 x K 5760) and LOSES 2 % of the image, because a tap change recomputes the per-lane gather offsets (now every slice
-// pair instead of every C / 64 slices) and these launches were not bound by the fabric in the first place.  Kept as a knob.
-inline int conv_chunk_slices(const da_gemm_params& p) {
-  static const int forced = [] { const char* v = getenv("DA_CONV_CHUNK"); return v ? atoi(v) : 0; }();
+// pair instead of every C / 64 slices) and these launches were not bound by the fabric in the first place.
+// Round 6, second form (DEFAULT; DA_CONV_CHUNK=0 restores the tap-major order everywhere, DA_CONV_CHUNK=<n> pins chunks of n channels):
+// chunk only the launches whose tap sweep does NOT stay in the L2 -- the rows of the tiles co-resident on an XCD (`rows_xcd`: 32 CUs,
+// one tile each, the rectangle's column tiles sharing rows) x all channels x 2 B above 3 MiB -- with the largest chunk whose sweep is
+// <= 2 MiB, and only if that chunk is >= 256 channels (a tap change, with its per-lane offset recompute, at most every fourth slice).
+// Shallow convs and the VAE's 128 / 256-channel levels keep the tap-major order.  Measured in situ (profiles/r06c_conv_knobs.md):
+// M 32768 x N 320 x K 5760 fetches 74 MB instead of 403 and runs 114 instead of 120 us, K 8640: 111 instead of 605 MB, 166 instead of
+// 173 us; M 8192 x N 640 x K 17280 235 instead of 454 MB at the same time; every other launch of the step is untouched; the image is
+// the same speed within the pair-to-pair spread (same box: 0.9870 / 0.9863 tap-major, 0.9865 / 0.9897 auto).
+inline int conv_chunk_slices(const da_gemm_params& p, long long rows_xcd = 0) {
+  static const int forced = [] { const char* v = getenv("DA_CONV_CHUNK"); return v ? (v[0] == 'a' ? -1 : atoi(v)) : -1; }();
   if (p.conv <= 1) return 0;
+  if (forced < 0) {
+    const long long ctot = p.C1 + p.C2;
+    if (rows_xcd <= 0 || rows_xcd * ctot * 2 <= 3ll * 1048576) return 0;
+    const long long ch = (2ll * 1048576 / (rows_xcd * 2)) / 64;
+    return (ch < 4 || ch * 64 >= ctot) ? 0 : (int)ch;
+  }
   return forced > 0 ? forced / 64 : 0;
+}
+// XCD rectangle of a k x k conv (DEFAULT on; DA_XCD_CONV=0 = the nn.Linear rule for every launch): weight rows count k * k times.  A
+// mapping only -- every tile computes the same sums -- so results are bit-identical.  In situ: M 2048 x N 1280 x K 11520 (ten launches
+// of a step) fetches 87 MB instead of 134, K 5760 36 instead of 65, M 8192 x N 640 x K 5760 60 instead of 80; times within 2 %.
+inline int xcd_conv_weighting(const da_gemm_params& p) {
+  static const int on = [] { const char* v = getenv("DA_XCD_CONV"); return v ? atoi(v) : 1; }();
+  return (on && p.conv > 1) ? p.conv * p.conv : 1;
 }
 
 // 31-bit offset budget of the buffer-addressed staging (as da_gemm::buffer_staging_fits, for tiles up to 256 rows)

@@ -21,10 +21,17 @@ extern "C" int da_set_launch_events(void* start_event, void* stop_event) {
   return DA_OK;
 }
 
-extern "C" int da_take_launch_events(hipEvent_t* start, hipEvent_t* stop) {
-  if (!g_ev_stop) return 0;
+static thread_local unsigned g_launch_flags = 0;
+extern "C" int da_set_launch_flags(unsigned flags) {
+  g_launch_flags = flags;
+  return DA_OK;
+}
+
+extern "C" int da_take_launch_events(hipEvent_t* start, hipEvent_t* stop, unsigned* flags) {
+  if (!g_ev_stop && !g_launch_flags) return 0;
   *start = g_ev_start;
   *stop = g_ev_stop;
+  *flags = g_launch_flags;
   g_ev_start = nullptr;
   return 1;
 }

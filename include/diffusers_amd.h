@@ -110,6 +110,11 @@ size_t da_sizeof_attention_params(void);
  * profiler reports it -- an event pair recorded around the call from the host also counts the marker packets' own processing.
  * Both or neither must be NULL.  Launch results do not depend on it. */
 int da_set_launch_events(void* start_event, void* stop_event);
+/* Experiment hook (no reference counterpart; tools/probe_anyorder.py): the `flags` word hipExtLaunchKernelGGL receives for every
+ * later launch of the calling thread (1 = hipExtAnyOrderLaunch: the dispatch packet is queued WITHOUT its barrier bit, so it may
+ * start before earlier launches of its stream have finished -- only for launches the caller knows to be independent).  0 = the
+ * ordinary in-order launch (default).  Not recorded by launch plans. */
+int da_set_launch_flags(unsigned flags);
 /* Box normaliser (no reference counterpart; bench.py `config.box_mfma_tflops`): a register-only loop of
  * v_mfma_f32_32x32x16_bf16 -- `blocks` workgroups of four waves, `iters` x 16 MFMAs per wave, no memory traffic.  Its rate is the
  * matrix pipe's issue rate times the clock THIS box sustains under matrix load; the pool's boxes differ by +- 8 % on one build, so

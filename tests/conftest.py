@@ -1,5 +1,12 @@
+import os
 import sys
 from pathlib import Path
+
+# The CPU suite runs tiny models through the kernel stand-ins (torch ops on bf16 tensors of a few KB): with torch's default of one
+# intra-op thread per core every such op pays a fork / join across 8 threads and the suite takes 15 minutes instead of 2.  Two threads,
+# set before torch is imported so that the ranks the distributed tests spawn inherit it.  A GPU box keeps its defaults.
+if not os.path.exists("/dev/kfd"):
+    os.environ.setdefault("OMP_NUM_THREADS", "2")
 
 import numpy as np
 import pytest

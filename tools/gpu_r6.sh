@@ -170,3 +170,41 @@ if [[ $WHAT == *r05ab* ]]; then
     done
   done
 fi
+if [[ $WHAT == *anyorder* ]]; then
+  hipcc --offload-arch=gfx950 -O2 -Iinclude tools/probe_anyorder.cpp -Ldiffusers_amd/_C -ldiffusers_amd -Wl,-rpath,$R/diffusers_amd/_C -o /tmp/probe_anyorder 2> $O/probe_anyorder_build.log; echo "probe build rc=$?"
+  timeout 300 /tmp/probe_anyorder > $O/r06c_anyorder_probe.jsonl 2> $O/probe_anyorder.err; echo "probe rc=$?"; cat $O/r06c_anyorder_probe.jsonl | cut -c1-220
+fi
+if [[ $WHAT == *convknobs* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  for v in base chunkauto xcdconv both; do
+    case $v in base) E="";; chunkauto) E="DA_CONV_CHUNK=auto";; xcdconv) E="DA_XCD_CONV=1";; both) E="DA_CONV_CHUNK=auto DA_XCD_CONV=1";; esac
+    rm -rf $O/pmc_ck_$v; mkdir -p $O/pmc_ck_$v
+    env $E DIFFUSERS_AMD_TUNE=0 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum -f csv -d $O/pmc_ck_$v/a -o sdxl -- python $R/tools/pmc_one_step.py 2 $O/pmc_ck_$v/launch_log.json > $O/pmc_ck_$v/a.log 2>&1; echo "pmc $v rc=$?"
+    (cd $R && python tools/pmc_insitu.py $O/pmc_ck_$v/launch_log.json 140 $O/r06c_insitu_$v.md $O/pmc_ck_$v/a > /dev/null 2>> $O/pmc_ck_$v/a.log)
+    find $O/pmc_ck_$v -name '*.csv' -size +4M -delete
+  done
+  cd $R
+  python - <<'PY'
+import json, os
+O = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out"
+tabs = {v: json.load(open(f"{O}/r06c_insitu_{v}.json")) for v in ("base", "chunkauto", "xcdconv", "both") if os.path.exists(f"{O}/r06c_insitu_{v}.json")}
+if "base" in tabs:
+    print("| population | " + " | ".join(f"{v} us / MB fetched" for v in tabs) + " |")
+    for k in tabs["base"]:
+        if "conv" not in k.split("::")[0]:
+            continue
+        cells = []
+        for v, t in tabs.items():
+            m = [e for kk, e in t.items() if kk.split("::")[0] == k.split("::")[0]]
+            cells.append(f"{m[0]['us_profiled']:.1f} / {m[0].get('TCC_EA0_RDREQ_sum', 0) * 128 / 1e6:.0f}" if m else "-")
+        print(f"| {k.split('::')[0]} | " + " | ".join(cells) + " |")
+PY
+fi
+if [[ $WHAT == *convab* ]]; then
+  for pass in 1 2; do
+  for v in base chunkauto xcdconv both; do
+    case $v in base) E="";; chunkauto) E="DA_CONV_CHUNK=auto";; xcdconv) E="DA_XCD_CONV=1";; both) E="DA_CONV_CHUNK=auto DA_XCD_CONV=1";; esac
+    env $E timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_ck_$v.json 2> $O/bench_ck_$v.err; echo "conv knobs $v rc=$? $(cut -c1-140 $O/bench_ck_$v.json | grep -o '"value": [0-9.]*')"
+  done
+  done
+fi
