@@ -110,8 +110,8 @@ int stats_parts(const da_gemm_params& p, int tile) {   // one partial per column
 bool tile_ok(const da_gemm_params& p, int tile) {
   if (tile <= 0 || tile >= kNumTiles) return false;
   if (is_k3(tile)) {  // nn.Linear, plain or GEGLU epilogue, nothing that needs the other families' extra instantiations
-    if (p.conv || p.split_k > 1 || p.stats_out || p.ln_stats || p.vt || p.xa_k) return false;
-    if (tile == DA_TILE_K3_256x320)   // the GEGLU projection's tile: whole tiles, aligned output rows
+    if (p.conv || p.split_k > 1 || p.stats_out || (p.ln_stats && tile != DA_TILE_K3_256x320) || p.vt || p.xa_k) return false;
+    if (tile == DA_TILE_K3_256x320)   // the GEGLU projection's tile: whole tiles, aligned output rows (round 6: also as a LayerNorm-fold consumer)
       return (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH) && (p.M % 256) == 0 && (p.N % 320) == 0 && !(p.ldc & 7) &&
              !((size_t)p.C & 15);
     return true;

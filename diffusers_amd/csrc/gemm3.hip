@@ -475,8 +475,11 @@ constexpr int G_BM = 256, G_BN = 320;
 constexpr int G_AH = 128 * 128, G_BH = 160 * 128;          // bytes of an A / B half-tile
 constexpr int G_KBUF = 2 * G_AH + 2 * G_BH;                // 72 KiB per slice
 constexpr int G_DUMP = 2 * G_KBUF, G_BIAS = G_DUMP + 1024, G_LDS = G_BIAS + 1024;
+// LayerNorm fold, consumer side (round 6: norm3 -> ff.net.0.proj on this tile; attention.py:1056, da_gemm_params.ln_*): the tile's 320
+// s[n] and c[n] (fp32, packed column order like the bias) and the (mean, rstd) of its 256 rows, behind the bias KiB
+constexpr int G_LNS = G_LDS, G_LNC = G_LNS + 2048, G_LNROW = G_LNC + 2048, G_LDS_LNF = G_LNROW + G_BM * 8;   // (2 KiB each: an LDS-DMA piece writes all 64 lanes)
 
-template <int PRIO>
+template <int PRIO, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm3_geglu_kernel(const da_gemm_params p, const int xcd_gx) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -548,6 +551,25 @@ __global__ __launch_bounds__(512) void gemm3_geglu_kernel(const da_gemm_params p
                                                             p.bias ? (size_t)G_BN * 2 : 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bias, K3_LDS(smem + G_BIAS), 16, lane * 16, 0, 0, 0);
   }
+  // LayerNorm fold: the statistics partials of the tile's 256 rows -- four lanes per row, six (sum, sum of squares) slots = three
+  // 16-byte loads each, rows t / 4 and 128 + t / 4, exactly the slots / order the other families' consumers read (gemm2_kernel.cuh
+  // ln_load) -- and the tile's s / c by LDS-DMA (waves 1 and 2: 1280 bytes = two pieces, range-checked).  Issued FIRST: older than every
+  // staged piece, so the "slice 0 landed" wait covers them and the loop's counted waits never see them.
+  float4 lq[LNF ? 2 : 1][3];
+  if constexpr (LNF) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const float* sp = p.ln_stats + (size_t)(m0 + 128 * rr + (t >> 2)) * p.ln_stats_ld;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) lq[rr][u] = *(const float4*)(sp + ((6 * (t & 3) + 2 * u < p.ln_parts) ? 12 * (t & 3) + 4 * u : 0));
+    }
+    if (wave == 1 || wave == 2) {
+      __amdgpu_buffer_rsrc_t rs_sc = da_gemm2::uniform_rsrc((wave == 1 ? p.ln_s : p.ln_c) + n0, (size_t)G_BN * 4);
+      unsigned char* dst = smem + (wave == 1 ? G_LNS : G_LNC);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sc, K3_LDS(dst), 16, lane * 16, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sc, K3_LDS(dst + 1024), 16, lane * 16, 1024, 0, 0);
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- prologue: slice 0 whole, then B0 / A1 / B1 of slice 1 (its A0 leaves in P1 of slice 0: the loop's order) ----
@@ -560,14 +582,17 @@ __global__ __launch_bounds__(512) void gemm3_geglu_kernel(const da_gemm_params p
   stage(I1, I3, 1);
 
   f32x4_t acc[2][2][2][5];   // [A half][B half: value / gate][row tile][column tile]
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int hp = 0; hp < 2; ++hp)
+      for (int hp = 0; hp < 2; ++hp)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) acc[h][hp][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < 5; ++j) acc[h][hp][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  if constexpr (!LNF) zero_acc();    // (LNF: behind the statistics reduce, whose 24 registers die there)
 
   const int fsw = (r16 >> 1) & 7;
   const int foff0 = r16 * 128 + ((kq ^ fsw) << 4), foff1 = r16 * 128 + (((kq ^ fsw) ^ 4) << 4);
@@ -645,6 +670,39 @@ __global__ __launch_bounds__(512) void gemm3_geglu_kernel(const da_gemm_params p
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   G3_FENCE();
+  if constexpr (LNF) {
+    // (mean, rstd) of rows t / 4 and 128 + t / 4 -- the partials landed with slice 0 -- in the summation order of the other families'
+    // consumers (six slots per lane in slot order, then (a + b) + (c + d) across the row's four lanes); lane 0 of a row parks the pair
+    // in LDS for the epilogue, so nothing rides through the loop
+    const float inv_c = 1.0f / (float)p.K;
+    const int q4 = t & 3;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int q = 6 * q4 + 2 * u;
+        s1 += (q < p.ln_parts ? lq[rr][u].x : 0.f) + (q + 1 < p.ln_parts ? lq[rr][u].z : 0.f);
+        s2 += (q < p.ln_parts ? lq[rr][u].y : 0.f) + (q + 1 < p.ln_parts ? lq[rr][u].w : 0.f);
+      }
+      s1 += __shfl_xor(s1, 1, 64);
+      s2 += __shfl_xor(s2, 1, 64);
+      s1 += __shfl_xor(s1, 2, 64);
+      s2 += __shfl_xor(s2, 2, 64);
+      const float mean = s1 * inv_c;
+      const float rs = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + p.ln_eps);
+      // (written through inline asm: behind a C++ store to LDS the compiler waits for EVERY outstanding LDS-DMA piece -- vmcnt(0), i.e.
+      // slice 1's round trip in front of the loop -- because it cannot see that no piece lands here; the phases' lgkmcnt(0) retire it)
+      if (q4 == 0) {
+        const unsigned dst = (unsigned)(size_t)(smem + G_LNROW + (128 * rr + (t >> 2)) * 8);
+        const float2 mr = make_float2(mean, rs);
+        asm volatile("ds_write_b64 %0, %1" : : "v"(dst), "v"(mr));
+      }
+    }
+    G3_FENCE();
+    zero_acc();
+    G3_FENCE();
+  }
   if (wc == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind group 0 from here on
   if constexpr (PRIO == 2) {
     if (wc == 1) __builtin_amdgcn_s_setprio(1);
@@ -681,6 +739,45 @@ __global__ __launch_bounds__(512) void gemm3_geglu_kernel(const da_gemm_params p
   int tl = t;
   asm volatile("" : "+v"(tl));
   const int lane_e = tl & 63, r16_e = tl & 15, kq_e = (tl >> 4) & 3;
+  if constexpr (LNF) {
+    // LayerNorm fold: acc <- rstd (alpha acc - mu s[n]) + c[n], in place, in front of the bias -- the arithmetic (and statement structure:
+    // -ffp-contract=on fuses inside one expression only) of gemm2_kernel.cuh ln_apply4.  Column tile outermost: the lane's s / c quads of a
+    // value tile and its gate tile are read once and serve its four rows.
+    float2 mr[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mr[h][i] = *(const float2*)(smem + G_LNROW + (64 * wr + 32 * h + 16 * i + r16_e) * 8);
+    const float* lns = (const float*)(smem + G_LNS);
+    const float* lnc = (const float*)(smem + G_LNC);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int T = 5 * wc + j;
+      const int cv0 = 64 * (T >> 1) + 16 * (T & 1) + 4 * kq_e;   // packed column of the value quad; its gate quad: + 32
+      const float4 sv = *(const float4*)(lns + cv0), cv = *(const float4*)(lnc + cv0);
+      const float4 sg = *(const float4*)(lns + cv0 + 32), cg = *(const float4*)(lnc + cv0 + 32);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float ln_mu = mr[h][i].x, ln_rs = mr[h][i].y;
+          float hq[4], gq[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hq[e] = acc[h][0][i][j][e] * p.alpha, gq[e] = acc[h][1][i][j][e] * p.alpha;
+          hq[0] = ln_rs * (hq[0] - ln_mu * sv.x) + cv.x;
+          hq[1] = ln_rs * (hq[1] - ln_mu * sv.y) + cv.y;
+          hq[2] = ln_rs * (hq[2] - ln_mu * sv.z) + cv.z;
+          hq[3] = ln_rs * (hq[3] - ln_mu * sv.w) + cv.w;
+          gq[0] = ln_rs * (gq[0] - ln_mu * sg.x) + cg.x;
+          gq[1] = ln_rs * (gq[1] - ln_mu * sg.y) + cg.y;
+          gq[2] = ln_rs * (gq[2] - ln_mu * sg.z) + cg.z;
+          gq[3] = ln_rs * (gq[3] - ln_mu * sg.w) + cg.w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[h][0][i][j][e] = hq[e], acc[h][1][i][j][e] = gq[e];
+        }
+    }
+    G3_FENCE();
+  }
   uint2 bias_v[2][5];
 #pragma unroll
   for (int hp = 0; hp < 2; ++hp)
@@ -702,10 +799,15 @@ __global__ __launch_bounds__(512) void gemm3_geglu_kernel(const da_gemm_params p
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           const uint2 bh = bias_v[0][j], bg = bias_v[1][j];      // zeros without a bias
-          float o[4];
+          float o[4], hq[4], gq[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float hv = acc[h][0][i][j][e] * p.alpha, gv = acc[h][1][i][j][e] * p.alpha;
+            hq[e] = LNF ? acc[h][0][i][j][e] : acc[h][0][i][j][e] * p.alpha;    // (LNF: alpha and the fold were applied above)
+            gq[e] = LNF ? acc[h][1][i][j][e] : acc[h][1][i][j][e] * p.alpha;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float hv = hq[e], gv = gq[e];
             hv += (e == 0) ? bf_lo(bh.x) : (e == 1) ? bf_hi(bh.x) : (e == 2) ? bf_lo(bh.y) : bf_hi(bh.y);
             gv += (e == 0) ? bf_lo(bg.x) : (e == 1) ? bf_hi(bg.x) : (e == 2) ? bf_lo(bg.y) : bf_hi(bg.y);
             hv = bf2f(f2bf(hv));   // the reference rounds the projection to bf16 before chunk / gelu / mul
@@ -742,18 +844,19 @@ __global__ __launch_bounds__(512) void gemm3_geglu_kernel(const da_gemm_params p
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int PRIO>
+template <int PRIO, bool LNF = false>
 int launch_geglu_prio(const da_gemm_params& p, hipStream_t s) {
   const int tiles_m = p.M / G_BM, tiles_n = p.N / G_BN;
   const int gx = da_gemm2::choose_xcd_gx2(tiles_m, tiles_n, G_BM, G_BN), gy = 8 / gx;
   const int grid = 8 * ((tiles_m + gy - 1) / gy) * ((tiles_n + gx - 1) / gx);
-  auto kern = gemm3_geglu_kernel<PRIO>;
+  auto kern = gemm3_geglu_kernel<PRIO, LNF>;
+  constexpr int LDSB = LNF ? G_LDS_LNF : G_LDS;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess) return DA_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) return DA_ERR_LAUNCH;
     attr_set = true;
   }
-  DA_LAUNCH(kern, dim3(grid), dim3(512), G_LDS, s, p, gx);
+  DA_LAUNCH(kern, dim3(grid), dim3(512), LDSB, s, p, gx);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -774,11 +877,18 @@ int launch(const da_gemm_params& p, hipStream_t s) {
 // nn.Linear, one ring form (DA_STAGE_LDS_DIRECT), no split-K / LayerNorm fold / transposed block / cross-attention epilogue
 int dispatch_lin(const da_gemm_params& p, int tile, int staging, hipStream_t s) {
   if ((tile != DA_TILE_K3_256x256 && tile != DA_TILE_K3_256x320) || staging != DA_STAGE_LDS_DIRECT) return DA_ERR_UNSUPPORTED;
-  if (p.conv || p.split_k > 1 || p.stats_out || p.ln_stats || p.vt || p.xa_k || !da_gemm2::staging_fits(p)) return DA_ERR_UNSUPPORTED;
+  if (p.conv || p.split_k > 1 || p.stats_out || (p.ln_stats && tile != DA_TILE_K3_256x320) || p.vt || p.xa_k || !da_gemm2::staging_fits(p))
+    return DA_ERR_UNSUPPORTED;
   const bool geglu = (p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH);
   if (tile == DA_TILE_K3_256x320) {   // the GEGLU projection's tile: whole tiles only, 16-byte aligned output rows
     if (!geglu || (p.M % G_BM) || (p.N % G_BN) || (p.ldc & 7) || ((size_t)p.C & 15)) return DA_ERR_UNSUPPORTED;
     static const int prio = [] { const char* v = getenv("DA_K3_PRIO"); return v ? atoi(v) : 2; }();
+    if (p.ln_stats) {   // LayerNorm fold, consumer side: 16-byte aligned s / c and partials (da_gemm.hip checked the rest)
+      if (((size_t)p.ln_s & 15) || ((size_t)p.ln_c & 15) || ((size_t)p.ln_stats & 15)) return DA_ERR_UNSUPPORTED;
+      if (prio == 0) return launch_geglu_prio<0, true>(p, s);
+      if (prio == 1) return launch_geglu_prio<1, true>(p, s);
+      return launch_geglu_prio<2, true>(p, s);
+    }
     if (prio == 0) return launch_geglu_prio<0>(p, s);
     if (prio == 1) return launch_geglu_prio<1>(p, s);
     return launch_geglu_prio<2>(p, s);

@@ -367,6 +367,14 @@ class FeedForwardGEGLU:
             self.fold = ops.LNFold(fold.s.index_select(0, order).contiguous(), fold.c.index_select(0, order).contiguous(),
                                    fold.eps)
 
+    def folds_here(self, rows: int) -> bool:
+        """ops.LN_FOLD == 3 (default): fold norm3 only where the folded launch runs on the GEGLU projection's own eight-phase tile
+        (ops.geglu_fold_on_k3: the shipped table sends the shape there) -- measured: + 1.4 % on an SDXL image there, a loss on the
+        tiles SD1.5's 32 x 32 / 16 x 16 levels use (profiles/r06d_*)."""
+        if self.w1_ln is None:
+            return False
+        return int(ops.LN_FOLD) == 1 or ops.geglu_fold_on_k3(rows, self.w1_ln.shape[0], self.w1_ln.shape[1])
+
     def __call__(self, x, residual, stats=None, stats_out=None):
         if stats is not None:
             h = ops.linear(x, self.w1_ln, self.b1, act=L.ACT_GEGLU, ln=(stats, self.fold))
@@ -386,8 +394,8 @@ class BasicTransformerBlock:
         self.norm3 = LayerNorm(w, prefix + ".norm3")
         # the folded copies (a second GEGLU up-projection, a second to_q, fp32 s / c vectors: ~1.7 GB for SDXL) exist only
         # when the opt-in fold was on at LOAD time; it is part of the packed-cache fingerprint (loading.py)
-        self.folded = int(ops.LN_FOLD)          # 0 off, 1 norm2 + norm3, 2 norm2 only (ops.LN_FOLD)
-        self.ff = FeedForwardGEGLU(w, prefix + ".ff", norm=self.norm3 if self.folded == 1 else None)
+        self.folded = int(ops.LN_FOLD)          # 0 off, 1 norm2 + norm3, 2 norm2 only, 3 norm2 + norm3 where it pays (ops.LN_FOLD)
+        self.ff = FeedForwardGEGLU(w, prefix + ".ff", norm=self.norm3 if self.folded in (1, 3) else None)
         if self.folded:
             self.attn2.fold_norm(self.norm2)
             self.attn1.fold_norm1(self.norm1)
@@ -398,7 +406,7 @@ class BasicTransformerBlock:
         norm1 is then applied inside the fused Q | K | V projection instead of as a kernel.  ``stats_out``: the FF-down of this
         block writes the statistics of ITS output there (for the next block's norm1)."""
         mode = int(ops.LN_FOLD)
-        if mode and (not self.folded or (mode == 1 and self.folded != 1)):
+        if mode and (not self.folded or (mode in (1, 3) and self.folded not in (1, 3))):
             raise RuntimeError("ops.LN_FOLD was switched on after this model was loaded: the folded weights are built at "
                                "load_state_dict() time (set DIFFUSERS_AMD_LN_FOLD / ops.LN_FOLD before loading)")
         if not mode:
@@ -420,13 +428,17 @@ class BasicTransformerBlock:
         # residual stream they produce, and attn2.to_q / the GEGLU projection apply the normalisation in their epilogue
         # (ops.linear(ln=)).  norm1 stays a kernel: its consumers are the Q|K projection AND the swapped V^T product,
         # where the normalised tokens are the column operand.
-        st1, st2 = ops.RowStats(x.shape[0], x.device), ops.RowStats(x.shape[0], x.device)
+        fold3 = self.ff.folds_here(x.shape[0])      # (mode 3: per shape; mode 1: always)
+        st1 = ops.RowStats(x.shape[0], x.device)
+        st2 = ops.RowStats(x.shape[0], x.device) if fold3 else None
         if use1:
             x = self.attn1(x, batch, seq, residual=x, stats=stats_in, stats_out=st1)
         else:
             x = self.attn1(self.norm1(x), batch, seq, residual=x, stats_out=st1)
         x = self.attn2(x, batch, seq, residual=x, kv=kv, stats=st1, stats_out=st2)
-        return self.ff(x, residual=x, stats=st2, stats_out=stats_out)
+        if fold3:
+            return self.ff(x, residual=x, stats=st2, stats_out=stats_out)
+        return self.ff(self.norm3(x), residual=x, stats_out=stats_out)
 
 
 class Transformer2DModel:

@@ -166,9 +166,15 @@ def splitk_error(device=None) -> bool:
 # Round 4: the second kernel family carries the fold.  Modes: 0 = off; 2 = norm2 only (attn1.to_out writes the statistics, attn2.to_q
 # applies them; measured: to_out > LayerNorm > to_q 42.7 -> 32.5 us per chain at the 1280 level, 40.7 -> 32.7 at 640,
 # profiles/r04b_layernorm_fold_k2.jsonl); 1 (or True) = norm2 and norm3 (the GEGLU projection as the second consumer).
-LN_FOLD = int(os.environ.get("DIFFUSERS_AMD_LN_FOLD", "2"))
+# Round 6: 3 (default) = norm2 everywhere and norm3 WHERE THE FOLDED GEGLU LAUNCH RUNS ON ITS OWN EIGHT-PHASE TILE (k3:256x320 carries the
+# consumer side since this round: geglu_fold_on_k3 below).  Same box, SDXL image: mode 2 0.9704 / 0.9716, mode 3 0.9836 / 0.9850
+# (+ 1.4 %: 60 of the 70 LayerNorm launches left in a step disappear), mode 1 with the folded launch on k1:128x320 0.9332; parity
+# unchanged (46.0 dB vs the reference in fp32); SD1.5, whose 32 x 32 / 16 x 16 levels run other tiles, loses 1.2 % under mode 1 and is
+# what the per-shape rule is for (profiles/r06d_layernorm_fold_k3.txt).
+LN_FOLD = int(os.environ.get("DIFFUSERS_AMD_LN_FOLD", "3"))
 LN_FOLD_NORM1 = os.environ.get("DIFFUSERS_AMD_LN_FOLD_NORM1", "1") == "1"   # with LN_FOLD: norm1 too, through the fused Q | K | V projection
 LN_FOLD_K2 = os.environ.get("DIFFUSERS_AMD_LN_FOLD_K2", "1") == "1"   # folded launches may use the second kernel family (round 4)
+LN_FOLD_K3 = os.environ.get("DIFFUSERS_AMD_LN_FOLD_K3", "1") == "1"   # a folded GEGLU projection may use its eight-phase tile (round 6)
 STATS_MAX_PARTS = 64          # DA_LN_MAX_PARTS: slots per row of a statistics buffer
 STATS_MAX_CONSUMED = 24       # 4 * DA_LN_PAIR_LOADS: partials per row a consumer launch reads
 
@@ -183,6 +189,15 @@ class RowStats:
     def __init__(self, rows: int, device):
         self.buf = torch.empty((rows, STATS_MAX_PARTS, 2), device=device, dtype=torch.float32)
         self.parts = 0
+
+
+def geglu_fold_on_k3(rows: int, n_packed: int, k: int) -> bool:
+    """Does a LayerNorm-folded GEGLU projection of this shape run on the projection's own eight-phase tile?  (The shipped / live
+    table sends the UNFOLDED problem to k3:256x320, whole tiles; linear(ln=) then keeps that tile.)"""
+    if not (LN_FOLD_K3 and TUNING) or rows % 256 or n_packed % 320:
+        return False
+    ent = tuning.table().get(f"lin:M{tuning._m_key(int(rows))}:N{int(n_packed)}:K{int(k)}:a{L.ACT_GEGLU}:f0:r0")
+    return ent is not None and ent[0] == L.TILE_K3_256x320
 
 
 class LNFold:
@@ -499,10 +514,14 @@ def _linear_params(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         # launch takes that (tile, staging); otherwise the first family's fixed choices (profiles/r02d_layernorm_fold.md).
         geglu_ = act in (L.ACT_GEGLU, L.ACT_GEGLU_TANH)
         ent = tuning.table().get(tuning.key_of(p)) if TUNING else None
-        if geglu_ and ent is not None and ent[0] in (L.TILE_K1_256x256, L.TILE_K1_128x256, L.TILE_K1_256x128, L.TILE_K1_256x320,
-                                                     L.TILE_K3_256x256, L.TILE_K3_256x320):
+        # round 6: the GEGLU projection's own eight-phase tile (k3:256x320) carries the consumer side of the fold itself (whole tiles,
+        # statistics rows of 16-byte aligned slots); DIFFUSERS_AMD_LN_FOLD_K3=0 sends folded GEGLU launches back to k1:128x320
+        k3_geglu = (geglu_ and LN_FOLD_K3 and ent is not None and ent[0] == L.TILE_K3_256x320 and ln is not None and stats_out is None
+                    and M % 256 == 0 and N % 320 == 0)
+        if geglu_ and not k3_geglu and ent is not None and ent[0] in (L.TILE_K1_256x256, L.TILE_K1_128x256, L.TILE_K1_256x128,
+                                                                      L.TILE_K1_256x320, L.TILE_K3_256x256, L.TILE_K3_256x320):
             ent = (L.TILE_K1_128x320, L.STAGE_LDS_DIRECT) + tuple(ent[2:])     # the GEGLU tile of that family that carries the fold
-        k2_ok = (ent is not None and ent[0] in ((L.TILE_K1_128x320,) if geglu_ else (L.TILE_K2_128x80, L.TILE_K2_128x160))
+        k2_ok = (ent is not None and ent[0] in ((L.TILE_K1_128x320, L.TILE_K3_256x320) if geglu_ else (L.TILE_K2_128x80, L.TILE_K2_128x160))
                  and not out_f32 and p.ldc % 8 == 0 and out.data_ptr() % 16 == 0 and N % 16 == 0 and gate is None
                  and (residual is None or (p.ldr % 8 == 0 and residual.data_ptr() % 16 == 0))
                  and not (ent[0] == L.TILE_K2_128x160 and ent[1] in (L.STAGE_LDS_DIRECT3, L.STAGE_PINGPONG3))

@@ -69,8 +69,8 @@ extern "C" {
 #define DA_TILE_K1_256x320 19 /* 4 x 2 waves of 64 x 160, W fragments streamed (nn.Linear; GEGLU with interleaved tile ownership) */
 /* Third structure (K3, gemm3.hip; round 5): the 256 x 256 tile as an eight-phase loop, the two wave rows of the workgroup half a
  * phase apart (one multiplies while the other reads LDS and issues LDS-DMA).  nn.Linear only, staging DA_STAGE_LDS_DIRECT only; no
- * split_k / LayerNorm fold / transposed block / cross-attention epilogue.  Bit-identical to the K1 tiles above (same K order, same
- * epilogue). */
+ * split_k / transposed block / cross-attention epilogue; LayerNorm fold: DA_TILE_K3_256x320 as a CONSUMER only (round 6: ln_stats / ln_s /
+ * ln_c, 16-byte aligned), neither tile as a producer.  Bit-identical to the K1 tiles above (same K order, same epilogue). */
 #define DA_TILE_K3_256x256 20 /* 2 x 4 waves of 128 x 64 (64 contiguous columns per wave: GEGLU pairs inside the wave) */
 #define DA_TILE_K3_256x320 21 /* 4 x 2 waves of 64 x 160, GEGLU epilogue ONLY (a wave owns five value tiles and their gate tiles), M % 256
                                  == 0, N % 320 == 0, 16-byte aligned output rows: M 2048 x N 10240 = exactly 256 tiles (SDXL's ff.net.0.proj) */

@@ -153,6 +153,69 @@ def test_k3_geglu_tile_bit_identical_to_k1(M, N2, K, tanh):
     assert float(out[:, N2 // 2:].abs().max()) == 0.0, "wrote outside its column block"
 
 
+# Round 6: the tile as the CONSUMER of a folded LayerNorm (norm3 -> ff.net.0.proj, attention.py:1056-1080): statistics partials of
+# the producing launch (16 per row at C 1280, 8 at C 640, 3 / 24 for the slot masks), mean / rstd formed in the prologue, the fold applied
+# to the accumulators in front of the bias.
+@pytest.mark.parametrize("M,C,N2", [(2048, 1280, 10240), (8192, 640, 5120), (256, 192, 640), (512, 1920, 1280), (256, 320, 640)])
+@pytest.mark.parametrize("tanh", [False, True])
+def test_k3_geglu_tile_layernorm_fold_bit_identical_to_k1(M, C, N2, tanh):
+    ops, L = _ops()
+    act = L.ACT_GEGLU_TANH if tanh else L.ACT_GEGLU
+    a, wprod, res = rnd((M, 192), 71), rnd((C, 192), 72, 192 ** -0.5), rnd((M, C), 73)
+    res = res + 8.0 * (torch.arange(M, device=DEV) % 3 == 0).to(bf16)[:, None]      # rows with a large mean
+    gamma, beta = rnd((C,), 74) * 0.3 + 1.0, rnd((C,), 75) * 0.2
+    w1, b1 = rnd((N2, C), 76, C ** -0.5), rnd((N2,), 77)
+    w1l, fold1 = ops.fold_layernorm(w1, gamma, beta, 1e-5)
+    w1p, b1p = ops.pack_geglu(w1l, b1)
+    n2 = N2 // 2
+    idx = torch.arange(n2, device=DEV).view(n2 // 32, 32)
+    order = torch.cat([idx, idx + n2], dim=1).reshape(-1)
+    fold1p = ops.LNFold(fold1.s[order].contiguous(), fold1.c[order].contiguous(), fold1.eps)
+    st = ops.RowStats(M, DEV)
+    x = ops.linear(a, wprod, residual=res, tile=L.TILE_K2_128x80, staging=L.STAGE_PINGPONG, stats_out=st)
+    assert st.parts == (C + 79) // 80
+    y = k3g(ops, L, x, w1p, b1p, act=act, ln=(st, fold1p))
+    want = ops.linear(x, w1p, b1p, act=act, tile=L.TILE_K1_128x320, staging=L.STAGE_LDS_DIRECT, ln=(st, fold1p))
+    assert torch.equal(y, want), f"k3:256x320 + LayerNorm fold {M}x{N2}x{C}: {int((y != want).sum())} outputs differ from k1:128x320"
+    ln_ref = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5)
+    g = ln_ref @ w1.float().t() + b1.float()
+    h_, g_ = g.chunk(2, dim=-1)
+    ref = h_ * F.gelu(g_, approximate="tanh" if tanh else "none")
+    assert_close_bf16(y, ref, f"k3:256x320 LN fold + GEGLU {M}x{N2}x{C}", rtol=2.5e-2, atol_rms=2.5e-2, rel_rms_max=8e-3)
+    # the same launch again and again with other traffic in between (the statistics loads and the s / c pieces are the OLDEST loads of
+    # the prologue: the counted waits of the loop must never see them), and without a bias / with alpha
+    noise = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    for it in range(6):
+        if it % 2:
+            noise.fill_(it)
+        assert torch.equal(k3g(ops, L, x, w1p, b1p, act=act, ln=(st, fold1p)), want), f"launch {it} differs"
+    y2 = k3g(ops, L, x, w1p, act=act, alpha=0.5, ln=(st, fold1p))
+    assert torch.equal(y2, ops.linear(x, w1p, act=act, alpha=0.5, tile=L.TILE_K1_128x320, staging=L.STAGE_LDS_DIRECT, ln=(st, fold1p)))
+
+
+def test_k3_geglu_tile_layernorm_fold_is_the_automatic_choice():
+    """ops.linear(ln=) without a pinned tile follows the shipped table onto k3:256x320 for SDXL's GEGLU projections (round 6; rounds 4-5
+    sent the folded launch to k1:128x320) -- same bits either way."""
+    ops, L = _ops()
+    from diffusers_amd import tuning
+    M, C, N2 = 2048, 1280, 10240
+    a, wprod, res = rnd((M, 192), 81), rnd((C, 192), 82, 192 ** -0.5), rnd((M, C), 83)
+    gamma, beta = rnd((C,), 84) * 0.3 + 1.0, rnd((C,), 85) * 0.2
+    w1, b1 = rnd((N2, C), 86, C ** -0.5), rnd((N2,), 87)
+    w1l, fold1 = ops.fold_layernorm(w1, gamma, beta, 1e-5)
+    w1p, b1p = ops.pack_geglu(w1l, b1)
+    idx = torch.arange(N2 // 2, device=DEV).view(N2 // 64, 32)
+    order = torch.cat([idx, idx + N2 // 2], dim=1).reshape(-1)
+    fold1p = ops.LNFold(fold1.s[order].contiguous(), fold1.c[order].contiguous(), fold1.eps)
+    st = ops.RowStats(M, DEV)
+    x = ops.linear(a, wprod, residual=res, stats_out=st)
+    ent = tuning.table().get(f"lin:M{M}:N{N2}:K{C}:a{L.ACT_GEGLU}:f0:r0")
+    if ent is None or ent[0] != L.TILE_K3_256x320:
+        pytest.skip("the table in use does not send this shape to k3:256x320")
+    y = ops.linear(x, w1p, b1p, act=L.ACT_GEGLU, ln=(st, fold1p))
+    assert torch.equal(y, k3g(ops, L, x, w1p, b1p, act=L.ACT_GEGLU, ln=(st, fold1p)))
+
+
 def test_k3_geglu_tile_race_screen():
     ops, L = _ops()
     M, N2, K = 2048, 10240, 1280

@@ -28,10 +28,11 @@ def _emulated_kernels(monkeypatch):
     monkeypatch.setattr(ops, "TUNING", False)
 
 
-@pytest.mark.parametrize("fold", [0, 1, 2])
+@pytest.mark.parametrize("fold", [0, 1, 2, 3])
 @pytest.mark.parametrize("name,added", [("tiny_unet_sdxl", True), ("tiny_unet_sd15", False)])
 def test_unet2d_condition(golden, name, added, fold, monkeypatch):
-    """``fold``: the LayerNorm fold (ops.LN_FOLD: 0 off, 1 norm2 + norm3, 2 norm2 only -- applied inside the GEMMs either side of them)."""
+    """``fold``: the LayerNorm fold (ops.LN_FOLD: 0 off, 1 norm2 + norm3, 2 norm2 only, 3 = the default: norm2, and norm3 where the folded
+    GEGLU launch runs on its eight-phase tile -- applied inside the GEMMs either side of them)."""
     from diffusers_amd.unet_2d_condition import UNet2DConditionModel
     monkeypatch.setattr(ops, "LN_FOLD", fold)
     cfg = dinit.TINY_SDXL_UNET if added else dinit.TINY_SD15_UNET
@@ -54,7 +55,29 @@ MID_SDXL_UNET = dict(sample_size=8, in_channels=4, out_channels=4, block_out_cha
                      projection_class_embeddings_input_dim=256)
 
 
-@pytest.mark.parametrize("fold", [0, 2, 1])
+def test_norm3_fold_is_decided_per_shape(monkeypatch):
+    """ops.LN_FOLD == 3: FeedForwardGEGLU.folds_here follows the table -- a shape the table sends to k3:256x320 (whole tiles) folds norm3
+    into the projection, every other shape keeps the norm3 launch; mode 1 folds always; without folded weights never."""
+    from diffusers_amd import _lib as LL
+    from diffusers_amd import tuning
+    from diffusers_amd.layers import FeedForwardGEGLU
+    ff = FeedForwardGEGLU.__new__(FeedForwardGEGLU)
+    ff.w1_ln = torch.zeros((10240, 1280), dtype=torch.bfloat16)
+    tab = {f"lin:M2048:N10240:K1280:a{LL.ACT_GEGLU}:f0:r0": [LL.TILE_K3_256x320, LL.STAGE_LDS_DIRECT, 50.0, 1],
+           f"lin:M512:N10240:K1280:a{LL.ACT_GEGLU}:f0:r0": [LL.TILE_K2_128x128, LL.STAGE_LDS_DIRECT, 30.0, 1]}
+    monkeypatch.setattr(tuning, "table", lambda: tab)
+    monkeypatch.setattr(ops, "TUNING", True)
+    monkeypatch.setattr(ops, "LN_FOLD", 3)
+    assert ff.folds_here(2048) and not ff.folds_here(512) and not ff.folds_here(4096) and not ff.folds_here(2048 + 128)
+    monkeypatch.setattr(ops, "LN_FOLD_K3", False)
+    assert not ff.folds_here(2048)
+    monkeypatch.setattr(ops, "LN_FOLD", 1)
+    assert ff.folds_here(512) and ff.folds_here(2048)
+    ff.w1_ln = None
+    assert not ff.folds_here(2048)
+
+
+@pytest.mark.parametrize("fold", [0, 2, 1, 3])
 def test_norm1_fold_through_the_fused_qkv_projection(fold, monkeypatch):
     """SDXL's head geometry (heads of 64, inner widths 320 / 640: 2 * inner is a multiple of 80) at a small size: with the LayerNorm
     fold on, the producer of every block input (proj_in, then each FF-down) writes row statistics and norm1 is applied inside ONE
@@ -82,7 +105,8 @@ def test_norm1_fold_through_the_fused_qkv_projection(fold, monkeypatch):
     blocks = sum(len(tr.blocks) for tr in unet._transformers())
     if fold:
         assert calls["qkv"] == blocks and calls["pair"] == 0, calls       # every self-attention took the fused projection
-        assert calls["ln"] == (blocks if fold == 2 else 0), calls         # norm3 stays a kernel in mode 2; nothing is left in mode 1
+        # norm3 stays a kernel in mode 2 -- and in mode 3 here, where no shape has a table entry on k3:256x320; nothing is left in mode 1
+        assert calls["ln"] == (blocks if fold in (2, 3) else 0), calls
     else:
         assert calls["qkv"] == 0 and calls["pair"] == blocks and calls["ln"] == 3 * blocks, calls
     cfg = dict(UD)

@@ -19,7 +19,7 @@ def t(g, k, dtype=bf16):
     return torch.from_numpy(g[k]).to(dtype).to(DEV)
 
 
-@pytest.mark.parametrize("fold", [0, 1, 2])
+@pytest.mark.parametrize("fold", [0, 1, 2, 3])
 @pytest.mark.parametrize("name,added", [("tiny_unet_sdxl", True), ("tiny_unet_sd15", False)])
 def test_tiny_unet_vs_reference(golden, name, added, fold, monkeypatch):
     from diffusers_amd import factory, init as dinit, ops

@@ -208,3 +208,21 @@ if [[ $WHAT == *convab* ]]; then
   done
   done
 fi
+if [[ $WHAT == *lnf3test* ]]; then
+  timeout 1500 python -m pytest tests/test_gemm_k3_gpu.py tests/test_gemm_k2_gpu.py -m gpu -q --timeout 900 -k "geglu or fold or LN or ln" > $O/pytest_lnf3.log 2>&1; echo "pytest lnf3 rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert" $O/pytest_lnf3.log | tail -20
+fi
+if [[ $WHAT == *lnf3ab* ]]; then
+  for pass in 1 2; do
+  for m in 2 1; do
+    DIFFUSERS_AMD_LN_FOLD=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_lnf$m.json 2> $O/bench_lnf$m.err; echo "LN_FOLD=$m rc=$? $(cut -c1-140 $O/bench_lnf$m.json | grep -o '"value": [0-9.]*')"
+  done
+  done
+  DIFFUSERS_AMD_LN_FOLD=1 DIFFUSERS_AMD_LN_FOLD_K3=0 timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_lnf1k1.json 2> $O/bench_lnf1k1.err; echo "LN_FOLD=1 on k1:128x320 rc=$? $(cut -c1-140 $O/bench_lnf1k1.json | grep -o '"value": [0-9.]*')"
+  DIFFUSERS_AMD_LN_FOLD=1 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-live-traffic > $O/bench_lnf1_parity.json 2> $O/bench_lnf1_parity.err; echo "LN_FOLD=1 with parity rc=$?"; grep -E "parity:|dropin:|timed region done" $O/bench_lnf1_parity.err | cut -c1-200
+  for c in sd15; do
+    for m in 2 1; do
+      DIFFUSERS_AMD_LN_FOLD=$m timeout 900 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_${c}_lnf$m.json 2> $O/bench_${c}_lnf$m.err; echo "$c LN_FOLD=$m rc=$? $(cut -c1-200 $O/bench_${c}_lnf$m.json | grep -o '"value": [0-9.]*')"
+    done
+  done
+fi
