@@ -226,3 +226,8 @@ if [[ $WHAT == *lnf3ab* ]]; then
     done
   done
 fi
+if [[ $WHAT == *driverline* ]]; then
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 $O/smoke.log | cut -c1-120)"
+  T0=$(date +%s); timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "bench (driver protocol) rc=$? in $(( $(date +%s) - T0 )) s"
+  cut -c1-260 $O/bench_driver.json; grep "^\[bench" $O/bench_driver.err | grep -E "timed region done|traffic|parity:|other_configs:" | cut -c1-200
+fi
