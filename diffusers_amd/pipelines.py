@@ -67,7 +67,11 @@ class _exclusive_decode:
     each by its own run under tools/: out-of-bounds writes (64 KiB canaries around every allocation of a decode and of a U-Net step:
     intact), the caching allocator (per-thread bump arenas: same result), a host-side launch race (a lock around every C-ABI call: same),
     split-K / one-launch GroupNorm / prefetch hints / the four-pixel conv_in (switched off: same), any single op looped next to a
-    decode (the decode stays intact); one hardware queue (GPU_MAX_HW_QUEUES=1) makes the difference disappear, and decodes replayed
+    decode (the decode stays intact), LDS writes outside a workgroup's allocation (tools/debug_lds_canary.py: canary workgroups of another
+    kernel kept resident on every CU through eager decodes, U-Net steps, the eight-phase tiles and D = 128 attention stay intact -- and a
+    positive control shows the hardware bounds plain ds_write AND LDS-DMA to the issuing workgroup's allocation in the first place,
+    profiles/r06f_lds_canary.jsonl), scratch memory (three kernel instantiations use any, none of them in a decode);
+    one hardware queue (GPU_MAX_HW_QUEUES=1) makes the difference disappear, and decodes replayed
     from their own HIP graphs reproduce their bits (48 of 48) -- but a graph-captured decode next to another pipeline's step graphs
     made things worse, not better.  The cause is NOT isolated.  Mitigation: a thread that set ``STREAM_DOMAIN.tag`` takes this lock around
     its decode and holds it until its stream has drained, so two decodes never overlap; with it 5 of 6 concurrent images reproduce their

@@ -231,3 +231,9 @@ if [[ $WHAT == *driverline* ]]; then
   T0=$(date +%s); timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "bench (driver protocol) rc=$? in $(( $(date +%s) - T0 )) s"
   cut -c1-260 $O/bench_driver.json; grep "^\[bench" $O/bench_driver.err | grep -E "timed region done|traffic|parity:|other_configs:" | cut -c1-200
 fi
+if [[ $WHAT == *ldscanary* ]]; then
+  timeout 900 python tools/debug_lds_canary.py $O/r06f_lds_canary.jsonl > $O/lds_canary.log 2>&1; echo "lds canary rc=$?"; grep -E "RESULT|Error|error" $O/lds_canary.log | cut -c1-330
+fi
+if [[ $WHAT == *rowtail* ]]; then
+  timeout 600 python tools/bench_rowtail.py $O/r06f_row_tail_split.jsonl > $O/rowtail.log 2>&1; echo "rowtail rc=$?"; tail -3 $O/rowtail.log | cut -c1-900
+fi
