@@ -576,9 +576,23 @@ inline SplitPlan split_plan(const da_attention_params& p, int QT, int unit_bytes
   const SplitPlan none = {nb, 0, 1, 0, nb >> 3};                              // balanced mapping, whole blocks
   if (p.kv_split == 1 || ntiles < 8) return none;
   const int cus = cu_count();
-  const int tail = nb % cus, full = nb - tail;
-  if (tail == 0 || (cus & 7) || (size_t)tail * 4 > (size_t)kSplitCounterBytes) return none;
+  int tail = nb % cus, full = nb - tail;
   auto valid = [&](int s) { const int tps = (ntiles + s - 1) / s; return s >= 2 && s <= 8 && tps >= 4 && (s - 1) * tps < ntiles; };   // units of >= 256 keys
+  // Experiment (round 6, second session; DA_ATTN_SPLIT_ALL=<s>): a D = 64 launch with at most two 128-query workgroups per CU (SDXL's
+  // S = 1024: 320 blocks, 1.25 waves per SIMD -- a lone wave runs a key tile in 0.80 us against 0.61 at three waves per SIMD) splits
+  // the keys of EVERY block over s units: s times the waves, each walking 1 / s of the keys, the partials combined by the last arriver.
+  // MEASURED, a loss (profiles/r06g_attention_split_all.jsonl, chained launches): S = 1024, 2 x 20 heads 20.0 us (tail split) -> 23.5 / 27.9 /
+  // 31.3 us at s = 2 / 3 / 4; SD1.5's 2 x 8 heads at S = 4096 79.3 -> 104 / 89 / 97; SDXL image 0.9965 / 1.0016 -> 0.9909 / 0.9935 (s = 2),
+  // 0.9692 / 0.9739 (s = 4) -- the partials' round trip through memory (35 KB per unit, write-through, read back by the last arriver)
+  // costs more than the extra waves per SIMD buy.  Off by default; what it would take instead is a combine inside the workgroup.
+  static const int split_all = [] { const char* v = getenv("DA_ATTN_SPLIT_ALL"); return v ? atoi(v) : 0; }();
+  if (split_all >= 2 && p.kv_split == 0 && p.D == 64 && QT == 128 && nb <= 2 * cus && !(cus & 7) && valid(split_all) &&
+      (size_t)nb * 4 <= (size_t)kSplitCounterBytes) {
+    const long long need_all = (long long)kSplitCounterBytes + (long long)nb * split_all * unit_bytes;
+    if (ws_bytes) *ws_bytes = need_all;
+    if (p.split_ws && p.split_ws_bytes >= need_all) return SplitPlan{0, nb, split_all, (ntiles + split_all - 1) / split_all, nb >> 3};
+  }
+  if (tail == 0 || (cus & 7) || (size_t)tail * 4 > (size_t)kSplitCounterBytes) return none;
   int best = 1;
   if (p.kv_split >= 2) {
     if (!valid(p.kv_split)) return none;

@@ -51,26 +51,27 @@ def plan(B, H, S, D, kv):
     return f.value, t.value, s.value
 
 
-out = open(sys.argv[1], "a") if len(sys.argv) > 1 else None
-shapes = ((2, 20, 1024, 64, "SDXL 32x32 level"), (2, 10, 4096, 64, "SDXL 64x64 level"), (1, 24, 4608, 128, "Flux joint"),
-          (2, 8, 4096, 64, "SD1.5 64x64 level (head 40 padded)"), (2, 12, 32760, 128, "Wan self"))
-for (B, H, S, D, what) in shapes:
-    inner = H * D
-    qk = rnd(B * S, 2 * inner)
-    vt = rnd(inner, B * S)
-    for kv in (1, 0, 1, 0, 2, 3, 4, 6, 8):
-        if kv > 1 and plan(B, H, S, D, kv)[2] != kv:
-            continue
-        if S > 8192 and kv > 1:
-            continue
-        fn = lambda: ops.attention(qk, qk[:, inner:], vt, B=B, H=H, D=D, Sq=S, Skv=S, Skv_alloc=S, q_row_stride=2 * inner,  # noqa: E731
-                                   k_row_stride=2 * inner, q_batch_stride=S * 2 * inner, k_batch_stride=S * 2 * inner, vt_ld=B * S,
-                                   vt_batch_stride=S, kv_split=kv)
-        us = graph_us(fn, n=20 if S <= 8192 else 3)
-        fl = 4.0 * B * H * S * S * D
-        f, t, s = plan(B, H, S, D, kv)
-        rec = {"op": "attention v2", "what": what, "B": B, "H": H, "S": S, "D": D, "kv_split": kv, "plan": {"whole": f, "tail": t, "units": s},
-               "us": round(us, 1), "tflops": round(fl / us / 1e6, 0), "frac": round(fl / us / 1e6 / 2500, 3)}
-        print(json.dumps(rec), flush=True)
-        if out:
-            out.write(json.dumps(rec) + "\n")
+if __name__ == "__main__":
+    out = open(sys.argv[1], "a") if len(sys.argv) > 1 else None
+    shapes = ((2, 20, 1024, 64, "SDXL 32x32 level"), (2, 10, 4096, 64, "SDXL 64x64 level"), (1, 24, 4608, 128, "Flux joint"),
+              (2, 8, 4096, 64, "SD1.5 64x64 level (head 40 padded)"), (2, 12, 32760, 128, "Wan self"))
+    for (B, H, S, D, what) in shapes:
+        inner = H * D
+        qk = rnd(B * S, 2 * inner)
+        vt = rnd(inner, B * S)
+        for kv in (1, 0, 1, 0, 2, 3, 4, 6, 8):
+            if kv > 1 and plan(B, H, S, D, kv)[2] != kv:
+                continue
+            if S > 8192 and kv > 1:
+                continue
+            fn = lambda: ops.attention(qk, qk[:, inner:], vt, B=B, H=H, D=D, Sq=S, Skv=S, Skv_alloc=S, q_row_stride=2 * inner,  # noqa: E731
+                                       k_row_stride=2 * inner, q_batch_stride=S * 2 * inner, k_batch_stride=S * 2 * inner, vt_ld=B * S,
+                                       vt_batch_stride=S, kv_split=kv)
+            us = graph_us(fn, n=20 if S <= 8192 else 3)
+            fl = 4.0 * B * H * S * S * D
+            f, t, s = plan(B, H, S, D, kv)
+            rec = {"op": "attention v2", "what": what, "B": B, "H": H, "S": S, "D": D, "kv_split": kv, "plan": {"whole": f, "tail": t, "units": s},
+                   "us": round(us, 1), "tflops": round(fl / us / 1e6, 0), "frac": round(fl / us / 1e6 / 2500, 3)}
+            print(json.dumps(rec), flush=True)
+            if out:
+                out.write(json.dumps(rec) + "\n")

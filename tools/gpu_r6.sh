@@ -237,3 +237,14 @@ fi
 if [[ $WHAT == *rowtail* ]]; then
   timeout 600 python tools/bench_rowtail.py $O/r06f_row_tail_split.jsonl > $O/rowtail.log 2>&1; echo "rowtail rc=$?"; tail -3 $O/rowtail.log | cut -c1-900
 fi
+if [[ $WHAT == *splitall* ]]; then
+  for m in 0 2 3 4; do
+    DA_ATTN_SPLIT_ALL=$m timeout 300 python tools/bench_attn_splitall.py 2>&1 | grep -E "^\{|Error" | cut -c1-420 | tee -a $O/r06g_attention_split_all.jsonl
+  done
+  DA_ATTN_SPLIT_ALL=2 timeout 900 python -m pytest tests/test_attention_split.py tests/test_kernels_gpu.py -m gpu -q --timeout 600 -k "attention or attn" > $O/pytest_splitall.log 2>&1; echo "pytest (split all 2) rc=$?"; grep -E "passed|failed|FAILED|Error|assert" $O/pytest_splitall.log | tail -8
+  for pass in 1 2; do
+  for m in 0 2 4; do
+    DA_ATTN_SPLIT_ALL=$m timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/bench_sa$m.json 2> $O/bench_sa$m.err; echo "split all $m rc=$? $(cut -c1-140 $O/bench_sa$m.json | grep -o '"value": [0-9.]*')"
+  done
+  done
+fi
