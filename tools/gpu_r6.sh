@@ -248,3 +248,14 @@ if [[ $WHAT == *splitall* ]]; then
   done
   done
 fi
+if [[ $WHAT == *profsd15* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  for c in sd15 ddpm; do
+    rm -rf $O/prof_$c
+    timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_$c -o $c -- python $R/bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-reference > $O/prof_$c.log 2>&1; echo "prof $c rc=$?"
+    grep '"metric"' $O/prof_$c.log | cut -c1-200
+    find $O/prof_$c -name '*kernel_trace*' -size +30M -delete
+    (cd $R && python tools/prof_summary.py $(find $O/prof_$c -name '*kernel_stats.csv' | head -1) "r06 $c bench (--steps 1 --warmup 1)" > $O/prof_summary_$c.md 2>> $O/prof_$c.log); head -45 $O/prof_summary_$c.md | cut -c1-170
+  done
+  cd $R
+fi
