@@ -94,3 +94,31 @@ def test_reference_archive_recipe(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     ver, where = r.stdout.strip().splitlines()[-1].split()
     assert ver == build_ref.EXPECT_VERSION and "diffusers_ref.zip" in where
+
+
+def test_live_traffic_leg_never_costs_the_line(monkeypatch):
+    """bench.live_traffic (roofline.traffic measured inside the run: two rocprofv3 --pmc subprocess passes) returns (None, reason)
+    instead of raising when the profiler is missing or a pass fails -- the caller then replays profiles/sdxl_traffic.json."""
+    import shutil
+    import subprocess
+    import sys
+    sys.path.insert(0, str(ROOT))
+    import bench
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    real_exists = Path.exists
+    monkeypatch.setattr(Path, "exists", lambda self: False if str(self).endswith("rocprofv3") else real_exists(self))
+    tr, why = bench.live_traffic(1.0)
+    assert tr is None and "rocprofv3 not found" in why
+    monkeypatch.undo()
+    # a pass that fails (here: the stand-in profiler exits non-zero) is reported, not raised
+    monkeypatch.setattr(shutil, "which", lambda name: "/bin/false")
+    calls = []
+    real_run = subprocess.run
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        return real_run(["/bin/false"], capture_output=True, text=True)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    tr, why = bench.live_traffic(1.0)
+    assert tr is None and "FETCH_SIZE pass failed" in why and len(calls) == 1
+    assert "--pmc" in calls[0] and "--kernel-trace" in calls[0] and not any(f in calls[0] for f in ("--sys-trace", "-s", "--hip-trace"))
