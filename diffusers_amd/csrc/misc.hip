@@ -153,12 +153,16 @@ __global__ __launch_bounds__(256) void conv_thin_in4_kernel(const uint16_t* __re
   constexpr int kk = 9 * CIN;
   const int co0 = blockIdx.y * coc;
   const int ncoc = min(coc, Cout - co0);
+  // (consecutive lanes take consecutive OUTPUT CHANNELS of one (tap, input channel): their LDS words are consecutive.  With consecutive k
+  // per lane -- the coalesced order of the global side -- the 64 lanes of a store hit ONE bank, coc * 4 bytes being a multiple of 256)
   for (int i = threadIdx.x; i < ncoc * kk; i += blockDim.x) {
-    const int co = i / kk, k = i - co * kk;
+    const int k = i / ncoc, co = i - k * ncoc;
     wsm[k * coc + co] = bf2f(w[(size_t)(co0 + co) * kk + k]);
   }
   __syncthreads();
   const int cgroups = ncoc >> 3;
+  const size_t sB = (size_t)CIN * H * W, sC = in_nchw ? (size_t)H * W : 1, sY = in_nchw ? (size_t)W : (size_t)W * CIN, sX = in_nchw ? 1 : CIN;
+  const bool convert_in = (in_div != 1.0f) || (in_add != 0.0f);
   const int wq = (W + 3) >> 2;                                 // pixel quads per row
   const size_t total = (size_t)B * H * wq * cgroups;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -168,31 +172,56 @@ __global__ __launch_bounds__(256) void conv_thin_in4_kernel(const uint16_t* __re
     const int yh = (int)((quad / wq) % H);
     const int b = (int)(quad / ((size_t)wq * H));
     float acc[4][8];
+    {
+      float bvs[8];
+      // (one 16-byte load when the eight channels' bias is 16-byte aligned; eight dependent 2-byte loads each waited for otherwise)
+      if (bias && (((size_t)(bias + co0 + cg * 8)) & 15) == 0) {
+        unpack8(*(const uint4*)(bias + co0 + cg * 8), bvs);
+      } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float bv = bias ? bf2f(bias[co0 + cg * 8 + e]) : 0.f;
+        for (int e = 0; e < 8; ++e) bvs[e] = bias ? bf2f(bias[co0 + cg * 8 + e]) : 0.f;
+      }
 #pragma unroll
-      for (int px = 0; px < 4; ++px) acc[px][e] = bv;
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) acc[px][e] = bvs[e];
     }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int iy = yh + kh - 1;
       const bool row_ok = (unsigned)iy < (unsigned)H;          // (a padded row adds nothing: skipped in the kernel above as well)
       float xin[6][CIN];
+      // The 6 * CIN input values of this kernel row are loaded UNCONDITIONALLY from clamped (always valid) addresses and zeroed by a
+      // select afterwards: behind `if (ok)` every load sat in its own exec-masked branch with its own s_waitcnt -- 72 serialised round
+      // trips per thread, which WAS the kernel (U-Net conv_in 4 -> 320 at 128 x 128: 58 us for 21 MB of output; round 6).  Same values.
+      // (layout strides instead of a per-element NCHW / NHWC select, and ONE uniform branch around the conversions: straight-line loads)
+      uint16_t raw[6][CIN];
+      const int iyc = min(max(iy, 0), H - 1);
+      const uint16_t* xrow = x + (size_t)b * sB + (size_t)iyc * sY;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const int ix = x0 + j - 1;
-        const bool ok = row_ok && (unsigned)ix < (unsigned)W;
+        const int ixc = min(max(x0 + j - 1, 0), W - 1);
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) {
-          float xv = 0.f;
-          if (ok) {
-            const size_t off = in_nchw ? (((size_t)b * CIN + c) * H + iy) * W + ix : (((size_t)b * H + iy) * W + ix) * CIN + c;
-            xv = bf2f(x[off]);
+        for (int c = 0; c < CIN; ++c) raw[j][c] = xrow[(size_t)ixc * sX + (size_t)c * sC];
+      }
+      if (convert_in) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const bool ok = row_ok && (unsigned)(x0 + j - 1) < (unsigned)W;
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) {
+            float xv = bf2f(raw[j][c]);
             if (in_div != 1.0f) xv = bf2f(f2bf(__fdiv_rn(xv, in_div)));
             if (in_add != 0.0f) xv = bf2f(f2bf(__fadd_rn(xv, in_add)));
+            xin[j][c] = ok ? xv : 0.f;
           }
-          xin[j][c] = xv;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const bool ok = row_ok && (unsigned)(x0 + j - 1) < (unsigned)W;
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) xin[j][c] = ok ? bf2f(raw[j][c]) : 0.f;
         }
       }
       if (!row_ok) continue;
