@@ -107,10 +107,16 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
     // the fold was a chain of 26-49 dependent L2 round trips in front of every block's first pixel
     for (int i = sl; i < nblk_stats; i += 16 * SL) {
       float2 pq[16];
+      // (UNCONDITIONAL loads from a clamped index, zeroed by a select: written as `cond ? load : 0` every load sat in its own
+      // exec-masked branch with its own s_waitcnt vmcnt(0) -- the sixteen "in flight" were sixteen serialised L2 round trips, twice
+      // over for 256 partials, in front of every block's first pixel; round 6, found in the ISA)
+      float2 raw[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) raw[u] = *(const float2*)(w + (size_t)min(i + u * SL, nblk_stats - 1) * G * 2);
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int idx = i + u * SL;                       // past the end: + 0.0, which changes nothing
-        pq[u] = (idx < nblk_stats) ? *(const float2*)(w + (size_t)idx * G * 2) : make_float2(0.f, 0.f);
+        pq[u] = (idx < nblk_stats) ? raw[u] : make_float2(0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -401,11 +407,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
     bq[i] = beta ? *(const uint4*)(beta + ch * 8) : make_uint4(0, 0, 0, 0);
   }
   float sum = 0.f;
+  // (the row's chunks are loaded UNCONDITIONALLY from clamped offsets and zeroed by a select: behind `if (ch < nchunks)` every chunk's
+  // load sat in its own exec-masked branch with its own s_waitcnt vmcnt(0) -- NCH serialised round trips per row instead of one; round 6)
+  uint4 xq[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) xq[i] = *(const uint4*)(xr + min(lane + 64 * i, nchunks - 1) * 8);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
+    unpack8(xq[i], v[i]);
     if (ch < nchunks) {
-      unpack8(*(const uint4*)(xr + ch * 8), v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) sum += v[i][e];
     } else {
@@ -498,12 +509,15 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(uint16_t* __restrict_
   uint16_t* xr = x + (size_t)row * ld + pp.col_off[part];
   float v[NCH][8];
   float ss[NCH];
+  uint4 xq[NCH];                                   // (unconditional clamped loads: see layernorm_kernel)
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) xq[i] = *(const uint4*)(xr + min(lane + 64 * i, nchunks - 1) * 8);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
     ss[i] = 0.f;
+    unpack8(xq[i], v[i]);
     if (ch < nchunks) {
-      unpack8(*(const uint4*)(xr + ch * 8), v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) ss[i] += v[i][e] * v[i][e];
     } else {
@@ -819,11 +833,14 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const uint16_t* __res
   float v[NCH][8];
   const uint16_t* xr = x + (size_t)row * ldx;
   float sq = 0.f;
+  uint4 xq[NCH];                                   // (unconditional clamped loads: see layernorm_kernel)
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) xq[i] = *(const uint4*)(xr + min(lane + 64 * i, nchunks - 1) * 8);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
+    unpack8(xq[i], v[i]);
     if (ch < nchunks) {
-      unpack8(*(const uint4*)(xr + ch * 8), v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) sq += v[i][e] * v[i][e];
     }
