@@ -55,14 +55,28 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const uint16_t* __r
 #pragma unroll
   for (int m = 0; m < MMAX; ++m) acc[m] = 0.f;
   const uint16_t* wr = W + (size_t)n * K;
-  for (int k = lane * 8; k < K; k += 512) {
-    float wf[8];
-    unpack8(*(const uint4*)(wr + k), wf);
+  // Four K chunks per trip: the weight row is met cold (a GEMV streams W once), and with one 16-byte load in flight per lane the
+  // launch was K / 512 serialised HBM round trips (12.7 us for the 7 MB of SDXL's time-embedding layers).  The loads are issued
+  // unconditionally from clamped offsets (chunks past K / rows past M are never accumulated / never stored); the accumulation order
+  // per lane -- chunks in k order -- is unchanged, so the results are bit-identical.
+  for (int k0 = lane * 8; k0 < K; k0 += 4 * 512) {
+    uint4 wq[4], xq[4][MMAX];
 #pragma unroll
-    for (int m = 0; m < MMAX; ++m) {
-      if (m < M) {
+    for (int u = 0; u < 4; ++u) {
+      const int kc = min(k0 + u * 512, K - 8);
+      wq[u] = *(const uint4*)(wr + kc);
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m) xq[u][m] = *(const uint4*)(x + (size_t)min(m, M - 1) * ldx + kc);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (k0 + u * 512 >= K) break;
+      float wf[8];
+      unpack8(wq[u], wf);
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m) {
         float xf[8];
-        unpack8(*(const uint4*)(x + (size_t)m * ldx + k), xf);
+        unpack8(xq[u][m], xf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float xv = xf[e];
