@@ -633,9 +633,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
         if (t == 0) __hip_atomic_store(flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
-      for (int sp = 0; sp < split - 1; ++sp) {
-        const int slot = slot0 + sp;
-        if (t == 0) {   // ONE lane polls ONE word, relaxed, with a bounded spin (a lost producer must not hang the GPU)
+      // Round 6: the reducer first waits for ALL producers (they finish within a microsecond of each other: equal K shares), then adds
+      // the partial tiles SB slots at a time -- the loads of SB slots' copy of one 32 x 32 sub-tile are in flight together, the adds
+      // stay in slot order (own slices, then slot 0, 1, ...: the same sums, bit for bit).  One slot and one sub-tile at a time, as
+      // before, the tail of a split-6 launch on a two-sub-tile tile was ten serialised round trips to the memory-side cache (the
+      // partials leave the XCD's L2 with their write-through stores): ~12 us of the 35 us the small-M deep-K convs of the SD1.5 /
+      // DDPM U-Nets take.
+      if (t == 0) {   // ONE lane polls ONE word at a time, relaxed, with a bounded spin (a lost producer must not hang the GPU)
+        for (int sp = 0; sp < split - 1; ++sp) {
+          const int slot = slot0 + sp;
           int spins = 0;
           while (__hip_atomic_load(flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             __builtin_amdgcn_s_sleep(8);
@@ -646,26 +652,39 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const da_gemm_
           }
           __hip_atomic_store(flags + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
         }
-        __syncthreads();
-        __amdgpu_buffer_rsrc_t rs = uniform_rsrc(ws + (size_t)slot * TILE_FLOATS, (size_t)TILE_FLOATS * 4);
+      }
+      __syncthreads();
+      constexpr int SB = (MT * NT <= 2) ? 4 : 2;           // slots in flight per sub-tile (16 VGPRs each)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            // one 32x32 sub-tile (4 x 16 B per lane in flight) at a time: without the fence the scheduler hoists every
-            // load of the slot above the first add and the kernel's VGPR budget grows by the whole partial tile
-            u32x4_t v[4];
+        for (int j = 0; j < NT; ++j) {
+          for (int sp0 = 0; sp0 < split - 1; sp0 += SB) {
+            // one 32x32 sub-tile of up to SB slots (4 x 16 B per lane and slot in flight): without the fences the scheduler hoists
+            // every load of every slot above the first add and the kernel's VGPR budget grows by the whole partial tiles
+            u32x4_t v[SB][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((((i * NT + j) * 4 + q) * NTHR) + t) * 16, 0, 16);
+            for (int u = 0; u < SB; ++u) {
+              // (a slot past the last one re-reads the last: loaded, never added)
+              const int slot = slot0 + min(sp0 + u, split - 2);
+              __amdgpu_buffer_rsrc_t rs = uniform_rsrc(ws + (size_t)slot * TILE_FLOATS, (size_t)TILE_FLOATS * 4);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              acc[i][j][4 * q + 0] += __uint_as_float(v[q].x); acc[i][j][4 * q + 1] += __uint_as_float(v[q].y);
-              acc[i][j][4 * q + 2] += __uint_as_float(v[q].z); acc[i][j][4 * q + 3] += __uint_as_float(v[q].w);
+              for (int q = 0; q < 4; ++q)
+                v[u][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((((i * NT + j) * 4 + q) * NTHR) + t) * 16, 0, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+              if (sp0 + u < split - 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  acc[i][j][4 * q + 0] += __uint_as_float(v[u][q].x); acc[i][j][4 * q + 1] += __uint_as_float(v[u][q].y);
+                  acc[i][j][4 * q + 2] += __uint_as_float(v[u][q].z); acc[i][j][4 * q + 3] += __uint_as_float(v[u][q].w);
+                }
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-      }
+        }
     }
   }
 
