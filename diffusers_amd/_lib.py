@@ -30,6 +30,7 @@ RING_SLOTS = (2, 2, 3, 4, 6, 8)  # LDS ring depth per staging code
 DTYPE_BF16, DTYPE_F32 = 0, 1
 SPLITK_FLAGS = 4096          # DA_SPLITK_FLAGS
 SPLITK_ERR_SLOT = SPLITK_FLAGS - 1
+SPLITK_MAX = 24              # DA_SPLITK_MAX
 PRED_EPSILON, PRED_V, PRED_SAMPLE = 0, 1, 2
 PRED_TYPES = {"epsilon": PRED_EPSILON, "v_prediction": PRED_V, "sample": PRED_SAMPLE}
 

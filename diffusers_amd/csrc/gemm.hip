@@ -88,7 +88,7 @@ int validate(da_gemm_params& p) {
       ((p.N & 127) || p.out_f32 || p.residual || p.rowvec || p.gate || p.bias_rows))
     return DA_ERR_UNSUPPORTED;
   if (p.act < 0 || p.act > DA_ACT_GEGLU_TANH) return DA_ERR_INVALID;
-  if (p.split_k < 0 || p.split_k > 8) return DA_ERR_INVALID;
+  if (p.split_k < 0 || p.split_k > DA_SPLITK_MAX) return DA_ERR_INVALID;
   if (p.split_k > 1 && (p.stats_out || p.ln_stats)) return DA_ERR_UNSUPPORTED;   // no split-K build of the LayerNorm fold
   if (p.k_valid < 0 || (p.k_valid > 0 && (p.k_valid > (p.conv ? p.C1 : p.K) || (p.conv && p.C2 != 0)))) return DA_ERR_INVALID;
   if (p.stats_out && (p.conv || p.out_f32 || p.act == DA_ACT_GEGLU || p.act == DA_ACT_GEGLU_TANH || p.stats_ld <= 0 || (p.stats_ld & 1)))
@@ -228,7 +228,9 @@ extern "C" int da_gemm_tune(const da_gemm_params* pp, const da_gemm_params* pair
   constexpr int n_stagings = sizeof(stagings) / sizeof(stagings[0]);
   // split factors tried next to the unsplit variants (round 4: up to 8 -- the 8 x 8 / 16 x 16 levels of the SD1.5 and DDPM
   // U-Nets are 3 x 3 convs with M = 64 .. 512 rows and K = 4.6 k .. 23 k: 8 .. 80 tiles walking 72 .. 360 K slices each)
-  static const int splits[] = {1, 2, 3, 4, 6, 8};
+  // Round 6: 12, 16 and 24 as well -- an M = 64 .. 128 conv of those levels is 10 .. 20 tiles streaming 10 .. 60 MB of weights, and at split 8
+  // only 80 .. 160 workgroups have loads in flight (0.8 TB/s: bound by bytes in flight, not by the fabric).
+  static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
   const int n_splits = (best_split && !pair && p.workspace && p.sync_flags) ? (int)(sizeof(splits) / sizeof(splits[0])) : 1;
   const int family = pp->tile;   // DA_TILE_AUTO: every variant; DA_TILE_FAMILY_1 / DA_TILE_FAMILY_K2: one kernel family only
   for (int spi = 0; spi < n_splits; ++spi) {

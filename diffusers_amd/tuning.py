@@ -114,7 +114,7 @@ def pair_key(pa: "L.GemmParams", pb: "L.GemmParams") -> str:
 
 def tune(p: "L.GemmParams", stream: int, pair: Optional["L.GemmParams"] = None) -> Tuple[int, int, float, int]:
     """Run da_gemm_tune for this problem (synchronises the stream) and remember the winner.  ``pair``: the two problems
-    are timed as ONE launch (da_gemm_pair_bf16).  When ``p`` carries a split-K workspace the split factors 2..8 compete
+    are timed as ONE launch (da_gemm_pair_bf16).  When ``p`` carries a split-K workspace the split factors 2..24 compete
     with the unsplit variants."""
     global _dirty, LIVE_COUNT
     LIVE_COUNT += 1

@@ -166,7 +166,7 @@ typedef struct da_gemm_params {
   int staging; /* DA_STAGE_* */
   int gate_f32; /* 1: gate is float and out = residual + bf16(xW+b) * gate in fp32, rounded once
                    (WanTransformerBlock, transformer_wan.py:491,:502); 0: Flux rounding (gate product rounded to bf16) */
-  int split_k;  /* 0 / 1: every tile is computed by one block.  2..8: the K range of each tile is dealt to
+  int split_k;  /* 0 / 1: every tile is computed by one block.  2..DA_SPLITK_MAX (24): the K range of each tile is dealt to
                    split_k co-resident blocks that hand fp32 partial tiles over through `workspace` (in-launch reduction,
                    fixed summation order: deterministic, but the last fp32 bit of a sum differs from split_k = 1).  For
                    problems with fewer tiles than the 256 CUs (SDXL: M = 2048, N = 1280 Linear and the 1280-channel convs). */
@@ -237,6 +237,7 @@ int da_gemm_stats_parts(const da_gemm_params* p);
 #define DA_LN_MAX_PARTS 64   /* slots per row of a statistics buffer */
 #define DA_LN_PAIR_LOADS 6   /* 16-byte loads per lane half in the consumer: rows with up to 24 partials (N <= 24 column tiles) */
 #define DA_SPLITK_FLAGS 4096
+#define DA_SPLITK_MAX 24   /* largest split_k (round 6: 8 -> 24 for the M <= 128 deep-K convs of the SD1.5 / DDPM U-Nets) */
 #define DA_SPLITK_ERR_SLOT (DA_SPLITK_FLAGS - 1) /* set to 1 by a reducer whose producer never arrived (bounded spin) */
 
 int da_gemm_bf16(const da_gemm_params* p, void* stream);
@@ -256,7 +257,7 @@ int da_gemm_pair_bf16(const da_gemm_params* a, const da_gemm_params* b, void* st
  * it per problem shape, the role torch's cublasLt/hipblasLt heuristic cache plays for F.linear / F.conv2d in the
  * reference).  Synchronises the stream; must not be called while the stream is being captured into a graph. */
 /* `pair` (may be NULL): time the two problems as ONE da_gemm_pair_bf16 launch.  `best_split` (may be NULL): when given and
- * p->workspace / p->sync_flags are set, split_k = 2, 3, 4, 6, 8 variants of every admissible tile are timed as well and the
+ * p->workspace / p->sync_flags are set, split_k = 2, 3, 4, 6, 8, 12, 16, 24 variants of every admissible tile are timed as well and the
  * winner's split factor is returned (1 = unsplit); otherwise only split_k = 1 is considered. */
 int da_gemm_tune(const da_gemm_params* p, const da_gemm_params* pair, void* stream, int iters, void* scratch,
                  size_t scratch_bytes, int* best_tile, int* best_staging, int* best_split, float* best_us);

@@ -439,9 +439,9 @@ def test_tuning_keys_bucket_giant_row_counts_only():
     sdxl = set(json.loads((Path(__file__).parent / "golden" / "sdxl_gemm_shape_keys.json").read_text())["keys"])
     for key, (tile, staging, us, *split) in table["entries"].items():
         assert 1 <= tile < len(L.TILE_NAMES) and 0 <= staging <= 7 and us > 0, key
-        # a split-K factor (fourth field, 2 .. 8): first kernel family only, and never on an SDXL shape (the headline path keeps one
+        # a split-K factor (fourth field, 2 .. DA_SPLITK_MAX): first kernel family only, and never on an SDXL shape (the headline path keeps one
         # summation order; the split variants serve the small-M, deep-K convs of the SD1.5 / DDPM U-Nets)
-        assert split == [] or (len(split) == 1 and 2 <= split[0] <= 8 and tile < L.FIRST_K2_TILE and key not in sdxl), key
+        assert split == [] or (len(split) == 1 and 2 <= split[0] <= L.SPLITK_MAX and tile < L.FIRST_K2_TILE and key not in sdxl), key
         # the eight-phase tile (csrc/gemm3.hip): nn.Linear only, one ring form, unsplit
         if tile in (L.TILE_K3_256x256, L.TILE_K3_256x320):
             assert key.startswith("lin:") and staging == L.STAGE_LDS_DIRECT and split == [], key

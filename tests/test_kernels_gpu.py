@@ -238,6 +238,49 @@ def test_conv_split_k(B, H, W, C1, C2, Co, stride, up):
     assert ran >= 4 and not ops.splitk_error()
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,Co", [(2, 8, 8, 1280, 0, 1280), (2, 8, 8, 1280, 1280, 1280), (2, 16, 16, 1280, 0, 1280), (1, 8, 8, 512, 512, 512)])
+def test_conv_split_k_wide_factors(B, H, W, C1, C2, Co):
+    """The split factors the shipped table uses on the 8 x 8 / 16 x 16 levels of the SD1.5 / DDPM U-Nets, up to DA_SPLITK_MAX (round 6:
+    8 -> 24; M = 64 .. 512 rows under K = 4.6 k .. 23 k): every factor the library accepts is deterministic across repeats and tiles,
+    within one bf16 ulp of the unsplit kernel and within the kernel tolerance of the fp32 reference; a factor past the maximum is
+    refused as INVALID; a launch that could not be co-resident is refused, never run."""
+    ops, L = _ops()
+    x1 = rnd((B, H, W, C1), 51)
+    x2 = rnd((B, H, W, C2), 52) if C2 else None
+    K = 9 * (C1 + C2)
+    w, b = rnd((Co, K), 53, K ** -0.5), rnd((Co,), 54)
+    rv, res = rnd((B, Co), 55), rnd((B, H, W, Co), 56)
+    kw = dict(ksize=3, x2=x2, rowvec=rv, residual=res)
+    base = ops.conv2d_nhwc(x1, w, b, tile=L.TILE_128x128, staging=L.STAGE_LDS_DIRECT, **kw)
+    xin = x1 if x2 is None else torch.cat([x1, x2], -1)
+    wf = w.float().view(Co, 3, 3, C1 + C2).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xin.float().permute(0, 3, 1, 2), wf, b.float(), padding=1).permute(0, 2, 3, 1) \
+        + rv.float()[:, None, None, :] + res.float()
+    ran = 0
+    for split in (6, 8, 12, 16, 24):
+        first = None
+        for tile, st in ((L.TILE_128x64, L.STAGE_LDS_DIRECT3), (L.TILE_64x128, L.STAGE_LDS_DIRECT3), (L.TILE_128x128, L.STAGE_LDS_DIRECT)):
+            y = None
+            for rep in range(3):
+                try:
+                    y = ops.conv2d_nhwc(x1, w, b, tile=tile, staging=st, split_k=split, **kw)
+                except RuntimeError as e:
+                    assert "UNSUPPORTED" in str(e) or "INVALID" in str(e)
+                    y = None
+                    break
+                if first is None:
+                    first = y.clone()
+                assert torch.equal(y, first), f"conv split {split} tile {tile}/{st} rep {rep}: not deterministic"
+            ran += y is not None
+        if first is not None:
+            assert_close_bf16(first, ref, f"conv split-K {split} M{B * H * W} K{K}")
+            ulp = (first.float() - base.float()).abs() / base.float().abs().clamp_min(2.0 ** -8)
+            assert float(ulp.max()) <= 2.0 ** -7, f"conv split {split}: more than one bf16 ulp from the unsplit kernel"
+    assert ran >= 5 and not ops.splitk_error()
+    with pytest.raises(RuntimeError):
+        ops.conv2d_nhwc(x1, w, b, tile=L.TILE_128x64, staging=L.STAGE_LDS_DIRECT3, split_k=L.SPLITK_MAX + 1, **kw)
+
+
 @pytest.mark.parametrize("M,C,N", [(2048, 1280, 1280), (520, 320, 384), (8192, 640, 640)])
 def test_layernorm_fold_producer_and_consumers(M, C, N):
     """LayerNorm folded into the GEMMs either side of it (da_gemm_params.stats_out / ln_*):

@@ -5,6 +5,45 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 WHAT=${1:-attnsplit}
+if [[ $WHAT == *retunesplit* ]]; then
+  # the shipped table's split-K entries (small-M, deep-K convs of the SD1.5 / DDPM U-Nets) tuned again with split factors up to 24 competing
+  timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q --timeout 600 -k "split_k" > $O/pytest_splitk.log 2>&1; echo "pytest splitk rc=$?"
+  tail -3 $O/pytest_splitk.log
+  python - <<PYEOF
+import json
+R, O = "$R", "$O"
+d = json.load(open(f"{R}/diffusers_amd/tuned/gfx950.json"))
+drop = [k for k, v in d["entries"].items() if len(v) > 3 and v[3] > 1]
+for k in drop:
+    del d["entries"][k]
+json.dump(d, open(f"{O}/table_pruned.json", "w"))
+print("entries to tune again:", len(drop))
+PYEOF
+  cp $O/table_pruned.json $O/table_retuned.json
+  for cfg in sd15 ddpm; do
+    DIFFUSERS_AMD_SPLITK=1 DIFFUSERS_AMD_GEMM_FAMILY=all DIFFUSERS_AMD_TUNE_DB=$O/table_retuned.json DIFFUSERS_AMD_TUNE_SAVE=$O/table_retuned.json timeout 900 python bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/retune_$cfg.json 2> $O/retune_$cfg.err; echo "retune $cfg rc=$? $(grep -o '"value": [0-9.]*' $O/retune_$cfg.json | head -1) $(grep -o '"tuned_live": [0-9]*' $O/retune_$cfg.json)"
+  done
+  python - <<PYEOF
+import json
+a = json.load(open("$R/diffusers_amd/tuned/gfx950.json"))["entries"]
+b = json.load(open("$O/table_retuned.json"))
+T = b["tiles"]
+n = 0
+for k, v in sorted(b["entries"].items()):
+    o = a.get(k)
+    if o is None or o[:2] != v[:2] or o[3:] != v[3:]:
+        n += 1
+        print(f"  {k:58s} {T[o[0]] if o else '-':11s} st{o[1] if o else '-'} split {o[3] if o and len(o) > 3 else 1} {o[2] if o else 0:7.1f}us -> {T[v[0]]:11s} st{v[1]} split {v[3] if len(v) > 3 else 1} {v[2]:7.1f}us")
+print("changed:", n)
+PYEOF
+  for rep in 1 2; do
+    for tb in $R/diffusers_amd/tuned/gfx950.json $O/table_retuned.json; do
+      for cfg in sd15 ddpm; do
+        DIFFUSERS_AMD_TUNE_DB=$tb timeout 600 python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/ab_$cfg.json 2> $O/ab_$cfg.err; echo "$(basename $tb) $cfg rc=$? $(grep -o '"value": [0-9.]*' $O/ab_$cfg.json | head -1) $(grep -o '"tuned_live": [0-9]*' $O/ab_$cfg.json) $(grep -o '"psnr[a-z_]*": [0-9.]*' $O/ab_$cfg.json | head -2 | tr '\n' ' ')"
+      done
+    done
+  done
+fi
 if [[ $WHAT == *attnsplit* ]]; then
   timeout 900 python -m pytest tests/test_attention_split.py -q -s --timeout 600 > $O/pytest_attnsplit.log 2>&1; echo "pytest attnsplit rc=$?"
   grep -E "passed|failed|FAILED|Error|assert|\[split\]" $O/pytest_attnsplit.log | tail -40
