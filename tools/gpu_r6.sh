@@ -44,6 +44,47 @@ PYEOF
     done
   done
 fi
+if [[ $WHAT == *retunesdxl* ]]; then
+  # third session: the SDXL U-Net entries (convs and plain nn.Linear; not the k3 GEGLU tiles, pair / qkv launches or the VAE) tuned again on the
+  # final library -- round 6 changed the conv kernels' K order and XCD rectangles after the table was last tuned -- then same-box A/B
+  python - <<PYEOF
+import json, re
+R, O = "$R", "$O"
+d = json.load(open(f"{R}/diffusers_amd/tuned/gfx950.json"))
+sdxl = set(json.load(open(f"{R}/tests/golden/sdxl_gemm_shape_keys.json"))["keys"])
+drop = []
+for k, v in d["entries"].items():
+    if k not in sdxl or k.startswith(("pair:", "qkv:")) or d["tiles"][v[0]].startswith("k3:"):
+        continue
+    m = re.match(r"(conv\d|lin):M(\d+):", k)
+    if m and int(m.group(2)) <= 32768 and ":N16384:" not in k and ":K16384:" not in k:
+        drop.append(k)
+for k in drop:
+    del d["entries"][k]
+json.dump(d, open(f"{O}/table_pruned_sdxl.json", "w"))
+print("entries to tune again:", len(drop))
+PYEOF
+  cp $O/table_pruned_sdxl.json $O/table_retuned_sdxl.json
+  DIFFUSERS_AMD_GEMM_FAMILY=all DIFFUSERS_AMD_TUNE_DB=$O/table_retuned_sdxl.json DIFFUSERS_AMD_TUNE_SAVE=$O/table_retuned_sdxl.json timeout 1200 python bench.py --steps 1 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/retune_sdxl.json 2> $O/retune_sdxl.err; echo "retune sdxl rc=$? $(grep -o '"value": [0-9.]*' $O/retune_sdxl.json | head -1) $(grep -o '"tuned_live": [0-9]*' $O/retune_sdxl.json)"
+  python - <<PYEOF
+import json
+a = json.load(open("$R/diffusers_amd/tuned/gfx950.json"))["entries"]
+b = json.load(open("$O/table_retuned_sdxl.json"))
+T = b["tiles"]
+n = 0
+for k, v in sorted(b["entries"].items()):
+    o = a.get(k)
+    if o is None or o[:2] != v[:2] or o[3:] != v[3:]:
+        n += 1
+        print(f"  {k:58s} {T[o[0]] if o else '-':11s} st{o[1] if o else '-'} {o[2] if o else 0:7.1f}us -> {T[v[0]]:11s} st{v[1]} {v[2]:7.1f}us")
+print("changed:", n)
+PYEOF
+  for rep in 1 2 3; do
+    for tb in $R/diffusers_amd/tuned/gfx950.json $O/table_retuned_sdxl.json; do
+      DIFFUSERS_AMD_TUNE_DB=$tb timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/ab_sdxl.json 2> $O/ab_sdxl.err; echo "$(basename $tb) sdxl rc=$? $(grep -o '"value": [0-9.]*' $O/ab_sdxl.json | head -1) $(grep -o '"tuned_live": [0-9]*' $O/ab_sdxl.json)"
+    done
+  done
+fi
 if [[ $WHAT == *attnsplit* ]]; then
   timeout 900 python -m pytest tests/test_attention_split.py -q -s --timeout 600 > $O/pytest_attnsplit.log 2>&1; echo "pytest attnsplit rc=$?"
   grep -E "passed|failed|FAILED|Error|assert|\[split\]" $O/pytest_attnsplit.log | tail -40
