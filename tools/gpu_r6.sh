@@ -85,6 +85,18 @@ PYEOF
     done
   done
 fi
+if [[ $WHAT == *tunestep* ]]; then
+  # third session: the step itself as the tuner's arbiter (tools/insitu_tune.py), then bench.py with the shipped and the in-situ table
+  timeout 1800 python tools/insitu_tune.py $O/r06j_insitu_tune.json ${INSITU_KEYS:-16} 16 0.15 ${INSITU_CAP:-1100} ${INSITU_SKIP:-} > $O/insitu_tune.log 2>&1; echo "insitu tune rc=$?"
+  grep "^\[insitu\]" $O/insitu_tune.log | grep -v "/st[0-9]*: " | cut -c1-260 | tail -60
+  if [[ -f $O/table_insitu.json ]]; then
+    for rep in 1 2 3; do
+      for tb in $R/diffusers_amd/tuned/gfx950.json $O/table_insitu.json; do
+        DIFFUSERS_AMD_TUNE_DB=$tb timeout 600 python bench.py --steps 3 --warmup 1 --no-reference --no-cpu-baseline --no-roofline --no-other-configs > $O/ab_sdxl.json 2> $O/ab_sdxl.err; echo "$(basename $tb) sdxl rc=$? $(grep -o '"value": [0-9.]*' $O/ab_sdxl.json | head -1) $(grep -o '"tuned_live": [0-9]*' $O/ab_sdxl.json)"
+      done
+    done
+  fi
+fi
 if [[ $WHAT == *attnsplit* ]]; then
   timeout 900 python -m pytest tests/test_attention_split.py -q -s --timeout 600 > $O/pytest_attnsplit.log 2>&1; echo "pytest attnsplit rc=$?"
   grep -E "passed|failed|FAILED|Error|assert|\[split\]" $O/pytest_attnsplit.log | tail -40
