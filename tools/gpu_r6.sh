@@ -97,6 +97,23 @@ if [[ $WHAT == *tunestep* ]]; then
     done
   fi
 fi
+if [[ $WHAT == *tuneother* ]]; then
+  # the same arbiter for the SD1.5 / DDPM configurations (their own entries only; chained: the second pass starts from the first one's table)
+  TB=$R/diffusers_amd/tuned/gfx950.json
+  for cfg in sd15 ddpm; do
+    DIFFUSERS_AMD_TUNE_DB=$TB timeout 1200 python tools/insitu_tune.py $O/r06j_insitu_tune_$cfg.json ${INSITU_KEYS:-20} 12 0.3 ${INSITU_CAP:-500} - $cfg > $O/insitu_tune_$cfg.log 2>&1; echo "insitu tune $cfg rc=$?"
+    grep "^\[insitu\]" $O/insitu_tune_$cfg.log | grep -v "/st[0-9]*: \|\] key " | cut -c1-260 | tail -40
+    [[ -f $O/table_insitu_$cfg.json ]] && TB=$O/table_insitu_$cfg.json
+  done
+  cp $TB $O/table_insitu_other.json
+  for rep in 1 2; do
+    for tb in $R/diffusers_amd/tuned/gfx950.json $O/table_insitu_other.json; do
+      for cfg in sd15 ddpm; do
+        DIFFUSERS_AMD_TUNE_DB=$tb timeout 600 python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/ab_$cfg.json 2> $O/ab_$cfg.err; echo "$(basename $tb) $cfg rc=$? $(grep -o '"value": [0-9.]*' $O/ab_$cfg.json | head -1) $(grep -o '"tuned_live": [0-9]*' $O/ab_$cfg.json) $(grep -o '"psnr[a-z_]*": [0-9.]*' $O/ab_$cfg.json | head -2 | tr '\n' ' ')"
+      done
+    done
+  done
+fi
 if [[ $WHAT == *attnsplit* ]]; then
   timeout 900 python -m pytest tests/test_attention_split.py -q -s --timeout 600 > $O/pytest_attnsplit.log 2>&1; echo "pytest attnsplit rc=$?"
   grep -E "passed|failed|FAILED|Error|assert|\[split\]" $O/pytest_attnsplit.log | tail -40

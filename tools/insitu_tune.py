@@ -9,7 +9,7 @@ N replays.  For each table key of the step, by share of the step, every other (t
 re-captured and timed; a candidate is kept when it beats the incumbent by more than `margin`.  A candidate the library refuses for
 the key's launches (`DA_ERR_UNSUPPORTED`: `ops._launch_gemm` would silently fall back to TILE_AUTO) is skipped, not timed.
 
-usage: insitu_tune.py <out.json> [max_keys] [replays] [margin_percent] [cap_seconds] [earlier_pass.json]
+usage: insitu_tune.py <out.json> [max_keys] [replays] [margin_percent] [cap_seconds] [earlier_pass.json | -] [sdxl | sd15 | ddpm | flux]
 Writes {"changed": {key: [old, new, ms_before, ms_after]}, "baseline_ms": ..., "final_ms": ..., "log": [...]} and, next to it,
 `table_insitu.json` (the shipped table with the winners) for a bench.py A/B via DIFFUSERS_AMD_TUNE_DB."""
 import ctypes as C
@@ -34,22 +34,11 @@ def main():
     replays = int(sys.argv[3]) if len(sys.argv) > 3 else 16
     margin = float(sys.argv[4]) / 100 if len(sys.argv) > 4 else 0.0015
     cap_s = float(sys.argv[5]) if len(sys.argv) > 5 else 1200.0        # stop exploring after this many seconds
-    skip = set(json.loads(Path(sys.argv[6]).read_text())["keys"]) if len(sys.argv) > 6 else set()   # keys an earlier pass explored
+    skip = set(json.loads(Path(sys.argv[6]).read_text())["keys"]) if len(sys.argv) > 6 and sys.argv[6] != "-" else set()   # keys an earlier pass explored
+    config = sys.argv[7] if len(sys.argv) > 7 else "sdxl"
     import bench
-    from diffusers_amd import _lib as L, factory, init as dinit, ops, tuning
-    from diffusers_amd.pipelines import StableDiffusionXLPipeline
-    from diffusers_amd.schedulers import EulerDiscreteScheduler
+    from diffusers_amd import _lib as L, ops, tuning
     dev = torch.device("cuda", 0)
-    unet, _ = factory.build_unet(dinit.SDXL_UNET, seed=0, device=dev, init_device=str(dev))
-    pipe = StableDiffusionXLPipeline(vae=None, unet=unet, scheduler=EulerDiscreteScheduler(**factory.SDXL_SCHEDULER))
-    inp = bench.synth_inputs(1, False, dev)
-    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]], dim=0).contiguous()
-    te = torch.cat([inp["negative_pooled"], inp["pooled"]], dim=0)
-    ids = torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]], device=dev).repeat(2, 1)
-    cond = unet.precompute_conditioning(pe, {"text_embeds": te, "time_ids": ids})
-    pipe.scheduler.set_timesteps(50, device=dev)
-    lat0 = inp["latents"].clone()
-    lat = lat0.clone()
     table = tuning.table()
 
     # ---- launches per key in one eager step, and a strict launcher for the key under test ----
@@ -67,36 +56,70 @@ def main():
         if rc == ops.DA_ERR_UNSUPPORTED and state["key"] in (k, "qkv:" + k):
             raise Unsupported(k)
         if rc == ops.DA_ERR_UNSUPPORTED and getattr(p, "_auto", False) and p.tile != L.TILE_AUTO:
-            if k == state["key"]:
-                raise Unsupported(k)
             p.tile, p.staging, p.split_k = L.TILE_AUTO, L.STAGE_LDS_DIRECT, 1
             rc = lib.da_gemm_bf16(C.byref(p), st)
         L.check(rc, what)
     ops._launch_gemm = launch
 
-    pipe.scheduler.reset(0)
-    pipe._step(lat, cond, bench.GUIDANCE, True)
-    torch.cuda.synchronize()
-    state["count"] = False
+    if config == "sdxl":
+        from diffusers_amd import factory, init as dinit
+        from diffusers_amd.pipelines import StableDiffusionXLPipeline
+        from diffusers_amd.schedulers import EulerDiscreteScheduler
+        unet, _ = factory.build_unet(dinit.SDXL_UNET, seed=0, device=dev, init_device=str(dev))
+        pipe = StableDiffusionXLPipeline(vae=None, unet=unet, scheduler=EulerDiscreteScheduler(**factory.SDXL_SCHEDULER))
+        inp = bench.synth_inputs(1, False, dev)
+        pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]], dim=0).contiguous()
+        te = torch.cat([inp["negative_pooled"], inp["pooled"]], dim=0)
+        ids = torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]], device=dev).repeat(2, 1)
+        cond = unet.precompute_conditioning(pe, {"text_embeds": te, "time_ids": ids})
+        pipe.scheduler.set_timesteps(50, device=dev)
+        lat0 = inp["latents"].clone()
+        lat = lat0.clone()
+        pipe.scheduler.reset(0)
+        pipe._step(lat, cond, bench.GUIDANCE, True)
+        torch.cuda.synchronize()
+        state["count"] = False
 
-    def step_ms():
-        """Re-capture the step with the live table, then time `replays` graph replays (two groups, the faster one)."""
-        pipe._graph = None
-        lat.copy_(lat0)
-        pipe._denoise(lat, cond, 1, bench.GUIDANCE, True, True)       # warm-up eager step + capture + one replay
-        best = 1e9
-        for _ in range(2):
+        def step_ms():
+            """Re-capture the step with the live table, then time `replays` graph replays (two groups, the faster one)."""
+            pipe._graph = None
             lat.copy_(lat0)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            pipe.scheduler.reset(0)
-            e0.record()
-            for _ in range(replays):
-                pipe._graph.replay()
-            e1.record()
-            e1.synchronize()
-            best = min(best, e0.elapsed_time(e1) / replays)
-        return best
+            pipe._denoise(lat, cond, 1, bench.GUIDANCE, True, True)       # warm-up eager step + capture + one replay
+            best = 1e9
+            for _ in range(2):
+                lat.copy_(lat0)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                pipe.scheduler.reset(0)
+                e0.record()
+                for _ in range(replays):
+                    pipe._graph.replay()
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) / replays)
+            return best
+    else:
+        # the other bench configurations (sd15 / ddpm / flux): the unit bench.py times (the engine pipeline's own call: `replays` sampler steps
+        # + decode), the graph thrown away and captured again for every candidate; ms per sampler step, decode included
+        pipe, unit = bench._build_other(config, dev, 0, False, False)
+        unit(1, graph=False)()
+        torch.cuda.synchronize()
+        state["count"] = False
+
+        def step_ms():
+            pipe._graph, pipe._graph_key = None, None
+            run = unit(replays)
+            run()                                                         # warm-up eager step + capture + the unit once
+            best = 1e9
+            for _ in range(2):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                run()
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) / replays)
+            return best
 
     base = [step_ms() for _ in range(3)]
     noise = (max(base) - min(base)) / min(base)
@@ -104,6 +127,8 @@ def main():
     log = [{"baseline_ms": base, "noise": noise}]
     print(f"[insitu] baseline step {base} ms (spread {100 * noise:.2f} %), margin {100 * margin:.2f} %", flush=True)
 
+    if config != "sdxl":      # the headline's entries are not this pass's to change
+        skip |= set(json.loads((ROOT / "tests" / "golden" / "sdxl_gemm_shape_keys.json").read_text())["keys"])
     keys = [k for k in counts if k in table and k not in skip and not L.TILE_NAMES[table[k][0]].startswith("k3:") and table[k][3] <= 1]
     keys.sort(key=lambda k: -counts[k] * table[k][2])
     keys = keys[:max_keys]
@@ -160,11 +185,11 @@ def main():
         table.clear(); table.update(final); b = step_ms()
         ab.append([a, b])
     print(f"[insitu] shipped vs final (ms per step): {ab}", flush=True)
-    raw = json.loads((ROOT / "diffusers_amd" / "tuned" / "gfx950.json").read_text())
+    raw = json.loads(Path(tuning.DB_PATH).read_text())                  # (DIFFUSERS_AMD_TUNE_DB chains passes: the table this pass started from)
     for k in changed:
         e = final[k]
         raw["entries"][k] = [e[0], e[1], round(e[2], 2)]
-    (out.parent / "table_insitu.json").write_text(json.dumps(raw))
+    (out.parent / ("table_insitu.json" if config == "sdxl" else f"table_insitu_{config}.json")).write_text(json.dumps(raw))
     out.write_text(json.dumps({"changed": changed, "baseline_ms": base, "shipped_vs_final_ms": ab, "keys": keys, "log": log}, indent=1))
     print(f"[insitu] changed {len(changed)} entries: {json.dumps(changed)}", flush=True)
 
