@@ -114,6 +114,17 @@ if [[ $WHAT == *tuneother* ]]; then
     done
   done
 fi
+if [[ $WHAT == *tuneflux* ]]; then
+  DIFFUSERS_AMD_TUNE_DB=$R/diffusers_amd/tuned/gfx950.json timeout 1500 python tools/insitu_tune.py $O/r06j_insitu_tune_flux.json ${INSITU_KEYS:-16} 8 0.3 ${INSITU_CAP:-600} - flux > $O/insitu_tune_flux.log 2>&1; echo "insitu tune flux rc=$?"
+  grep "^\[insitu\]" $O/insitu_tune_flux.log | grep -v "/st[0-9]*: " | cut -c1-260 | tail -50
+  if [[ -f $O/table_insitu_flux.json ]]; then
+    for rep in 1 2; do
+      for tb in $R/diffusers_amd/tuned/gfx950.json $O/table_insitu_flux.json; do
+        DIFFUSERS_AMD_TUNE_DB=$tb timeout 600 python bench.py --config flux --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/ab_flux.json 2> $O/ab_flux.err; echo "$(basename $tb) flux rc=$? $(grep -o '"value": [0-9.]*' $O/ab_flux.json | head -1) $(grep -o '"tuned_live": [0-9]*' $O/ab_flux.json)"
+      done
+    done
+  fi
+fi
 if [[ $WHAT == *attnsplit* ]]; then
   timeout 900 python -m pytest tests/test_attention_split.py -q -s --timeout 600 > $O/pytest_attnsplit.log 2>&1; echo "pytest attnsplit rc=$?"
   grep -E "passed|failed|FAILED|Error|assert|\[split\]" $O/pytest_attnsplit.log | tail -40
